@@ -1,0 +1,132 @@
+/*
+ * sketchycolor_hip.h -- C ABI of libsketchycolor_hip.so (gfx950 / MI355X).
+ *
+ * The reference (SketchyScene/SketchySceneColorization) has no FFI: every op of
+ * its hot path is a stock TensorFlow-1 op invoked from Python.  Each entry point
+ * below therefore names the TF op / reference call site it replaces
+ * (paths relative to Foreground_Instance_Colorization/obj_lib/).
+ *
+ * Conventions: every pointer is a DEVICE pointer unless it is a descriptor
+ * struct (host memory, read during the call); `stream` is a hipStream_t passed
+ * as void*; return value 0 = ok, non-zero = hipError_t or a negative argument
+ * error.  No ownership is transferred, no global state is kept, nothing is
+ * allocated: callers hand in workspaces.  Activations are NHWC fp32 internally
+ * (channel counts padded to a multiple of 4 where noted); filters keep the TF
+ * layouts ([kh,kw,Cin,Cout] for conv, [kh,kw,Cout,Cin] for conv-transpose).
+ */
+#ifndef SKETCHYCOLOR_HIP_H
+#define SKETCHYCOLOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activation codes applied on load (after the per-channel affine) */
+#define SSC_ACT_NONE 0
+#define SSC_ACT_RELU 1   /* tf.nn.relu                 models_collection.py:518,531 */
+#define SSC_ACT_LRELU 2  /* tf.maximum(0.2*x, x)       models_collection.py:51-53   */
+
+/*
+ * A "gather view": one or two NHWC tensors seen as a single [N,H,W,C0+C1]
+ * tensor (tf.concat on channels, models_collection.py:512-516), with an
+ * optional per-channel affine a*x+b (the folded batch-statistics norm,
+ * models_collection.py:36-46) followed by an activation, evaluated while the
+ * tile is loaded.  Out-of-image taps read 0 (tf.pad CONSTANT, :388).
+ */
+typedef struct ssc_gview {
+    const float* s0;   /* [N,H,W,C0] */
+    const float* s1;   /* [N,H,W,C1] or NULL */
+    const float* ab;   /* [2][C0+C1]: a then b; NULL = identity */
+    int32_t C0, C1;    /* both multiples of 4 */
+    int32_t H, W;
+    int32_t act;
+    int32_t _pad;
+} ssc_gview;
+
+/*
+ * Implicit-GEMM convolution, forward form:
+ *   out[pix][n] = sum_{tap,k} X[pix@tap][k] * F(tap,k,n)
+ * Replaces tf.nn.conv2d (models_collection.py:389, residual_util.py:24,33),
+ * tf.nn.conv2d_transpose (models_collection.py:402; nphase=4 sub-pixel form)
+ * and the data-gradient of both, plus tf.matmul (1x1 form; BasicLSTMCell and
+ * fully_connected, models_collection.py:184-236, mru.py:52-92).
+ */
+typedef struct ssc_conv_desc {
+    ssc_gview x;
+    const float* w;       /* filter [KH][KW][wC0][wC1] */
+    const float* bias;    /* [Nn] or NULL */
+    float* out;           /* [NB,OH,OW,ldc] */
+    int32_t NB, PH, PW;   /* output lattice: M = NB*PH*PW */
+    int32_t TH, TW;       /* taps per lattice point */
+    int32_t in_stride;    /* iy = py*in_stride + ioff_y + ty */
+    int32_t ioff_y, ioff_x;
+    int32_t nphase;       /* 1, or 4 = stride-2 transposed conv (k=4, pad 1) */
+    int32_t ky0, kx0, kstep;  /* filter row = ky0 + ty*kstep */
+    int32_t KH, KW, wC0, wC1;
+    int32_t bmode;        /* 0: k->wC0, n->wC1 ("KN"); 1: n->wC0, k->wC1 ("NK") */
+    int32_t k_real;       /* real K channels in the filter (<= x.C0+x.C1) */
+    int32_t n_off, Nn;    /* first filter n index, number of real outputs */
+    int32_t Nstore;       /* columns stored (>= Nn; extra ones are written 0) */
+    int32_t OH, OW, ldc;
+    int32_t out_stride, ooff_y, ooff_x; /* oy = py*out_stride + ooff_y */
+    int32_t epi;          /* 0 none, 1 tanh (models_collection.py:533) */
+    int32_t accumulate;   /* 1: out += result */
+} ssc_conv_desc;
+
+/*
+ * Implicit-GEMM filter gradient:
+ *   dF[(tap,cg)][cd] = sum_pix G[pix@tap][cg] * D[pix][cd]
+ * G is the gathered (higher-resolution) side, D the 1x1 side at the lattice.
+ * Replaces the filter-gradient of tf.nn.conv2d / conv2d_transpose / matmul
+ * produced by optim.compute_gradients (graph_single.py:24-30, 309-312).
+ */
+typedef struct ssc_wgrad_desc {
+    ssc_gview g;
+    ssc_gview d;
+    float* out;           /* [(tap*Cg_real + cg)][ldc] */
+    int32_t NB, PH, PW;
+    int32_t TH, TW, in_stride, ioff_y, ioff_x;
+    int32_t Cg_real;      /* real gathered channels (<= g.C0+g.C1) */
+    int32_t Nn;           /* real dense channels (<= d.C0+d.C1) */
+    int32_t ldc;
+    int32_t accumulate;
+} ssc_wgrad_desc;
+
+/* library / device info */
+int ssc_version(void);
+int ssc_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
+
+/* implicit GEMM (igemm.hip).  ws: split-K slab workspace (may be NULL). */
+int ssc_conv_forward(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, void* stream);
+int ssc_conv_wgrad(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void* stream);
+
+/* --- layout (elementwise.hip) --- */
+/* dst[n,hw,coff+c] = src[n,c,hw]; tf.transpose NCHW->NHWC (models_collection.py:381) */
+int ssc_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int ldc, int coff, void* stream);
+/* dst[n,c,hw] = src[n,hw,coff+c] */
+int ssc_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, int ldc, int coff, void* stream);
+int ssc_fill(float* dst, float value, int64_t n, void* stream);
+
+/* --- batch-statistics norm (tf.nn.moments + tf.nn.batch_normalization,
+ *     models_collection.py:36-46) --- */
+/* per-channel mean/biased var over M rows of x[M,ldx] (C channels) folded with
+ * scale/offset into ab=[a;b] (y = a*x+b); stats = [mean; rstd].  ws >= nblk*2*C floats. */
+int ssc_bn_stats(const float* x, int64_t M, int C, int ldx, const float* scale, const float* offset,
+                 float eps, float* ab, float* stats, float* ws, int64_t ws_bytes, void* stream);
+/*
+ * Backward of y = act(a*x+b) for up to two consumers (g1 through act1, g2
+ * through act2):  dz = g1*act1'(z) + g2*act2'(z).
+ * has_bn=1: dx = a*(dz - mean(dz) - xhat*mean(dz*xhat)), dscale = sum(dz*xhat),
+ * doffset = sum(dz).  has_bn=0: dx = dz (ab/stats ignored, z = x).
+ */
+int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, const float* ab, const float* stats,
+                        const float* scale, const float* g1, int ldg1, int act1, const float* g2, int ldg2,
+                        int act2, int has_bn, float* dx, int lddx, float* dscale, float* doffset, float* ws,
+                        int64_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKETCHYCOLOR_HIP_H */

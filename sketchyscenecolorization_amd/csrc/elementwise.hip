@@ -1,0 +1,304 @@
+// elementwise.hip -- HBM-bound helper kernels (layout, batch-statistics norm, its backward).
+// All tensors fp32; channel-contiguous (NHWC) rows are read as float4 so a
+// wavefront's 64 lanes cover 1 KiB per load instruction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sketchycolor_hip.h"
+
+#define CHECK_LAUNCH() ((int)hipGetLastError())
+
+// ------------------------------------------------------------------ layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW,
+                                    int ldc, int coff) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * HW) return;
+    const int n = (int)(i / HW);
+    const int p = (int)(i - (long)n * HW);
+    for (int c = 0; c < C; ++c) dst[i * ldc + coff + c] = src[((long)n * C + c) * HW + p];
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW,
+                                    int ldc, int coff) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * HW) return;
+    const int n = (int)(i / HW);
+    const int p = (int)(i - (long)n * HW);
+    for (int c = 0; c < C; ++c) dst[((long)n * C + c) * HW + p] = src[i * ldc + coff + c];
+}
+
+__global__ void fill_kernel(float* __restrict__ dst, float v, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = v;
+}
+
+extern "C" int ssc_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int ldc, int coff, void* stream) {
+    const long tot = (long)N * HW;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, N, C, HW, ldc, coff);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int ssc_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, int ldc, int coff, void* stream) {
+    const long tot = (long)N * HW;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, N, C, HW, ldc, coff);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int ssc_fill(float* dst, float value, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dst, value, (long)n);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ column reductions
+// Common shape: x[M, ld] with C (multiple of 4) channels; a block owns float4-column groups
+// [cg0, cg0+tcg) and a strided set of rows; lanes with the same column group are reduced
+// through LDS; block b writes partial[b][q][c] for q in the Q accumulated quantities.
+static inline void col_grid(int64_t M, int C, int& tcg, int& rl, int& nblk_rows, int& nblk_cols) {
+    const int cg = C / 4;
+    tcg = cg < 256 ? cg : 256;
+    // round tcg down to a power of two divisor of 256 that covers cg in ceil(cg/tcg) column blocks
+    int t = 1;
+    while (t * 2 <= tcg) t *= 2;
+    tcg = t;
+    rl = 256 / tcg;
+    nblk_cols = (cg + tcg - 1) / tcg;
+    int64_t rows_per_blk = (int64_t)rl * 16;
+    int64_t nb = (M + rows_per_blk - 1) / rows_per_blk;
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    nblk_rows = (int)nb;
+}
+
+__device__ __forceinline__ float dact(float z, int act) {
+    if (act == SSC_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == SSC_ACT_LRELU) return z > 0.f ? 1.f : 0.2f;
+    return 1.f;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long M, int C, int ldx,
+                                                                int tcg, float* __restrict__ partial) {
+    __shared__ float4 sh[2][256];
+    const int rl = 256 / tcg;
+    const int cgi = blockIdx.y * tcg + (threadIdx.x % tcg);
+    const int rlane = threadIdx.x / tcg;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (cgi * 4 < C) {
+        for (long r = (long)blockIdx.x * rl + rlane; r < M; r += (long)gridDim.x * rl) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + cgi * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+        }
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    if (rlane == 0 && cgi * 4 < C) {
+        for (int k = 1; k < rl; ++k) {
+            const float4 a = sh[0][k * tcg + threadIdx.x], b = sh[1][k * tcg + threadIdx.x];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+        }
+        float* p = partial + (long)blockIdx.x * 2 * C;
+        *reinterpret_cast<float4*>(p + cgi * 4) = s;
+        *reinterpret_cast<float4*>(p + C + cgi * 4) = q;
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
+                                         const float* __restrict__ scale, const float* __restrict__ offset, float eps,
+                                         float* __restrict__ ab, float* __restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)partial[(long)b * 2 * C + c];
+        q += (double)partial[(long)b * 2 * C + C + c];
+    }
+    const double mean = s / (double)M;
+    double var = q / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float a = rstd * scale[c];
+    ab[c] = a;
+    ab[C + c] = offset[c] - (float)mean * a;
+    stats[c] = (float)mean;
+    stats[C + c] = rstd;
+}
+
+extern "C" int ssc_bn_stats(const float* x, int64_t M, int C, int ldx, const float* scale, const float* offset,
+                            float eps, float* ab, float* stats, float* ws, int64_t ws_bytes, void* stream) {
+    if ((C & 3) || (ldx & 3)) return -1;
+    int tcg, rl, nbr, nbc;
+    col_grid(M, C, tcg, rl, nbr, nbc);
+    if ((int64_t)nbr * 2 * C * (int64_t)sizeof(float) > ws_bytes) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, x, (long)M, C, ldx, tcg, ws);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ws, nbr, C, (long)M, scale,
+                       offset, eps, ab, stats);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ norm + activation backward
+struct BnBwdArgs {
+    const float* x; long M; int C; int ldx;
+    const float* ab; const float* stats;
+    const float* g1; int ldg1; int act1;
+    const float* g2; int ldg2; int act2;
+    int has_bn;
+};
+
+__device__ __forceinline__ void bn_bwd_dz(const BnBwdArgs& a, long r, int c, const float4& aa, const float4& bb,
+                                          float4& xv, float4& dz) {
+    xv = *reinterpret_cast<const float4*>(a.x + r * a.ldx + c);
+    float4 z;
+    if (a.has_bn) {
+        z.x = fmaf(aa.x, xv.x, bb.x); z.y = fmaf(aa.y, xv.y, bb.y);
+        z.z = fmaf(aa.z, xv.z, bb.z); z.w = fmaf(aa.w, xv.w, bb.w);
+    } else {
+        z = xv;
+    }
+    const float4 g = *reinterpret_cast<const float4*>(a.g1 + r * a.ldg1 + c);
+    dz.x = g.x * dact(z.x, a.act1); dz.y = g.y * dact(z.y, a.act1);
+    dz.z = g.z * dact(z.z, a.act1); dz.w = g.w * dact(z.w, a.act1);
+    if (a.g2 != nullptr) {
+        const float4 h = *reinterpret_cast<const float4*>(a.g2 + r * a.ldg2 + c);
+        dz.x += h.x * dact(z.x, a.act2); dz.y += h.y * dact(z.y, a.act2);
+        dz.z += h.z * dact(z.z, a.act2); dz.w += h.w * dact(z.w, a.act2);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(BnBwdArgs a, int tcg, float* __restrict__ partial) {
+    __shared__ float4 sh[2][256];
+    const int rl = 256 / tcg;
+    const int cgi = blockIdx.y * tcg + (threadIdx.x % tcg);
+    const int rlane = threadIdx.x / tcg;
+    const int c = cgi * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (c < a.C) {
+        const float4 aa = *reinterpret_cast<const float4*>(a.ab + c);
+        const float4 bb = *reinterpret_cast<const float4*>(a.ab + a.C + c);
+        const float4 mu = *reinterpret_cast<const float4*>(a.stats + c);
+        const float4 rs = *reinterpret_cast<const float4*>(a.stats + a.C + c);
+        for (long r = (long)blockIdx.x * rl + rlane; r < a.M; r += (long)gridDim.x * rl) {
+            float4 xv, dz;
+            bn_bwd_dz(a, r, c, aa, bb, xv, dz);
+            s.x += dz.x; s.y += dz.y; s.z += dz.z; s.w += dz.w;
+            q.x += dz.x * (xv.x - mu.x) * rs.x; q.y += dz.y * (xv.y - mu.y) * rs.y;
+            q.z += dz.z * (xv.z - mu.z) * rs.z; q.w += dz.w * (xv.w - mu.w) * rs.w;
+        }
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    if (rlane == 0 && c < a.C) {
+        for (int k = 1; k < rl; ++k) {
+            const float4 u = sh[0][k * tcg + threadIdx.x], v = sh[1][k * tcg + threadIdx.x];
+            s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+            q.x += v.x; q.y += v.y; q.z += v.z; q.w += v.w;
+        }
+        float* p = partial + (long)blockIdx.x * 2 * a.C;
+        *reinterpret_cast<float4*>(p + c) = s;
+        *reinterpret_cast<float4*>(p + a.C + c) = q;
+    }
+}
+
+// coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat); dscale/doffset written (or accumulated)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
+                                       float* __restrict__ coef, float* __restrict__ dscale,
+                                       float* __restrict__ doffset) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)partial[(long)b * 2 * C + c];
+        q += (double)partial[(long)b * 2 * C + C + c];
+    }
+    coef[c] = (float)(s / (double)M);
+    coef[C + c] = (float)(q / (double)M);
+    if (dscale != nullptr) dscale[c] = (float)q;
+    if (doffset != nullptr) doffset[c] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const float* __restrict__ coef,
+                                                            float* __restrict__ dx, int lddx) {
+    const int cg = a.C / 4;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = a.M * cg;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < tot; i += stride) {
+        const long r = i / cg;
+        const int c = (int)(i - r * cg) * 4;
+        float4 aa = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.has_bn) {
+            aa = *reinterpret_cast<const float4*>(a.ab + c);
+            bb = *reinterpret_cast<const float4*>(a.ab + a.C + c);
+        }
+        float4 xv, dz;
+        bn_bwd_dz(a, r, c, aa, bb, xv, dz);
+        float4 o = dz;
+        if (a.has_bn) {
+            const float4 mu = *reinterpret_cast<const float4*>(a.stats + c);
+            const float4 rs = *reinterpret_cast<const float4*>(a.stats + a.C + c);
+            const float4 c1 = *reinterpret_cast<const float4*>(coef + c);
+            const float4 c2 = *reinterpret_cast<const float4*>(coef + a.C + c);
+            o.x = aa.x * (dz.x - c1.x - (xv.x - mu.x) * rs.x * c2.x);
+            o.y = aa.y * (dz.y - c1.y - (xv.y - mu.y) * rs.y * c2.y);
+            o.z = aa.z * (dz.z - c1.z - (xv.z - mu.z) * rs.z * c2.z);
+            o.w = aa.w * (dz.w - c1.w - (xv.w - mu.w) * rs.w * c2.w);
+        }
+        *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
+    }
+}
+
+extern "C" int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, const float* ab, const float* stats,
+                                   const float* scale, const float* g1, int ldg1, int act1, const float* g2,
+                                   int ldg2, int act2, int has_bn, float* dx, int lddx, float* dscale,
+                                   float* doffset, float* ws, int64_t ws_bytes, void* stream) {
+    (void)scale;
+    if ((C & 3) || (ldx & 3) || (ldg1 & 3) || (lddx & 3) || (g2 != nullptr && (ldg2 & 3))) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    BnBwdArgs a;
+    a.x = x; a.M = (long)M; a.C = C; a.ldx = ldx; a.ab = ab; a.stats = stats;
+    a.g1 = g1; a.ldg1 = ldg1; a.act1 = act1; a.g2 = g2; a.ldg2 = ldg2; a.act2 = act2; a.has_bn = has_bn;
+    float* coef = nullptr;
+    if (has_bn) {
+        int tcg, rl, nbr, nbc;
+        col_grid(M, C, tcg, rl, nbr, nbc);
+        if (((int64_t)nbr * 2 * C + 2 * C) * (int64_t)sizeof(float) > ws_bytes) return -2;
+        coef = ws + (int64_t)nbr * 2 * C;
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, a, tcg, ws);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ws, nbr, C, (long)M, coef,
+                           dscale, doffset);
+    }
+    long tot = (long)M * (C / 4);
+    long blocks = (tot + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, coef, dx, lddx);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ info
+extern "C" int ssc_version(void) { return 100; }
+
+extern "C" int ssc_device_info(int* cu_count, int* wave_size, char* arch, int arch_len) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return (int)e;
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (wave_size) *wave_size = prop.warpSize;
+    if (arch && arch_len > 0) {
+        int i = 0;
+        for (; i < arch_len - 1 && prop.gcnArchName[i]; ++i) arch[i] = prop.gcnArchName[i];
+        arch[i] = 0;
+    }
+    return 0;
+}

@@ -1,0 +1,635 @@
+// igemm.hip -- implicit-GEMM convolution kernels for gfx950 (MI355X, CDNA4).
+//
+// fp32 in / fp32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32: exact
+// f32, 157 TFLOP/s peak), 64-wide wavefronts, 4 waves per workgroup, LDS-staged
+// tiles with register prefetch of the next K-tile (one barrier per K-tile).
+//
+// Two kernels share the tile loaders:
+//   conv_fwd_kernel  : out[pix][n]      = sum_{tap,k} X[pix@tap][k] * F(tap,k,n)
+//   conv_wgrad_kernel: dF[(tap,cg)][cd] = sum_pix     G[pix@tap][cg] * D[pix][cd]
+// X/G/D are "gather views" (ssc_gview): NHWC tensors (optionally the channel
+// concat of two) with the folded batch-stat norm a*x+b and the activation
+// applied while the tile is loaded, zero outside the image.  This is how the
+// reference's  lrelu -> conv -> batchnorm  /  relu(concat) -> deconv -> batchnorm
+// blocks (models_collection.py:434-439, 510-526) are fused: the norm+activation
+// of layer L is evaluated inside the loads of layer L+1, so normalised tensors
+// are never written to HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sketchycolor_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == SSC_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == SSC_ACT_LRELU) return fmaxf(v, 0.2f * v);
+    return v;
+}
+
+// raw 4-channel load from a gather view at pixel offset `pix` (= (n*H+iy)*W+ix), channel c
+__device__ __forceinline__ float4 gview_load4(const ssc_gview& g, long pix, int c) {
+    const float* p = (c < g.C0) ? (g.s0 + pix * g.C0 + c) : (g.s1 + pix * g.C1 + (c - g.C0));
+    return *reinterpret_cast<const float4*>(p);
+}
+
+__device__ __forceinline__ void gview_affine4(const ssc_gview& g, int c, float4& a, float4& b) {
+    if (g.ab != nullptr) {
+        const int C = g.C0 + g.C1;
+        a = *reinterpret_cast<const float4*>(g.ab + c);
+        b = *reinterpret_cast<const float4*>(g.ab + C + c);
+    } else {
+        a = make_float4(1.f, 1.f, 1.f, 1.f);
+        b = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__device__ __forceinline__ float4 xform4(float4 v, const float4& a, const float4& b, int act, bool valid) {
+    float4 r;
+    r.x = valid ? act_apply(fmaf(a.x, v.x, b.x), act) : 0.f;
+    r.y = valid ? act_apply(fmaf(a.y, v.y, b.y), act) : 0.f;
+    r.z = valid ? act_apply(fmaf(a.z, v.z, b.z), act) : 0.f;
+    r.w = valid ? act_apply(fmaf(a.w, v.w, b.w), act) : 0.f;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward form
+// ---------------------------------------------------------------------------------------------
+struct FwdPhase {
+    int ioff_y, ioff_x, ky0, kx0, ooff_y, ooff_x;
+};
+
+__device__ __forceinline__ FwdPhase fwd_phase(const ssc_conv_desc& d, int phase) {
+    FwdPhase p;
+    if (d.nphase == 4) {   // stride-2 transposed conv, k=4, pad 1: output parity (ry,rx)
+        const int ry = phase >> 1, rx = phase & 1;
+        p.ioff_y = ry - 1; p.ioff_x = rx - 1;
+        p.ky0 = 3 - ry;    p.kx0 = 3 - rx;
+        p.ooff_y = ry;     p.ooff_x = rx;
+    } else {
+        p.ioff_y = d.ioff_y; p.ioff_x = d.ioff_x;
+        p.ky0 = d.ky0;       p.kx0 = d.kx0;
+        p.ooff_y = d.ooff_y; p.ooff_x = d.ooff_x;
+    }
+    return p;
+}
+
+template <int WM, int WN, int SM, int SN, int BMODE>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, float* __restrict__ slab_base,
+                                                        long slab_stride, int splitk) {
+    constexpr int BM = WM * SM * 32;
+    constexpr int BN = WN * SN * 32;
+    constexpr int A_LD = BK + 1;
+    constexpr int A_SZ = BM * A_LD;
+    constexpr int B_LD = (BMODE == 0) ? BN : (BK + 1);
+    constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * (BK + 1);
+    constexpr int A_ROWS = BM / 32;   // rows of the A tile per thread
+    constexpr int B_SLOTS = BN / 32;  // float4 slots of the B tile per thread
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][A_SZ]
+    float* Bs = smem + 2 * A_SZ;      // [2][B_SZ]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int C = d.x.C0 + d.x.C1;
+    const int Ktot = d.TH * d.TW * C;
+    const long M = (long)d.NB * d.PH * d.PW;
+    const int phase = blockIdx.z / splitk;
+    const int ks = blockIdx.z % splitk;
+    const FwdPhase ph = fwd_phase(d, phase);
+
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- per-thread A rows: pixel decode (fixed for the whole kernel) ----
+    const int a_col4 = tid & 7;            // float4 column inside the K tile
+    int a_iyb[A_ROWS], a_ixb[A_ROWS];
+    long a_nb[A_ROWS];
+    bool a_mv[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        const long m = m0 + (tid >> 3) + 32 * i;
+        a_mv[i] = m < M;
+        const long mm = a_mv[i] ? m : 0;
+        const int n = (int)(mm / (d.PH * d.PW));
+        const int rem = (int)(mm - (long)n * d.PH * d.PW);
+        const int py = rem / d.PW, px = rem - py * d.PW;
+        a_iyb[i] = py * d.in_stride + ph.ioff_y;
+        a_ixb[i] = px * d.in_stride + ph.ioff_x;
+        a_nb[i] = (long)n * d.x.H * d.x.W;
+    }
+
+    const int nkt = (Ktot + BK - 1) / BK;
+    const int per = (nkt + splitk - 1) / splitk;
+    const int kt_begin = ks * per;
+    const int kt_end = min(nkt, kt_begin + per);
+
+    f32x16 acc[SM][SN];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging registers
+    float4 ra[A_ROWS];
+    bool rav[A_ROWS];
+    float4 raa, rab;
+    float4 rb[B_SLOTS];
+
+    auto load_tile = [&](int kt) {
+        // ---- A (gather view) ----
+        const int kcol = kt * BK + a_col4 * 4;
+        const bool kv = kcol < Ktot;
+        const int tap = kv ? kcol / C : 0;
+        const int c = kv ? kcol - tap * C : 0;
+        const int ty = tap / d.TW, tx = tap - ty * d.TW;
+        gview_affine4(d.x, c, raa, rab);
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const int iy = a_iyb[i] + ty, ix = a_ixb[i] + tx;
+            const bool v = kv && a_mv[i] && iy >= 0 && iy < d.x.H && ix >= 0 && ix < d.x.W;
+            rav[i] = v;
+            ra[i] = v ? gview_load4(d.x, a_nb[i] + (long)iy * d.x.W + ix, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // ---- B (filter) ----
+        if (BMODE == 0) {
+            // KN: tile [BK rows k][BN cols n], n contiguous in memory
+            constexpr int RP = 1024 / BN;
+            const int col4 = tid % (BN / 4);
+            const int n = n0 + col4 * 4;
+#pragma unroll
+            for (int s = 0; s < B_SLOTS; ++s) {
+                const int krow = kt * BK + tid / (BN / 4) + RP * s;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (krow < Ktot) {
+                    const int tp = krow / C;
+                    const int kc = krow - tp * C;
+                    const int tty = tp / d.TW, ttx = tp - tty * d.TW;
+                    const int ky = ph.ky0 + tty * d.kstep, kx = ph.kx0 + ttx * d.kstep;
+                    if (kc < d.k_real) {
+                        const float* wp = d.w + ((long)(ky * d.KW + kx) * d.wC0 + kc) * d.wC1 + d.n_off + n;
+                        if (n + 3 < d.Nn && ((d.wC1 | d.n_off) & 3) == 0) {
+                            v = *reinterpret_cast<const float4*>(wp);
+                        } else {
+                            if (n + 0 < d.Nn) v.x = wp[0];
+                            if (n + 1 < d.Nn) v.y = wp[1];
+                            if (n + 2 < d.Nn) v.z = wp[2];
+                            if (n + 3 < d.Nn) v.w = wp[3];
+                        }
+                    }
+                }
+                rb[s] = v;
+            }
+        } else {
+            // NK: tile [BN rows n][BK cols k], k contiguous in memory
+            const int kc4 = kt * BK + (tid & 7) * 4;
+            const bool kvb = kc4 < Ktot;
+            const int tp = kvb ? kc4 / C : 0;
+            const int kc = kvb ? kc4 - tp * C : 0;
+            const int tty = tp / d.TW, ttx = tp - tty * d.TW;
+            const int ky = ph.ky0 + tty * d.kstep, kx = ph.kx0 + ttx * d.kstep;
+#pragma unroll
+            for (int s = 0; s < B_SLOTS; ++s) {
+                const int n = n0 + (tid >> 3) + 32 * s;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kvb && n < d.Nn) {
+                    const float* wp = d.w + ((long)(ky * d.KW + kx) * d.wC0 + d.n_off + n) * d.wC1 + kc;
+                    if (kc + 3 < d.k_real && (d.wC1 & 3) == 0) {
+                        v = *reinterpret_cast<const float4*>(wp);
+                    } else {
+                        if (kc + 0 < d.k_real) v.x = wp[0];
+                        if (kc + 1 < d.k_real) v.y = wp[1];
+                        if (kc + 2 < d.k_real) v.z = wp[2];
+                        if (kc + 3 < d.k_real) v.w = wp[3];
+                    }
+                }
+                rb[s] = v;
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* Ab = As + buf * A_SZ;
+        float* Bb = Bs + buf * B_SZ;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const float4 v = xform4(ra[i], raa, rab, d.x.act, rav[i]);
+            float* p = Ab + ((tid >> 3) + 32 * i) * A_LD + a_col4 * 4;
+            p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+        }
+        if (BMODE == 0) {
+            constexpr int RP = 1024 / BN;
+            const int col4 = tid % (BN / 4);
+#pragma unroll
+            for (int s = 0; s < B_SLOTS; ++s) {
+                const int row = tid / (BN / 4) + RP * s;
+                *reinterpret_cast<float4*>(Bb + row * B_LD + col4 * 4) = rb[s];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < B_SLOTS; ++s) {
+                float* p = Bb + ((tid >> 3) + 32 * s) * B_LD + (tid & 7) * 4;
+                p[0] = rb[s].x; p[1] = rb[s].y; p[2] = rb[s].z; p[3] = rb[s].w;
+            }
+        }
+    };
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = (kt + 1) < kt_end;
+        if (more) load_tile(kt + 1);
+        const float* Ab = As + cur * A_SZ + (wm * SM * 32 + l31) * A_LD + lhi;
+        const float* Bb = (BMODE == 0) ? (Bs + cur * B_SZ + lhi * B_LD + wn * SN * 32 + l31)
+                                       : (Bs + cur * B_SZ + (wn * SN * 32 + l31) * B_LD + lhi);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float av[SM], bv[SN];
+#pragma unroll
+            for (int i = 0; i < SM; ++i) av[i] = Ab[i * 32 * A_LD + kk * 2];
+#pragma unroll
+            for (int j = 0; j < SN; ++j)
+                bv[j] = (BMODE == 0) ? Bb[kk * 2 * B_LD + j * 32] : Bb[j * 32 * B_LD + kk * 2];
+#pragma unroll
+            for (int i = 0; i < SM; ++i)
+#pragma unroll
+                for (int j = 0; j < SN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue ----
+    float* outp = (splitk > 1) ? (slab_base + (long)ks * slab_stride) : d.out;
+    const bool final_pass = (splitk == 1);
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = m0 + wm * SM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (m >= M) continue;
+            const int n = (int)(m / (d.PH * d.PW));
+            const int rem = (int)(m - (long)n * d.PH * d.PW);
+            const int py = rem / d.PW, px = rem - py * d.PW;
+            const long opix = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
+#pragma unroll
+            for (int j = 0; j < SN; ++j) {
+                const int col = n0 + wn * SN * 32 + j * 32 + l31;
+                if (col >= d.Nstore) continue;
+                float v = acc[i][j][r];
+                float* o = outp + opix * d.ldc + col;
+                if (final_pass) {
+                    if (d.bias != nullptr && col < d.Nn) v += d.bias[col];
+                    if (d.epi == 1) v = tanhf(v);
+                    if (d.accumulate) v += *o;
+                }
+                *o = v;
+            }
+        }
+    }
+}
+
+// sum split-K slabs; applies the epilogue that the partial passes skipped
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splitk,
+                                   float* __restrict__ out, long count, int ldc, int Nn, int Nstore,
+                                   const float* bias, int epi, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int col = (int)(i % ldc);
+    if (col >= Nstore) return;   // columns the partial passes never wrote
+    float v = 0.f;
+    for (int s = 0; s < splitk; ++s) v += slabs[(long)s * slab_stride + i];
+    if (bias != nullptr && col < Nn) v += bias[col];
+    if (epi == 1) v = tanhf(v);
+    if (accumulate) v += out[i];
+    out[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter-gradient form
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int SM, int SN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d, float* __restrict__ slab_base,
+                                                          long slab_stride, int splitk) {
+    constexpr int BM = WM * SM * 32;
+    constexpr int BN = WN * SN * 32;
+    constexpr int A_LD = BM;
+    constexpr int B_LD = BN;
+    constexpr int A_SZ = BK * BM;
+    constexpr int B_SZ = BK * BN;
+    constexpr int A_SLOTS = BM / 32;
+    constexpr int B_SLOTS = BN / 32;
+    constexpr int A_RP = 1024 / BM;   // pixel rows per pass
+    constexpr int B_RP = 1024 / BN;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * A_SZ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int Cg = d.g.C0 + d.g.C1;
+    const int Cd = d.d.C0 + d.d.C1;
+    const int Mtot = d.TH * d.TW * Cg;
+    const long P = (long)d.NB * d.PH * d.PW;
+    const int ks = blockIdx.z;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // fixed per-thread columns
+    const int a_col = m0 + (tid % (BM / 4)) * 4;
+    const bool a_cv = a_col < Mtot;
+    const int a_tap = a_cv ? a_col / Cg : 0;
+    const int a_c = a_cv ? a_col - a_tap * Cg : 0;
+    const int a_ty = a_tap / d.TW, a_tx = a_tap - a_ty * d.TW;
+    float4 aa, ab;
+    gview_affine4(d.g, a_c, aa, ab);
+    const int b_col = n0 + (tid % (BN / 4)) * 4;
+    const bool b_cv = b_col < Cd;
+    const int b_c = b_cv ? b_col : 0;
+    float4 ba, bb;
+    gview_affine4(d.d, b_c, ba, bb);
+
+    const long nkt = (P + BK - 1) / BK;
+    const long per = (nkt + splitk - 1) / splitk;
+    const long kt_begin = ks * per;
+    const long kt_end = min(nkt, kt_begin + per);
+
+    f32x16 acc[SM][SN];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[A_SLOTS], rb[B_SLOTS];
+    bool rav[A_SLOTS], rbv[B_SLOTS];
+
+    auto load_tile = [&](long kt) {
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) {
+            const long p = kt * BK + tid / (BM / 4) + A_RP * s;
+            bool v = a_cv && p < P;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v) {
+                const int n = (int)(p / (d.PH * d.PW));
+                const int rem = (int)(p - (long)n * d.PH * d.PW);
+                const int py = rem / d.PW, px = rem - py * d.PW;
+                const int iy = py * d.in_stride + d.ioff_y + a_ty;
+                const int ix = px * d.in_stride + d.ioff_x + a_tx;
+                v = iy >= 0 && iy < d.g.H && ix >= 0 && ix < d.g.W;
+                if (v) val = gview_load4(d.g, ((long)n * d.g.H + iy) * d.g.W + ix, a_c);
+            }
+            rav[s] = v;
+            ra[s] = val;
+        }
+#pragma unroll
+        for (int s = 0; s < B_SLOTS; ++s) {
+            const long p = kt * BK + tid / (BN / 4) + B_RP * s;
+            const bool v = b_cv && p < P;   // D lattice == its own pixel grid (d.d.H==PH, d.d.W==PW)
+            rbv[s] = v;
+            rb[s] = v ? gview_load4(d.d, p, b_c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* Ab = As + buf * A_SZ;
+        float* Bb = Bs + buf * B_SZ;
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) {
+            const int row = tid / (BM / 4) + A_RP * s;
+            *reinterpret_cast<float4*>(Ab + row * A_LD + (tid % (BM / 4)) * 4) = xform4(ra[s], aa, ab, d.g.act, rav[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < B_SLOTS; ++s) {
+            const int row = tid / (BN / 4) + B_RP * s;
+            *reinterpret_cast<float4*>(Bb + row * B_LD + (tid % (BN / 4)) * 4) = xform4(rb[s], ba, bb, d.d.act, rbv[s]);
+        }
+    };
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int cur = 0;
+    for (long kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = (kt + 1) < kt_end;
+        if (more) load_tile(kt + 1);
+        const float* Ab = As + cur * A_SZ + lhi * A_LD + wm * SM * 32 + l31;
+        const float* Bb = Bs + cur * B_SZ + lhi * B_LD + wn * SN * 32 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float av[SM], bv[SN];
+#pragma unroll
+            for (int i = 0; i < SM; ++i) av[i] = Ab[kk * 2 * A_LD + i * 32];
+#pragma unroll
+            for (int j = 0; j < SN; ++j) bv[j] = Bb[kk * 2 * B_LD + j * 32];
+#pragma unroll
+            for (int i = 0; i < SM; ++i)
+#pragma unroll
+                for (int j = 0; j < SN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* outp = (splitk > 1) ? (slab_base + (long)ks * slab_stride) : d.out;
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * SM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (m >= Mtot) continue;
+            const int tap = m / Cg;
+            const int c = m - tap * Cg;
+            if (c >= d.Cg_real) continue;
+            const long orow = (long)tap * d.Cg_real + c;
+#pragma unroll
+            for (int j = 0; j < SN; ++j) {
+                const int col = n0 + wn * SN * 32 + j * 32 + l31;
+                if (col >= d.Nn) continue;
+                float v = acc[i][j][r];
+                float* o = outp + orow * d.ldc + col;
+                if (splitk == 1 && d.accumulate) v += *o;
+                *o = v;
+            }
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splitk,
+                                    float* __restrict__ out, long count, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float v = 0.f;
+    for (int s = 0; s < splitk; ++s) v += slabs[(long)s * slab_stride + i];
+    if (accumulate) v += out[i];
+    out[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers (C ABI)
+// ---------------------------------------------------------------------------------------------
+static int g_num_cu = 0;
+static int num_cu() {
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_num_cu;
+}
+
+template <int WM, int WN, int SM, int SN, int BMODE>
+static int launch_fwd(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hipStream_t st) {
+    constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
+    constexpr int A_SZ = BM * (BK + 1);
+    constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * (BK + 1);
+    constexpr size_t lds = 2 * (A_SZ + B_SZ) * sizeof(float);
+    const long M = (long)d.NB * d.PH * d.PW;
+    const int C = d.x.C0 + d.x.C1;
+    const int Ktot = d.TH * d.TW * C;
+    const int nkt = (Ktot + BK - 1) / BK;
+    const long mt = (M + BM - 1) / BM;
+    const int nt = (d.Nstore + BN - 1) / BN;
+    const long blocks = mt * nt * d.nphase;
+    // split-K when the grid cannot fill the chip (2 workgroups per CU resident)
+    int splitk = 1;
+    const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
+    const int target = 2 * num_cu();
+    if (ws != nullptr && blocks < target && nkt >= 8) {
+        splitk = (int)((target + blocks - 1) / blocks);
+        if (splitk > nkt / 4) splitk = nkt / 4;
+        if (splitk > 32) splitk = 32;
+        while (splitk > 1 && (int64_t)splitk * out_count * (int64_t)sizeof(float) > ws_bytes) --splitk;
+        if (splitk < 1) splitk = 1;
+        // avoid empty trailing splits
+        const int per = (nkt + splitk - 1) / splitk;
+        splitk = (nkt + per - 1) / per;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<WM, WN, SM, SN, BMODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
+    hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, SM, SN, BMODE>), grid, dim3(256), lds, st, d, ws, out_count, splitk);
+    if (splitk > 1) {
+        const int thr = 256;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
+                           out_count, splitk, d.out, out_count, d.ldc, d.Nn, d.Nstore, d.bias, d.epi, d.accumulate);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, void* stream) {
+    const ssc_conv_desc& d = *dp;
+    hipStream_t st = (hipStream_t)stream;
+    if ((d.x.C0 & 3) || (d.x.C1 & 3) || d.Nstore < d.Nn || d.Nstore > d.ldc) return -1;
+    if (d.nphase != 1 && d.nphase != 4) return -2;
+    if (d.nphase == 4 && (d.TH != 2 || d.TW != 2 || d.KH != 4 || d.KW != 4 || d.kstep != -2 || d.out_stride != 2 ||
+                          d.in_stride != 1))
+        return -3;
+    // split-K partial slabs cover the whole output; with 4 phases every phase writes a disjoint
+    // quarter of each slab, so unwritten entries must not exist: require all phases present (true).
+    const long M = (long)d.NB * d.PH * d.PW;
+    const bool smallM = M <= 2304;   // few row tiles: use the 64-row tile for more workgroups
+    if (d.bmode == 0) {
+        if (d.Nstore > 64) return smallM ? launch_fwd<2, 2, 1, 2, 0>(d, ws, ws_bytes, st)
+                                         : launch_fwd<2, 2, 2, 2, 0>(d, ws, ws_bytes, st);
+        if (d.Nstore > 32) return launch_fwd<2, 2, 2, 1, 0>(d, ws, ws_bytes, st);
+        return launch_fwd<4, 1, 1, 1, 0>(d, ws, ws_bytes, st);
+    } else {
+        if (d.Nstore > 64) return smallM ? launch_fwd<2, 2, 1, 2, 1>(d, ws, ws_bytes, st)
+                                         : launch_fwd<2, 2, 2, 2, 1>(d, ws, ws_bytes, st);
+        if (d.Nstore > 32) return launch_fwd<2, 2, 2, 1, 1>(d, ws, ws_bytes, st);
+        return launch_fwd<4, 1, 1, 1, 1>(d, ws, ws_bytes, st);
+    }
+}
+
+template <int WM, int WN, int SM, int SN>
+static int launch_wgrad(const ssc_wgrad_desc& d, float* ws, int64_t ws_bytes, hipStream_t st) {
+    constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
+    constexpr size_t lds = 2 * (BK * BM + BK * BN) * sizeof(float);
+    const int Cg = d.g.C0 + d.g.C1;
+    const int Mtot = d.TH * d.TW * Cg;
+    const long P = (long)d.NB * d.PH * d.PW;
+    const long nkt = (P + BK - 1) / BK;
+    const int mt = (Mtot + BM - 1) / BM;
+    const int nt = (d.Nn + BN - 1) / BN;
+    const long blocks = (long)mt * nt;
+    const long out_count = (long)d.TH * d.TW * d.Cg_real * d.ldc;
+    int splitk = 1;
+    const int target = 3 * num_cu();
+    if (ws != nullptr && blocks < target && nkt >= 8) {
+        long s = (target + blocks - 1) / blocks;
+        if (s > nkt / 4) s = nkt / 4;
+        if (s > 256) s = 256;
+        while (s > 1 && s * out_count * (long)sizeof(float) > ws_bytes) --s;
+        if (s < 1) s = 1;
+        const long per = (nkt + s - 1) / s;
+        splitk = (int)((nkt + per - 1) / per);
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<WM, WN, SM, SN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)splitk);
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, SM, SN>), grid, dim3(256), lds, st, d, ws, out_count, splitk);
+    if (splitk > 1) {
+        const int thr = 256;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
+                           out_count, splitk, d.out, out_count, d.accumulate);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int ssc_conv_wgrad(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream) {
+    const ssc_wgrad_desc& d = *dp;
+    hipStream_t st = (hipStream_t)stream;
+    if ((d.g.C0 & 3) || (d.g.C1 & 3) || (d.d.C0 & 3) || (d.d.C1 & 3)) return -1;
+    if (d.d.H != d.PH || d.d.W != d.PW) return -2;
+    // the filter-gradient slab is dense [TH*TW*Cg_real][ldc]; rows/cols skipped by the kernel
+    // (padding channels) do not exist in it, so every slab entry is written when ldc == Nn.
+    if (d.ldc != d.Nn) return -3;
+    const int Cg = d.g.C0 + d.g.C1;
+    const int Mtot = d.TH * d.TW * Cg;
+    if (d.Nn > 64) {
+        if (Mtot > 64) return launch_wgrad<2, 2, 2, 2>(d, ws, ws_bytes, st);
+        return launch_wgrad<1, 4, 2, 1>(d, ws, ws_bytes, st);
+    }
+    if (d.Nn > 32) {
+        if (Mtot > 64) return launch_wgrad<2, 2, 2, 1>(d, ws, ws_bytes, st);
+        return launch_wgrad<2, 2, 1, 1>(d, ws, ws_bytes, st);
+    }
+    return launch_wgrad<4, 1, 1, 1>(d, ws, ws_bytes, st);
+}

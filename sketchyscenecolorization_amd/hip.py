@@ -1,0 +1,342 @@
+"""ctypes binding of libsketchycolor_hip.so (C ABI in include/sketchycolor_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call
+fails, this module raises.  PyTorch is used only to own device memory and the
+stream; kernels receive raw device pointers.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsketchycolor_hip.so')
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+ACT_MIU = 3     # only for the pointwise kernels, never on load
+
+
+class GView(C.Structure):
+    _fields_ = [('s0', C.c_void_p), ('s1', C.c_void_p), ('ab', C.c_void_p),
+                ('C0', C.c_int32), ('C1', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('act', C.c_int32), ('_pad', C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x', GView), ('w', C.c_void_p), ('bias', C.c_void_p), ('out', C.c_void_p),
+                ('NB', C.c_int32), ('PH', C.c_int32), ('PW', C.c_int32),
+                ('TH', C.c_int32), ('TW', C.c_int32), ('in_stride', C.c_int32),
+                ('ioff_y', C.c_int32), ('ioff_x', C.c_int32), ('nphase', C.c_int32),
+                ('ky0', C.c_int32), ('kx0', C.c_int32), ('kstep', C.c_int32),
+                ('KH', C.c_int32), ('KW', C.c_int32), ('wC0', C.c_int32), ('wC1', C.c_int32),
+                ('bmode', C.c_int32), ('k_real', C.c_int32), ('n_off', C.c_int32), ('Nn', C.c_int32),
+                ('Nstore', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32), ('ldc', C.c_int32),
+                ('out_stride', C.c_int32), ('ooff_y', C.c_int32), ('ooff_x', C.c_int32),
+                ('epi', C.c_int32), ('accumulate', C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('g', GView), ('d', GView), ('out', C.c_void_p),
+                ('NB', C.c_int32), ('PH', C.c_int32), ('PW', C.c_int32),
+                ('TH', C.c_int32), ('TW', C.c_int32), ('in_stride', C.c_int32),
+                ('ioff_y', C.c_int32), ('ioff_x', C.c_int32),
+                ('Cg_real', C.c_int32), ('Nn', C.c_int32), ('ldc', C.c_int32), ('accumulate', C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raise loudly when it is not there (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libsketchycolor_hip.so is missing (%s): run `python -c "import __graft_entry__ as g; '
+                               'g.build()"` or `python -m sketchyscenecolorization_amd.build`' % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argtypes (restype is always int); mirrors include/sketchycolor_hip.h
+SIGNATURES = {
+    'ssc_version': [],
+    'ssc_device_info': [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, _I],
+    'ssc_conv_forward': [C.POINTER(ConvDesc), _P, _L, _P],
+    'ssc_conv_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
+    'ssc_nchw_to_nhwc': [_P, _P, _I, _I, _I, _I, _I, _P],
+    'ssc_nhwc_to_nchw': [_P, _P, _I, _I, _I, _I, _I, _P],
+    'ssc_fill': [_P, _F, _L, _P],
+    'ssc_bn_stats': [_P, _L, _I, _I, _P, _P, _F, _P, _P, _P, _L, _P],
+    'ssc_bn_act_backward': [_P, _L, _I, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _L, _P],
+}
+
+
+def _declare(l):
+    for name, args in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed with code %d' % (what, rc))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32), (t.device, t.dtype)
+    return C.c_void_p(t.data_ptr())
+
+
+# ---------------------------------------------------------------------------
+# workspace (split-K slabs, reduction partials) -- one per device, grown on demand
+# ---------------------------------------------------------------------------
+_ws = {}
+
+
+def workspace(nbytes=256 << 20):
+    dev = torch.cuda.current_device()
+    w = _ws.get(dev)
+    if w is None or w.numel() * 4 < nbytes:
+        w = torch.empty(nbytes // 4, dtype=torch.float32, device='cuda')
+        _ws[dev] = w
+    return w
+
+
+class View(object):
+    """Host-side mirror of ssc_gview: NHWC tensor(s) + folded norm + activation."""
+
+    def __init__(self, s0, s1=None, ab=None, act=ACT_NONE):
+        assert s0.dim() == 4 and s0.is_contiguous()
+        self.s0, self.s1, self.ab, self.act = s0, s1, ab, act
+        self.N, self.H, self.W, self.C0 = s0.shape
+        self.C1 = 0
+        if s1 is not None:
+            assert s1.is_contiguous() and s1.shape[:3] == s0.shape[:3]
+            self.C1 = s1.shape[3]
+        self.C = self.C0 + self.C1
+        if ab is not None:
+            assert ab.numel() == 2 * self.C and ab.is_contiguous()
+
+    def c(self):
+        g = GView()
+        g.s0 = self.s0.data_ptr()
+        g.s1 = self.s1.data_ptr() if self.s1 is not None else None
+        g.ab = self.ab.data_ptr() if self.ab is not None else None
+        g.C0, g.C1, g.H, g.W, g.act = self.C0, self.C1, self.H, self.W, self.act
+        return g
+
+
+def _run_conv(d):
+    ws = workspace()
+    check(lib().ssc_conv_forward(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_forward')
+
+
+def _run_wgrad(d):
+    ws = workspace()
+    check(lib().ssc_conv_wgrad(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_wgrad')
+
+
+def _out_geom(out, coff):
+    assert out.dim() == 4 and out.is_contiguous()
+    return out.data_ptr() + 4 * coff, out.shape[1], out.shape[2], out.shape[3]
+
+
+def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, accumulate=False):
+    """tf.pad + tf.nn.conv2d(VALID): x View, w [KH,KW,Cin_real,Cout] -> out[..., coff:coff+Cout]."""
+    KH, KW, ci, co = w.shape
+    d = ConvDesc()
+    d.x = x.c()
+    d.w, d.bias = w.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.out, OH, OW, ldc = _out_geom(out, coff)
+    d.NB, d.PH, d.PW = x.N, (x.H + 2 * pad - KH) // stride + 1, (x.W + 2 * pad - KW) // stride + 1
+    assert (OH, OW) == (d.PH, d.PW), ((OH, OW), (d.PH, d.PW))
+    d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x, d.nphase = KH, KW, stride, -pad, -pad, 1
+    d.ky0, d.kx0, d.kstep = 0, 0, 1
+    d.KH, d.KW, d.wC0, d.wC1, d.bmode, d.k_real = KH, KW, ci, co, 0, ci
+    assert ci <= x.C
+    d.n_off, d.Nn, d.Nstore = 0, co, (nstore if nstore is not None else co)
+    d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 1, 0, 0
+    d.epi, d.accumulate = epi, int(accumulate)
+    _run_conv(d)
+
+
+def deconv_forward(x, f, out, coff=0, nstore=None, epi=0):
+    """tf.nn.conv2d_transpose(k=4, s=2, SAME): x View [N,H,W,Cin], f [4,4,Cout,Cin] -> out [N,2H,2W,*]."""
+    KH, KW, co, ci = f.shape
+    assert KH == 4 and KW == 4 and ci == x.C
+    d = ConvDesc()
+    d.x = x.c()
+    d.w, d.bias = f.data_ptr(), None
+    d.out, OH, OW, ldc = _out_geom(out, coff)
+    assert (OH, OW) == (2 * x.H, 2 * x.W)
+    d.NB, d.PH, d.PW = x.N, x.H, x.W
+    d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x, d.nphase = 2, 2, 1, 0, 0, 4
+    d.ky0, d.kx0, d.kstep = 0, 0, -2
+    d.KH, d.KW, d.wC0, d.wC1, d.bmode, d.k_real = 4, 4, co, ci, 1, ci
+    d.n_off, d.Nn, d.Nstore = 0, co, (nstore if nstore is not None else co)
+    d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 2, 0, 0
+    d.epi, d.accumulate = epi, 0
+    _run_conv(d)
+
+
+def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=None):
+    """Gradient of conv (k=4, pad 1) w.r.t. its input channels [n_off, n_off+nn): dy View -> out [N,Hin,Win,*]."""
+    KH, KW, ci, co = w.shape
+    assert KH == 4 and KW == 4 and pad == 1
+    nn = ci - n_off if nn is None else nn
+    d = ConvDesc()
+    d.x = dy.c()
+    d.w, d.bias = w.data_ptr(), None
+    d.out, OH, OW, ldc = _out_geom(out, 0)
+    d.NB = dy.N
+    if stride == 2:
+        assert (OH, OW) == (2 * dy.H, 2 * dy.W)
+        d.PH, d.PW, d.TH, d.TW, d.in_stride, d.nphase, d.kstep, d.out_stride = dy.H, dy.W, 2, 2, 1, 4, -2, 2
+        d.ky0 = d.kx0 = 0
+        d.ioff_y = d.ioff_x = 0
+    else:
+        assert stride == 1 and (OH, OW) == (dy.H + 1, dy.W + 1)
+        d.PH, d.PW, d.TH, d.TW, d.in_stride, d.nphase, d.kstep, d.out_stride = OH, OW, 4, 4, 1, 1, -1, 1
+        d.ky0 = d.kx0 = 3
+        d.ioff_y = d.ioff_x = -2
+    d.KH, d.KW, d.wC0, d.wC1, d.bmode = 4, 4, ci, co, 1
+    d.k_real = co if k_real is None else k_real
+    d.n_off, d.Nn, d.Nstore = n_off, nn, (nstore if nstore is not None else nn)
+    d.OH, d.OW, d.ldc, d.ooff_y, d.ooff_x = OH, OW, ldc, 0, 0
+    d.epi, d.accumulate = 0, 0
+    _run_conv(d)
+
+
+def deconv_dgrad(dy, f, out, n_off=0, nn=None):
+    """Gradient of the k=4 s=2 transposed conv w.r.t. its input channels: a stride-2 conv of dy with f as HWIO."""
+    KH, KW, co, ci = f.shape
+    nn = ci - n_off if nn is None else nn
+    d = ConvDesc()
+    d.x = dy.c()
+    d.w, d.bias = f.data_ptr(), None
+    d.out, OH, OW, ldc = _out_geom(out, 0)
+    d.NB, d.PH, d.PW = dy.N, dy.H // 2, dy.W // 2
+    assert (OH, OW) == (d.PH, d.PW) and co <= dy.C
+    d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x, d.nphase = 4, 4, 2, -1, -1, 1
+    d.ky0, d.kx0, d.kstep = 0, 0, 1
+    d.KH, d.KW, d.wC0, d.wC1, d.bmode, d.k_real = 4, 4, co, ci, 0, co
+    d.n_off, d.Nn, d.Nstore = n_off, nn, nn
+    d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 1, 0, 0
+    d.epi, d.accumulate = 0, 0
+    _run_conv(d)
+
+
+def conv_wgrad(x, dy, w_grad, stride, pad, accumulate=False):
+    """dW[kh,kw,ci,co] = sum_pix x[pix@tap][ci] * dy[pix][co]  (w_grad in the conv's TF layout)."""
+    KH, KW, ci, co = w_grad.shape
+    d = WgradDesc()
+    d.g, d.d = x.c(), dy.c()
+    d.out = w_grad.data_ptr()
+    d.NB, d.PH, d.PW = dy.N, dy.H, dy.W
+    d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = KH, KW, stride, -pad, -pad
+    d.Cg_real, d.Nn, d.ldc, d.accumulate = ci, co, co, int(accumulate)
+    assert ci <= x.C and co <= dy.C
+    _run_wgrad(d)
+
+
+def deconv_wgrad(x, dy, f_grad, accumulate=False):
+    """dF[kh,kw,co,ci] = sum_pix dy[pix@tap][co] * x[pix][ci]  (f_grad in the transposed-conv TF layout)."""
+    KH, KW, co, ci = f_grad.shape
+    d = WgradDesc()
+    d.g, d.d = dy.c(), x.c()
+    d.out = f_grad.data_ptr()
+    d.NB, d.PH, d.PW = x.N, x.H, x.W
+    d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = 4, 4, 2, -1, -1
+    d.Cg_real, d.Nn, d.ldc, d.accumulate = co, ci, ci, int(accumulate)
+    assert co <= dy.C and ci == x.C
+    _run_wgrad(d)
+
+
+def _mat_view(a, ab=None, act=ACT_NONE):
+    assert a.dim() == 2 and a.is_contiguous()
+    return View(a.view(1, 1, a.shape[0], a.shape[1]), None, ab, act)
+
+
+def matmul(a, b, out, bias=None, accumulate=False, a_ab=None, a_act=ACT_NONE):
+    """out[M,N] = a[M,K] @ b[K,N] (+bias)   -- tf.matmul."""
+    M, K = a.shape
+    K2, N = b.shape
+    assert K == K2 and out.shape == (M, N) and out.is_contiguous()
+    conv_forward(_mat_view(a, a_ab, a_act), b.view(1, 1, K, N), 1, 0, out.view(1, 1, M, N), bias=bias,
+                 accumulate=accumulate)
+
+
+def matmul_nt(a, b, out, accumulate=False):
+    """out[M,N] = a[M,K] @ b[N,K]^T."""
+    M, K = a.shape
+    N, K2 = b.shape
+    assert K == K2 and out.shape == (M, N)
+    d = ConvDesc()
+    d.x = _mat_view(a).c()
+    d.w, d.bias, d.out = b.data_ptr(), None, out.data_ptr()
+    d.NB, d.PH, d.PW, d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x, d.nphase = 1, 1, M, 1, 1, 1, 0, 0, 1
+    d.ky0, d.kx0, d.kstep, d.KH, d.KW, d.wC0, d.wC1, d.bmode, d.k_real = 0, 0, 1, 1, 1, N, K, 1, K
+    d.n_off, d.Nn, d.Nstore, d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = 0, N, N, 1, M, N, 1, 0, 0
+    d.epi, d.accumulate = 0, int(accumulate)
+    _run_conv(d)
+
+
+def matmul_tn(a, b, out, accumulate=False, a_ab=None, a_act=ACT_NONE):
+    """out[K,N] = a[M,K]^T @ b[M,N]."""
+    M, K = a.shape
+    M2, N = b.shape
+    assert M == M2 and out.shape == (K, N) and out.is_contiguous()
+    d = WgradDesc()
+    d.g, d.d = _mat_view(a, a_ab, a_act).c(), _mat_view(b).c()
+    d.out = out.data_ptr()
+    d.NB, d.PH, d.PW, d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = 1, 1, M, 1, 1, 1, 0, 0
+    d.Cg_real, d.Nn, d.ldc, d.accumulate = K, N, N, int(accumulate)
+    _run_wgrad(d)
+
+
+# ---------------------------------------------------------------------------
+# layout + norm helpers
+# ---------------------------------------------------------------------------
+def nchw_to_nhwc(src, dst, coff=0):
+    n, c, h, w = src.shape
+    assert dst.shape[:3] == (n, h, w) and src.is_contiguous() and dst.is_contiguous()
+    check(lib().ssc_nchw_to_nhwc(ptr(src), ptr(dst), n, c, h * w, dst.shape[3], coff, stream_ptr()), 'nchw_to_nhwc')
+
+
+def nhwc_to_nchw(src, dst, coff=0):
+    n, c, h, w = dst.shape
+    assert src.shape[:3] == (n, h, w) and src.is_contiguous() and dst.is_contiguous()
+    check(lib().ssc_nhwc_to_nchw(ptr(src), ptr(dst), n, c, h * w, src.shape[3], coff, stream_ptr()), 'nhwc_to_nchw')
+
+
+def fill(t, value):
+    check(lib().ssc_fill(ptr(t), float(value), t.numel(), stream_ptr()), 'fill')
+
+
+def bn_stats(x2d, scale, offset, ab, stats, eps=1e-5):
+    """x2d [M, C] rows -> ab=[a;b] (y=a*x+b), stats=[mean;rstd]."""
+    M, Cc = x2d.shape
+    ws = workspace()
+    check(lib().ssc_bn_stats(ptr(x2d), M, Cc, x2d.stride(0), ptr(scale), ptr(offset), eps, ptr(ab), ptr(stats),
+                             ptr(ws), ws.numel() * 4, stream_ptr()), 'bn_stats')
+
+
+def bn_act_backward(x2d, ab, stats, g1, act1, dx, g2=None, act2=ACT_NONE, dscale=None, doffset=None):
+    """Backward through act(a*x+b) (has_bn when ab is given) for one or two consumers."""
+    M, Cc = x2d.shape
+    ws = workspace()
+    has_bn = ab is not None
+    check(lib().ssc_bn_act_backward(ptr(x2d), M, Cc, x2d.stride(0), ptr(ab), ptr(stats), None,
+                                    ptr(g1), g1.stride(0), act1, ptr(g2), (g2.stride(0) if g2 is not None else 0),
+                                    act2, int(has_bn), ptr(dx), dx.stride(0), ptr(dscale), ptr(doffset),
+                                    ptr(ws), ws.numel() * 4, stream_ptr()), 'bn_act_backward')

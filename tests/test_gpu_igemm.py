@@ -1,0 +1,261 @@
+"""HIP implicit-GEMM kernels vs the CPU oracle (oracle/tf_ops.py) on seeded inputs.
+
+Tolerances: fp32 MFMA == fp32 fmaf chain; the oracle sums in a different order,
+so compare with 1e-4 relative to the output scale (north-star budget is 1e-3).
+"""
+import pytest
+import torch
+
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from sketchyscenecolorization_amd import hip
+    return hip
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, tol=2e-4):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max()) / scale
+    assert err < tol, err
+
+
+def act_ref(x, act):
+    if act == 1:
+        return torch.relu(x)
+    if act == 2:
+        return T.lrelu(x, 0.2)
+    return x
+
+
+def rnd(*shape, seed=0, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * std
+
+
+@pytest.mark.parametrize('n,h,ci,co,stride,act', [
+    (2, 20, 8, 64, 2, 0), (3, 16, 64, 128, 2, 2), (2, 12, 32, 160, 1, 1), (1, 24, 128, 40, 2, 2),
+])
+def test_conv_forward(n, h, ci, co, stride, act):
+    hip = _hip()
+    x = rnd(n, ci, h, h, seed=1)
+    w = rnd(4, 4, ci, co, seed=2, std=0.05)
+    ab = torch.cat([1.0 + 0.1 * rnd(ci, seed=3), 0.2 * rnd(ci, seed=4)])
+    ref = T.conv2d_valid_pad(act_ref(x * ab[:ci].view(1, -1, 1, 1) + ab[ci:].view(1, -1, 1, 1), act), w, stride, 1)
+    oh = ref.shape[2]
+    out = torch.full((n, oh, oh, co), float('nan'), device='cuda')
+    hip.conv_forward(hip.View(nhwc(x).cuda(), None, ab.cuda(), act), w.cuda(), stride, 1, out)
+    close(nchw(out), ref)
+
+
+def test_conv_forward_padded_channels_and_cout1():
+    hip = _hip()
+    n, h = 2, 24
+    x3 = rnd(n, 3, h, h, seed=5)
+    x4 = torch.zeros(n, h, h, 4)
+    x4[..., :3] = nhwc(x3)
+    w = rnd(4, 4, 3, 64, seed=6, std=0.05)
+    ref = T.conv2d_valid_pad(x3, w, 2, 1)
+    out = torch.full((n, 12, 12, 64), float('nan'), device='cuda')
+    hip.conv_forward(hip.View(x4.cuda()), w.cuda(), 2, 1, out)
+    close(nchw(out), ref)
+    # Cout = 1, stride 1, stored into a 4-channel padded tensor
+    x = rnd(n, 64, 13, 13, seed=7)
+    w1 = rnd(4, 4, 64, 1, seed=8, std=0.05)
+    ref1 = T.conv2d_valid_pad(x, w1, 1, 1)
+    out1 = torch.full((n, 12, 12, 4), float('nan'), device='cuda')
+    hip.conv_forward(hip.View(nhwc(x).cuda()), w1.cuda(), 1, 1, out1, nstore=4)
+    close(out1[..., 0], ref1[:, 0])
+    assert float(out1[..., 1:].abs().max()) == 0.0
+
+
+def test_conv_forward_splitk_small_m():
+    hip = _hip()
+    n, h, ci, co = 2, 12, 512, 512
+    x = rnd(n, ci, h, h, seed=9)
+    w = rnd(4, 4, ci, co, seed=10, std=0.02)
+    ref = T.conv2d_valid_pad(T.lrelu(x, 0.2), w, 2, 1)
+    out = torch.full((n, 6, 6, co), float('nan'), device='cuda')
+    hip.conv_forward(hip.View(nhwc(x).cuda(), None, None, 2), w.cuda(), 2, 1, out)
+    close(nchw(out), ref)
+
+
+@pytest.mark.parametrize('n,h,c0,c1,co', [(2, 6, 512, 64, 512), (2, 12, 64, 64, 3), (1, 10, 128, 0, 64)])
+def test_deconv_forward(n, h, c0, c1, co):
+    hip = _hip()
+    xa = rnd(n, c0, h, h, seed=11)
+    xb = rnd(n, c1, h, h, seed=12) if c1 else None
+    x = torch.cat([xa, xb], 1) if c1 else xa
+    ci = c0 + c1
+    f = rnd(4, 4, co, ci, seed=13, std=0.05)
+    ab = torch.cat([1.0 + 0.1 * rnd(ci, seed=14), 0.2 * rnd(ci, seed=15)])
+    ref = T.conv2d_transpose_same_s2(torch.relu(x * ab[:ci].view(1, -1, 1, 1) + ab[ci:].view(1, -1, 1, 1)), f)
+    ldc = 8 if co == 3 else co
+    coff = 3 if co == 3 else 0
+    out = torch.zeros((n, 2 * h, 2 * h, ldc), device='cuda')
+    v = hip.View(nhwc(xa).cuda(), nhwc(xb).cuda() if c1 else None, ab.cuda(), 1)
+    hip.deconv_forward(v, f.cuda(), out, coff=coff, epi=(1 if co == 3 else 0))
+    got = nchw(out[..., coff:coff + co])
+    close(got, torch.tanh(ref) if co == 3 else ref)
+    if co == 3:
+        assert float(out[..., :3].abs().max()) == 0.0 and float(out[..., 6:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('stride,h', [(2, 16), (1, 13)])
+def test_conv_dgrad_and_wgrad(stride, h):
+    hip = _hip()
+    n, ci, co = 2, 64, 96
+    x = rnd(n, ci, h, h, seed=21).requires_grad_(True)
+    w = rnd(4, 4, ci, co, seed=22, std=0.05).requires_grad_(True)
+    ab = torch.cat([1.0 + 0.1 * rnd(ci, seed=23), 0.2 * rnd(ci, seed=24)])
+    xa = T.lrelu(x * ab[:ci].view(1, -1, 1, 1) + ab[ci:].view(1, -1, 1, 1), 0.2)
+    xa.retain_grad()
+    y = T.conv2d_valid_pad(xa, w, stride, 1)
+    dy = rnd(*y.shape, seed=25)
+    y.backward(dy)
+    dx = torch.full((n, h, h, ci), float('nan'), device='cuda')
+    hip.conv_dgrad(hip.View(nhwc(dy).cuda()), w.detach().cuda(), stride, 1, dx)
+    close(nchw(dx), xa.grad)
+    # split: channels [32, 64) only
+    dxs = torch.full((n, h, h, 32), float('nan'), device='cuda')
+    hip.conv_dgrad(hip.View(nhwc(dy).cuda()), w.detach().cuda(), stride, 1, dxs, n_off=32, nn=32)
+    close(nchw(dxs), xa.grad[:, 32:])
+    dw = torch.full((4, 4, ci, co), float('nan'), device='cuda')
+    hip.conv_wgrad(hip.View(nhwc(x.detach()).cuda(), None, ab.cuda(), 2), hip.View(nhwc(dy).cuda()), dw, stride, 1)
+    close(dw, w.grad)
+
+
+def test_conv_wgrad_padded_small():
+    hip = _hip()
+    n, h = 2, 32
+    x3 = rnd(n, 3, h, h, seed=31)
+    w = rnd(4, 4, 3, 64, seed=32, std=0.05).requires_grad_(True)
+    y = T.conv2d_valid_pad(x3, w, 2, 1)
+    dy = rnd(*y.shape, seed=33)
+    y.backward(dy)
+    x4 = torch.zeros(n, h, h, 4)
+    x4[..., :3] = nhwc(x3)
+    dw = torch.full((4, 4, 3, 64), float('nan'), device='cuda')
+    hip.conv_wgrad(hip.View(x4.cuda()), hip.View(nhwc(dy).cuda()), dw, 2, 1)
+    close(dw, w.grad)
+    # Cout = 1 (dy padded to 4 channels)
+    x = rnd(n, 64, 13, 13, seed=34)
+    w1 = rnd(4, 4, 64, 1, seed=35, std=0.05).requires_grad_(True)
+    y1 = T.conv2d_valid_pad(x, w1, 1, 1)
+    dy1 = rnd(*y1.shape, seed=36)
+    y1.backward(dy1)
+    dy4 = torch.zeros(n, 12, 12, 4)
+    dy4[..., :1] = nhwc(dy1)
+    dw1 = torch.full((4, 4, 64, 1), float('nan'), device='cuda')
+    hip.conv_wgrad(hip.View(nhwc(x).cuda()), hip.View(dy4.cuda()), dw1, 1, 1)
+    close(dw1, w1.grad)
+    # dgrad of the Cout=1 conv
+    xg = x.clone().requires_grad_(True)
+    T.conv2d_valid_pad(xg, w1.detach(), 1, 1).backward(dy1)
+    dx = torch.full((n, 13, 13, 64), float('nan'), device='cuda')
+    hip.conv_dgrad(hip.View(dy4.cuda()), w1.detach().cuda(), 1, 1, dx, k_real=1)
+    close(nchw(dx), xg.grad)
+
+
+def test_deconv_dgrad_and_wgrad():
+    hip = _hip()
+    n, h, c0, c1, co = 2, 8, 64, 32, 48
+    ci = c0 + c1
+    x = rnd(n, ci, h, h, seed=41).requires_grad_(True)
+    f = rnd(4, 4, co, ci, seed=42, std=0.05).requires_grad_(True)
+    ab = torch.cat([1.0 + 0.1 * rnd(ci, seed=43), 0.2 * rnd(ci, seed=44)])
+    xa = torch.relu(x * ab[:ci].view(1, -1, 1, 1) + ab[ci:].view(1, -1, 1, 1))
+    xa.retain_grad()
+    y = T.conv2d_transpose_same_s2(xa, f)
+    dy = rnd(*y.shape, seed=45)
+    y.backward(dy)
+    dyv = hip.View(nhwc(dy).cuda())
+    d0 = torch.full((n, h, h, c0), float('nan'), device='cuda')
+    d1 = torch.full((n, h, h, c1), float('nan'), device='cuda')
+    hip.deconv_dgrad(dyv, f.detach().cuda(), d0, n_off=0, nn=c0)
+    hip.deconv_dgrad(dyv, f.detach().cuda(), d1, n_off=c0, nn=c1)
+    close(nchw(d0), xa.grad[:, :c0])
+    close(nchw(d1), xa.grad[:, c0:])
+    xd = x.detach()
+    v = hip.View(nhwc(xd[:, :c0]).cuda(), nhwc(xd[:, c0:]).cuda(), ab.cuda(), 1)
+    df = torch.full((4, 4, co, ci), float('nan'), device='cuda')
+    hip.deconv_wgrad(v, dyv, df)
+    close(df, f.grad)
+
+
+def test_matmuls():
+    hip = _hip()
+    a = rnd(300, 512, seed=51)
+    b = rnd(512, 260, seed=52)
+    bias = rnd(260, seed=53)
+    out = torch.full((300, 260), float('nan'), device='cuda')
+    hip.matmul(a.cuda(), b.cuda(), out, bias=bias.cuda())
+    close(out, a @ b + bias, tol=1e-4)
+    bt = rnd(260, 512, seed=54)
+    out2 = torch.full((300, 260), float('nan'), device='cuda')
+    hip.matmul_nt(a.cuda(), bt.cuda(), out2)
+    close(out2, a @ bt.t(), tol=1e-4)
+    c = rnd(300, 132, seed=55)
+    out3 = torch.full((512, 132), float('nan'), device='cuda')
+    hip.matmul_tn(a.cuda(), c.cuda(), out3)
+    close(out3, a.t() @ c, tol=1e-4)
+    # accumulate
+    hip.matmul_tn(a.cuda(), c.cuda(), out3, accumulate=True)
+    close(out3, 2 * (a.t() @ c), tol=1e-4)
+
+
+@pytest.mark.parametrize('m,c', [(5000, 64), (333, 512), (70000, 128)])
+def test_bn_stats_and_backward(m, c):
+    hip = _hip()
+    x = (rnd(m, c, seed=61) * 2.0 + 0.5).requires_grad_(True)
+    scale = (1.0 + 0.1 * rnd(c, seed=62)).requires_grad_(True)
+    offset = (0.1 * rnd(c, seed=63)).requires_grad_(True)
+    x4 = x.t().reshape(1, c, m, 1)
+    y = T.batchnorm(x4, scale, offset)
+    z1 = T.lrelu(y, 0.2)
+    z2 = torch.relu(y)
+    g1 = rnd(m, c, seed=64)
+    g2 = rnd(m, c, seed=65)
+    loss = (z1.reshape(c, m).t() * g1).sum() + (z2.reshape(c, m).t() * g2).sum()
+    loss.backward()
+    ab = torch.empty(2 * c, device='cuda')
+    st = torch.empty(2 * c, device='cuda')
+    xd = x.detach().cuda()
+    hip.bn_stats(xd, scale.detach().cuda(), offset.detach().cuda(), ab, st)
+    yk = xd * ab[:c] + ab[c:]
+    close(yk, y.reshape(c, m).t())
+    dx = torch.full((m, c), float('nan'), device='cuda')
+    ds = torch.empty(c, device='cuda')
+    do = torch.empty(c, device='cuda')
+    hip.bn_act_backward(xd, ab, st, g1.cuda(), 2, dx, g2=g2.cuda(), act2=1, dscale=ds, doffset=do)
+    close(dx, x.grad, tol=5e-4)
+    close(ds, scale.grad, tol=5e-4)
+    close(do, offset.grad, tol=5e-4)
+    # no-norm form: dx = g1*lrelu'(x) + g2*relu'(x)
+    dx2 = torch.full((m, c), float('nan'), device='cuda')
+    hip.bn_act_backward(xd, None, None, g1.cuda(), 2, dx2, g2=g2.cuda(), act2=1)
+    xr = x.detach()
+    ref = g1 * torch.where(xr > 0, torch.ones_like(xr), torch.full_like(xr, 0.2)) + g2 * (xr > 0).float()
+    close(dx2, ref)
+
+
+def test_layout_roundtrip():
+    hip = _hip()
+    x = rnd(3, 3, 10, 12, seed=71)
+    d = torch.zeros(3, 10, 12, 8, device='cuda')
+    hip.nchw_to_nhwc(x.cuda(), d, coff=3)
+    close(d[..., 3:6], nhwc(x))
+    back = torch.empty(3, 3, 10, 12, device='cuda')
+    hip.nhwc_to_nchw(d, back, coff=3)
+    close(back, x)
