@@ -38,7 +38,8 @@ extern "C" {
 typedef struct ssc_gview {
     const float* s0;   /* [N,H,W,C0] */
     const float* s1;   /* [N,H,W,C1] or NULL */
-    const float* ab;   /* [2][C0+C1]: a then b; NULL = identity */
+    const float* ab0;  /* [2][C0]: a then b for s0; NULL = identity */
+    const float* ab1;  /* [2][C1]: a then b for s1; NULL = identity */
     int32_t C0, C1;    /* both multiples of 4 */
     int32_t H, W;
     int32_t act;
@@ -125,6 +126,60 @@ int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, const float* 
                         const float* scale, const float* g1, int ldg1, int act1, const float* g2, int ldg2,
                         int act2, int has_bn, float* dx, int lddx, float* dscale, float* doffset, float* ws,
                         int64_t ws_bytes, void* stream);
+
+/* --- caption branch (text_lstm.hip): encode_feat_with_text, models_collection.py:150-248 --- */
+/* tf.nn.embedding_lookup (:182) and its (dense) gradient; tok rows are time-major [T*N] */
+int ssc_embedding_gather(const float* table, const int* tok, int rows, int C, float* out, void* stream);
+int ssc_embedding_scatter_add(float* dtable, const int* tok, int rows, int C, const float* g, void* stream);
+/* tf.nn.l2_normalize over channels (:202,216); z = a*x+b when ab != NULL; ss[row] = sum z^2 */
+int ssc_row_l2norm_fwd(const float* x, int ldx, const float* ab, int64_t M, int C, float* y, float* ss, void* stream);
+int ssc_row_l2norm_bwd(const float* y, const float* ss, const float* dy, int64_t M, int C, float* dz, int accumulate,
+                       void* stream);
+/* BasicLSTMCell gate math (state_is_tuple=False, forget_bias=1) with the tf.cond pad-token skip (:235).
+ * gates[row] = g0[row] + g1[row] + g2[row/div2]; acts = activated i,j,f,o kept for the backward pass. */
+int ssc_lstm_pointwise_fwd(const float* g0, const float* g1, const float* g2, int div2, const int* mask, int mdiv,
+                           const float* c_in, const float* h_in, int64_t rows, int C, float* c_out, float* h_out,
+                           float* acts, void* stream);
+int ssc_lstm_pointwise_bwd(const float* dh, const float* dc, const float* acts, const float* c_in, const float* c_out,
+                           const int* mask, int mdiv, int64_t rows, int C, float* dg, float* dc_in, float* dh_pass,
+                           float* gacc, void* stream);
+/* relu(0.5*(log(1+1e-3+h) - log(1+1e-3-h)))  (:238-242) */
+int ssc_squash_fwd(const float* h, int64_t n, float* o, void* stream);
+int ssc_squash_bwd(const float* h, const float* o, const float* go, int64_t n, float* dh, void* stream);
+/* out[g][c] (+)= sum of G consecutive rows (bias gradients, 6x6 tile reduction) */
+int ssc_group_rowsum(const float* x, int ldx, int64_t groups, int G, int C, float* out, int accumulate, void* stream);
+/* tf.reduce_mean over H,W of act(a*x+b) (:838) and the broadcast of its gradient */
+int ssc_act_mean_hw(const float* x, const float* ab, int act, int N, int P, int C, float* out, void* stream);
+int ssc_add_row_bcast(float* g, const float* v, float scale, int N, int P, int C, void* stream);
+/* miu_relu (:63-65) fused with the [N,C*P] -> [N,P,C] reshape of the noise head (:493-499) */
+int ssc_miu_permute_fwd(const float* pre, int N, int Cc, int P, float* out, void* stream);
+int ssc_miu_permute_bwd(const float* pre, const float* g, int N, int Cc, int P, float* dpre, void* stream);
+
+/* --- losses / optimizer (losses_optim.hip): graph_single.py:317-593 --- */
+/* loss_acc += scale*sum softplus(sign*x[r*ld]); grad[r*ld] = gscale*sign*sigmoid(sign*x)   (:401-402) */
+int ssc_softplus_loss(const float* x, int ld, int64_t rows, float sign, float scale, float* loss_acc, float* grad,
+                      float gscale, void* stream);
+/* sparse softmax CE (focal=0) or (1-p_true)^2 * CE (focal=1), mean over N, times coef   (:340-353) */
+int ssc_acgan_loss(const float* logits, const int* labels, int N, int K, int focal, float coef, float* loss_acc,
+                   float* dlogits, void* stream);
+/* smooth-L1(img - gen) mean * coef (:551-555) + incoming discriminator gradient, through tanh' */
+int ssc_gen_output_grad(const float* gen, int ldg, const float* img, int ldi, const float* gd, int ldd, int64_t npix,
+                        float coef, float* loss_acc, float* dpre, void* stream);
+/* ly.l2_regularizer: loss_acc += rate*sum(w^2)/2; grad += rate*w   (mru.py:55,60) */
+int ssc_l2_reg(const float* w, int64_t n, float rate, float* loss_acc, float* grad, void* stream);
+/* tf.train.AdamOptimizer dense apply (graph_single.py:588); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host */
+int ssc_adam_tf(float* var, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                float eps, float gscale, void* stream);
+/* spectral_normed_weight, one power iteration (sn.py:12-52) and its full gradient */
+int ssc_sn_forward(const float* W, const float* u, int m, int n, float* v, float* u_new, float* wbar, float* aux,
+                   void* stream);
+int ssc_sn_backward(const float* W, const float* u, const float* v, const float* u_new, const float* aux,
+                    const float* G, int m, int n, float* dW, int accumulate, float* scratch, void* stream);
+int ssc_axpy(float* y, const float* x, float a, int64_t n, void* stream);
+/* fully_connected with <= 64 outputs (class logits, models_collection.py:839): y = x W + b, and its gradients */
+int ssc_fc_small_fwd(const float* x, const float* W, const float* b, int N, int K, int J, float* y, void* stream);
+int ssc_fc_small_bwd(const float* x, const float* W, const float* dy, int N, int K, int J, float* dx, float* dW,
+                     float* db, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -35,10 +35,13 @@ __device__ __forceinline__ float4 gview_load4(const ssc_gview& g, long pix, int 
 }
 
 __device__ __forceinline__ void gview_affine4(const ssc_gview& g, int c, float4& a, float4& b) {
-    if (g.ab != nullptr) {
-        const int C = g.C0 + g.C1;
-        a = *reinterpret_cast<const float4*>(g.ab + c);
-        b = *reinterpret_cast<const float4*>(g.ab + C + c);
+    const bool first = c < g.C0;
+    const float* ab = first ? g.ab0 : g.ab1;
+    if (ab != nullptr) {
+        const int cc = first ? c : c - g.C0;
+        const int Cs = first ? g.C0 : g.C1;
+        a = *reinterpret_cast<const float4*>(ab + cc);
+        b = *reinterpret_cast<const float4*>(ab + Cs + cc);
     } else {
         a = make_float4(1.f, 1.f, 1.f, 1.f);
         b = make_float4(0.f, 0.f, 0.f, 0.f);

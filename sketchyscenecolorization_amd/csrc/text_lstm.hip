@@ -1,0 +1,355 @@
+// text_lstm.hip -- pointwise / reduction kernels of the caption branch
+// (encode_feat_with_text, models_collection.py:150-248) and of the small dense heads.
+//
+// The two BasicLSTMCell matmuls are decomposed on the host side
+// (gates = visual*Kv + (emb*Kw + lang*Kl) + h*Kh) and run
+// on the implicit-GEMM kernel; this file holds what surrounds them: embedding
+// lookup, l2-normalisation (wavefront reductions), the gate nonlinearities with
+// the per-sample "token == 0 -> skip the step" select (tf.cond, :235), the
+// atanh-like squash (:238-242) and their backward forms.  All HBM-bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sketchycolor_hip.h"
+
+#define CHECK_LAUNCH() ((int)hipGetLastError())
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ------------------------------------------------------------------ embedding
+__global__ void embedding_gather_kernel(const float* __restrict__ table, const int* __restrict__ tok, int rows, int C,
+                                        float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = C / 4;
+    if (i >= (long)rows * c4) return;
+    const int r = (int)(i / c4), c = (int)(i - (long)r * c4) * 4;
+    *reinterpret_cast<float4*>(out + (long)r * C + c) = *reinterpret_cast<const float4*>(table + (long)tok[r] * C + c);
+}
+
+__global__ void embedding_scatter_add_kernel(float* __restrict__ dtable, const int* __restrict__ tok, int rows, int C,
+                                             const float* __restrict__ g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * C) return;
+    const int r = (int)(i / C), c = (int)(i - (long)r * C);
+    const int t = tok[r];
+    if (t == 0) return;   // pad steps never touch the table (tf.cond skips the lookup's consumer)
+    atomicAdd(dtable + (long)t * C + c, g[i]);
+}
+
+extern "C" int ssc_embedding_gather(const float* table, const int* tok, int rows, int C, float* out, void* stream) {
+    if (C & 3) return -1;
+    const long tot = (long)rows * (C / 4);
+    hipLaunchKernelGGL(embedding_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       table, tok, rows, C, out);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int ssc_embedding_scatter_add(float* dtable, const int* tok, int rows, int C, const float* g,
+                                         void* stream) {
+    const long tot = (long)rows * C;
+    hipLaunchKernelGGL(embedding_scatter_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, dtable, tok, rows, C, g);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ row l2-normalise (tf.nn.l2_normalize)
+// one wavefront per row; z = a*x+b (folded norm) when ab != NULL
+__global__ __launch_bounds__(256) void row_l2norm_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                              const float* __restrict__ ab, long M, int C,
+                                                              float* __restrict__ y, float* __restrict__ ss) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+        if (ab != nullptr) {
+            const float4 a = *reinterpret_cast<const float4*>(ab + c), b = *reinterpret_cast<const float4*>(ab + C + c);
+            v.x = fmaf(a.x, v.x, b.x); v.y = fmaf(a.y, v.y, b.y); v.z = fmaf(a.z, v.z, b.z); v.w = fmaf(a.w, v.w, b.w);
+        }
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = wave_sum(s);
+    const float r = rsqrtf(fmaxf(s, 1e-12f));
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+        if (ab != nullptr) {
+            const float4 a = *reinterpret_cast<const float4*>(ab + c), b = *reinterpret_cast<const float4*>(ab + C + c);
+            v.x = fmaf(a.x, v.x, b.x); v.y = fmaf(a.y, v.y, b.y); v.z = fmaf(a.z, v.z, b.z); v.w = fmaf(a.w, v.w, b.w);
+        }
+        v.x *= r; v.y *= r; v.z *= r; v.w *= r;
+        *reinterpret_cast<float4*>(y + row * C + c) = v;
+    }
+    if (lane == 0) ss[row] = s;
+}
+
+// dz = r*(dy - y*(dy.y)) when the sum of squares was not clamped, else r*dy
+__global__ __launch_bounds__(256) void row_l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ ss,
+                                                              const float* __restrict__ dy, long M, int C,
+                                                              float* __restrict__ dz, int accumulate) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float dot = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(y + row * C + c);
+        const float4 g = *reinterpret_cast<const float4*>(dy + row * C + c);
+        dot += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+    }
+    dot = wave_sum(dot);
+    const float s = ss[row];
+    const float r = rsqrtf(fmaxf(s, 1e-12f));
+    if (s < 1e-12f) dot = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(y + row * C + c);
+        const float4 g = *reinterpret_cast<const float4*>(dy + row * C + c);
+        float4 o;
+        o.x = r * (g.x - a.x * dot); o.y = r * (g.y - a.y * dot);
+        o.z = r * (g.z - a.z * dot); o.w = r * (g.w - a.w * dot);
+        float4* p = reinterpret_cast<float4*>(dz + row * C + c);
+        if (accumulate) { const float4 q = *p; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+        *p = o;
+    }
+}
+
+extern "C" int ssc_row_l2norm_fwd(const float* x, int ldx, const float* ab, int64_t M, int C, float* y, float* ss,
+                                  void* stream) {
+    if ((C & 3) || (ldx & 3)) return -1;
+    hipLaunchKernelGGL(row_l2norm_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       ab, (long)M, C, y, ss);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int ssc_row_l2norm_bwd(const float* y, const float* ss, const float* dy, int64_t M, int C, float* dz,
+                                  int accumulate, void* stream) {
+    if (C & 3) return -1;
+    hipLaunchKernelGGL(row_l2norm_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, ss,
+                       dy, (long)M, C, dz, accumulate);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ BasicLSTMCell pointwise
+// gates[row] = g0[row] + g1[row] (opt) + g2[row / div2] (opt), split i,j,f,o (each C wide);
+// c' = c*sigmoid(f+1) + sigmoid(i)*tanh(j); h' = tanh(c')*sigmoid(o).
+// mask[row / mdiv] == 0 -> the step is skipped for that sample (state copied through).
+__global__ void lstm_fwd_kernel(const float* __restrict__ g0, const float* __restrict__ g1,
+                                const float* __restrict__ g2, int div2, const int* __restrict__ mask, int mdiv,
+                                const float* __restrict__ c_in, const float* __restrict__ h_in, long rows, int C,
+                                float* __restrict__ c_out, float* __restrict__ h_out, float* __restrict__ acts) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    const long r = i / C;
+    const int u = (int)(i - r * C);
+    const float c0 = c_in[i], h0 = h_in[i];
+    if (mask[r / mdiv] == 0) {
+        c_out[i] = c0;
+        h_out[i] = h0;
+        return;     // acts are never read for skipped steps
+    }
+    const long gb = r * 4 * C + u;
+    float gi = g0[gb], gj = g0[gb + C], gf = g0[gb + 2 * C], go = g0[gb + 3 * C];
+    if (g1 != nullptr) { gi += g1[gb]; gj += g1[gb + C]; gf += g1[gb + 2 * C]; go += g1[gb + 3 * C]; }
+    if (g2 != nullptr) {
+        const long q = (r / div2) * 4 * C + u;
+        gi += g2[q]; gj += g2[q + C]; gf += g2[q + 2 * C]; go += g2[q + 3 * C];
+    }
+    const float ai = sigmoidf_(gi), aj = tanhf(gj), af = sigmoidf_(gf + 1.0f), ao = sigmoidf_(go);
+    const float c1 = c0 * af + ai * aj;
+    c_out[i] = c1;
+    h_out[i] = tanhf(c1) * ao;
+    acts[gb] = ai; acts[gb + C] = aj; acts[gb + 2 * C] = af; acts[gb + 3 * C] = ao;
+}
+
+// dh/dc: gradients w.r.t. (h_out, c_out).  Writes pre-activation gate gradients dg[rows,4C],
+// dc_in, and dh_pass (= dh for skipped steps, 0 otherwise; the h-part GEMM accumulates onto it).
+// gacc (optional) += dg  (step-invariant addend, e.g. visual*Kv).
+__global__ void lstm_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc,
+                                const float* __restrict__ acts, const float* __restrict__ c_in,
+                                const float* __restrict__ c_out, const int* __restrict__ mask, int mdiv, long rows,
+                                int C, float* __restrict__ dg, float* __restrict__ dc_in,
+                                float* __restrict__ dh_pass, float* __restrict__ gacc) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    const long r = i / C;
+    const int u = (int)(i - r * C);
+    const long gb = r * 4 * C + u;
+    const float dhv = dh[i], dcv = dc[i];
+    if (mask[r / mdiv] == 0) {
+        dg[gb] = 0.f; dg[gb + C] = 0.f; dg[gb + 2 * C] = 0.f; dg[gb + 3 * C] = 0.f;
+        dc_in[i] = dcv;
+        dh_pass[i] = dhv;
+        return;
+    }
+    const float ai = acts[gb], aj = acts[gb + C], af = acts[gb + 2 * C], ao = acts[gb + 3 * C];
+    const float tc = tanhf(c_out[i]);
+    const float dct = dcv + dhv * ao * (1.f - tc * tc);
+    const float di = dct * aj * ai * (1.f - ai);
+    const float dj = dct * ai * (1.f - aj * aj);
+    const float df = dct * c_in[i] * af * (1.f - af);
+    const float dO = dhv * tc * ao * (1.f - ao);
+    dg[gb] = di; dg[gb + C] = dj; dg[gb + 2 * C] = df; dg[gb + 3 * C] = dO;
+    dc_in[i] = dct * af;
+    dh_pass[i] = 0.f;
+    if (gacc != nullptr) { gacc[gb] += di; gacc[gb + C] += dj; gacc[gb + 2 * C] += df; gacc[gb + 3 * C] += dO; }
+}
+
+extern "C" int ssc_lstm_pointwise_fwd(const float* g0, const float* g1, const float* g2, int div2, const int* mask,
+                                      int mdiv, const float* c_in, const float* h_in, int64_t rows, int C,
+                                      float* c_out, float* h_out, float* acts, void* stream) {
+    const long tot = (long)rows * C;
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g0, g1,
+                       g2, div2 > 0 ? div2 : 1, mask, mdiv > 0 ? mdiv : 1, c_in, h_in, (long)rows, C, c_out, h_out, acts);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int ssc_lstm_pointwise_bwd(const float* dh, const float* dc, const float* acts, const float* c_in,
+                                      const float* c_out, const int* mask, int mdiv, int64_t rows, int C, float* dg,
+                                      float* dc_in, float* dh_pass, float* gacc, void* stream) {
+    const long tot = (long)rows * C;
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, dc,
+                       acts, c_in, c_out, mask, mdiv > 0 ? mdiv : 1, (long)rows, C, dg, dc_in, dh_pass, gacc);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ squash: relu(0.5*(log(1+1e-3+h) - log(1+1e-3-h)))
+__global__ void squash_fwd_kernel(const float* __restrict__ h, long n, float* __restrict__ o) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = h[i];
+    const float s = 0.5f * (logf(1.0f + 1e-3f + v) - logf(1.0f + 1e-3f - v));
+    o[i] = fmaxf(s, 0.f);
+}
+
+// dh = go * [o>0] * 0.5*(1/(1.001+h) + 1/(1.001-h))
+__global__ void squash_bwd_kernel(const float* __restrict__ h, const float* __restrict__ o,
+                                  const float* __restrict__ go, long n, float* __restrict__ dh) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = h[i];
+    const float d = 0.5f * (1.f / (1.0f + 1e-3f + v) + 1.f / (1.0f + 1e-3f - v));
+    dh[i] = o[i] > 0.f ? go[i] * d : 0.f;
+}
+
+extern "C" int ssc_squash_fwd(const float* h, int64_t n, float* o, void* stream) {
+    hipLaunchKernelGGL(squash_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h,
+                       (long)n, o);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int ssc_squash_bwd(const float* h, const float* o, const float* go, int64_t n, float* dh, void* stream) {
+    hipLaunchKernelGGL(squash_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h, o,
+                       go, (long)n, dh);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ small reductions
+// out[g][c] (+)= sum_{r in group g} x[g*G + r][c]     (G rows per group; G = M -> column sum)
+__global__ void group_rowsum_kernel(const float* __restrict__ x, int ldx, long groups, int G, int C,
+                                    float* __restrict__ out, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * C) return;
+    const long g = i / C;
+    const int c = (int)(i - g * C);
+    float s = 0.f;
+    const float* p = x + (g * G) * ldx + c;
+    for (int r = 0; r < G; ++r) s += p[(long)r * ldx];
+    if (accumulate) s += out[i];
+    out[i] = s;
+}
+
+extern "C" int ssc_group_rowsum(const float* x, int ldx, int64_t groups, int G, int C, float* out, int accumulate,
+                                void* stream) {
+    const long tot = (long)groups * C;
+    hipLaunchKernelGGL(group_rowsum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, (long)groups, G, C, out, accumulate);
+    return CHECK_LAUNCH();
+}
+
+// out[n][c] = mean_p act(a*x[n,p,c]+b)      (tf.reduce_mean over H,W; models_collection.py:838)
+__global__ void act_mean_hw_kernel(const float* __restrict__ x, const float* __restrict__ ab, int act, int N, int P,
+                                   int C, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * C) return;
+    const int n = (int)(i / C), c = (int)(i - (long)n * C);
+    const float a = ab != nullptr ? ab[c] : 1.f, b = ab != nullptr ? ab[C + c] : 0.f;
+    float s = 0.f;
+    const float* p = x + (long)n * P * C + c;
+    for (int q = 0; q < P; ++q) {
+        float v = fmaf(a, p[(long)q * C], b);
+        if (act == SSC_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == SSC_ACT_LRELU) v = fmaxf(v, 0.2f * v);
+        s += v;
+    }
+    out[i] = s / (float)P;
+}
+
+// g[n,p,c] += v[n,c]*scale
+__global__ void add_row_bcast_kernel(float* __restrict__ g, const float* __restrict__ v, float scale, int N, int P,
+                                     int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * P * C) return;
+    const int c = (int)(i % C);
+    const int n = (int)(i / ((long)P * C));
+    g[i] += v[(long)n * C + c] * scale;
+}
+
+extern "C" int ssc_act_mean_hw(const float* x, const float* ab, int act, int N, int P, int C, float* out,
+                               void* stream) {
+    const long tot = (long)N * C;
+    hipLaunchKernelGGL(act_mean_hw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ab,
+                       act, N, P, C, out);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int ssc_add_row_bcast(float* g, const float* v, float scale, int N, int P, int C, void* stream) {
+    const long tot = (long)N * P * C;
+    hipLaunchKernelGGL(add_row_bcast_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, v,
+                       scale, N, P, C);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ noise head: miu_relu + NCHW->NHWC reshape
+// pre[n, c*P + p] -> out[n, p, c] = (x + sqrt(0.09 + x^2))/2      (models_collection.py:63-65, 493-499)
+__global__ void miu_permute_fwd_kernel(const float* __restrict__ pre, int N, int Cc, int P, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * Cc * P) return;
+    const int c = (int)(i % Cc);
+    const int p = (int)((i / Cc) % P);
+    const int n = (int)(i / ((long)Cc * P));
+    const float x = pre[(long)n * Cc * P + (long)c * P + p];
+    out[i] = 0.5f * (x + sqrtf(0.09f + x * x));
+}
+
+// dpre[n, c*P+p] = g[n,p,c] * [out>0] * 0.5*(1 + x/sqrt(0.09+x^2))
+__global__ void miu_permute_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ g, int N, int Cc, int P,
+                                       float* __restrict__ dpre) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * Cc * P) return;
+    const int p = (int)(i % P);
+    const int c = (int)((i / P) % Cc);
+    const int n = (int)(i / ((long)Cc * P));
+    const float x = pre[i];
+    const float sq = sqrtf(0.09f + x * x);
+    const float o = 0.5f * (x + sq);
+    const float gv = g[((long)n * P + p) * Cc + c];
+    dpre[i] = o > 0.f ? gv * 0.5f * (1.f + x / sq) : 0.f;
+}
+
+extern "C" int ssc_miu_permute_fwd(const float* pre, int N, int Cc, int P, float* out, void* stream) {
+    const long tot = (long)N * Cc * P;
+    hipLaunchKernelGGL(miu_permute_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       pre, N, Cc, P, out);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int ssc_miu_permute_bwd(const float* pre, const float* g, int N, int Cc, int P, float* dpre, void* stream) {
+    const long tot = (long)N * Cc * P;
+    hipLaunchKernelGGL(miu_permute_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       pre, g, N, Cc, P, dpre);
+    return CHECK_LAUNCH();
+}

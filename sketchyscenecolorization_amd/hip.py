@@ -17,7 +17,7 @@ ACT_MIU = 3     # only for the pointwise kernels, never on load
 
 
 class GView(C.Structure):
-    _fields_ = [('s0', C.c_void_p), ('s1', C.c_void_p), ('ab', C.c_void_p),
+    _fields_ = [('s0', C.c_void_p), ('s1', C.c_void_p), ('ab0', C.c_void_p), ('ab1', C.c_void_p),
                 ('C0', C.c_int32), ('C1', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('act', C.c_int32), ('_pad', C.c_int32)]
 
@@ -71,6 +71,29 @@ SIGNATURES = {
     'ssc_fill': [_P, _F, _L, _P],
     'ssc_bn_stats': [_P, _L, _I, _I, _P, _P, _F, _P, _P, _P, _L, _P],
     'ssc_bn_act_backward': [_P, _L, _I, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _L, _P],
+    'ssc_embedding_gather': [_P, _P, _I, _I, _P, _P],
+    'ssc_embedding_scatter_add': [_P, _P, _I, _I, _P, _P],
+    'ssc_row_l2norm_fwd': [_P, _I, _P, _L, _I, _P, _P, _P],
+    'ssc_row_l2norm_bwd': [_P, _P, _P, _L, _I, _P, _I, _P],
+    'ssc_lstm_pointwise_fwd': [_P, _P, _P, _I, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P],
+    'ssc_lstm_pointwise_bwd': [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P],
+    'ssc_squash_fwd': [_P, _L, _P, _P],
+    'ssc_squash_bwd': [_P, _P, _P, _L, _P, _P],
+    'ssc_group_rowsum': [_P, _I, _L, _I, _I, _P, _I, _P],
+    'ssc_act_mean_hw': [_P, _P, _I, _I, _I, _I, _P, _P],
+    'ssc_add_row_bcast': [_P, _P, _F, _I, _I, _I, _P],
+    'ssc_miu_permute_fwd': [_P, _I, _I, _I, _P, _P],
+    'ssc_miu_permute_bwd': [_P, _P, _I, _I, _I, _P, _P],
+    'ssc_softplus_loss': [_P, _I, _L, _F, _F, _P, _P, _F, _P],
+    'ssc_acgan_loss': [_P, _P, _I, _I, _I, _F, _P, _P, _P],
+    'ssc_gen_output_grad': [_P, _I, _P, _I, _P, _I, _L, _F, _P, _P, _P],
+    'ssc_l2_reg': [_P, _L, _F, _P, _P, _P],
+    'ssc_adam_tf': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P],
+    'ssc_sn_forward': [_P, _P, _I, _I, _P, _P, _P, _P, _P],
+    'ssc_sn_backward': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P],
+    'ssc_axpy': [_P, _P, _F, _L, _P],
+    'ssc_fc_small_fwd': [_P, _P, _P, _I, _I, _I, _P, _P],
+    'ssc_fc_small_bwd': [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
 }
 
 
@@ -115,23 +138,24 @@ def workspace(nbytes=256 << 20):
 class View(object):
     """Host-side mirror of ssc_gview: NHWC tensor(s) + folded norm + activation."""
 
-    def __init__(self, s0, s1=None, ab=None, act=ACT_NONE):
+    def __init__(self, s0, s1=None, ab0=None, act=ACT_NONE, ab1=None):
         assert s0.dim() == 4 and s0.is_contiguous()
-        self.s0, self.s1, self.ab, self.act = s0, s1, ab, act
+        self.s0, self.s1, self.ab0, self.ab1, self.act = s0, s1, ab0, ab1, act
         self.N, self.H, self.W, self.C0 = s0.shape
         self.C1 = 0
         if s1 is not None:
             assert s1.is_contiguous() and s1.shape[:3] == s0.shape[:3]
             self.C1 = s1.shape[3]
         self.C = self.C0 + self.C1
-        if ab is not None:
-            assert ab.numel() == 2 * self.C and ab.is_contiguous()
+        assert ab0 is None or (ab0.numel() == 2 * self.C0 and ab0.is_contiguous())
+        assert ab1 is None or (ab1.numel() == 2 * self.C1 and ab1.is_contiguous())
 
     def c(self):
         g = GView()
         g.s0 = self.s0.data_ptr()
         g.s1 = self.s1.data_ptr() if self.s1 is not None else None
-        g.ab = self.ab.data_ptr() if self.ab is not None else None
+        g.ab0 = self.ab0.data_ptr() if self.ab0 is not None else None
+        g.ab1 = self.ab1.data_ptr() if self.ab1 is not None else None
         g.C0, g.C1, g.H, g.W, g.act = self.C0, self.C1, self.H, self.W, self.act
         return g
 
@@ -340,3 +364,22 @@ def bn_act_backward(x2d, ab, stats, g1, act1, dx, g2=None, act2=ACT_NONE, dscale
                                     ptr(g1), g1.stride(0), act1, ptr(g2), (g2.stride(0) if g2 is not None else 0),
                                     act2, int(has_bn), ptr(dx), dx.stride(0), ptr(dscale), ptr(doffset),
                                     ptr(ws), ws.numel() * 4, stream_ptr()), 'bn_act_backward')
+
+
+# ---------------------------------------------------------------------------
+# thin typed wrappers over the remaining entry points
+# ---------------------------------------------------------------------------
+def call(name, *args):
+    """Invoke a C-ABI entry point with the current stream appended; raise on error."""
+    conv = []
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            conv.append(ptr(a))
+        else:
+            conv.append(a)
+    check(getattr(lib(), name)(*conv, stream_ptr()), name)
+
+
+def bn_stats_view(x4d, scale, offset, ab, stats, eps=1e-5):
+    n, h, w, c = x4d.shape
+    bn_stats(x4d.view(n * h * w, c), scale, offset, ab, stats, eps)

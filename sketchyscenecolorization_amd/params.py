@@ -1,0 +1,180 @@
+"""Parameter registry keyed by the TF variable names of the reference graph.
+
+The reference owns its variables in a global tf.Graph under the scopes
+``generator`` / ``discriminator`` (graph_single.py:296-299).  Here every scope is
+one flat fp32 device buffer (parameters, gradients, Adam second moments) so that
+TF-style Adam is a single kernel launch and the data-parallel gradient exchange
+is a few large RCCL all-reduces over contiguous memory; named parameters are
+views into the flat buffer in their TF layouts (checkpoints map 1:1 to TF names).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+ALIGN = 64  # floats (256 B): keeps every view 16-byte aligned for float4 loads
+
+SIZE = 64           # models_collection.py:10
+NUM_CLASSES = 25    # input_pipeline.py:11
+
+
+def pix2pix_param_specs(vocab_size=58, img=192, num_classes=NUM_CLASSES, size=SIZE):
+    """(name, shape, init) for every variable of generate_pix2pix / discriminate_pix2pix
+    (models_collection.py:408-538, 789-841), in graph-creation order."""
+    g = []
+    enc = [(3, size), (size, size * 2), (size * 2, size * 4), (size * 4, size * 8), (size * 8, size * 8)]
+    for k, (ci, co) in enumerate(enc, start=1):
+        g.append(('generator/encoder_%d/conv/filter' % k, (4, 4, ci, co), ('normal', 0.0, 0.02)))
+        if k > 1:
+            g.append(('generator/encoder_%d/offset' % k, (co,), ('zeros',)))
+            g.append(('generator/encoder_%d/scale' % k, (co,), ('normal', 1.0, 0.02)))
+    c = size * 8
+    g.append(('generator/TextLSTM/embedding', (vocab_size, c), ('uniform', -0.08, 0.08)))
+    for cell, rows in (('WLSTM', 2 * c), ('ALSTM', 4 * c)):
+        base = 'generator/TextLSTM/RNN/%s/multi_rnn_cell/cell_0/basic_lstm_cell/' % cell
+        g.append((base + 'kernel', (rows, 4 * c), ('glorot',)))
+        g.append((base + 'bias', (4 * c,), ('zeros',)))
+    hw = img // 32
+    cd = c // 8
+    g.append(('generator/fully_connected/weights', (256, cd * hw * hw), ('glorot',)))
+    g.append(('generator/fully_connected/biases', (cd * hw * hw,), ('zeros',)))
+    dec = [(5, c + cd, size * 8), (4, size * 16, size * 4), (3, size * 8, size * 2), (2, size * 4, size),
+           (1, size * 2, 3)]
+    for k, ci, co in dec:
+        g.append(('generator/decoder_%d/deconv/filter' % k, (4, 4, co, ci), ('normal', 0.0, 0.02)))
+        if k > 1:
+            g.append(('generator/decoder_%d/offset' % k, (co,), ('zeros',)))
+            g.append(('generator/decoder_%d/scale' % k, (co,), ('normal', 1.0, 0.02)))
+    d = []
+    dl = [(1, 6, size), (2, size, size * 2), (3, size * 2, size * 4), (4, size * 4, size * 8), (5, size * 8, 1)]
+    for k, ci, co in dl:
+        d.append(('discriminator/layer_%d/conv/filter' % k, (4, 4, ci, co), ('normal', 0.0, 0.02)))
+        if 2 <= k <= 4:
+            d.append(('discriminator/layer_%d/offset' % k, (co,), ('zeros',)))
+            d.append(('discriminator/layer_%d/scale' % k, (co,), ('normal', 1.0, 0.02)))
+    d.append(('discriminator/fully_connected/weights', (size * 8, num_classes), ('glorot',)))
+    d.append(('discriminator/fully_connected/biases', (num_classes,), ('zeros',)))
+    nontrainable = [('discriminator/fully_connected/u', (1, num_classes), ('truncated_normal',))]
+    return g, d, nontrainable
+
+
+def _init_tensor(shape, init, gen):
+    kind = init[0]
+    if kind == 'zeros':
+        return torch.zeros(shape)
+    if kind == 'normal':
+        return torch.randn(shape, generator=gen) * init[2] + init[1]
+    if kind == 'uniform':
+        return torch.rand(shape, generator=gen) * (init[2] - init[1]) + init[1]
+    if kind == 'glorot':        # xavier/glorot uniform (mru.py:54; TF default for BasicLSTMCell kernels)
+        lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+        return torch.rand(shape, generator=gen) * 2 * lim - lim
+    if kind == 'truncated_normal':      # sn.py:18
+        t = torch.randn(shape, generator=gen)
+        while bool((t.abs() > 2).any()):
+            t = torch.where(t.abs() > 2, torch.randn(shape, generator=gen), t)
+        return t
+    raise ValueError(kind)
+
+
+class Scope(object):
+    """One variable scope = flat parameter / gradient / Adam-v buffers + named views."""
+
+    def __init__(self, name, specs, device):
+        self.name = name
+        self.specs = specs
+        self.offsets = OrderedDict()
+        off = 0
+        for n, shape, _ in specs:
+            self.offsets[n] = (off, int(np.prod(shape)), tuple(shape))
+            off += (int(np.prod(shape)) + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.adam_v = torch.zeros(off, dtype=torch.float32, device=device)
+        self.adam_t = 0
+        self.p = OrderedDict((n, self.flat[o:o + k].view(s)) for n, (o, k, s) in self.offsets.items())
+        self.g = OrderedDict((n, self.grad[o:o + k].view(s)) for n, (o, k, s) in self.offsets.items())
+
+    def names(self):
+        return list(self.offsets.keys())
+
+
+class ParamStore(object):
+    """All variables of one model instance (generator + discriminator + non-trainables)."""
+
+    def __init__(self, block_type='Pix2Pix', vocab_size=58, img=192, device='cuda', seed=0):
+        if block_type != 'Pix2Pix':
+            raise NotImplementedError('block_type %r: only the Pix2Pix variant is built so far' % block_type)
+        g, d, nt = pix2pix_param_specs(vocab_size, img)
+        self.device = device
+        self.generator = Scope('generator', g, device)
+        self.discriminator = Scope('discriminator', d, device)
+        self.nontrainable = OrderedDict((n, torch.zeros(s, dtype=torch.float32, device=device)) for n, s, _ in nt)
+        self._nt_specs = nt
+        self.initialize(seed)
+
+    def scope(self, name):
+        return self.generator if name == 'generator' else self.discriminator
+
+    def initialize(self, seed=0):
+        """Reference initialisers, identical on every rank for one seed."""
+        gen = torch.Generator().manual_seed(seed)
+        for sc in (self.generator, self.discriminator):
+            for n, shape, init in sc.specs:
+                sc.p[n].copy_(_init_tensor(shape, init, gen))
+            sc.adam_v.zero_()
+            sc.adam_t = 0
+        for n, shape, init in self._nt_specs:
+            self.nontrainable[n].copy_(_init_tensor(shape, init, gen))
+
+    def __getitem__(self, name):
+        if name in self.nontrainable:
+            return self.nontrainable[name]
+        return self.scope(name.split('/', 1)[0]).p[name]
+
+    def grad(self, name):
+        return self.scope(name.split('/', 1)[0]).g[name]
+
+    def names(self):
+        return self.generator.names() + self.discriminator.names() + list(self.nontrainable.keys())
+
+    def load_dict(self, d):
+        """Copy values from a {tf_name: tensor/ndarray} mapping (checkpoints, test fixtures)."""
+        for n in self.names():
+            if n in d:
+                self[n].copy_(torch.as_tensor(d[n], dtype=torch.float32).reshape(self[n].shape))
+
+    def state_dict(self):
+        out = OrderedDict((n, self[n].detach().cpu()) for n in self.names())
+        for sc in (self.generator, self.discriminator):
+            out['__adam_v__/' + sc.name] = sc.adam_v.detach().cpu()
+            out['__adam_t__/' + sc.name] = torch.tensor(sc.adam_t)
+        return out
+
+    def load_state_dict(self, sd):
+        self.load_dict(sd)
+        for sc in (self.generator, self.discriminator):
+            if '__adam_v__/' + sc.name in sd:
+                sc.adam_v.copy_(sd['__adam_v__/' + sc.name])
+                sc.adam_t = int(sd['__adam_t__/' + sc.name])
+
+    def parameter_count(self, scope):
+        return sum(k for _, (o, k, s) in self.scope(scope).offsets.items())
+
+
+class Buffers(object):
+    """Named activation buffers, allocated once per shape and reused across iterations."""
+
+    def __init__(self, device='cuda'):
+        self.device = device
+        self._b = {}
+
+    def get(self, name, shape, dtype=torch.float32, zero_on_alloc=False):
+        shape = tuple(int(s) for s in shape)
+        t = self._b.get(name)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = (torch.zeros if zero_on_alloc else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._b[name] = t
+        return t

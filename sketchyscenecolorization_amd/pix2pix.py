@@ -1,0 +1,318 @@
+"""Pix2Pix-variant generator and discriminator (models_collection.py:408-538, 789-841)
+as explicit forward / hand-written backward passes over the HIP kernels.
+
+Layout: activations NHWC fp32 (3-channel images padded to 4, the 6-channel
+discriminator input to 8).  Every conv output is stored RAW (pre-norm); the
+batch-statistics norm is folded to a per-channel (a, b) pair by ``bn_stats`` and
+applied, together with the lrelu/relu of the *next* block and the skip concat,
+inside that block's tile loads (hip.View).  Nothing normalised, activated or
+concatenated is ever written to HBM.
+"""
+import torch
+
+from . import hip
+from .hip import ACT_LRELU, ACT_NONE, ACT_RELU, View
+from .text_fusion import TextFusion
+
+
+def _rows(t):
+    return t.view(-1, t.shape[-1])
+
+
+class Pix2PixGenerator(object):
+    """generate_pix2pix: 5 stride-2 convs, caption fusion, noise head, 5 stride-2 transposed convs."""
+
+    def __init__(self, store, bufs, lstm_hybrid=True):
+        self.s, self.b = store, bufs
+        self.lstm_hybrid = bool(lstm_hybrid)
+        self.text = TextFusion(store, bufs)
+
+    def forward(self, sketches, text, noise_vec, tag='g', out=None, out_coff=0):
+        """sketches NCHW [N,3,H,W] (device), text int [N,T] (host), noise_vec [N,256] (device).
+        Writes tanh output into ``out[..., out_coff:out_coff+3]`` (NHWC) and returns the context."""
+        s, B = self.s, self.b
+        N, _, H, W = sketches.shape
+        xs = B.get(tag + '/xs', (N, H, W, 4), zero_on_alloc=True)
+        hip.nchw_to_nhwc(sketches, xs, 0)
+        e, ab, st = [None] * 6, [None] * 6, [None] * 6
+        chans = [None, 64, 128, 256, 512, 512]
+        h = H
+        for k in range(1, 6):
+            h //= 2
+            e[k] = B.get(tag + '/e%d' % k, (N, h, h * W // H, chans[k]))
+            if k == 1:
+                hip.conv_forward(View(xs), s['generator/encoder_1/conv/filter'], 2, 1, e[1])
+            else:
+                hip.conv_forward(View(e[k - 1], None, ab[k - 1], ACT_LRELU), s['generator/encoder_%d/conv/filter' % k],
+                                 2, 1, e[k])
+                ab[k] = B.get(tag + '/ab_e%d' % k, (2 * chans[k],))
+                st[k] = B.get(tag + '/st_e%d' % k, (2 * chans[k],))
+                hip.bn_stats(_rows(e[k]), s['generator/encoder_%d/scale' % k], s['generator/encoder_%d/offset' % k],
+                             ab[k], st[k])
+        ctx = {'tag': tag, 'N': N, 'H': H, 'W': W, 'xs': xs, 'e': e, 'ab': ab, 'st': st, 'noise_vec': noise_vec}
+        hh, ww = e[5].shape[1], e[5].shape[2]
+        P = hh * ww
+        if self.lstm_hybrid:
+            feat, tctx = self.text.forward(e[5], ab[5], text, tag)
+            ctx['tctx'] = tctx
+            v5 = lambda noise: View(feat, noise, None, ACT_RELU, None)
+        else:
+            feat = e[5]
+            v5 = lambda noise: View(feat, noise, ab[5], ACT_RELU, None)
+        ctx['feat'] = feat
+        # noise head: fully_connected(256 -> 64*P) + miu_relu, reshaped NCHW->NHWC
+        cd = chans[5] // 8
+        pre = B.get(tag + '/noise_pre', (N, cd * P))
+        hip.matmul(noise_vec, s['generator/fully_connected/weights'], pre, bias=s['generator/fully_connected/biases'])
+        noise = B.get(tag + '/noise', (N, hh, ww, cd))
+        hip.call('ssc_miu_permute_fwd', pre, N, cd, P, noise)
+        ctx['noise_pre'], ctx['noise'] = pre, noise
+        # decoders
+        d, abd, std = [None] * 6, [None] * 6, [None] * 6
+        dch = [None, 3, 64, 128, 256, 512]
+        views = {}
+        for k in (5, 4, 3, 2):
+            if k == 5:
+                v = v5(noise)
+            else:
+                v = View(d[k + 1], e[k], abd[k + 1], ACT_RELU, ab[k])
+            views[k] = v
+            d[k] = B.get(tag + '/d%d' % k, (N, 2 * v.H, 2 * v.W, dch[k]))
+            hip.deconv_forward(v, s['generator/decoder_%d/deconv/filter' % k], d[k])
+            abd[k] = B.get(tag + '/ab_d%d' % k, (2 * dch[k],))
+            std[k] = B.get(tag + '/st_d%d' % k, (2 * dch[k],))
+            hip.bn_stats(_rows(d[k]), s['generator/decoder_%d/scale' % k], s['generator/decoder_%d/offset' % k],
+                         abd[k], std[k])
+        v1 = View(d[2], e[1], abd[2], ACT_RELU, None)
+        views[1] = v1
+        if out is None:
+            out = B.get(tag + '/gen', (N, H, W, 4))
+            out_coff = 0
+        nstore = 4 if out.shape[3] == 4 and out_coff == 0 else 3
+        hip.deconv_forward(v1, s['generator/decoder_1/deconv/filter'], out, coff=out_coff, nstore=nstore, epi=1)
+        ctx.update(d=d, abd=abd, std=std, views=views, out=out, out_coff=out_coff)
+        return ctx
+
+    def output_nchw(self, ctx):
+        N, H, W = ctx['N'], ctx['H'], ctx['W']
+        o = torch.empty((N, 3, H, W), dtype=torch.float32, device=ctx['out'].device)
+        hip.nhwc_to_nchw(ctx['out'], o, ctx['out_coff'])
+        return o
+
+    def backward(self, ctx, dpre, on_section=None):
+        """dpre [N,H,W,4]: gradient w.r.t. the pre-tanh output.  Writes every generator gradient.
+        ``on_section(name)`` is called when a contiguous block of the flat gradient buffer is final
+        ('decoders' = noise head + decoders, 'text', 'encoders') so the caller can start its all-reduce."""
+        s, B = self.s, self.b
+        done = on_section if on_section is not None else (lambda name: None)
+        tag, N = ctx['tag'], ctx['N']
+        e, ab, st, d, abd, std, views = ctx['e'], ctx['ab'], ctx['st'], ctx['d'], ctx['abd'], ctx['std'], ctx['views']
+        gcur = dpre
+        g_skip = [None] * 6
+        g_feat = g_noise = None
+        for k in (1, 2, 3, 4, 5):
+            f = s['generator/decoder_%d/deconv/filter' % k]
+            v = views[k]
+            dyv = View(gcur)
+            hip.deconv_wgrad(v, dyv, s.grad('generator/decoder_%d/deconv/filter' % k))
+            g0 = B.get(tag + '/gb/d%d_in0' % k, (N, v.H, v.W, v.C0))
+            g1 = B.get(tag + '/gb/d%d_in1' % k, (N, v.H, v.W, v.C1))
+            hip.deconv_dgrad(dyv, f, g0, n_off=0, nn=v.C0)
+            hip.deconv_dgrad(dyv, f, g1, n_off=v.C0, nn=v.C1)
+            if k < 5:
+                g_skip[k] = g1          # through relu to encoder_k's output
+                src = d[k + 1]
+                dx = B.get(tag + '/gb/dd%d' % (k + 1), src.shape)
+                hip.bn_act_backward(_rows(src), abd[k + 1], std[k + 1], _rows(g0), ACT_RELU, _rows(dx),
+                                    dscale=s.grad('generator/decoder_%d/scale' % (k + 1)),
+                                    doffset=s.grad('generator/decoder_%d/offset' % (k + 1)))
+                gcur = dx
+            else:
+                g_feat, g_noise = g0, g1
+        # noise head
+        P = ctx['noise'].shape[1] * ctx['noise'].shape[2]
+        cd = ctx['noise'].shape[3]
+        dpre_fc = B.get(tag + '/gb/noise_dpre', (N, cd * P))
+        hip.call('ssc_miu_permute_bwd', ctx['noise_pre'], g_noise, N, cd, P, dpre_fc)
+        hip.matmul_tn(ctx['noise_vec'], dpre_fc, s.grad('generator/fully_connected/weights'))
+        hip.call('ssc_group_rowsum', dpre_fc, cd * P, 1, N, cd * P, s.grad('generator/fully_connected/biases'), 0)
+        done('decoders')
+        # caption branch -> gradient w.r.t. normalised encoder_5 output
+        de5 = B.get(tag + '/gb/de5', e[5].shape)
+        if self.lstm_hybrid:
+            dy5 = self.text.backward(ctx['tctx'], g_feat)
+            done('text')
+            if dy5 is None:
+                hip.fill(de5, 0.0)
+                hip.fill(s.grad('generator/encoder_5/scale'), 0.0)
+                hip.fill(s.grad('generator/encoder_5/offset'), 0.0)
+            else:
+                hip.bn_act_backward(_rows(e[5]), ab[5], st[5], dy5, ACT_NONE, _rows(de5),
+                                    dscale=s.grad('generator/encoder_5/scale'),
+                                    doffset=s.grad('generator/encoder_5/offset'))
+        else:
+            for nm in ('embedding', 'RNN/WLSTM/multi_rnn_cell/cell_0/basic_lstm_cell/kernel',
+                       'RNN/WLSTM/multi_rnn_cell/cell_0/basic_lstm_cell/bias',
+                       'RNN/ALSTM/multi_rnn_cell/cell_0/basic_lstm_cell/kernel',
+                       'RNN/ALSTM/multi_rnn_cell/cell_0/basic_lstm_cell/bias'):
+                hip.fill(s.grad('generator/TextLSTM/' + nm), 0.0)
+            done('text')
+            hip.bn_act_backward(_rows(e[5]), ab[5], st[5], _rows(g_feat), ACT_RELU, _rows(de5),
+                                dscale=s.grad('generator/encoder_5/scale'),
+                                doffset=s.grad('generator/encoder_5/offset'))
+        gcur = de5
+        for k in (5, 4, 3, 2):
+            w = s['generator/encoder_%d/conv/filter' % k]
+            xin = View(e[k - 1], None, ab[k - 1], ACT_LRELU)
+            dyv = View(gcur)
+            hip.conv_wgrad(xin, dyv, s.grad('generator/encoder_%d/conv/filter' % k), 2, 1)
+            gin = B.get(tag + '/gb/e%d_in' % k, e[k - 1].shape)
+            hip.conv_dgrad(dyv, w, 2, 1, gin)
+            dx = B.get(tag + '/gb/de%d' % (k - 1), e[k - 1].shape)
+            if k - 1 >= 2:
+                hip.bn_act_backward(_rows(e[k - 1]), ab[k - 1], st[k - 1], _rows(gin), ACT_LRELU, _rows(dx),
+                                    g2=_rows(g_skip[k - 1]), act2=ACT_RELU,
+                                    dscale=s.grad('generator/encoder_%d/scale' % (k - 1)),
+                                    doffset=s.grad('generator/encoder_%d/offset' % (k - 1)))
+            else:
+                hip.bn_act_backward(_rows(e[1]), None, None, _rows(gin), ACT_LRELU, _rows(dx),
+                                    g2=_rows(g_skip[1]), act2=ACT_RELU)
+            gcur = dx
+        hip.conv_wgrad(View(ctx['xs']), View(gcur), s.grad('generator/encoder_1/conv/filter'), 2, 1)
+        done('encoders')
+
+
+class Pix2PixDiscriminator(object):
+    """discriminate_pix2pix: 70x70-style PatchGAN + spectral-normed auxiliary classifier."""
+
+    def __init__(self, store, bufs, sn=True):
+        self.s, self.b = store, bufs
+        self.sn = bool(sn)
+        self.chans = [8, 64, 128, 256, 512, 1]
+        self.strides = [None, 2, 2, 2, 1, 1]
+
+    def prepare_sn(self):
+        """One power iteration on fully_connected/weights (sn.py), shared by every call of this step."""
+        s, B = self.s, self.b
+        W = s['discriminator/fully_connected/weights']
+        m, n = W.shape
+        if not self.sn:
+            return {'wbar': W}
+        sn = {'v': B.get('d/sn/v', (m,)), 'u_new': B.get('d/sn/u_new', (1, n)), 'wbar': B.get('d/sn/wbar', (m, n)),
+              'aux': B.get('d/sn/aux', (4,)), 'gwbar': B.get('d/sn/gwbar', (m, n)), 'n_acc': 0}
+        hip.call('ssc_sn_forward', W, s['discriminator/fully_connected/u'], m, n, sn['v'], sn['u_new'], sn['wbar'],
+                 sn['aux'])
+        return sn
+
+    def forward(self, xd, sn, tag):
+        """xd NHWC [N,H,W,8] = [discrim_inputs(3), discrim_targets(3), 0, 0]."""
+        s, B = self.s, self.b
+        N, H, W, _ = xd.shape
+        l, ab, st = [None] * 6, [None] * 6, [None] * 6
+        l[0] = xd
+        h, w = H, W
+        for k in range(1, 6):
+            if self.strides[k] == 2:
+                h, w = h // 2, w // 2
+            else:
+                h, w = h - 1, w - 1
+            co = self.chans[k]
+            l[k] = B.get(tag + '/l%d' % k, (N, h, w, 4 if k == 5 else co))
+            if k == 1:
+                v = View(xd)
+            elif k == 2:
+                v = View(l[1], None, None, ACT_LRELU)
+            else:
+                v = View(l[k - 1], None, ab[k - 1], ACT_LRELU)
+            hip.conv_forward(v, s['discriminator/layer_%d/conv/filter' % k], self.strides[k], 1, l[k],
+                             nstore=(4 if k == 5 else None))
+            if 2 <= k <= 4:
+                ab[k] = B.get(tag + '/ab%d' % k, (2 * co,))
+                st[k] = B.get(tag + '/st%d' % k, (2 * co,))
+                hip.bn_stats(_rows(l[k]), s['discriminator/layer_%d/scale' % k], s['discriminator/layer_%d/offset' % k],
+                             ab[k], st[k])
+        P4 = l[4].shape[1] * l[4].shape[2]
+        img = B.get(tag + '/img', (N, 512))
+        hip.call('ssc_act_mean_hw', l[4], ab[4], ACT_LRELU, N, P4, 512, img)
+        K = s['discriminator/fully_connected/weights'].shape[1]
+        logits = B.get(tag + '/logits', (N, K))
+        hip.call('ssc_fc_small_fwd', img, sn['wbar'], s['discriminator/fully_connected/biases'], N, 512, K, logits)
+        return {'tag': tag, 'N': N, 'l': l, 'ab': ab, 'st': st, 'img': img, 'logits': logits, 'disc': l[5], 'P4': P4}
+
+    def backward(self, ctx, dl5, dlogits, sn, need_params, need_input, accumulate):
+        """dl5 [N,h5,w5,4] (channel 0 real), dlogits [N,K] or None.
+        need_params: write (accumulate=False) or add (True) the filter/norm gradients.
+        need_input: return d loss / d discrim_targets as NHWC [N,H,W,4]."""
+        s, B = self.s, self.b
+        tag, N, l, ab, st = ctx['tag'], ctx['N'], ctx['l'], ctx['ab'], ctx['st']
+        gname = lambda k, what: s.grad('discriminator/layer_%d/%s' % (k, what))
+        # layer 5 (Cout = 1)
+        x5 = View(l[4], None, ab[4], ACT_LRELU)
+        dyv = View(dl5)
+        if need_params:
+            hip.conv_wgrad(x5, dyv, gname(5, 'conv/filter'), 1, 1, accumulate=accumulate)
+        g4 = B.get(tag + '/gb/g4', l[4].shape)
+        hip.conv_dgrad(dyv, s['discriminator/layer_5/conv/filter'], 1, 1, g4, k_real=1)
+        if dlogits is not None:
+            dimg = B.get(tag + '/gb/dimg', (N, 512))
+            K = dlogits.shape[1]
+            gw, gb_, acc = None, None, 0
+            if need_params:
+                gb_ = s.grad('discriminator/fully_connected/biases')
+                if self.sn:     # gradient w.r.t. W_bar, summed over the calls of this step
+                    gw, acc = sn['gwbar'], int(sn['n_acc'] > 0)
+                    sn['n_acc'] += 1
+                else:
+                    gw, acc = s.grad('discriminator/fully_connected/weights'), int(accumulate)
+            hip.call('ssc_fc_small_bwd', ctx['img'], sn['wbar'], dlogits, N, 512, K, dimg, gw, gb_, acc)
+            hip.call('ssc_add_row_bcast', g4, dimg, 1.0 / ctx['P4'], N, ctx['P4'], 512)
+        gcur = g4
+        dgen = None
+        for k in (4, 3, 2, 1):
+            dx = B.get(tag + '/gb/dl%d' % k, l[k].shape)
+            if k >= 2:
+                ds = do = None
+                if need_params and accumulate:
+                    tmp_s = B.get(tag + '/gb/tmp_scale%d' % k, (2, self.chans[k]))
+                    ds, do = tmp_s[0], tmp_s[1]
+                elif need_params:
+                    ds, do = gname(k, 'scale'), gname(k, 'offset')
+                hip.bn_act_backward(_rows(l[k]), ab[k], st[k], _rows(gcur), ACT_LRELU, _rows(dx), dscale=ds, doffset=do)
+                if need_params and accumulate:
+                    hip.call('ssc_axpy', gname(k, 'scale'), ds, 1.0, self.chans[k])
+                    hip.call('ssc_axpy', gname(k, 'offset'), do, 1.0, self.chans[k])
+            else:
+                hip.bn_act_backward(_rows(l[1]), None, None, _rows(gcur), ACT_LRELU, _rows(dx))
+            if k == 1:
+                xin = View(l[0])
+            elif k == 2:
+                xin = View(l[1], None, None, ACT_LRELU)
+            else:
+                xin = View(l[k - 1], None, ab[k - 1], ACT_LRELU)
+            dyv = View(dx)
+            w = s['discriminator/layer_%d/conv/filter' % k]
+            if need_params:
+                hip.conv_wgrad(xin, dyv, gname(k, 'conv/filter'), self.strides[k], 1, accumulate=accumulate)
+            if k > 1:
+                gin = B.get(tag + '/gb/g%d' % (k - 1), l[k - 1].shape)
+                hip.conv_dgrad(dyv, w, self.strides[k], 1, gin)
+                gcur = gin
+            elif need_input:
+                dgen = B.get(tag + '/gb/dgen', (N, l[0].shape[1], l[0].shape[2], 4))
+                hip.conv_dgrad(dyv, w, 2, 1, dgen, n_off=3, nn=3, nstore=4)
+        return dgen
+
+    def finish_sn_backward(self, sn, accumulate=False):
+        """d loss / d W from the accumulated d loss / d W_bar, through sigma and the power iteration."""
+        s, B = self.s, self.b
+        if not self.sn:
+            return
+        W = s['discriminator/fully_connected/weights']
+        m, n = W.shape
+        gW = s.grad('discriminator/fully_connected/weights')
+        if sn['n_acc'] == 0:
+            if not accumulate:
+                hip.fill(gW, 0.0)
+            return
+        hip.call('ssc_sn_backward', W, s['discriminator/fully_connected/u'], sn['v'], sn['u_new'], sn['aux'],
+                 sn['gwbar'], m, n, gW, int(accumulate), B.get('d/sn/scratch', (m,)))

@@ -1,0 +1,184 @@
+"""Caption branch: encode_feat_with_text (models_collection.py:150-248) on HIP kernels.
+
+The reference unrolls, per sample, 15 ``tf.cond`` steps of a word LSTM and a
+per-position ("1x1 convolutional") multimodal LSTM whose input is the tiled
+concat [l2n(visual), w_emb, l2n(h_w)].  Here the whole batch advances together
+and the ALSTM matmul is split by kernel row block (only the summation order
+changes):
+
+    gates = visual @ Ka[0:C]            (once, all positions)      + bias
+          + emb_t  @ Ka[C:2C]           (one row per sample, all steps in one GEMM)
+          + lang_t @ Ka[2C:3C]          (idem)
+          + h_a    @ Ka[3C:4C]          (the only per-step GEMM)
+
+so the tile/concat tensor is never materialised.  Steps whose token is 0 are
+skipped per sample by a mask inside the pointwise kernel (tf.cond, :235); steps
+where every sample is padded are not launched at all.  Forward keeps what the
+hand-written BPTT needs.
+"""
+import numpy as np
+import torch
+
+from . import hip
+
+PFX_W = 'generator/TextLSTM/RNN/WLSTM/multi_rnn_cell/cell_0/basic_lstm_cell/'
+PFX_A = 'generator/TextLSTM/RNN/ALSTM/multi_rnn_cell/cell_0/basic_lstm_cell/'
+
+
+class TextFusion(object):
+    def __init__(self, store, bufs):
+        self.s = store
+        self.b = bufs
+
+    def forward(self, e5, ab5, text, tag='g'):
+        """e5 raw [N,h,w,C] (+ folded norm ab5), text int [N,T] on the HOST -> feat [N,h,w,C]."""
+        s, B = self.s, self.b
+        N, hh, ww, C = e5.shape
+        P = hh * ww
+        R = N * P
+        text = np.asarray(text.cpu() if isinstance(text, torch.Tensor) else text).astype(np.int32).reshape(N, -1)
+        steps = [t for t in range(text.shape[1]) if (text[:, t] != 0).any()]
+        S = len(steps)
+        ctx = {'N': N, 'P': P, 'C': C, 'S': S, 'tag': tag, 'shape': (N, hh, ww, C)}
+        feat = B.get(tag + '/tf/feat', (N, hh, ww, C))
+        if S == 0:      # every caption is all padding: relu(atanh(0)) = 0
+            hip.fill(feat, 0.0)
+            return feat, ctx
+        tok_np = np.ascontiguousarray(text[:, steps].T).reshape(-1)        # time-major [S*N]
+        tok = B.get(tag + '/tf/tok', (S * N,), torch.int32)
+        tok.copy_(torch.from_numpy(tok_np), non_blocking=True)
+        mask = B.get(tag + '/tf/mask', (S, N), torch.int32)
+        mask.copy_(torch.from_numpy((tok_np != 0).astype(np.int32)).view(S, N), non_blocking=True)
+        E = s['generator/TextLSTM/embedding']
+        Kw, bw = s[PFX_W + 'kernel'], s[PFX_W + 'bias']
+        Ka, ba = s[PFX_A + 'kernel'], s[PFX_A + 'bias']
+        G4 = 4 * C
+
+        vis = B.get(tag + '/tf/vis', (R, C))
+        vis_ss = B.get(tag + '/tf/vis_ss', (R,))
+        hip.call('ssc_row_l2norm_fwd', e5, C, ab5, R, C, vis, vis_ss)
+        Gv = B.get(tag + '/tf/Gv', (R, G4))
+        hip.matmul(vis, Ka[0:C], Gv, bias=ba)
+        emb = B.get(tag + '/tf/emb', (S * N, C))
+        hip.call('ssc_embedding_gather', E, tok, S * N, C, emb)
+        EW = B.get(tag + '/tf/EW', (S * N, G4))
+        hip.matmul(emb, Kw[0:C], EW, bias=bw)
+
+        # ---- word LSTM (state [c,h], batch rows) ----
+        cw = B.get(tag + '/tf/cw', (S + 1, N, C))
+        hw = B.get(tag + '/tf/hw', (S + 1, N, C))
+        acts_w = B.get(tag + '/tf/acts_w', (S, N, G4))
+        tmp_w = B.get(tag + '/tf/tmp_w', (N, G4))
+        hip.fill(cw[0], 0.0)
+        hip.fill(hw[0], 0.0)
+        for i in range(S):
+            hip.matmul(hw[i], Kw[C:2 * C], tmp_w)
+            hip.call('ssc_lstm_pointwise_fwd', tmp_w, EW[i * N:(i + 1) * N], None, 1, mask[i], 1, cw[i], hw[i], N, C,
+                     cw[i + 1], hw[i + 1], acts_w[i])
+        lang = B.get(tag + '/tf/lang', (S * N, C))
+        lang_ss = B.get(tag + '/tf/lang_ss', (S * N,))
+        hip.call('ssc_row_l2norm_fwd', hw[1:], C, None, S * N, C, lang, lang_ss)
+        Rall = B.get(tag + '/tf/Rall', (S * N, G4))
+        hip.matmul(emb, Ka[C:2 * C], Rall)
+        hip.matmul(lang, Ka[2 * C:3 * C], Rall, accumulate=True)
+
+        # ---- multimodal LSTM (state per spatial position) ----
+        ca = B.get(tag + '/tf/ca', (S + 1, R, C))
+        ha = B.get(tag + '/tf/ha', (S + 1, R, C))
+        acts_a = B.get(tag + '/tf/acts_a', (S, R, G4))
+        tmp_a = B.get(tag + '/tf/tmp_a', (R, G4))
+        hip.fill(ca[0], 0.0)
+        hip.fill(ha[0], 0.0)
+        for i in range(S):
+            if i == 0:
+                hip.fill(tmp_a, 0.0)        # h_a = 0: skip the GEMM
+            else:
+                hip.matmul(ha[i], Ka[3 * C:4 * C], tmp_a)
+            hip.call('ssc_lstm_pointwise_fwd', tmp_a, Gv, Rall[i * N:(i + 1) * N], P, mask[i], P, ca[i], ha[i], R, C,
+                     ca[i + 1], ha[i + 1], acts_a[i])
+        hip.call('ssc_squash_fwd', ha[S], R * C, feat)
+        ctx.update(tok=tok, mask=mask, vis=vis, vis_ss=vis_ss, emb=emb, lang=lang, lang_ss=lang_ss, cw=cw, hw=hw,
+                   acts_w=acts_w, ca=ca, ha=ha, acts_a=acts_a, feat=feat, Gv=Gv)
+        return feat, ctx
+
+    def backward(self, ctx, g_feat):
+        """g_feat [N,h,w,C]: gradient w.r.t. the fused feature.  Fills the TextLSTM parameter
+        gradients and returns the gradient w.r.t. the *normalised* encoder_5 output [R,C]
+        (None when no step ran)."""
+        s, B = self.s, self.b
+        N, P, C, S, tag = ctx['N'], ctx['P'], ctx['C'], ctx['S'], ctx['tag']
+        R, G4 = N * P, 4 * C
+        gE, gKw, gbw = s.grad('generator/TextLSTM/embedding'), s.grad(PFX_W + 'kernel'), s.grad(PFX_W + 'bias')
+        gKa, gba = s.grad(PFX_A + 'kernel'), s.grad(PFX_A + 'bias')
+        if S == 0:
+            for g in (gE, gKw, gbw, gKa, gba):
+                hip.fill(g, 0.0)
+            return None
+        Kw, Ka = s[PFX_W + 'kernel'], s[PFX_A + 'kernel']
+        ca, ha, acts_a, mask = ctx['ca'], ctx['ha'], ctx['acts_a'], ctx['mask']
+        dh = B.get(tag + '/tfb/dh0', (R, C))
+        dh2 = B.get(tag + '/tfb/dh1', (R, C))
+        dc = B.get(tag + '/tfb/dc0', (R, C))
+        dc2 = B.get(tag + '/tfb/dc1', (R, C))
+        dg = B.get(tag + '/tfb/dg', (R, G4))
+        dGv = B.get(tag + '/tfb/dGv', (R, G4))
+        dR = B.get(tag + '/tfb/dR', (S * N, G4))
+        hip.call('ssc_squash_bwd', ha[S], ctx['feat'], g_feat, R * C, dh)
+        hip.fill(dc, 0.0)
+        hip.fill(dGv, 0.0)
+        first = True
+        for i in range(S - 1, -1, -1):
+            hip.call('ssc_lstm_pointwise_bwd', dh, dc, acts_a[i], ca[i], ca[i + 1], mask[i], P, R, C, dg, dc2, dh2, dGv)
+            hip.call('ssc_group_rowsum', dg, G4, N, P, G4, dR[i * N:(i + 1) * N], 0)
+            if i > 0:       # h_a[0] = 0: no contribution, and nothing upstream of it
+                hip.matmul_tn(ha[i], dg, gKa[3 * C:4 * C], accumulate=not first)
+                first = False
+                hip.matmul_nt(dg, Ka[3 * C:4 * C], dh2, accumulate=True)
+            dh, dh2 = dh2, dh
+            dc, dc2 = dc2, dc
+        if first:
+            hip.fill(gKa[3 * C:4 * C], 0.0)
+        hip.call('ssc_group_rowsum', dGv, G4, 1, R, G4, gba, 0)
+        hip.matmul_tn(ctx['vis'], dGv, gKa[0:C])
+        dvis = B.get(tag + '/tfb/dvis', (R, C))
+        hip.matmul_nt(dGv, Ka[0:C], dvis)
+        hip.matmul_tn(ctx['emb'], dR, gKa[C:2 * C])
+        hip.matmul_tn(ctx['lang'], dR, gKa[2 * C:3 * C])
+        demb = B.get(tag + '/tfb/demb', (S * N, C))
+        hip.matmul_nt(dR, Ka[C:2 * C], demb)
+        dlang = B.get(tag + '/tfb/dlang', (S * N, C))
+        hip.matmul_nt(dR, Ka[2 * C:3 * C], dlang)
+        dhw_ext = B.get(tag + '/tfb/dhw_ext', (S * N, C))
+        hip.call('ssc_row_l2norm_bwd', ctx['lang'], ctx['lang_ss'], dlang, S * N, C, dhw_ext, 0)
+
+        # ---- word LSTM BPTT ----
+        cw, hw, acts_w = ctx['cw'], ctx['hw'], ctx['acts_w']
+        dEW = B.get(tag + '/tfb/dEW', (S * N, G4))
+        wh = B.get(tag + '/tfb/wdh0', (N, C))
+        wh2 = B.get(tag + '/tfb/wdh1', (N, C))
+        wc = B.get(tag + '/tfb/wdc0', (N, C))
+        wc2 = B.get(tag + '/tfb/wdc1', (N, C))
+        hip.fill(wh, 0.0)
+        hip.fill(wc, 0.0)
+        first = True
+        for i in range(S - 1, -1, -1):
+            hip.call('ssc_axpy', wh, dhw_ext[i * N:(i + 1) * N], 1.0, N * C)
+            dgw = dEW[i * N:(i + 1) * N]
+            hip.call('ssc_lstm_pointwise_bwd', wh, wc, acts_w[i], cw[i], cw[i + 1], mask[i], 1, N, C, dgw, wc2, wh2,
+                     None)
+            if i > 0:
+                hip.matmul_tn(hw[i], dgw, gKw[C:2 * C], accumulate=not first)
+                first = False
+                hip.matmul_nt(dgw, Kw[C:2 * C], wh2, accumulate=True)
+            wh, wh2 = wh2, wh
+            wc, wc2 = wc2, wc
+        if first:
+            hip.fill(gKw[C:2 * C], 0.0)
+        hip.matmul_tn(ctx['emb'], dEW, gKw[0:C])
+        hip.matmul_nt(dEW, Kw[0:C], demb, accumulate=True)
+        hip.call('ssc_group_rowsum', dEW, G4, 1, S * N, G4, gbw, 0)
+        hip.fill(gE, 0.0)
+        hip.call('ssc_embedding_scatter_add', gE, ctx['tok'], S * N, C, demb)
+        dy5 = B.get(tag + '/tfb/dy5', (R, C))
+        hip.call('ssc_row_l2norm_bwd', ctx['vis'], ctx['vis_ss'], dvis, R, C, dy5, 0)
+        return dy5

@@ -1,0 +1,177 @@
+"""One tower of the reference training graph as eager HIP work:
+build_single_graph + get_losses + optimize (graph_single.py:221-629).
+
+D-step  = sess.run([opt_d, loss_d])  (main_procedure.py:202-216):
+          G forward, D(real) + D(fake) forward, D backward (filter/norm grads), TF-Adam on D.
+G-step  = sess.run([opt_g, loss_g, ...]) (:219-232):
+          G forward, D(fake) forward, D data-gradient only, G backward, TF-Adam on G,
+          spectral-norm ``u`` assignment (graph_single.py:178-210).
+
+Data parallelism (graph_single.py:33-68, average_gradients): one process per GPU,
+each rank = one tower with its own batch statistics; flat gradient buffers are
+summed with RCCL all-reduce on a side HIP stream as soon as a contiguous section
+of the backward pass has produced them, and the 1/world factor is folded into the
+Adam kernel.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import hip
+from .params import Buffers, ParamStore
+from .pix2pix import Pix2PixDiscriminator, Pix2PixGenerator
+
+
+class Pix2PixTrainer(object):
+    def __init__(self, img=192, vocab_size=58, lstm_hybrid=True, lr_g=2e-4, lr_d=1e-4, max_iter_step=100000,
+                 seed=0, sn=True, process_group=None, device='cuda'):
+        if not torch.cuda.is_available():
+            raise RuntimeError('Pix2PixTrainer needs an MI355X (HIP) device: there is no CPU fallback')
+        hip.lib()
+        self.store = ParamStore('Pix2Pix', vocab_size, img, device, seed)
+        self.bufs = Buffers(device)
+        self.G = Pix2PixGenerator(self.store, self.bufs, lstm_hybrid)
+        self.D = Pix2PixDiscriminator(self.store, self.bufs, sn)
+        self.lr_g, self.lr_d, self.max_iter_step = lr_g, lr_d, max_iter_step
+        self.beta1, self.beta2, self.eps = 0.0, 0.9, 1e-8     # graph_single.py:588
+        self.loss = torch.zeros(2, dtype=torch.float32, device=device)   # [loss_g, loss_d]
+        self.pg = process_group
+        self.world = 1
+        self.comm_stream = None
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+            if self.world > 1:
+                self.comm_stream = torch.cuda.Stream()
+        g = self.store.generator.offsets
+        self._g_sections = self._sections(g)
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _sections(offsets):
+        """Contiguous flat ranges in the order the generator backward finishes them."""
+        names = list(offsets.keys())
+        i_emb = names.index('generator/TextLSTM/embedding')
+        i_fc = names.index('generator/fully_connected/weights')
+        end = offsets[names[-1]][0] + (offsets[names[-1]][1] + 63) // 64 * 64
+        o_emb, o_fc = offsets[names[i_emb]][0], offsets[names[i_fc]][0]
+        return {'decoders': (o_fc, end), 'text': (o_emb, o_fc), 'encoders': (0, o_emb)}
+
+    def decay(self, counter):
+        """graph_single.py:139 in fp32: max(0.2, 1 - counter/max_iter*0.9)."""
+        c = np.float32(counter) / np.float32(self.max_iter_step) * np.float32(0.9)
+        return float(max(np.float32(0.2), np.float32(1.0) - c))
+
+    def _allreduce_async(self, flat, lo, hi):
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _allreduce_wait(self):
+        if self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def _adam(self, scope, lr):
+        scope.adam_t += 1
+        t = scope.adam_t
+        lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        hip.call('ssc_adam_tf', scope.flat, scope.grad, None, scope.adam_v, scope.numel, float(lr_t), self.beta1,
+                 self.beta2, self.eps, 1.0 / self.world)
+
+    def _pack_fake(self, batch):
+        B = self.bufs
+        N, _, H, W = batch['sketches'].shape
+        xd_f = B.get('xd_fake', (N, H, W, 8), zero_on_alloc=True)
+        hip.nchw_to_nhwc(batch['sketches'], xd_f, 0)
+        gctx = self.G.forward(batch['sketches'], batch['text'], batch['noise_vec'], 'g', out=xd_f, out_coff=3)
+        return xd_f, gctx
+
+    # ------------------------------------------------------------------ steps
+    def d_step(self, batch, counter=0):
+        """One discriminator update; returns the device scalar loss_d (a view of self.loss)."""
+        B, s = self.bufs, self.store
+        N, _, H, W = batch['sketches'].shape
+        xd_f, gctx = self._pack_fake(batch)
+        xd_r = B.get('xd_real', (N, H, W, 8), zero_on_alloc=True)
+        hip.nchw_to_nhwc(batch['sketches'], xd_r, 0)
+        hip.nchw_to_nhwc(batch['images_d'], xd_r, 3)
+        sn = self.D.prepare_sn()
+        cr = self.D.forward(xd_r, sn, 'dr')
+        cf = self.D.forward(xd_f, sn, 'df')
+        loss_d = self.loss[1:2]
+        hip.fill(loss_d, 0.0)
+        rows = cr['disc'].shape[0] * cr['disc'].shape[1] * cr['disc'].shape[2]
+        dl5_r = B.get('dl5_r', cr['disc'].shape, zero_on_alloc=True)
+        dl5_f = B.get('dl5_f', cf['disc'].shape, zero_on_alloc=True)
+        hip.call('ssc_softplus_loss', cf['disc'], 4, rows, 1.0, 1.0 / rows, loss_d, dl5_f, 1.0 / rows)
+        hip.call('ssc_softplus_loss', cr['disc'], 4, rows, -1.0, 1.0 / rows, loss_d, dl5_r, 1.0 / rows)
+        K = cr['logits'].shape[1]
+        dlog_r = B.get('dlog_r', (N, K))
+        hip.call('ssc_acgan_loss', cr['logits'], batch['class_id_d'], N, K, 1, 1.0, loss_d, dlog_r)
+        self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False)
+        self.D.backward(cf, dl5_f, None, sn, True, False, accumulate=True)
+        self.D.finish_sn_backward(sn)
+        hip.call('ssc_l2_reg', s['discriminator/fully_connected/weights'],
+                 s['discriminator/fully_connected/weights'].numel(), 1e-6, loss_d,
+                 s.grad('discriminator/fully_connected/weights'))
+        sc = s.discriminator
+        self._allreduce_async(sc.grad, 0, sc.numel)
+        self._allreduce_wait()
+        self._adam(sc, self.lr_d * self.decay(counter))
+        self.last = {'gctx': gctx, 'cr': cr, 'cf': cf}
+        return loss_d
+
+    def g_step(self, batch, counter=0):
+        """One generator update (+ spectral-norm u assignment); returns the device scalar loss_g."""
+        B, s = self.bufs, self.store
+        N, _, H, W = batch['sketches'].shape
+        xd_f, gctx = self._pack_fake(batch)
+        sn = self.D.prepare_sn()
+        cf = self.D.forward(xd_f, sn, 'df')
+        loss_g = self.loss[0:1]
+        hip.fill(loss_g, 0.0)
+        rows = cf['disc'].shape[0] * cf['disc'].shape[1] * cf['disc'].shape[2]
+        dl5_f = B.get('dl5_f', cf['disc'].shape, zero_on_alloc=True)
+        hip.call('ssc_softplus_loss', cf['disc'], 4, rows, -1.0, 1.0 / rows, loss_g, dl5_f, 1.0 / rows)
+        K = cf['logits'].shape[1]
+        dlog_f = B.get('dlog_f', (N, K))
+        hip.call('ssc_acgan_loss', cf['logits'], batch['class_id'], N, K, 0, 0.5, loss_g, dlog_f)
+        dgen = self.D.backward(cf, dl5_f, dlog_f, sn, False, True, accumulate=False)
+        img4 = B.get('img4', (N, H, W, 4), zero_on_alloc=True)
+        hip.nchw_to_nhwc(batch['images'], img4, 0)
+        dpre = B.get('dpre', (N, H, W, 4))
+        hip.call('ssc_gen_output_grad', xd_f.view(-1)[3:], 8, img4, 4, dgen, 4, N * H * W, 100.0, loss_g, dpre)
+        sc = s.generator
+        self.G.backward(gctx, dpre, on_section=lambda name: self._section_done(sc, name))
+        self._allreduce_wait()
+        self._adam(sc, self.lr_g * self.decay(counter))
+        if self.D.sn:
+            s['discriminator/fully_connected/u'].copy_(sn['u_new'])
+        self.last = {'gctx': gctx, 'cf': cf}
+        return loss_g
+
+    def _section_done(self, sc, name):
+        s = self.store
+        if name == 'decoders':      # the noise head's regulariser lives in this section
+            hip.call('ssc_l2_reg', s['generator/fully_connected/weights'],
+                     s['generator/fully_connected/weights'].numel(), 1e-6, self.loss[0:1],
+                     s.grad('generator/fully_connected/weights'))
+        lo, hi = self._g_sections[name]
+        self._allreduce_async(sc.grad, lo, hi)
+
+    def train_iteration(self, batch_d, batch_g, counter=0):
+        """D-step then G-step on independent batches (main_procedure.py:178-232)."""
+        ld = self.d_step(batch_d, counter)
+        lg = self.g_step(batch_g, counter)
+        return lg, ld
+
+    def generate(self, sketches, text, noise_vec):
+        """Inference path of build_single_graph (training=False): NCHW in, NCHW out."""
+        ctx = self.G.forward(sketches, text, noise_vec, 'g')
+        return self.G.output_nchw(ctx)

@@ -104,7 +104,9 @@ def test_deconv_forward(n, h, c0, c1, co):
     ldc = 8 if co == 3 else co
     coff = 3 if co == 3 else 0
     out = torch.zeros((n, 2 * h, 2 * h, ldc), device='cuda')
-    v = hip.View(nhwc(xa).cuda(), nhwc(xb).cuda() if c1 else None, ab.cuda(), 1)
+    ab0 = torch.cat([ab[:c0], ab[ci:ci + c0]]).cuda()
+    ab1 = torch.cat([ab[c0:ci], ab[ci + c0:]]).cuda() if c1 else None
+    v = hip.View(nhwc(xa).cuda(), nhwc(xb).cuda() if c1 else None, ab0, 1, ab1)
     hip.deconv_forward(v, f.cuda(), out, coff=coff, epi=(1 if co == 3 else 0))
     got = nchw(out[..., coff:coff + co])
     close(got, torch.tanh(ref) if co == 3 else ref)
@@ -188,7 +190,9 @@ def test_deconv_dgrad_and_wgrad():
     close(nchw(d0), xa.grad[:, :c0])
     close(nchw(d1), xa.grad[:, c0:])
     xd = x.detach()
-    v = hip.View(nhwc(xd[:, :c0]).cuda(), nhwc(xd[:, c0:]).cuda(), ab.cuda(), 1)
+    ab0 = torch.cat([ab[:c0], ab[ci:ci + c0]]).cuda()
+    ab1 = torch.cat([ab[c0:ci], ab[ci + c0:]]).cuda()
+    v = hip.View(nhwc(xd[:, :c0]).cuda(), nhwc(xd[:, c0:]).cuda(), ab0, 1, ab1)
     df = torch.full((4, 4, co, ci), float('nan'), device='cuda')
     hip.deconv_wgrad(v, dyv, df)
     close(df, f.grad)
