@@ -155,18 +155,19 @@ int ssc_add_row_bcast(float* g, const float* v, float scale, int N, int P, int C
 int ssc_miu_permute_fwd(const float* pre, int N, int Cc, int P, float* out, void* stream);
 int ssc_miu_permute_bwd(const float* pre, const float* g, int N, int Cc, int P, float* dpre, void* stream);
 
-/* --- losses / optimizer (losses_optim.hip): graph_single.py:317-593 --- */
+/* --- losses / optimizer (losses_optim.hip): graph_single.py:317-593 ---
+ * loss_acc points to a DOUBLE device scalar that the kernels add into (zero it first). */
 /* loss_acc += scale*sum softplus(sign*x[r*ld]); grad[r*ld] = gscale*sign*sigmoid(sign*x)   (:401-402) */
-int ssc_softplus_loss(const float* x, int ld, int64_t rows, float sign, float scale, float* loss_acc, float* grad,
+int ssc_softplus_loss(const float* x, int ld, int64_t rows, float sign, float scale, double* loss_acc, float* grad,
                       float gscale, void* stream);
 /* sparse softmax CE (focal=0) or (1-p_true)^2 * CE (focal=1), mean over N, times coef   (:340-353) */
-int ssc_acgan_loss(const float* logits, const int* labels, int N, int K, int focal, float coef, float* loss_acc,
+int ssc_acgan_loss(const float* logits, const int* labels, int N, int K, int focal, float coef, double* loss_acc,
                    float* dlogits, void* stream);
 /* smooth-L1(img - gen) mean * coef (:551-555) + incoming discriminator gradient, through tanh' */
 int ssc_gen_output_grad(const float* gen, int ldg, const float* img, int ldi, const float* gd, int ldd, int64_t npix,
-                        float coef, float* loss_acc, float* dpre, void* stream);
+                        float coef, double* loss_acc, float* dpre, void* stream);
 /* ly.l2_regularizer: loss_acc += rate*sum(w^2)/2; grad += rate*w   (mru.py:55,60) */
-int ssc_l2_reg(const float* w, int64_t n, float rate, float* loss_acc, float* grad, void* stream);
+int ssc_l2_reg(const float* w, int64_t n, float rate, double* loss_acc, float* grad, void* stream);
 /* tf.train.AdamOptimizer dense apply (graph_single.py:588); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host */
 int ssc_adam_tf(float* var, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
                 float eps, float gscale, void* stream);

@@ -255,6 +255,19 @@ def build_single_graph(p, images, sketches, images_d, class_id, class_id_d, text
             'real_logit': real_logit.detach(), 'fake_logit': fake_logit.detach()}
 
 
+def build_single_graph_f64(p, **batch):
+    """The same restatement evaluated in float64: the arbiter when two fp32 paths disagree
+    (batch-stat-norm gradients are ill-conditioned: fp32 torch differs from fp64 by up to ~7e-3)."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        p64 = OrderedDict((k, v.double()) for k, v in p.items())
+        b64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+        return build_single_graph(p64, **b64)
+    finally:
+        torch.set_default_dtype(old)
+
+
 class TrainState(object):
     """Adam slots + step counts for the two optimizers (graph_single.py:138-142)."""
 

@@ -30,7 +30,7 @@ __device__ __forceinline__ float sigmoidf2_(float x) { return 1.f / (1.f + expf(
 // ------------------------------------------------------------------ patch GAN loss (get_loss_wgan_sn, :388-419)
 // loss_acc[slot] += scale * sum_r softplus(sign*x[r*ld]);  grad[r*ld] = gscale*sign*sigmoid(sign*x)
 __global__ __launch_bounds__(256) void softplus_loss_kernel(const float* __restrict__ x, int ld, long rows, float sign,
-                                                             float scale, float* __restrict__ loss_acc,
+                                                             float scale, double* __restrict__ loss_acc,
                                                              float* __restrict__ grad, float gscale) {
     __shared__ float sh[4];
     float s = 0.f;
@@ -40,10 +40,10 @@ __global__ __launch_bounds__(256) void softplus_loss_kernel(const float* __restr
         if (grad != nullptr) grad[r * ld] = gscale * sign * sigmoidf2_(v);
     }
     const float t = block_sum_256(s, sh);
-    if (threadIdx.x == 0) atomicAdd(loss_acc, scale * t);
+    if (threadIdx.x == 0) atomicAdd(loss_acc, (double)scale * (double)t);
 }
 
-extern "C" int ssc_softplus_loss(const float* x, int ld, int64_t rows, float sign, float scale, float* loss_acc,
+extern "C" int ssc_softplus_loss(const float* x, int ld, int64_t rows, float sign, float scale, double* loss_acc,
                                  float* grad, float gscale, void* stream) {
     long blocks = (rows + 255) / 256;
     if (blocks > 64) blocks = 64;
@@ -56,7 +56,7 @@ extern "C" int ssc_softplus_loss(const float* x, int ld, int64_t rows, float sig
 // focal=0: loss += coef*mean CE;  focal=1: loss += coef*mean (1-p_t)^2 * CE.  One wavefront per sample, K <= 64.
 __global__ __launch_bounds__(64) void acgan_loss_kernel(const float* __restrict__ logits, const int* __restrict__ labels,
                                                          int N, int K, int focal, float coef,
-                                                         float* __restrict__ loss_acc, float* __restrict__ dlogits) {
+                                                         double* __restrict__ loss_acc, float* __restrict__ dlogits) {
     const int n = blockIdx.x;
     const int lane = threadIdx.x;
     const float v = lane < K ? logits[(long)n * K + lane] : -INFINITY;
@@ -81,11 +81,11 @@ __global__ __launch_bounds__(64) void acgan_loss_kernel(const float* __restrict_
         g = p - (lane == t ? 1.f : 0.f);
     }
     if (lane < K && dlogits != nullptr) dlogits[(long)n * K + lane] = coef * g / (float)N;
-    if (lane == 0) atomicAdd(loss_acc, coef * loss / (float)N);
+    if (lane == 0) atomicAdd(loss_acc, (double)coef * (double)loss / (double)N);
 }
 
 extern "C" int ssc_acgan_loss(const float* logits, const int* labels, int N, int K, int focal, float coef,
-                              float* loss_acc, float* dlogits, void* stream) {
+                              double* loss_acc, float* dlogits, void* stream) {
     if (K > 64) return -1;
     hipLaunchKernelGGL(acgan_loss_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, logits, labels, N, K, focal, coef,
                        loss_acc, dlogits);
@@ -98,7 +98,7 @@ extern "C" int ssc_acgan_loss(const float* logits, const int* labels, int N, int
 __global__ __launch_bounds__(256) void gen_output_grad_kernel(const float* __restrict__ gen, int ldg,
                                                                const float* __restrict__ img, int ldi,
                                                                const float* __restrict__ gd, int ldd, long npix,
-                                                               float coef, float* __restrict__ loss_acc,
+                                                               float coef, double* __restrict__ loss_acc,
                                                                float* __restrict__ dpre) {
     __shared__ float sh[4];
     const float inv = 1.f / (3.f * (float)npix);
@@ -119,11 +119,11 @@ __global__ __launch_bounds__(256) void gen_output_grad_kernel(const float* __res
         if (dpre != nullptr) *reinterpret_cast<float4*>(dpre + p * 4) = o;
     }
     const float t = block_sum_256(s, sh);
-    if (threadIdx.x == 0) atomicAdd(loss_acc, coef * inv * t);
+    if (threadIdx.x == 0) atomicAdd(loss_acc, (double)coef * (double)inv * (double)t);
 }
 
 extern "C" int ssc_gen_output_grad(const float* gen, int ldg, const float* img, int ldi, const float* gd, int ldd,
-                                   int64_t npix, float coef, float* loss_acc, float* dpre, void* stream) {
+                                   int64_t npix, float coef, double* loss_acc, float* dpre, void* stream) {
     long blocks = (npix + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(gen_output_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gen, ldg, img,
@@ -134,7 +134,7 @@ extern "C" int ssc_gen_output_grad(const float* gen, int ldg, const float* img, 
 // ------------------------------------------------------------------ l2 regulariser (ly.l2_regularizer, mru.py:55,60)
 // loss += rate*sum(w^2)/2 ; grad += rate*w
 __global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ w, long n, float rate,
-                                                      float* __restrict__ loss_acc, float* __restrict__ grad) {
+                                                      double* __restrict__ loss_acc, float* __restrict__ grad) {
     __shared__ float sh[4];
     float s = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -143,10 +143,10 @@ __global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ w
         if (grad != nullptr) grad[i] += rate * v;
     }
     const float t = block_sum_256(s, sh);
-    if (threadIdx.x == 0 && loss_acc != nullptr) atomicAdd(loss_acc, 0.5f * rate * t);
+    if (threadIdx.x == 0 && loss_acc != nullptr) atomicAdd(loss_acc, 0.5 * (double)rate * (double)t);
 }
 
-extern "C" int ssc_l2_reg(const float* w, int64_t n, float rate, float* loss_acc, float* grad, void* stream) {
+extern "C" int ssc_l2_reg(const float* w, int64_t n, float rate, double* loss_acc, float* grad, void* stream) {
     long blocks = (n + 255) / 256;
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(l2_reg_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (long)n, rate,

@@ -35,7 +35,7 @@ class Pix2PixTrainer(object):
         self.D = Pix2PixDiscriminator(self.store, self.bufs, sn)
         self.lr_g, self.lr_d, self.max_iter_step = lr_g, lr_d, max_iter_step
         self.beta1, self.beta2, self.eps = 0.0, 0.9, 1e-8     # graph_single.py:588
-        self.loss = torch.zeros(2, dtype=torch.float32, device=device)   # [loss_g, loss_d]
+        self.loss = torch.zeros(2, dtype=torch.float64, device=device)   # [loss_g, loss_d], summed in double
         self.pg = process_group
         self.world = 1
         self.comm_stream = None
@@ -105,7 +105,7 @@ class Pix2PixTrainer(object):
         cr = self.D.forward(xd_r, sn, 'dr')
         cf = self.D.forward(xd_f, sn, 'df')
         loss_d = self.loss[1:2]
-        hip.fill(loss_d, 0.0)
+        loss_d.zero_()
         rows = cr['disc'].shape[0] * cr['disc'].shape[1] * cr['disc'].shape[2]
         dl5_r = B.get('dl5_r', cr['disc'].shape, zero_on_alloc=True)
         dl5_f = B.get('dl5_f', cf['disc'].shape, zero_on_alloc=True)
@@ -135,7 +135,7 @@ class Pix2PixTrainer(object):
         sn = self.D.prepare_sn()
         cf = self.D.forward(xd_f, sn, 'df')
         loss_g = self.loss[0:1]
-        hip.fill(loss_g, 0.0)
+        loss_g.zero_()
         rows = cf['disc'].shape[0] * cf['disc'].shape[1] * cf['disc'].shape[2]
         dl5_f = B.get('dl5_f', cf['disc'].shape, zero_on_alloc=True)
         hip.call('ssc_softplus_loss', cf['disc'], 4, rows, -1.0, 1.0 / rows, loss_g, dl5_f, 1.0 / rows)

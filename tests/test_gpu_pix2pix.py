@@ -54,29 +54,39 @@ def test_discriminator_forward_parity():
     assert float((c['logits'].cpu() - logits).abs().max()) < 1e-3
 
 
-def _check_grads(scope, ref_grads, tol):
-    worst = ('', 0.0)
+def _check_grads(scope, ref_grads, tol_l2=3e-3, tol_max=3e-2):
+    """Relative L2 error per variable vs the float64 oracle, plus a loose max-abs bound: a
+    relu/lrelu input within fp32 noise of 0 flips its derivative and moves single entries by
+    O(gradient) in ANY fp32 evaluation (torch-CPU fp32 shows the same outliers vs float64)."""
+    worst_l2, worst_max = ('', 0.0), ('', 0.0)
     for name, g in ref_grads.items():
-        e = relerr(scope.g[name], g)
-        if e > worst[1]:
-            worst = (name, e)
-    assert worst[1] < tol, worst
+        a = scope.g[name].detach().cpu().double()
+        l2 = float((a - g).norm() / g.norm())
+        mx = float((a - g).abs().max() / g.abs().max())
+        if l2 > worst_l2[1]:
+            worst_l2 = (name, l2)
+        if mx > worst_max[1]:
+            worst_max = (name, mx)
+    assert worst_l2[1] < tol_l2, worst_l2
+    assert worst_max[1] < tol_max, worst_max
 
 
 @pytest.mark.parametrize('n,img', [(2, 192), (3, 64)])
 def test_train_step_gradients_parity(n, img):
-    """loss_d / loss_g and every gradient of one tower vs torch autograd on the oracle."""
+    """loss_d / loss_g and every gradient of one tower vs autograd on the oracle.  The oracle is
+    evaluated in float64 here: gradients through batch-statistics norm are ill-conditioned and
+    the fp32 torch-CPU oracle itself is up to 7e-3 away from float64 (see oracle/pix2pix.py)."""
     p, tr, b, dev = make(n, img)
-    r = O.build_single_graph(p, **b)
+    r = O.build_single_graph_f64(p, **b)
     ld = tr.d_step(dev, counter=0)
-    assert abs(float(ld) - float(r['loss_d'])) < 1e-3 * max(1.0, abs(float(r['loss_d'])))
+    assert abs(float(ld) - float(r['loss_d'])) < 1e-5 * max(1.0, abs(float(r['loss_d'])))
     # gradients are still in the flat buffer after the update
-    _check_grads(tr.store.discriminator, r['grad_d'], 2e-3)
+    _check_grads(tr.store.discriminator, r['grad_d'])
     # undo the D update so the G-step sees the same weights as the oracle graph
     tr.store.load_dict(p)
     lg = tr.g_step(dev, counter=0)
-    assert abs(float(lg) - float(r['loss_g'])) < 1e-3 * max(1.0, abs(float(r['loss_g'])))
-    _check_grads(tr.store.generator, r['grad_g'], 2e-3)
+    assert abs(float(lg) - float(r['loss_g'])) < 1e-5 * max(1.0, abs(float(r['loss_g'])))
+    _check_grads(tr.store.generator, r['grad_g'])
     assert relerr(tr.store['discriminator/fully_connected/u'], r['u_new']) < 1e-4
 
 
