@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""Headline benchmark: train images/sec of the Foreground_Instance_Colorization GAN step
+(192x192, generator + PatchGAN discriminator, forward + backward + TF-Adam), Pix2Pix variant,
+batch 32 per GPU (BASELINE.json configs[2]; with --gpus N it is configs[3], weak scaling).
+
+One "step" = one D-step + one G-step on two independent resident batches, exactly the work of
+one iteration of main_procedure.train (reference main_procedure.py:178-232).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline     : the dominant implicit-GEMM kernel's algorithmic TFLOP/s from HIP events, vs the
+                 157.3 TFLOP/s fp32 MFMA peak of MI355X
+  cpu_baseline : the torch-CPU fp32 oracle (a port of the reference arithmetic; TensorFlow is not
+                 installable here) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+F_G, F_D = 10.84e9, 3.55e9         # forward FLOPs per image as written in the reference
+
+
+def cpu_baseline(img, n=4):
+    """Reference arithmetic on the host CPU: one D-step + one G-step of the torch-fp32 oracle."""
+    from oracle import pix2pix as O
+    torch.manual_seed(0)
+    p = O.init_params(0, img=img)
+    st = O.TrainState(p)
+    b1, b2 = O.synthetic_batch(n, seed=1, img=img), O.synthetic_batch(n, seed=2, img=img)
+    t0 = time.time()
+    O.d_step(p, st, b1, 1e-4, 0, 100000)
+    O.g_step(p, st, b2, 2e-4, 0, 100000)
+    dt = time.time() - t0
+    return {'value': n / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 train iteration (D-step + G-step) at batch %d, %dx%d, torch-CPU fp32 oracle '
+                      '(oracle/pix2pix.py), %.1f s' % (n, img, img, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (reference --batch_size is per GPU)')
+    ap.add_argument('--img', type=int, default=192)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        pg = dist.group.WORLD
+
+    from sketchyscenecolorization_amd import hip
+    from sketchyscenecolorization_amd.synthetic import synthetic_batch
+    from sketchyscenecolorization_amd.trainer import Pix2PixTrainer
+
+    tr = Pix2PixTrainer(img=args.img, seed=0, process_group=pg)
+    bd = synthetic_batch(args.batch, 1234 + rank, args.img)
+    bg = synthetic_batch(args.batch, 5678 + rank, args.img)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        tr.train_iteration(bd, bg, counter=i)
+    barrier()
+    prof = None if args.no_kernel_events else []
+    hip.PROFILE = prof
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        tr.train_iteration(bd, bg, counter=args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    hip.PROFILE = None
+    loss_g, loss_d = [float(v) for v in tr.loss.tolist()]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+
+    if rank == 0:
+        global_batch = args.batch * world
+        ms = dt / args.steps * 1e3
+        value = global_batch * args.steps / dt
+        flops_step = (4 * F_G + 8 * F_D) * args.batch       # per GPU, as-written reference FLOPs
+        out = {'metric': 'train images/sec (192x192, gen+disc fwd+bwd)', 'value': value, 'unit': 'images/sec',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32',
+               'data': 'synthetic',
+               'config': {'workload': 'Foreground_Instance_Colorization Pix2Pix GAN train step '
+                                      '(D-step + G-step, TF-Adam), %dx%d, batch %d per GPU' % (args.img, args.img,
+                                                                                             args.batch),
+                          'global_batch': global_batch, 'parallelism': 'dp%d' % world,
+                          'block_type': 'Pix2Pix', 'loss_g': loss_g, 'loss_d': loss_d},
+               'step_tflops_as_written': flops_step / (ms * 1e-3) / 1e12,
+               'step_frac_of_fp32_peak': flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        if prof:
+            agg = {}
+            for name, fl, e0, e1 in prof:
+                a = agg.setdefault(name, [0.0, 0.0, 0])
+                a[0] += fl
+                a[1] += e0.elapsed_time(e1) * 1e-3
+                a[2] += 1
+            dom = max(agg.items(), key=lambda kv: kv[1][1])
+            name, (fl, sec, cnt) = dom
+            tot_sec = sum(v[1] for v in agg.values())
+            ach = fl / sec / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                               'launches': cnt, 'avg_launch_ms': sec / cnt * 1e3,
+                               'igemm_time_frac_of_step': tot_sec / dt,
+                               'all_igemm_tflops': sum(v[0] for v in agg.values()) / tot_sec / 1e12,
+                               'per_kernel': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / args.steps * 1e3,
+                                                  'launches_per_step': v[2] / args.steps}
+                                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(args.img)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

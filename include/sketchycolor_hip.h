@@ -102,6 +102,9 @@ int ssc_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
 /* implicit GEMM (igemm.hip).  ws: split-K slab workspace (may be NULL). */
 int ssc_conv_forward(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, void* stream);
 int ssc_conv_wgrad(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void* stream);
+/* name of the tile configuration the launcher picks for a descriptor (host only; for profiling) */
+int ssc_conv_forward_kernel_name(const ssc_conv_desc* d, char* buf, int len);
+int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* d, char* buf, int len);
 
 /* --- layout (elementwise.hip) --- */
 /* dst[n,hw,coff+c] = src[n,c,hw]; tf.transpose NCHW->NHWC (models_collection.py:381) */

@@ -552,6 +552,29 @@ static int launch_fwd(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hipSt
     return (int)hipGetLastError();
 }
 
+// tile configuration ids: 0 = 128x128, 1 = 64x128 (few rows), 2 = 128x64, 3 = 128x32
+static int select_fwd_cfg(const ssc_conv_desc& d) {
+    const long M = (long)d.NB * d.PH * d.PW;
+    const bool smallM = M <= 2304;   // few row tiles: use the 64-row tile for more workgroups
+    if (d.Nstore > 64) return smallM ? 1 : 0;
+    if (d.Nstore > 32) return 2;
+    return 3;
+}
+
+static void copy_name(const char* src, char* dst, int len) {
+    int i = 0;
+    for (; i < len - 1 && src[i]; ++i) dst[i] = src[i];
+    if (len > 0) dst[i] = 0;
+}
+
+extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, int len) {
+    static const char* names[2][4] = {
+        {"conv_fwd<128x128,KN>", "conv_fwd<64x128,KN>", "conv_fwd<128x64,KN>", "conv_fwd<128x32,KN>"},
+        {"conv_fwd<128x128,NK>", "conv_fwd<64x128,NK>", "conv_fwd<128x64,NK>", "conv_fwd<128x32,NK>"}};
+    copy_name(names[dp->bmode ? 1 : 0][select_fwd_cfg(*dp)], buf, len);
+    return 0;
+}
+
 extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, void* stream) {
     const ssc_conv_desc& d = *dp;
     hipStream_t st = (hipStream_t)stream;
@@ -562,18 +585,21 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
         return -3;
     // split-K partial slabs cover the whole output; with 4 phases every phase writes a disjoint
     // quarter of each slab, so unwritten entries must not exist: require all phases present (true).
-    const long M = (long)d.NB * d.PH * d.PW;
-    const bool smallM = M <= 2304;   // few row tiles: use the 64-row tile for more workgroups
+    const int cfg = select_fwd_cfg(d);
     if (d.bmode == 0) {
-        if (d.Nstore > 64) return smallM ? launch_fwd<2, 2, 1, 2, 0>(d, ws, ws_bytes, st)
-                                         : launch_fwd<2, 2, 2, 2, 0>(d, ws, ws_bytes, st);
-        if (d.Nstore > 32) return launch_fwd<2, 2, 2, 1, 0>(d, ws, ws_bytes, st);
-        return launch_fwd<4, 1, 1, 1, 0>(d, ws, ws_bytes, st);
+        switch (cfg) {
+            case 0: return launch_fwd<2, 2, 2, 2, 0>(d, ws, ws_bytes, st);
+            case 1: return launch_fwd<2, 2, 1, 2, 0>(d, ws, ws_bytes, st);
+            case 2: return launch_fwd<2, 2, 2, 1, 0>(d, ws, ws_bytes, st);
+            default: return launch_fwd<4, 1, 1, 1, 0>(d, ws, ws_bytes, st);
+        }
     } else {
-        if (d.Nstore > 64) return smallM ? launch_fwd<2, 2, 1, 2, 1>(d, ws, ws_bytes, st)
-                                         : launch_fwd<2, 2, 2, 2, 1>(d, ws, ws_bytes, st);
-        if (d.Nstore > 32) return launch_fwd<2, 2, 2, 1, 1>(d, ws, ws_bytes, st);
-        return launch_fwd<4, 1, 1, 1, 1>(d, ws, ws_bytes, st);
+        switch (cfg) {
+            case 0: return launch_fwd<2, 2, 2, 2, 1>(d, ws, ws_bytes, st);
+            case 1: return launch_fwd<2, 2, 1, 2, 1>(d, ws, ws_bytes, st);
+            case 2: return launch_fwd<2, 2, 2, 1, 1>(d, ws, ws_bytes, st);
+            default: return launch_fwd<4, 1, 1, 1, 1>(d, ws, ws_bytes, st);
+        }
     }
 }
 
@@ -616,6 +642,21 @@ static int launch_wgrad(const ssc_wgrad_desc& d, float* ws, int64_t ws_bytes, hi
     return (int)hipGetLastError();
 }
 
+// 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
+static int select_wgrad_cfg(const ssc_wgrad_desc& d) {
+    const int Mtot = d.TH * d.TW * (d.g.C0 + d.g.C1);
+    if (d.Nn > 64) return Mtot > 64 ? 0 : 1;
+    if (d.Nn > 32) return Mtot > 64 ? 2 : 3;
+    return 4;
+}
+
+extern "C" int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* dp, char* buf, int len) {
+    static const char* names[5] = {"conv_wgrad<128x128>", "conv_wgrad<64x128>", "conv_wgrad<128x64>",
+                                   "conv_wgrad<64x64>", "conv_wgrad<128x32>"};
+    copy_name(names[select_wgrad_cfg(*dp)], buf, len);
+    return 0;
+}
+
 extern "C" int ssc_conv_wgrad(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream) {
     const ssc_wgrad_desc& d = *dp;
     hipStream_t st = (hipStream_t)stream;
@@ -624,15 +665,11 @@ extern "C" int ssc_conv_wgrad(const ssc_wgrad_desc* dp, float* ws, int64_t ws_by
     // the filter-gradient slab is dense [TH*TW*Cg_real][ldc]; rows/cols skipped by the kernel
     // (padding channels) do not exist in it, so every slab entry is written when ldc == Nn.
     if (d.ldc != d.Nn) return -3;
-    const int Cg = d.g.C0 + d.g.C1;
-    const int Mtot = d.TH * d.TW * Cg;
-    if (d.Nn > 64) {
-        if (Mtot > 64) return launch_wgrad<2, 2, 2, 2>(d, ws, ws_bytes, st);
-        return launch_wgrad<1, 4, 2, 1>(d, ws, ws_bytes, st);
+    switch (select_wgrad_cfg(d)) {
+        case 0: return launch_wgrad<2, 2, 2, 2>(d, ws, ws_bytes, st);
+        case 1: return launch_wgrad<1, 4, 2, 1>(d, ws, ws_bytes, st);
+        case 2: return launch_wgrad<2, 2, 2, 1>(d, ws, ws_bytes, st);
+        case 3: return launch_wgrad<2, 2, 1, 1>(d, ws, ws_bytes, st);
+        default: return launch_wgrad<4, 1, 1, 1>(d, ws, ws_bytes, st);
     }
-    if (d.Nn > 32) {
-        if (Mtot > 64) return launch_wgrad<2, 2, 2, 1>(d, ws, ws_bytes, st);
-        return launch_wgrad<2, 2, 1, 1>(d, ws, ws_bytes, st);
-    }
-    return launch_wgrad<4, 1, 1, 1>(d, ws, ws_bytes, st);
 }

@@ -66,6 +66,8 @@ SIGNATURES = {
     'ssc_device_info': [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, _I],
     'ssc_conv_forward': [C.POINTER(ConvDesc), _P, _L, _P],
     'ssc_conv_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
+    'ssc_conv_forward_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, _I],
+    'ssc_conv_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, _I],
     'ssc_nchw_to_nhwc': [_P, _P, _I, _I, _I, _I, _I, _P],
     'ssc_nhwc_to_nchw': [_P, _P, _I, _I, _I, _I, _I, _P],
     'ssc_fill': [_P, _F, _L, _P],
@@ -160,14 +162,41 @@ class View(object):
         return g
 
 
+# When PROFILE is a list, every implicit-GEMM launch is bracketed by HIP events on the launch
+# stream and (kernel name, algorithmic FLOPs, start, stop) is appended (bench.py roofline leg).
+PROFILE = None
+
+
+def _kernel_name(fn, d):
+    buf = C.create_string_buffer(64)
+    getattr(lib(), fn)(C.byref(d), buf, 64)
+    return buf.value.decode()
+
+
 def _run_conv(d):
     ws = workspace()
+    if PROFILE is None:
+        check(lib().ssc_conv_forward(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_forward')
+        return
+    flops = 2.0 * d.NB * d.PH * d.PW * d.nphase * d.TH * d.TW * d.k_real * d.Nn
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib().ssc_conv_forward(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_forward')
+    e1.record()
+    PROFILE.append((_kernel_name('ssc_conv_forward_kernel_name', d), flops, e0, e1))
 
 
 def _run_wgrad(d):
     ws = workspace()
+    if PROFILE is None:
+        check(lib().ssc_conv_wgrad(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_wgrad')
+        return
+    flops = 2.0 * d.NB * d.PH * d.PW * d.TH * d.TW * d.Cg_real * d.Nn
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib().ssc_conv_wgrad(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_wgrad')
+    e1.record()
+    PROFILE.append((_kernel_name('ssc_conv_wgrad_kernel_name', d), flops, e0, e1))
 
 
 def _out_geom(out, coff):
