@@ -109,16 +109,28 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
-                                         const float* __restrict__ scale, const float* __restrict__ offset, float eps,
-                                         float* __restrict__ ab, float* __restrict__ stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one wavefront per channel: lanes stride over the row-block partials, reduce in double
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                                 long M, const float* __restrict__ scale,
+                                                                 const float* __restrict__ offset, float eps,
+                                                                 float* __restrict__ ab, float* __restrict__ stats) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         s += (double)partial[(long)b * 2 * C + c];
         q += (double)partial[(long)b * 2 * C + C + c];
     }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane != 0) return;
     const double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -138,7 +150,7 @@ extern "C" int ssc_bn_stats(const float* x, int64_t M, int C, int ldx, const flo
     if ((int64_t)nbr * 2 * C * (int64_t)sizeof(float) > ws_bytes) return -2;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, x, (long)M, C, ldx, tcg, ws);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ws, nbr, C, (long)M, scale,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, ws, nbr, C, (long)M, scale,
                        offset, eps, ab, stats);
     return CHECK_LAUNCH();
 }
@@ -208,16 +220,21 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(BnBwdArgs a, int tc
 }
 
 // coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat); dscale/doffset written (or accumulated)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
-                                       float* __restrict__ coef, float* __restrict__ dscale,
-                                       float* __restrict__ doffset) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                               long M, float* __restrict__ coef,
+                                                               float* __restrict__ dscale,
+                                                               float* __restrict__ doffset) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         s += (double)partial[(long)b * 2 * C + c];
         q += (double)partial[(long)b * 2 * C + C + c];
     }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane != 0) return;
     coef[c] = (float)(s / (double)M);
     coef[C + c] = (float)(q / (double)M);
     if (dscale != nullptr) dscale[c] = (float)q;
@@ -272,7 +289,7 @@ extern "C" int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, co
         if (((int64_t)nbr * 2 * C + 2 * C) * (int64_t)sizeof(float) > ws_bytes) return -2;
         coef = ws + (int64_t)nbr * 2 * C;
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, a, tcg, ws);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ws, nbr, C, (long)M, coef,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, ws, nbr, C, (long)M, coef,
                            dscale, doffset);
     }
     long tot = (long)M * (C / 4);

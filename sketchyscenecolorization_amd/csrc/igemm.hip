@@ -28,24 +28,55 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
-// raw 4-channel load from a gather view at pixel offset `pix` (= (n*H+iy)*W+ix), channel c
-__device__ __forceinline__ float4 gview_load4(const ssc_gview& g, long pix, int c) {
-    const float* p = (c < g.C0) ? (g.s0 + pix * g.C0 + c) : (g.s1 + pix * g.C1 + (c - g.C0));
-    return *reinterpret_cast<const float4*>(p);
+// Exact division by a launch-constant through multiply-high (the tile loaders run every K-tile:
+// no integer-division expansions, no branches, so all global loads of a tile issue back to back
+// and their latency hides under the MFMA loop of the current tile).
+struct Magics {
+    unsigned mC, oneC;          // kcol / C   (kcol < 2^20, C < 2^12); one* = ~0 when the divisor is 1
+    unsigned mTW, oneTW;        // tap / TW
+    unsigned long mPW, onePW;   // rem / PW   (64-bit magic: exact for every 32-bit numerator)
+    unsigned long mPHPW, onePHPW; // m / (PH*PW)
+};
+static inline unsigned magic32(unsigned d) { return d == 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; }
+static inline unsigned long magic64(unsigned long d) {
+    return d == 1 ? 0UL : (unsigned long)((((unsigned __int128)1) << 64) / d) + 1UL;
+}
+static Magics make_magics(unsigned C, unsigned TW, unsigned long PW, unsigned long PHW) {
+    Magics m;
+    m.mC = magic32(C); m.oneC = C == 1 ? ~0u : 0u;
+    m.mTW = magic32(TW); m.oneTW = TW == 1 ? ~0u : 0u;
+    m.mPW = magic64(PW); m.onePW = PW == 1 ? ~0UL : 0UL;
+    m.mPHPW = magic64(PHW); m.onePHPW = PHW == 1 ? ~0UL : 0UL;
+    return m;
+}
+__device__ __forceinline__ int div32(int n, unsigned magic, unsigned one) {
+    return (int)(__umulhi((unsigned)n, magic) + ((unsigned)n & one));
+}
+__device__ __forceinline__ long div64(long n, unsigned long magic, unsigned long one) {
+    return (long)(__umul64hi((unsigned long)n, magic) + ((unsigned long)n & one));
 }
 
+// per-thread affine (a, b) for channels [c, c+4) of a gather view; identity when the source has none.
+// Branch-free: a null table is replaced by a valid dummy address and the result by (1, 0).
 __device__ __forceinline__ void gview_affine4(const ssc_gview& g, int c, float4& a, float4& b) {
     const bool first = c < g.C0;
     const float* ab = first ? g.ab0 : g.ab1;
-    if (ab != nullptr) {
-        const int cc = first ? c : c - g.C0;
-        const int Cs = first ? g.C0 : g.C1;
-        a = *reinterpret_cast<const float4*>(ab + cc);
-        b = *reinterpret_cast<const float4*>(ab + Cs + cc);
-    } else {
-        a = make_float4(1.f, 1.f, 1.f, 1.f);
-        b = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    const bool has = ab != nullptr;
+    const int cc = first ? c : c - g.C0;
+    const int Cs = first ? g.C0 : g.C1;
+    const float* pa = has ? ab + cc : g.s0;
+    const float* pb = has ? ab + Cs + cc : g.s0;
+    const float4 va = *reinterpret_cast<const float4*>(pa);
+    const float4 vb = *reinterpret_cast<const float4*>(pb);
+    a = has ? va : make_float4(1.f, 1.f, 1.f, 1.f);
+    b = has ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// base pointer + row stride of the source holding channel c (c, C0 multiples of 4)
+__device__ __forceinline__ void gview_src(const ssc_gview& g, int c, const float*& base, int& cs) {
+    const bool first = c < g.C0;
+    base = first ? g.s0 + c : g.s1 + (c - g.C0);
+    cs = first ? g.C0 : g.C1;
 }
 
 __device__ __forceinline__ float4 xform4(float4 v, const float4& a, const float4& b, int act, bool valid) {
@@ -79,9 +110,10 @@ __device__ __forceinline__ FwdPhase fwd_phase(const ssc_conv_desc& d, int phase)
     return p;
 }
 
-template <int WM, int WN, int SM, int SN, int BMODE>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, float* __restrict__ slab_base,
-                                                        long slab_stride, int splitk) {
+template <int WM, int WN, int SM, int SN, int BMODE, bool VECB>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, const Magics mg,
+                                                        float* __restrict__ slab_base, long slab_stride,
+                                                        int splitk) {
     constexpr int BM = WM * SM * 32;
     constexpr int BN = WN * SN * 32;
     constexpr int A_LD = BK + 1;
@@ -95,6 +127,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, fl
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [2][A_SZ]
     float* Bs = smem + 2 * A_SZ;      // [2][B_SZ]
+    long* rowpix = reinterpret_cast<long*>(smem + 2 * A_SZ + 2 * B_SZ);   // [BM] output pixel of each tile row
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,6 +137,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, fl
     const int C = d.x.C0 + d.x.C1;
     const int Ktot = d.TH * d.TW * C;
     const long M = (long)d.NB * d.PH * d.PW;
+    const int PHW = d.PH * d.PW;
     const int phase = blockIdx.z / splitk;
     const int ks = blockIdx.z % splitk;
     const FwdPhase ph = fwd_phase(d, phase);
@@ -118,15 +152,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, fl
     bool a_mv[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-        const long m = m0 + (tid >> 3) + 32 * i;
+        const int row = (tid >> 3) + 32 * i;
+        const long m = m0 + row;
         a_mv[i] = m < M;
         const long mm = a_mv[i] ? m : 0;
-        const int n = (int)(mm / (d.PH * d.PW));
-        const int rem = (int)(mm - (long)n * d.PH * d.PW);
-        const int py = rem / d.PW, px = rem - py * d.PW;
+        const int n = (int)div64(mm, mg.mPHPW, mg.onePHPW);
+        const int rem = (int)(mm - (long)n * PHW);
+        const int py = (int)div64(rem, mg.mPW, mg.onePW), px = rem - py * d.PW;
         a_iyb[i] = py * d.in_stride + ph.ioff_y;
         a_ixb[i] = px * d.in_stride + ph.ioff_x;
         a_nb[i] = (long)n * d.x.H * d.x.W;
+        if (a_col4 == 0)
+            rowpix[row] = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
     }
 
     const int nkt = (Ktot + BK - 1) / BK;
@@ -147,21 +184,29 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, fl
     bool rav[A_ROWS];
     float4 raa, rab;
     float4 rb[B_SLOTS];
+    int rbm[B_SLOTS];     // per-element validity bits of the staged filter values
 
     auto load_tile = [&](int kt) {
-        // ---- A (gather view) ----
-        const int kcol = kt * BK + a_col4 * 4;
-        const bool kv = kcol < Ktot;
-        const int tap = kv ? kcol / C : 0;
-        const int c = kv ? kcol - tap * C : 0;
-        const int ty = tap / d.TW, tx = tap - ty * d.TW;
-        gview_affine4(d.x, c, raa, rab);
+        // ---- A (gather view): every load unconditional from a clamped address ----
+        {
+            const int kcol = kt * BK + a_col4 * 4;
+            const bool kv = kcol < Ktot;
+            const int kk = kv ? kcol : 0;
+            const int tap = div32(kk, mg.mC, mg.oneC);
+            const int c = kk - tap * C;
+            const int ty = div32(tap, mg.mTW, mg.oneTW), tx = tap - ty * d.TW;
+            gview_affine4(d.x, c, raa, rab);
+            const float* base;
+            int cs;
+            gview_src(d.x, c, base, cs);
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) {
-            const int iy = a_iyb[i] + ty, ix = a_ixb[i] + tx;
-            const bool v = kv && a_mv[i] && iy >= 0 && iy < d.x.H && ix >= 0 && ix < d.x.W;
-            rav[i] = v;
-            ra[i] = v ? gview_load4(d.x, a_nb[i] + (long)iy * d.x.W + ix, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < A_ROWS; ++i) {
+                const int iy = a_iyb[i] + ty, ix = a_ixb[i] + tx;
+                const bool v = kv && a_mv[i] && iy >= 0 && iy < d.x.H && ix >= 0 && ix < d.x.W;
+                const long pix = v ? a_nb[i] + (long)iy * d.x.W + ix : 0;
+                rav[i] = v;
+                ra[i] = *reinterpret_cast<const float4*>(base + pix * cs);
+            }
         }
         // ---- B (filter) ----
         if (BMODE == 0) {
@@ -172,50 +217,57 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, fl
 #pragma unroll
             for (int s = 0; s < B_SLOTS; ++s) {
                 const int krow = kt * BK + tid / (BN / 4) + RP * s;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (krow < Ktot) {
-                    const int tp = krow / C;
-                    const int kc = krow - tp * C;
-                    const int tty = tp / d.TW, ttx = tp - tty * d.TW;
-                    const int ky = ph.ky0 + tty * d.kstep, kx = ph.kx0 + ttx * d.kstep;
-                    if (kc < d.k_real) {
-                        const float* wp = d.w + ((long)(ky * d.KW + kx) * d.wC0 + kc) * d.wC1 + d.n_off + n;
-                        if (n + 3 < d.Nn && ((d.wC1 | d.n_off) & 3) == 0) {
-                            v = *reinterpret_cast<const float4*>(wp);
-                        } else {
-                            if (n + 0 < d.Nn) v.x = wp[0];
-                            if (n + 1 < d.Nn) v.y = wp[1];
-                            if (n + 2 < d.Nn) v.z = wp[2];
-                            if (n + 3 < d.Nn) v.w = wp[3];
-                        }
-                    }
+                const bool kv = krow < Ktot;
+                const int kk = kv ? krow : 0;
+                const int tp = div32(kk, mg.mC, mg.oneC);
+                const int kc = kk - tp * C;
+                const int tty = div32(tp, mg.mTW, mg.oneTW), ttx = tp - tty * d.TW;
+                const int ky = ph.ky0 + tty * d.kstep, kx = ph.kx0 + ttx * d.kstep;
+                const bool rowv = kv && kc < d.k_real;
+                const int kcs = rowv ? kc : 0;
+                const float* wp = d.w + ((long)(ky * d.KW + kx) * d.wC0 + kcs) * d.wC1 + d.n_off;
+                if (VECB) {
+                    const bool cv = n < d.Nn;       // Nn % 4 == 0: the whole float4 is in or out
+                    rb[s] = *reinterpret_cast<const float4*>(wp + (cv ? n : 0));
+                    rbm[s] = (rowv && cv) ? 15 : 0;
+                } else {
+                    const bool v0 = rowv && n + 0 < d.Nn, v1 = rowv && n + 1 < d.Nn;
+                    const bool v2 = rowv && n + 2 < d.Nn, v3 = rowv && n + 3 < d.Nn;
+                    rb[s].x = wp[v0 ? n + 0 : 0];
+                    rb[s].y = wp[v1 ? n + 1 : 0];
+                    rb[s].z = wp[v2 ? n + 2 : 0];
+                    rb[s].w = wp[v3 ? n + 3 : 0];
+                    rbm[s] = (v0 ? 1 : 0) | (v1 ? 2 : 0) | (v2 ? 4 : 0) | (v3 ? 8 : 0);
                 }
-                rb[s] = v;
             }
         } else {
             // NK: tile [BN rows n][BK cols k], k contiguous in memory
             const int kc4 = kt * BK + (tid & 7) * 4;
             const bool kvb = kc4 < Ktot;
-            const int tp = kvb ? kc4 / C : 0;
-            const int kc = kvb ? kc4 - tp * C : 0;
-            const int tty = tp / d.TW, ttx = tp - tty * d.TW;
+            const int kk = kvb ? kc4 : 0;
+            const int tp = div32(kk, mg.mC, mg.oneC);
+            const int kc = kk - tp * C;
+            const int tty = div32(tp, mg.mTW, mg.oneTW), ttx = tp - tty * d.TW;
             const int ky = ph.ky0 + tty * d.kstep, kx = ph.kx0 + ttx * d.kstep;
+            const long tapoff = (long)(ky * d.KW + kx) * d.wC0 + d.n_off;
 #pragma unroll
             for (int s = 0; s < B_SLOTS; ++s) {
                 const int n = n0 + (tid >> 3) + 32 * s;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kvb && n < d.Nn) {
-                    const float* wp = d.w + ((long)(ky * d.KW + kx) * d.wC0 + d.n_off + n) * d.wC1 + kc;
-                    if (kc + 3 < d.k_real && (d.wC1 & 3) == 0) {
-                        v = *reinterpret_cast<const float4*>(wp);
-                    } else {
-                        if (kc + 0 < d.k_real) v.x = wp[0];
-                        if (kc + 1 < d.k_real) v.y = wp[1];
-                        if (kc + 2 < d.k_real) v.z = wp[2];
-                        if (kc + 3 < d.k_real) v.w = wp[3];
-                    }
+                const bool nv = kvb && n < d.Nn;
+                const float* wp = d.w + (tapoff + (nv ? n : 0)) * d.wC1;
+                if (VECB) {
+                    const bool cv = kc < d.k_real;  // k_real % 4 == 0
+                    rb[s] = *reinterpret_cast<const float4*>(wp + (cv ? kc : 0));
+                    rbm[s] = (nv && cv) ? 15 : 0;
+                } else {
+                    const bool v0 = nv && kc + 0 < d.k_real, v1 = nv && kc + 1 < d.k_real;
+                    const bool v2 = nv && kc + 2 < d.k_real, v3 = nv && kc + 3 < d.k_real;
+                    rb[s].x = wp[v0 ? kc + 0 : 0];
+                    rb[s].y = wp[v1 ? kc + 1 : 0];
+                    rb[s].z = wp[v2 ? kc + 2 : 0];
+                    rb[s].w = wp[v3 ? kc + 3 : 0];
+                    rbm[s] = (v0 ? 1 : 0) | (v1 ? 2 : 0) | (v2 ? 4 : 0) | (v3 ? 8 : 0);
                 }
-                rb[s] = v;
             }
         }
     };
@@ -235,13 +287,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, fl
 #pragma unroll
             for (int s = 0; s < B_SLOTS; ++s) {
                 const int row = tid / (BN / 4) + RP * s;
-                *reinterpret_cast<float4*>(Bb + row * B_LD + col4 * 4) = rb[s];
+                float4 v;
+                v.x = (rbm[s] & 1) ? rb[s].x : 0.f; v.y = (rbm[s] & 2) ? rb[s].y : 0.f;
+                v.z = (rbm[s] & 4) ? rb[s].z : 0.f; v.w = (rbm[s] & 8) ? rb[s].w : 0.f;
+                *reinterpret_cast<float4*>(Bb + row * B_LD + col4 * 4) = v;
             }
         } else {
 #pragma unroll
             for (int s = 0; s < B_SLOTS; ++s) {
                 float* p = Bb + ((tid >> 3) + 32 * s) * B_LD + (tid & 7) * 4;
-                p[0] = rb[s].x; p[1] = rb[s].y; p[2] = rb[s].z; p[3] = rb[s].w;
+                p[0] = (rbm[s] & 1) ? rb[s].x : 0.f; p[1] = (rbm[s] & 2) ? rb[s].y : 0.f;
+                p[2] = (rbm[s] & 4) ? rb[s].z : 0.f; p[3] = (rbm[s] & 8) ? rb[s].w : 0.f;
             }
         }
     };
@@ -286,12 +342,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, fl
     for (int i = 0; i < SM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long m = m0 + wm * SM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (m >= M) continue;
-            const int n = (int)(m / (d.PH * d.PW));
-            const int rem = (int)(m - (long)n * d.PH * d.PW);
-            const int py = rem / d.PW, px = rem - py * d.PW;
-            const long opix = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
+            const int row = wm * SM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (m0 + row >= M) continue;
+            const long opix = rowpix[row];
 #pragma unroll
             for (int j = 0; j < SN; ++j) {
                 const int col = n0 + wn * SN * 32 + j * 32 + l31;
@@ -329,8 +382,9 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_st
 // filter-gradient form
 // ---------------------------------------------------------------------------------------------
 template <int WM, int WN, int SM, int SN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d, float* __restrict__ slab_base,
-                                                          long slab_stride, int splitk) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d, const Magics mg,
+                                                          float* __restrict__ slab_base, long slab_stride,
+                                                          int splitk) {
     constexpr int BM = WM * SM * 32;
     constexpr int BN = WN * SN * 32;
     constexpr int A_LD = BM;
@@ -355,23 +409,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     const int Cd = d.d.C0 + d.d.C1;
     const int Mtot = d.TH * d.TW * Cg;
     const long P = (long)d.NB * d.PH * d.PW;
+    const int PHW = d.PH * d.PW;
     const int ks = blockIdx.z;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
 
-    // fixed per-thread columns
+    // fixed per-thread columns: (tap, channel) of the gathered side, channel of the dense side
     const int a_col = m0 + (tid % (BM / 4)) * 4;
     const bool a_cv = a_col < Mtot;
-    const int a_tap = a_cv ? a_col / Cg : 0;
-    const int a_c = a_cv ? a_col - a_tap * Cg : 0;
-    const int a_ty = a_tap / d.TW, a_tx = a_tap - a_ty * d.TW;
+    const int a_cc = a_cv ? a_col : 0;
+    const int a_tap = div32(a_cc, mg.mC, mg.oneC);
+    const int a_c = a_cc - a_tap * Cg;
+    const int a_ty = div32(a_tap, mg.mTW, mg.oneTW), a_tx = a_tap - a_ty * d.TW;
     float4 aa, ab;
     gview_affine4(d.g, a_c, aa, ab);
+    const float* a_base;
+    int a_cs;
+    gview_src(d.g, a_c, a_base, a_cs);
     const int b_col = n0 + (tid % (BN / 4)) * 4;
     const bool b_cv = b_col < Cd;
     const int b_c = b_cv ? b_col : 0;
     float4 ba, bb;
     gview_affine4(d.d, b_c, ba, bb);
+    const float* b_base;
+    int b_cs;
+    gview_src(d.d, b_c, b_base, b_cs);
 
     const long nkt = (P + BK - 1) / BK;
     const long per = (nkt + splitk - 1) / splitk;
@@ -393,26 +455,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
 #pragma unroll
         for (int s = 0; s < A_SLOTS; ++s) {
             const long p = kt * BK + tid / (BM / 4) + A_RP * s;
-            bool v = a_cv && p < P;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v) {
-                const int n = (int)(p / (d.PH * d.PW));
-                const int rem = (int)(p - (long)n * d.PH * d.PW);
-                const int py = rem / d.PW, px = rem - py * d.PW;
-                const int iy = py * d.in_stride + d.ioff_y + a_ty;
-                const int ix = px * d.in_stride + d.ioff_x + a_tx;
-                v = iy >= 0 && iy < d.g.H && ix >= 0 && ix < d.g.W;
-                if (v) val = gview_load4(d.g, ((long)n * d.g.H + iy) * d.g.W + ix, a_c);
-            }
+            const bool pv = a_cv && p < P;
+            const long pp = pv ? p : 0;
+            const int n = (int)div64(pp, mg.mPHPW, mg.onePHPW);
+            const int rem = (int)(pp - (long)n * PHW);
+            const int py = (int)div64(rem, mg.mPW, mg.onePW), px = rem - py * d.PW;
+            const int iy = py * d.in_stride + d.ioff_y + a_ty;
+            const int ix = px * d.in_stride + d.ioff_x + a_tx;
+            const bool v = pv && iy >= 0 && iy < d.g.H && ix >= 0 && ix < d.g.W;
+            const long pix = v ? ((long)n * d.g.H + iy) * d.g.W + ix : 0;
             rav[s] = v;
-            ra[s] = val;
+            ra[s] = *reinterpret_cast<const float4*>(a_base + pix * a_cs);
         }
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
             const long p = kt * BK + tid / (BN / 4) + B_RP * s;
             const bool v = b_cv && p < P;   // D lattice == its own pixel grid (d.d.H==PH, d.d.W==PW)
             rbv[s] = v;
-            rb[s] = v ? gview_load4(d.d, p, b_c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[s] = *reinterpret_cast<const float4*>(b_base + (v ? p : 0) * b_cs);
         }
     };
     auto store_tile = [&](int buf) {
@@ -468,7 +528,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * SM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
             if (m >= Mtot) continue;
-            const int tap = m / Cg;
+            const int tap = div32(m, mg.mC, mg.oneC);
             const int c = m - tap * Cg;
             if (c >= d.Cg_real) continue;
             const long orow = (long)tap * d.Cg_real + c;
@@ -509,14 +569,15 @@ static int num_cu() {
     return g_num_cu;
 }
 
-template <int WM, int WN, int SM, int SN, int BMODE>
-static int launch_fwd(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hipStream_t st) {
+template <int WM, int WN, int SM, int SN, int BMODE, bool VECB>
+static int launch_fwd_v(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
     constexpr int A_SZ = BM * (BK + 1);
     constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * (BK + 1);
-    constexpr size_t lds = 2 * (A_SZ + B_SZ) * sizeof(float);
+    constexpr size_t lds = 2 * (A_SZ + B_SZ) * sizeof(float) + BM * sizeof(long);
     const long M = (long)d.NB * d.PH * d.PW;
     const int C = d.x.C0 + d.x.C1;
+    const Magics mg = make_magics((unsigned)C, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW);
     const int Ktot = d.TH * d.TW * C;
     const int nkt = (Ktot + BK - 1) / BK;
     const long mt = (M + BM - 1) / BM;
@@ -538,18 +599,27 @@ static int launch_fwd(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hipSt
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<WM, WN, SM, SN, BMODE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
-    hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, SM, SN, BMODE>), grid, dim3(256), lds, st, d, ws, out_count, splitk);
+    hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk);
     if (splitk > 1) {
         const int thr = 256;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
                            out_count, splitk, d.out, out_count, d.ldc, d.Nn, d.Nstore, d.bias, d.epi, d.accumulate);
     }
     return (int)hipGetLastError();
+}
+
+template <int WM, int WN, int SM, int SN, int BMODE>
+static int launch_fwd(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hipStream_t st) {
+    // float4 filter loads need 16-byte aligned, fully in-range groups of 4
+    const bool vec = (BMODE == 0) ? (((d.wC1 | d.n_off) & 3) == 0 && (d.Nn & 3) == 0)
+                                  : ((d.wC1 & 3) == 0 && (d.k_real & 3) == 0);
+    return vec ? launch_fwd_v<WM, WN, SM, SN, BMODE, true>(d, ws, ws_bytes, st)
+               : launch_fwd_v<WM, WN, SM, SN, BMODE, false>(d, ws, ws_bytes, st);
 }
 
 // tile configuration ids: 0 = 128x128, 1 = 64x128 (few rows), 2 = 128x64, 3 = 128x32
@@ -610,6 +680,7 @@ static int launch_wgrad(const ssc_wgrad_desc& d, float* ws, int64_t ws_bytes, hi
     const int Cg = d.g.C0 + d.g.C1;
     const int Mtot = d.TH * d.TW * Cg;
     const long P = (long)d.NB * d.PH * d.PW;
+    const Magics mg = make_magics((unsigned)Cg, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW);
     const long nkt = (P + BK - 1) / BK;
     const int mt = (Mtot + BM - 1) / BM;
     const int nt = (d.Nn + BN - 1) / BN;
@@ -633,7 +704,7 @@ static int launch_wgrad(const ssc_wgrad_desc& d, float* ws, int64_t ws_bytes, hi
         attr_set = true;
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)splitk);
-    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, SM, SN>), grid, dim3(256), lds, st, d, ws, out_count, splitk);
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, SM, SN>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk);
     if (splitk > 1) {
         const int thr = 256;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,

@@ -327,14 +327,19 @@ extern "C" int ssc_axpy(float* y, const float* x, float a, int64_t n, void* stre
 
 // ------------------------------------------------------------------ small dense head (fully_connected, mru.py:52-92)
 // y[n][j] = sum_k x[n][k] W[k][j] + b[j]; one wavefront per sample, J <= 64 outputs (class logits, J = 25).
-__global__ __launch_bounds__(64) void fc_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                           const float* __restrict__ b, int K, int J,
-                                                           float* __restrict__ y) {
-    const int n = blockIdx.x, lane = threadIdx.x;
-    float acc = 0.f;     // lane j < J owns output j: coalesced reads of W rows
-    if (lane < J)
-        for (int k = 0; k < K; ++k) acc += x[(long)n * K + k] * W[(long)k * J + lane];
-    if (lane < J) y[(long)n * J + lane] = acc + (b != nullptr ? b[lane] : 0.f);
+// block per sample: thread = (output j = tid & 63, k-lane = tid >> 6), LDS reduce over the 4 k-lanes
+__global__ __launch_bounds__(256) void fc_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                            const float* __restrict__ b, int K, int J,
+                                                            float* __restrict__ y) {
+    __shared__ float sh[256];
+    const int n = blockIdx.x, j = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (j < J)
+        for (int k = kl; k < K; k += 4) acc += x[(long)n * K + k] * W[(long)k * J + j];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (kl == 0 && j < J)
+        y[(long)n * J + j] = sh[j] + sh[64 + j] + sh[128 + j] + sh[192 + j] + (b != nullptr ? b[j] : 0.f);
 }
 
 // dx[n][k] = sum_j dy[n][j] W[k][j];  dW[k][j] (+)= sum_n x[n][k] dy[n][j];  db[j] (+)= sum_n dy[n][j]
@@ -368,7 +373,7 @@ __global__ void fc_small_bwd_dw_kernel(const float* __restrict__ x, const float*
 extern "C" int ssc_fc_small_fwd(const float* x, const float* W, const float* b, int N, int K, int J, float* y,
                                 void* stream) {
     if (J > 64) return -1;
-    hipLaunchKernelGGL(fc_small_fwd_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, x, W, b, K, J, y);
+    hipLaunchKernelGGL(fc_small_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, W, b, K, J, y);
     return CHECK_LAUNCH();
 }
 

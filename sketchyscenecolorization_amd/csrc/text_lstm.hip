@@ -249,43 +249,57 @@ extern "C" int ssc_squash_bwd(const float* h, const float* o, const float* go, i
 
 // ------------------------------------------------------------------ small reductions
 // out[g][c] (+)= sum_{r in group g} x[g*G + r][c]     (G rows per group; G = M -> column sum)
-__global__ void group_rowsum_kernel(const float* __restrict__ x, int ldx, long groups, int G, int C,
-                                    float* __restrict__ out, int accumulate) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= groups * C) return;
-    const long g = i / C;
-    const int c = (int)(i - g * C);
+// block = 64 columns x 4 row lanes; grid = (column chunks, groups)
+__global__ __launch_bounds__(256) void group_rowsum_kernel(const float* __restrict__ x, int ldx, long groups, int G,
+                                                            int C, float* __restrict__ out, int accumulate) {
+    __shared__ float sh[256];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long g = blockIdx.y;
     float s = 0.f;
-    const float* p = x + (g * G) * ldx + c;
-    for (int r = 0; r < G; ++r) s += p[(long)r * ldx];
-    if (accumulate) s += out[i];
-    out[i] = s;
+    if (c < C) {
+        const float* p = x + (g * G) * ldx + c;
+        for (int r = rl; r < G; r += 4) s += p[(long)r * ldx];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        s = sh[cl] + sh[64 + cl] + sh[128 + cl] + sh[192 + cl];
+        const long i = g * C + c;
+        if (accumulate) s += out[i];
+        out[i] = s;
+    }
 }
 
 extern "C" int ssc_group_rowsum(const float* x, int ldx, int64_t groups, int G, int C, float* out, int accumulate,
                                 void* stream) {
-    const long tot = (long)groups * C;
-    hipLaunchKernelGGL(group_rowsum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
-                       ldx, (long)groups, G, C, out, accumulate);
+    hipLaunchKernelGGL(group_rowsum_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)groups), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, (long)groups, G, C, out, accumulate);
     return CHECK_LAUNCH();
 }
 
 // out[n][c] = mean_p act(a*x[n,p,c]+b)      (tf.reduce_mean over H,W; models_collection.py:838)
-__global__ void act_mean_hw_kernel(const float* __restrict__ x, const float* __restrict__ ab, int act, int N, int P,
-                                   int C, float* __restrict__ out) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)N * C) return;
-    const int n = (int)(i / C), c = (int)(i - (long)n * C);
-    const float a = ab != nullptr ? ab[c] : 1.f, b = ab != nullptr ? ab[C + c] : 0.f;
+// block = 64 channels x 4 row lanes; grid = (channel chunks, N)
+__global__ __launch_bounds__(256) void act_mean_hw_kernel(const float* __restrict__ x, const float* __restrict__ ab,
+                                                           int act, int N, int P, int C, float* __restrict__ out) {
+    __shared__ float sh[256];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int n = blockIdx.y;
     float s = 0.f;
-    const float* p = x + (long)n * P * C + c;
-    for (int q = 0; q < P; ++q) {
-        float v = fmaf(a, p[(long)q * C], b);
-        if (act == SSC_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (act == SSC_ACT_LRELU) v = fmaxf(v, 0.2f * v);
-        s += v;
+    if (c < C) {
+        const float a = ab != nullptr ? ab[c] : 1.f, b = ab != nullptr ? ab[C + c] : 0.f;
+        const float* p = x + (long)n * P * C + c;
+        for (int q = rl; q < P; q += 4) {
+            float v = fmaf(a, p[(long)q * C], b);
+            if (act == SSC_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == SSC_ACT_LRELU) v = fmaxf(v, 0.2f * v);
+            s += v;
+        }
     }
-    out[i] = s / (float)P;
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) out[(long)n * C + c] = (sh[cl] + sh[64 + cl] + sh[128 + cl] + sh[192 + cl]) / (float)P;
 }
 
 // g[n,p,c] += v[n,c]*scale
@@ -300,9 +314,8 @@ __global__ void add_row_bcast_kernel(float* __restrict__ g, const float* __restr
 
 extern "C" int ssc_act_mean_hw(const float* x, const float* ab, int act, int N, int P, int C, float* out,
                                void* stream) {
-    const long tot = (long)N * C;
-    hipLaunchKernelGGL(act_mean_hw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ab,
-                       act, N, P, C, out);
+    hipLaunchKernelGGL(act_mean_hw_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)N), dim3(256), 0,
+                       (hipStream_t)stream, x, ab, act, N, P, C, out);
     return CHECK_LAUNCH();
 }
 
