@@ -1,0 +1,49 @@
+"""Data-parallel plumbing: one process per GPU, each process = one "tower" of the reference
+(graph_single.py:128-173).  ``average_gradients`` (:33-68: per-variable mean over towers) becomes a
+sum all-reduce of flat gradient sections (RCCL over xGMI on GPUs, gloo in CPU tests) issued on a side
+stream as soon as the backward pass has finished a section; the 1/world factor is applied by the
+consumer (the Adam kernel's gradient scale)."""
+import torch
+
+
+def tower_slice(global_n, batch_size, rank, world, batch_portion=None):
+    """Sample range [lo, hi) of tower ``rank`` (input_pipeline.split_inputs semantics)."""
+    portion = [1] * world if batch_portion is None else list(batch_portion)
+    lo = sum(int(batch_size * p) for p in portion[:rank])
+    hi = lo + int(batch_size * portion[rank])
+    assert hi <= global_n
+    return lo, hi
+
+
+class GradReducer(object):
+    def __init__(self, process_group=None):
+        self.pg = process_group
+        self.world = 1
+        self.stream = None
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+            if self.world > 1 and torch.cuda.is_available():
+                self.stream = torch.cuda.Stream()
+
+    def reduce_async(self, flat, lo, hi):
+        """Sum flat[lo:hi] over all towers; asynchronous w.r.t. the compute stream on GPUs."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        if self.stream is None:         # CPU / gloo: synchronous
+            dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+
+    def wait(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world

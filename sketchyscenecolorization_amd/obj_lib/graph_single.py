@@ -1,0 +1,174 @@
+"""Graph assembly API of obj_lib/graph_single.py over the eager HIP tower.
+
+  build_single_graph(...)       reference :221-314   one tower: [gen, images, sketches] or
+                                                      (loss_g, loss_d, grad_g, grad_d)
+  build_multi_tower_graph(...)  reference :107-218   -> (opt_g, opt_d, loss_g, loss_d, summaries)
+
+The reference returns symbolic tensors/ops to be fetched with ``sess.run``; the objects returned here
+are fetched with ``Session().run([...])`` with the same grouping semantics: fetching ``opt_d`` runs one
+discriminator update on a freshly dequeued batch, fetching ``opt_g`` one generator update.
+Multi-GPU: the reference loops towers inside one process; here every process is one tower
+(torch.distributed world_size == num_gpu) and average_gradients (:33-68) is an RCCL all-reduce.
+"""
+import numpy as np
+import torch
+
+from . import models_collection as models
+from .config import Config
+from .input_pipeline import get_num_classes, split_inputs
+
+
+def _value(x):
+    return x() if callable(x) else x
+
+
+def _dev(x, dtype=torch.float32):
+    if isinstance(x, torch.Tensor):
+        return x.to(device='cuda', dtype=dtype).contiguous()
+    return torch.as_tensor(np.asarray(x)).to(device='cuda', dtype=dtype).contiguous()
+
+
+def _batch(images, sketches, images_d, cls, cls_d, text, noise_vec=None):
+    text = _value(text)
+    text = text.cpu().numpy() if isinstance(text, torch.Tensor) else np.asarray(text)
+    sk = _dev(_value(sketches))
+    n = sk.shape[0]
+    b = {'sketches': sk, 'text': text.astype(np.int32),
+         'noise_vec': _dev(noise_vec) if noise_vec is not None else torch.randn(n, 256, device='cuda')}
+    if images is not None:
+        b['images'] = _dev(_value(images))
+    if images_d is not None:
+        b['images_d'] = _dev(_value(images_d))
+    if cls is not None:
+        b['class_id'] = _dev(_value(cls), torch.int32)
+    if cls_d is not None:
+        b['class_id_d'] = _dev(_value(cls_d), torch.int32)
+    return b
+
+
+def get_optimizer(optimizer_name, **kwargs):
+    """graph_single.py:584-593.  Only Adam(beta1=0, beta2=0.9) is a live path in the reference."""
+    if optimizer_name.lower() != 'adam':
+        raise NotImplementedError('--optimizer %s: the reference default (Adam, beta1=0, beta2=0.9) is the only '
+                                  'optimizer built' % optimizer_name)
+    return {'name': 'Adam', 'beta1': 0.0, 'beta2': 0.9}
+
+
+def build_single_graph(images, sketches, images_d, image_data_class_id, image_data_class_id_d,
+                       text_vocab_indiceses, batch_size, training, LSTM_hybrid, vocab_size, ld=10,
+                       data_format='NCHW', distance_map=True, optim_g=None, optim_d=None, block_type='MRU',
+                       noise_vec=None):
+    """One tower.  training=False: [image_gens, images, sketches] (reference :265-266).
+    training=True: (loss_g, loss_d, grad_g, grad_d) with grad_* = list of (gradient, variable name)."""
+    assert block_type in ['MRU', 'Pix2Pix', 'Residual']
+    models.set_param(data_format=data_format)
+    sk = _dev(_value(sketches))
+    assert sk.shape[0] == batch_size, 'batch_size is baked into the reference graph (models_collection.py:162)'
+    tr = models.get_trainer(block_type, vocab_size, sk.shape[2])
+    tr.G.lstm_hybrid = bool(LSTM_hybrid)
+    if not training:
+        b = _batch(None, sk, None, None, None, text_vocab_indiceses, noise_vec)
+        gen = tr.generate(b['sketches'], b['text'], b['noise_vec'])
+        return [gen, _value(images), sk]
+    b = _batch(images, sk, images_d, image_data_class_id, image_data_class_id_d, text_vocab_indiceses, noise_vec)
+    loss_d = float(tr.d_gradients(b))
+    grad_d = [(g.clone(), n) for n, g in tr.store.discriminator.g.items()]
+    loss_g = float(tr.g_gradients(b))
+    grad_g = [(g.clone(), n) for n, g in tr.store.generator.g.items()]
+    return loss_g, loss_d, grad_g, grad_d
+
+
+class Fetch(object):
+    def __init__(self, graph, kind):
+        self.graph, self.kind = graph, kind
+
+
+class Counter(object):
+    """tf.Variable(int32) + assign_add used for the lr schedule (main_procedure.py:105-106)."""
+
+    def __init__(self, value=0):
+        self.value = int(value)
+
+    def assign(self, v):
+        self.value = int(v)
+
+
+class TowerGraph(object):
+    def __init__(self, trainer, inputs, counter, rank, world, batch_size, batch_portion):
+        self.tr, self.inputs, self.counter = trainer, inputs, counter
+        self.rank, self.world, self.batch_size, self.batch_portion = rank, world, batch_size, batch_portion
+        self.last = {'loss_g': float('nan'), 'loss_d': float('nan')}
+
+    def _dequeue(self):
+        vals = [_value(x) for x in self.inputs]
+        if self.world > 1:      # split_inputs: this process is tower `rank`
+            vals = [split_inputs(v, self.batch_size, self.batch_portion, self.world)[self.rank] for v in vals]
+        images, sketches, images_d, cls, cls_d, text = vals
+        return _batch(images, sketches, images_d, cls, cls_d, text)
+
+    def run(self, fetches):
+        kinds = [f.kind for f in fetches]
+        c = self.counter.value if isinstance(self.counter, Counter) else int(_value(self.counter))
+        if 'opt_d' in kinds:
+            self.last['loss_d'] = self.tr.d_step(self._dequeue(), c)
+        if 'opt_g' in kinds:
+            self.last['loss_g'] = self.tr.g_step(self._dequeue(), c)
+        out = []
+        for k in kinds:
+            if k in ('loss_g', 'loss_d'):
+                out.append(np.float32(float(self.last[k])))
+            elif k == 'counter':
+                out.append(c)
+            elif k == 'counter_add':
+                self.counter.value += 1
+                out.append(self.counter.value)
+            elif k == 'summaries':
+                out.append({'total_loss/g': float(self.last['loss_g']), 'total_loss/d': float(self.last['loss_d']),
+                            'learning_rate_g': self.tr.lr_g * self.tr.decay(c)})
+            else:
+                out.append(None)
+        return out
+
+
+class Session(object):
+    """Minimal stand-in for tf.Session.run over Fetch objects."""
+
+    def run(self, fetches, **kw):
+        single = not isinstance(fetches, (list, tuple))
+        fl = [fetches] if single else list(fetches)
+        res = fl[0].graph.run(fl)
+        return res[0] if single else res
+
+
+def build_multi_tower_graph(images, sketches, images_d, image_paired_class_ids, image_paired_class_ids_d,
+                            text_vocab_indiceses, LSTM_hybrid, vocab_size, batch_size, num_gpu, batch_portion,
+                            training, learning_rates, counter, max_iter_step, ld=10, data_format='NCHW',
+                            distance_map=True, optimizer='Adam', block_type='MRU'):
+    """Inputs are tensors/arrays or zero-argument callables (the reference passes queue outputs).
+    Returns (opt_g, opt_d, loss_g, loss_d, summaries) to be fetched through Session.run."""
+    models.set_param(data_format=data_format)
+    get_optimizer(optimizer)
+    if distance_map:
+        raise NotImplementedError('--distance_map 1 is a dead-but-selectable reference flag (SURVEY appendix B.12)')
+    pg, rank, world = None, 0, 1
+    if num_gpu > 1:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() == num_gpu):
+            raise RuntimeError('num_gpu=%d needs one process per GPU: launch with `python -m torch.distributed.run '
+                               '--nproc-per-node %d ...` (the reference looped towers in one process)' % (num_gpu, num_gpu))
+        pg, rank, world = dist.group.WORLD, dist.get_rank(), num_gpu
+    probe = _value(sketches)
+    img = probe.shape[2]
+    tr = models.get_trainer(block_type, vocab_size, img, process_group=pg)
+    tr.G.lstm_hybrid = bool(LSTM_hybrid)
+    tr.lr_g, tr.lr_d = learning_rates['generator'], learning_rates['discriminator']
+    tr.max_iter_step = max_iter_step
+    if callable(sketches):      # do not consume a queue element for the probe
+        first = {'v': probe}
+        orig = sketches
+
+        def sketches():
+            return first.pop('v') if 'v' in first else orig()
+    g = TowerGraph(tr, [images, sketches, images_d, image_paired_class_ids, image_paired_class_ids_d,
+                        text_vocab_indiceses], counter, rank, world, batch_size, list(batch_portion))
+    return Fetch(g, 'opt_g'), Fetch(g, 'opt_d'), Fetch(g, 'loss_g'), Fetch(g, 'loss_d'), Fetch(g, 'summaries')

@@ -1,0 +1,315 @@
+"""Procedures of obj_lib/main_procedure.py: train (:62-242), validation (:245-358), test (:361-492),
+inference (:495-621) -- same names, same Config-driven behaviour, same output files -- over the HIP tower.
+
+Differences that are forced by the environment and kept observable-equivalent:
+  * TFRecord queues are out of scope: ``train`` draws batches from
+    ``Config.data_source`` ('synthetic' by default: sketchyscenecolorization_amd.synthetic);
+  * checkpoints are ``torch.save`` dicts keyed by the TF variable names, written under the reference's
+    file names (``snapshot/model_<i>.ckpt-<i>`` + a ``checkpoint`` index like tf.train.Saver);
+  * images are written with PIL (cv2 is absent); the reference's RGB->BGR flip + cv2.imwrite
+    (main_procedure.py:609-621) yields the same RGB file content.
+"""
+import json
+import os
+from time import time
+
+import numpy as np
+import torch
+
+from ..data_processing.text_processing import load_vocab_dict_from_file, preprocess_sentence
+from . import models_collection as models
+from .config import Config
+from .graph_single import Counter, Session, build_multi_tower_graph, build_single_graph
+from .input_pipeline import resize_and_padding_mask_image, thicken_drawings
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CATEGORIES = ['bench', 'bird', 'bus', 'butterfly', 'car', 'cat', 'chair', 'chicken', 'cloud', 'cow', 'dog', 'duck',
+              'grass', 'horse', 'house', 'moon', 'person', 'pig', 'rabbit', 'road', 'sheep', 'star', 'sun', 'tree',
+              'truck']      # sorted(os.listdir('data/captions')) of the reference dataset
+SIZE = {True: (64, 64), False: (192, 192)}
+
+
+# ----------------------------------------------------------------------------- checkpoints (tf.train.Saver look-alike)
+def save_checkpoint(store, ckpt_dir, name, global_step):
+    os.makedirs(ckpt_dir, exist_ok=True)
+    path = os.path.join(ckpt_dir, '%s-%d' % (name, global_step))
+    torch.save(store.state_dict(), path)
+    with open(os.path.join(ckpt_dir, 'checkpoint'), 'w') as f:
+        f.write('model_checkpoint_path: "%s"\n' % os.path.basename(path))
+    return path
+
+
+def latest_checkpoint(ckpt_dir):
+    idx = os.path.join(ckpt_dir, 'checkpoint')
+    if not os.path.exists(idx):
+        return None
+    with open(idx) as f:
+        line = f.readline()
+    name = line.split('"')[1]
+    path = os.path.join(ckpt_dir, name)
+    return path if os.path.exists(path) else None
+
+
+def restore_checkpoint(store, path):
+    store.load_state_dict(torch.load(path, map_location='cpu'))
+
+
+def print_parameter_count(store, verbose=False):
+    for scope in ('generator', 'discriminator'):
+        print(scope)
+        print('total_parameters', store.parameter_count(scope))
+
+
+# ----------------------------------------------------------------------------- data
+class SyntheticQueue(object):
+    """Stands in for build_input_queue_paired (input_pipeline.py:131-154): a pool of seeded batches."""
+
+    def __init__(self, batch_size, img, vocab_size, seed, pool=4):
+        from ..synthetic import synthetic_batch
+        self.pool = [synthetic_batch(batch_size, seed + i, img, vocab_size) for i in range(pool)]
+        self.i = 0
+        self.cur = self.pool[0]
+
+    def advance(self):
+        self.cur = self.pool[self.i % len(self.pool)]
+        self.i += 1
+
+    def field(self, name, advance=False):
+        def f():
+            if advance:
+                self.advance()
+            return self.cur[name]
+        return f
+
+
+def _write_png(path, arr_uint8):
+    from PIL import Image
+    Image.fromarray(arr_uint8).save(path)
+
+
+def _postprocess(nchw):
+    """NCHW float [-1,1] -> NHWC uint8 with the reference's truncating cast (main_procedure.py:601-610)."""
+    x = np.transpose(np.asarray(nchw.detach().cpu() if isinstance(nchw, torch.Tensor) else nchw), (0, 2, 3, 1))
+    return (((x + 1) / 2.) * 255).astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------- train
+def train(**kwargs):
+    status = 0
+    batch_size = Config.batch_size
+    max_iter_step = Config.max_iter_step
+    Diters = Config.disc_iterations
+    num_gpu = Config.num_gpu
+    ckpt_dir = Config.ckpt_dir
+    log_dir = Config.log_dir
+    small = Config.small_img != 0
+    LSTM_hybrid = Config.LSTM_hybrid != 0
+    distance_map = Config.distance_map != 0
+    summary_write_freq = Config.summary_write_freq
+    save_model_freq = Config.save_model_freq
+    count_left_time_freq = Config.count_left_time_freq
+    batch_portion = np.array([1, 1, 1, 1] + [1] * max(0, num_gpu - 4), dtype=np.int32)
+    iter_from = kwargs['iter_from']
+    img = SIZE[small][0]
+
+    if num_gpu > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group('nccl')
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+    rank = int(os.environ.get('RANK', 0))
+
+    models.reset_default_graph()
+    print('Iteration starts from: %d' % iter_from)
+    counter = Counter(iter_from)
+
+    # two INDEPENDENT queues, as in the reference (main_procedure.py:109-122): the discriminator's
+    # "real" images are not paired with the sketches it sees
+    q1 = SyntheticQueue(batch_size * num_gpu, img, Config.vocab_size, seed=1234 + 1000 * rank)
+    q2 = SyntheticQueue(batch_size * num_gpu, img, Config.vocab_size, seed=998244 + 1000 * rank)
+    opt_g, opt_d, loss_g, loss_d, merged_all = build_multi_tower_graph(
+        q1.field('images', advance=True), q1.field('sketches'), q2.field('images_d', advance=True),
+        q1.field('class_id'), q2.field('class_id_d'), q1.field('text'),
+        LSTM_hybrid=LSTM_hybrid, vocab_size=Config.vocab_size, batch_size=batch_size, num_gpu=num_gpu,
+        batch_portion=batch_portion, training=True,
+        learning_rates={"generator": Config.lr_G, "discriminator": Config.lr_D},
+        counter=counter, max_iter_step=max_iter_step, ld=Config.ld, data_format=Config.data_format,
+        distance_map=distance_map, optimizer=Config.optimizer, block_type=Config.block_type)
+    tower = opt_g.graph
+    store = tower.tr.store
+    sess = Session()
+    if iter_from > 0:
+        path = latest_checkpoint(ckpt_dir)
+        print('Restore:', path)
+        restore_checkpoint(store, path)
+    print_parameter_count(store)
+    counter.assign(iter_from)
+    log_f = open(os.path.join(log_dir, 'scalars.jsonl'), 'a') if rank == 0 else None
+    prev_time = float("-inf")
+    fetch_counter, fetch_add = type(opt_g)(tower, 'counter'), type(opt_g)(tower, 'counter_add')
+
+    for i in range(iter_from, max_iter_step):
+        if i % count_left_time_freq == 0:
+            curr_time = time()
+            elapsed = curr_time - prev_time
+            print("Now at iteration %d. Elapsed time: %.5fs. Average time: %.5fs/iter" % (i, elapsed, elapsed / 100.))
+            if elapsed != float("inf"):
+                left_sec = (max_iter_step - i) * (elapsed / 100.)
+                d_ = int(left_sec / 86400)
+                h_ = int((left_sec - 86400 * d_) / 3600)
+                m_ = int((left_sec - 86400 * d_ - 3600 * h_) / 60)
+                print("Left time:%dd %dh %dm" % (d_, h_, m_))
+            prev_time = curr_time
+        for j in range(Diters):
+            _, loss_d_out = sess.run([opt_d, loss_d])
+            if np.isnan(np.sum(loss_d_out)):
+                print("NaN occurred during training D")
+                return -1
+        _, loss_g_out, counter_out, _ = sess.run([opt_g, loss_g, fetch_counter, fetch_add])
+        if np.isnan(np.sum(loss_g_out)):
+            print("NaN occurred during training G")
+            return -1
+        if log_f is not None and i % summary_write_freq == 0:
+            summ = sess.run(merged_all)
+            summ['step'] = i
+            log_f.write(json.dumps(summ) + '\n')
+            log_f.flush()
+        if i % save_model_freq == save_model_freq - 1 and rank == 0:
+            save_checkpoint(store, ckpt_dir, 'model_{}.ckpt'.format(i), global_step=i)
+            print('Save model_{}.ckpt'.format(i))
+    return status
+
+
+# ----------------------------------------------------------------------------- inference / test / validation
+def _load_sketch(path, img_dim, category):
+    from PIL import Image
+    sketch_image = Image.open(path).convert("RGB")
+    if sketch_image.width != img_dim[0] or sketch_image.height != img_dim[1]:
+        margin_size = 0 if category in ['road'] else 10
+        sketch = resize_and_padding_mask_image(sketch_image, img_dim[0], margin_size=margin_size).astype(np.float32)
+    else:
+        sketch = np.array(sketch_image, dtype=np.float32)
+    return sketch
+
+
+def _normalise(sketch_hwc):
+    x = sketch_hwc / 255. * 2. - 1
+    return np.transpose(np.expand_dims(x, axis=0), [0, 3, 1, 2]).astype(np.float32)
+
+
+def _categories():
+    captions_base_dir = os.path.join('data', 'captions')
+    if os.path.isdir(captions_base_dir):
+        c = os.listdir(captions_base_dir)
+        c.sort()
+        return c
+    return list(CATEGORIES)
+
+
+def _vocab_file():
+    return 'data/vocab.txt' if os.path.exists('data/vocab.txt') else os.path.join(PKG_DIR, 'data', 'vocab.txt')
+
+
+def inference(img_name, instruction):
+    """One sketch + one caption -> <name>_output.png / <name>_input.png (main_procedure.py:495-621)."""
+    wild_data_base_dir = 'examples'
+    wild_cate = img_name[:img_name.find('.png')]
+    T = 15
+    categories = _categories()
+    if wild_cate not in categories:
+        wild_cate = categories[2]
+    small = Config.small_img != 0
+    LSTM_hybrid = Config.LSTM_hybrid != 0
+    img_dim = SIZE[small]
+    output_folder = Config.results_dir
+    print('output_folder:', output_folder)
+    os.makedirs(output_folder, exist_ok=True)
+    vocab_dict = load_vocab_dict_from_file(_vocab_file())
+
+    models.reset_default_graph()
+    store, _ = models.get_store(Config.block_type, Config.vocab_size, img_dim[0])
+    path = latest_checkpoint(Config.ckpt_dir)
+    print('Restore trained model:', path)
+    restore_checkpoint(store, path)
+
+    sketch = _load_sketch(os.path.join(wild_data_base_dir, img_name), img_dim, wild_cate)
+    sketch_image = _normalise(sketch)
+    class_id = np.array([categories.index(wild_cate)])
+    vocab_indices = np.expand_dims(np.array(preprocess_sentence(instruction, vocab_dict, T), dtype=np.int32), axis=0)
+    try:
+        generated_img, _, input_sketch = build_single_graph(
+            sketch_image, sketch_image, None, class_id, None, vocab_indices, batch_size=1, training=False,
+            LSTM_hybrid=LSTM_hybrid, vocab_size=Config.vocab_size, data_format=Config.data_format,
+            distance_map=Config.distance_map != 0, block_type=Config.block_type)
+    except Exception as e:      # the reference swallows sess.run errors and prints them (:590-599)
+        print(e.args)
+        raise
+    gen_u8 = _postprocess(generated_img)
+    in_u8 = _postprocess(input_sketch)
+    img_out_filename = img_name[:-4] + '_output.png'
+    _write_png(os.path.join(output_folder, img_out_filename), gen_u8[0])
+    _write_png(os.path.join(output_folder, img_name[:-4] + '_input.png'), in_u8[0])
+    print('Saved file %s' % img_out_filename)
+
+
+def test():
+    """Loop of the inference body over data/captions/<cat>/test.json (main_procedure.py:361-492)."""
+    T = 15
+    small = Config.small_img != 0
+    img_dim = SIZE[small]
+    categories = _categories()
+    vocab_dict = load_vocab_dict_from_file(_vocab_file())
+    os.makedirs(Config.results_dir, exist_ok=True)
+    models.reset_default_graph()
+    store, _ = models.get_store(Config.block_type, Config.vocab_size, img_dim[0])
+    restore_checkpoint(store, latest_checkpoint(Config.ckpt_dir))
+    for cate in categories:
+        cap_path = os.path.join('data', 'captions', cate, 'test.json')
+        if not os.path.exists(cap_path):
+            continue
+        with open(cap_path) as f:
+            caps = json.load(f)
+        for key, text in (caps.items() if isinstance(caps, dict) else []):
+            if isinstance(text, (list, tuple)):
+                text = text[0]
+            from PIL import Image
+            sk = Image.open(os.path.join('data', 'images', cate, 'sketch', key)).convert('RGB')
+            margin = 0 if cate in ['road'] else 10
+            sketch = resize_and_padding_mask_image(sk, img_dim[0], margin_size=margin)
+            if cate in ['house', 'road']:
+                sketch = thicken_drawings(sketch)
+            x = _normalise(sketch.astype(np.float32))
+            idx = np.expand_dims(np.array(preprocess_sentence(text, vocab_dict, T), dtype=np.int32), 0)
+            gen, _, ins = build_single_graph(x, x, None, np.array([categories.index(cate)]), None, idx, batch_size=1,
+                                             training=False, LSTM_hybrid=Config.LSTM_hybrid != 0,
+                                             vocab_size=Config.vocab_size, data_format=Config.data_format,
+                                             distance_map=False, block_type=Config.block_type)
+            stem = '%s_%s' % (cate, key[:-4])
+            _write_png(os.path.join(Config.results_dir, stem + '_output.png'), _postprocess(gen)[0])
+            _write_png(os.path.join(Config.results_dir, stem + '_input.png'), _postprocess(ins)[0])
+
+
+def validation(**kwargs):
+    """The reference validates from the data/tfrecord/val queue (main_procedure.py:245-358); with the
+    TFRecord pipeline out of scope this runs one synthetic batch through the restored generator and writes
+    validation_results/with_text/<category>_<name>_{output,target,input}.png."""
+    small = Config.small_img != 0
+    img = SIZE[small][0]
+    from ..synthetic import synthetic_batch
+    models.reset_default_graph()
+    store, _ = models.get_store(Config.block_type, Config.vocab_size, img)
+    restore_checkpoint(store, latest_checkpoint(Config.ckpt_dir))
+    out_dir = os.path.join(Config.results_dir, 'with_text' if Config.LSTM_hybrid != 0 else 'without_text')
+    os.makedirs(out_dir, exist_ok=True)
+    b = synthetic_batch(Config.batch_size, 4321, img, Config.vocab_size)
+    gen, images, sketches = build_single_graph(b['images'], b['sketches'], None, b['class_id'], None, b['text'],
+                                               batch_size=Config.batch_size, training=False,
+                                               LSTM_hybrid=Config.LSTM_hybrid != 0, vocab_size=Config.vocab_size,
+                                               data_format=Config.data_format, distance_map=False,
+                                               block_type=Config.block_type)
+    cls = b['class_id'].cpu().numpy()
+    for i in range(Config.batch_size):
+        stem = '%s_%04d' % (CATEGORIES[int(cls[i])], i)
+        _write_png(os.path.join(out_dir, stem + '_output.png'), _postprocess(gen)[i])
+        _write_png(os.path.join(out_dir, stem + '_target.png'), _postprocess(images)[i])
+        _write_png(os.path.join(out_dir, stem + '_input.png'), _postprocess(sketches)[i])

@@ -1,0 +1,112 @@
+"""Model-construction API of obj_lib/models_collection.py (:896-932 aliases and set_param).
+
+The reference functions add nodes to the default tf.Graph and create variables under
+``scope_name``; these run the network eagerly on the MI355X.  Variables live in a per-scope
+registry keyed by TF variable names (``get_store``); ``reuse=True`` re-uses them exactly like
+tf.variable_scope(reuse=True).  The generator returns ``(image [N,3,H,W], noise_vec [N,256])`` and the
+discriminator ``(patch_logits [N,1,h,w], class_logits [N,25])`` as the reference does.
+"""
+import numpy as np
+import torch
+
+from .. import hip
+from ..params import Buffers, ParamStore
+from ..pix2pix import Pix2PixDiscriminator, Pix2PixGenerator
+from .config import Config
+
+SIZE = 64
+NUM_BLOCKS = 1
+
+model_data_format = None
+normalizer_fn_e = normalizer_fn_g = normalizer_fn_d = None
+normalizer_params_e = normalizer_params_g = normalizer_params_d = None
+
+_REGISTRY = {}
+
+
+def reset_default_graph():
+    """tf.reset_default_graph(): forget every variable and activation buffer."""
+    _REGISTRY.clear()
+
+
+def get_store(block_type='Pix2Pix', vocab_size=58, img=192, seed=0):
+    """The variable store of the 'default graph' (created on first use, like tf.get_variable)."""
+    key = (block_type, vocab_size, img)
+    if key not in _REGISTRY:
+        _REGISTRY[key] = {'store': ParamStore(block_type, vocab_size, img, 'cuda', seed), 'bufs': Buffers('cuda')}
+    return _REGISTRY[key]['store'], _REGISTRY[key]['bufs']
+
+
+def set_param(data_format='NCHW'):
+    """models_collection.py:902-911: select the (batch-statistics) normaliser for encoder/generator."""
+    global model_data_format, normalizer_fn_e, normalizer_fn_g, normalizer_fn_d
+    global normalizer_params_e, normalizer_params_g, normalizer_params_d
+    if data_format != 'NCHW':
+        raise Exception('unsupported')
+    model_data_format = data_format
+    normalizer_fn_e = normalizer_fn_g = 'batchnorm'
+    normalizer_params_e = {'data_format': data_format}
+    normalizer_params_g = {'data_format': data_format}
+    normalizer_fn_d = normalizer_params_d = None
+
+
+def _as_device(x, dtype=torch.float32):
+    t = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x)
+    return t.to(device='cuda', dtype=dtype).contiguous()
+
+
+def generate_pix2pix(z, text_vocab_indices, LSTM_hybrid, output_channel, num_classes, vocab_size, reuse=False,
+                     data_format='NCHW', labels=None, scope_name=None, noise_vec=None):
+    """models_collection.py:444-538.  ``noise_vec`` may be injected (the reference samples
+    tf.random_normal inside the graph, :493, and returns it); it is returned either way."""
+    assert data_format == 'NCHW' and output_channel == 3
+    z = _as_device(z)
+    n, _, h, w = z.shape
+    store, bufs = get_store('Pix2Pix', vocab_size, h)
+    if noise_vec is None:
+        noise_vec = torch.randn(n, 256, device='cuda')
+    noise_vec = _as_device(noise_vec)
+    text = text_vocab_indices.cpu().numpy() if isinstance(text_vocab_indices, torch.Tensor) else np.asarray(text_vocab_indices)
+    assert text.shape[0] == n
+    g = Pix2PixGenerator(store, bufs, LSTM_hybrid)
+    ctx = g.forward(z, text, noise_vec, tag=scope_name or 'generator')
+    return g.output_nchw(ctx), noise_vec
+
+
+def discriminate_pix2pix(discrim_inputs, discrim_targets, num_classes, labels=None, reuse=False,
+                         data_format='NCHW', scope_name=None):
+    """models_collection.py:789-841: PatchGAN logits [N,1,h-2.. ] + spectral-normed class logits."""
+    assert data_format == 'NCHW'
+    if type(discrim_targets) is list:
+        discrim_targets = discrim_targets[-1]
+    a, b = _as_device(discrim_inputs), _as_device(discrim_targets)
+    n, _, h, w = a.shape
+    store, bufs = get_store('Pix2Pix', 58, h)
+    xd = bufs.get((scope_name or 'discriminator') + '/api_xd', (n, h, w, 8), zero_on_alloc=True)
+    hip.nchw_to_nhwc(a, xd, 0)
+    hip.nchw_to_nhwc(b, xd, 3)
+    d = Pix2PixDiscriminator(store, bufs, Config.sn)
+    sn = d.prepare_sn()
+    c = d.forward(xd, sn, (scope_name or 'discriminator') + ('/reuse' if reuse else ''))
+    disc = c['disc'][..., 0:1].permute(0, 3, 1, 2).contiguous()
+    return disc, c['logits'].clone()
+
+
+def _not_built(name):
+    def f(*a, **k):
+        raise NotImplementedError('%s: only the Pix2Pix variant (--block_type Pix2Pix) is built in this round; '
+                                  'MRU/Residual follow (SURVEY.md section 7, step 7)' % name)
+    return f
+
+
+generate_mru = _not_built('generate_mru')
+discriminate_mru = _not_built('discriminate_mru')
+generate_residual = _not_built('generate_residual')
+discriminate_residual = _not_built('discriminate_residual')
+
+generator_mru = generate_mru
+discriminator_mru = discriminate_mru
+generator_pix2pix = generate_pix2pix
+discriminator_pix2pix = discriminate_pix2pix
+generator_residual = generate_residual
+discriminator_residual = discriminate_residual

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import hip
+from .dist_utils import GradReducer
 from .params import Buffers, ParamStore
 from .pix2pix import Pix2PixDiscriminator, Pix2PixGenerator
 
@@ -36,16 +37,11 @@ class Pix2PixTrainer(object):
         self.lr_g, self.lr_d, self.max_iter_step = lr_g, lr_d, max_iter_step
         self.beta1, self.beta2, self.eps = 0.0, 0.9, 1e-8     # graph_single.py:588
         self.loss = torch.zeros(2, dtype=torch.float64, device=device)   # [loss_g, loss_d], summed in double
-        self.pg = process_group
-        self.world = 1
-        self.comm_stream = None
-        if process_group is not None:
-            import torch.distributed as dist
-            self.world = dist.get_world_size(process_group)
-            if self.world > 1:
-                self.comm_stream = torch.cuda.Stream()
+        self.reducer = GradReducer(process_group)
+        self.world = self.reducer.world
         g = self.store.generator.offsets
         self._g_sections = self._sections(g)
+        self._sn_pending = None
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -64,18 +60,10 @@ class Pix2PixTrainer(object):
         return float(max(np.float32(0.2), np.float32(1.0) - c))
 
     def _allreduce_async(self, flat, lo, hi):
-        if self.world == 1:
-            return
-        import torch.distributed as dist
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.comm_stream.wait_event(ev)
-        with torch.cuda.stream(self.comm_stream):
-            dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+        self.reducer.reduce_async(flat, lo, hi)
 
     def _allreduce_wait(self):
-        if self.world > 1:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.reducer.wait()
 
     def _adam(self, scope, lr):
         scope.adam_t += 1
@@ -95,6 +83,19 @@ class Pix2PixTrainer(object):
     # ------------------------------------------------------------------ steps
     def d_step(self, batch, counter=0):
         """One discriminator update; returns the device scalar loss_d (a view of self.loss)."""
+        loss_d = self.d_gradients(batch)
+        self.apply_d(counter)
+        return loss_d
+
+    def apply_d(self, counter=0):
+        """optim_d.apply_gradients on the (all-reduced) discriminator gradients."""
+        sc = self.store.discriminator
+        self._allreduce_async(sc.grad, 0, sc.numel)
+        self._allreduce_wait()
+        self._adam(sc, self.lr_d * self.decay(counter))
+
+    def d_gradients(self, batch):
+        """loss_d and d loss_d / d discriminator variables (compute_gradients, graph_single.py:309-312)."""
         B, s = self.bufs, self.store
         N, _, H, W = batch['sketches'].shape
         xd_f, gctx = self._pack_fake(batch)
@@ -120,15 +121,25 @@ class Pix2PixTrainer(object):
         hip.call('ssc_l2_reg', s['discriminator/fully_connected/weights'],
                  s['discriminator/fully_connected/weights'].numel(), 1e-6, loss_d,
                  s.grad('discriminator/fully_connected/weights'))
-        sc = s.discriminator
-        self._allreduce_async(sc.grad, 0, sc.numel)
-        self._allreduce_wait()
-        self._adam(sc, self.lr_d * self.decay(counter))
         self.last = {'gctx': gctx, 'cr': cr, 'cf': cf}
         return loss_d
 
     def g_step(self, batch, counter=0):
         """One generator update (+ spectral-norm u assignment); returns the device scalar loss_g."""
+        loss_g = self.g_gradients(batch)
+        self.apply_g(counter)
+        return loss_g
+
+    def apply_g(self, counter=0):
+        """optim_g.apply_gradients under control_dependencies(spectral-norm u assigns)."""
+        self._allreduce_wait()
+        self._adam(self.store.generator, self.lr_g * self.decay(counter))
+        if self.D.sn and self._sn_pending is not None:
+            self.store['discriminator/fully_connected/u'].copy_(self._sn_pending)
+            self._sn_pending = None
+
+    def g_gradients(self, batch):
+        """loss_g and d loss_g / d generator variables; section all-reduces start as they finish."""
         B, s = self.bufs, self.store
         N, _, H, W = batch['sketches'].shape
         xd_f, gctx = self._pack_fake(batch)
@@ -149,10 +160,7 @@ class Pix2PixTrainer(object):
         hip.call('ssc_gen_output_grad', xd_f.view(-1)[3:], 8, img4, 4, dgen, 4, N * H * W, 100.0, loss_g, dpre)
         sc = s.generator
         self.G.backward(gctx, dpre, on_section=lambda name: self._section_done(sc, name))
-        self._allreduce_wait()
-        self._adam(sc, self.lr_g * self.decay(counter))
-        if self.D.sn:
-            s['discriminator/fully_connected/u'].copy_(sn['u_new'])
+        self._sn_pending = sn['u_new'] if self.D.sn else None
         self.last = {'gctx': gctx, 'cf': cf}
         return loss_g
 
