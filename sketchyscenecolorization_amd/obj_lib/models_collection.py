@@ -10,7 +10,6 @@ import numpy as np
 import torch
 
 from .. import hip
-from ..params import Buffers, ParamStore
 from ..pix2pix import Pix2PixDiscriminator, Pix2PixGenerator
 from .config import Config
 
@@ -29,12 +28,22 @@ def reset_default_graph():
     _REGISTRY.clear()
 
 
-def get_store(block_type='Pix2Pix', vocab_size=58, img=192, seed=0):
-    """The variable store of the 'default graph' (created on first use, like tf.get_variable)."""
+def get_trainer(block_type='Pix2Pix', vocab_size=58, img=192, seed=0, **kw):
+    """The tower (variables + activation buffers + optimizer slots) of the 'default graph',
+    created on first use like tf.get_variable."""
+    if block_type != 'Pix2Pix':
+        raise NotImplementedError('block_type %r: only the Pix2Pix variant is built in this round; MRU/Residual '
+                                  'follow (SURVEY.md section 7, step 7)' % block_type)
+    from ..trainer import Pix2PixTrainer
     key = (block_type, vocab_size, img)
     if key not in _REGISTRY:
-        _REGISTRY[key] = {'store': ParamStore(block_type, vocab_size, img, 'cuda', seed), 'bufs': Buffers('cuda')}
-    return _REGISTRY[key]['store'], _REGISTRY[key]['bufs']
+        _REGISTRY[key] = Pix2PixTrainer(img=img, vocab_size=vocab_size, seed=seed, sn=Config.sn, **kw)
+    return _REGISTRY[key]
+
+
+def get_store(block_type='Pix2Pix', vocab_size=58, img=192, seed=0):
+    t = get_trainer(block_type, vocab_size, img, seed)
+    return t.store, t.bufs
 
 
 def set_param(data_format='NCHW'):
