@@ -116,7 +116,7 @@ def main():
                'step_frac_of_fp32_peak': flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         if prof:
             agg = {}
-            for name, fl, e0, e1 in prof:
+            for name, fl, e0, e1, _shape in prof:
                 a = agg.setdefault(name, [0.0, 0.0, 0])
                 a[0] += fl
                 a[1] += e0.elapsed_time(e1) * 1e-3

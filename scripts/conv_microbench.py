@@ -1,0 +1,41 @@
+"""Single-layer microbenchmark of the implicit-GEMM kernel (for rocprofv3 --pmc passes).
+usage: conv_microbench.py <layer> [iters];  layers: enc2 enc3 enc4 d4 dec3 wg3"""
+import sys
+import torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sketchyscenecolorization_amd import hip
+from sketchyscenecolorization_amd.hip import View
+layer = sys.argv[1] if len(sys.argv) > 1 else 'enc2'
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+N = 32
+g = torch.Generator(device='cuda').manual_seed(0)
+r = lambda *s: torch.randn(*s, device='cuda', generator=g)
+if layer in ('enc2', 'enc3', 'enc4', 'd4'):
+    hin, ci, co, stride = {'enc2': (96, 64, 128, 2), 'enc3': (48, 128, 256, 2), 'enc4': (24, 256, 512, 2),
+                           'd4': (24, 256, 512, 1)}[layer]
+    x, w = r(N, hin, hin, ci), r(4, 4, ci, co) * 0.02
+    ab = torch.cat([torch.ones(ci, device='cuda'), torch.zeros(ci, device='cuda')])
+    ho = hin // 2 if stride == 2 else hin - 1
+    out = torch.empty(N, ho, ho, co, device='cuda')
+    fn = lambda: hip.conv_forward(View(x, None, ab, 2), w, stride, 1, out)
+    flops = 2.0 * N * ho * ho * co * 16 * ci
+elif layer == 'dec3':
+    x0, x1, f = r(N, 24, 24, 256), r(N, 24, 24, 256), r(4, 4, 128, 512) * 0.02
+    out = torch.empty(N, 48, 48, 128, device='cuda')
+    fn = lambda: hip.deconv_forward(View(x0, x1, None, 1, None), f, out)
+    flops = 2.0 * N * 48 * 48 * 128 * 4 * 512
+elif layer == 'wg3':
+    x, dy, dw = r(N, 48, 48, 128), r(N, 24, 24, 256), torch.empty(4, 4, 128, 256, device='cuda')
+    fn = lambda: hip.conv_wgrad(View(x, None, None, 2), View(dy), dw, 2, 1)
+    flops = 2.0 * N * 24 * 24 * 256 * 16 * 128
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    fn()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+print('%s: %.3f ms  %.1f TFLOP/s' % (layer, ms, flops / ms / 1e9))

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pix2pix as O
 from tests.test_gpu_pix2pix import make, relerr
 n, img = int(sys.argv[1]), int(sys.argv[2])

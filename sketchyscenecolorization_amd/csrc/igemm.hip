@@ -22,31 +22,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BK 32
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == SSC_ACT_RELU) return fmaxf(v, 0.f);
-    if (act == SSC_ACT_LRELU) return fmaxf(v, 0.2f * v);
-    return v;
-}
-
 // Exact division by a launch-constant through multiply-high (the tile loaders run every K-tile:
-// no integer-division expansions, no branches, so all global loads of a tile issue back to back
-// and their latency hides under the MFMA loop of the current tile).
+// no integer-division expansions, no branches).
 struct Magics {
     unsigned mC, oneC;          // kcol / C   (kcol < 2^20, C < 2^12); one* = ~0 when the divisor is 1
     unsigned mTW, oneTW;        // tap / TW
     unsigned long mPW, onePW;   // rem / PW   (64-bit magic: exact for every 32-bit numerator)
     unsigned long mPHPW, onePHPW; // m / (PH*PW)
+    unsigned mPW32, mPHPW32;    // 32-bit forms, valid when use32 (numerator * divisor < 2^32)
+    int use32, _pad;
 };
 static inline unsigned magic32(unsigned d) { return d == 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; }
 static inline unsigned long magic64(unsigned long d) {
     return d == 1 ? 0UL : (unsigned long)((((unsigned __int128)1) << 64) / d) + 1UL;
 }
-static Magics make_magics(unsigned C, unsigned TW, unsigned long PW, unsigned long PHW) {
+static Magics make_magics(unsigned C, unsigned TW, unsigned long PW, unsigned long PHW, unsigned long maxnum) {
     Magics m;
     m.mC = magic32(C); m.oneC = C == 1 ? ~0u : 0u;
     m.mTW = magic32(TW); m.oneTW = TW == 1 ? ~0u : 0u;
     m.mPW = magic64(PW); m.onePW = PW == 1 ? ~0UL : 0UL;
     m.mPHPW = magic64(PHW); m.onePHPW = PHW == 1 ? ~0UL : 0UL;
+    m.mPW32 = magic32((unsigned)PW); m.mPHPW32 = magic32((unsigned)PHW);
+    m.use32 = (maxnum * PHW < 0xFFFFFFFFUL && PHW < 0xFFFFFFFFUL) ? 1 : 0;
+    m._pad = 0;
     return m;
 }
 __device__ __forceinline__ int div32(int n, unsigned magic, unsigned one) {
@@ -79,13 +77,23 @@ __device__ __forceinline__ void gview_src(const ssc_gview& g, int c, const float
     cs = first ? g.C0 : g.C1;
 }
 
-__device__ __forceinline__ float4 xform4(float4 v, const float4& a, const float4& b, int act, bool valid) {
+// act(a*v+b)*m with act(t) = max(t, slope*t): slope 1 = identity, 0 = relu, 0.2 = lrelu; m in {0,1} zeroes the
+// out-of-image / out-of-range elements.  Straight-line code: fp32 MFMA shares the vector lanes with VALU on
+// gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so every VALU instruction here is paid for in matrix throughput.
+__device__ __forceinline__ float act_slope(int act) {
+    return act == SSC_ACT_RELU ? 0.f : (act == SSC_ACT_LRELU ? 0.2f : 1.f);
+}
+__device__ __forceinline__ float4 xform4(float4 v, const float4& a, const float4& b, float slope, float m) {
     float4 r;
-    r.x = valid ? act_apply(fmaf(a.x, v.x, b.x), act) : 0.f;
-    r.y = valid ? act_apply(fmaf(a.y, v.y, b.y), act) : 0.f;
-    r.z = valid ? act_apply(fmaf(a.z, v.z, b.z), act) : 0.f;
-    r.w = valid ? act_apply(fmaf(a.w, v.w, b.w), act) : 0.f;
+    float t;
+    t = fmaf(a.x, v.x, b.x); r.x = fmaxf(t, slope * t) * m;
+    t = fmaf(a.y, v.y, b.y); r.y = fmaxf(t, slope * t) * m;
+    t = fmaf(a.z, v.z, b.z); r.z = fmaxf(t, slope * t) * m;
+    t = fmaf(a.w, v.w, b.w); r.w = fmaxf(t, slope * t) * m;
     return r;
+}
+__device__ __forceinline__ float4 mask4(float4 v, float m) {
+    return make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -110,7 +118,10 @@ __device__ __forceinline__ FwdPhase fwd_phase(const ssc_conv_desc& d, int phase)
     return p;
 }
 
-template <int WM, int WN, int SM, int SN, int BMODE, bool VECB>
+// UT ("uniform tap"): every K-tile lies inside one filter tap and one source tensor (C, C0 multiples of 32,
+// no channel padding, float4 filter loads).  Then the tap decode, source selection and filter base are
+// wave-uniform (scalar unit) and a staged row costs ~8 vector instructions instead of ~25.
+template <int WM, int WN, int SM, int SN, int BMODE, bool VECB, bool UT>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, const Magics mg,
                                                         float* __restrict__ slab_base, long slab_stride,
                                                         int splitk) {
@@ -122,6 +133,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
     constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * (BK + 1);
     constexpr int A_ROWS = BM / 32;   // rows of the A tile per thread
     constexpr int B_SLOTS = BN / 32;  // float4 slots of the B tile per thread
+    constexpr int B_RP = 1024 / BN;   // filter rows per pass (KN)
     static_assert(WM * WN == 4, "4 waves per workgroup");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -149,6 +161,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
     const int a_col4 = tid & 7;            // float4 column inside the K tile
     int a_iyb[A_ROWS], a_ixb[A_ROWS];
     long a_nb[A_ROWS];
+    int a_off0[A_ROWS], a_off1[A_ROWS];    // UT: element offsets of (n, iyb, ixb) in source 0 / 1
     bool a_mv[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
@@ -162,9 +175,30 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
         a_iyb[i] = py * d.in_stride + ph.ioff_y;
         a_ixb[i] = px * d.in_stride + ph.ioff_x;
         a_nb[i] = (long)n * d.x.H * d.x.W;
+        const int pix0 = (n * d.x.H + a_iyb[i]) * d.x.W + a_ixb[i];
+        a_off0[i] = pix0 * d.x.C0 + a_col4 * 4;
+        a_off1[i] = pix0 * d.x.C1 + a_col4 * 4;
         if (a_col4 == 0)
             rowpix[row] = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
     }
+    // ---- per-thread filter offsets (UT): constant over the K loop ----
+    int b_off[B_SLOTS];
+    float b_m[B_SLOTS];
+#pragma unroll
+    for (int s = 0; s < B_SLOTS; ++s) {
+        if (BMODE == 0) {
+            const int n = n0 + (tid % (BN / 4)) * 4;
+            const bool v = n < d.Nn;
+            b_off[s] = v ? (tid / (BN / 4) + B_RP * s) * d.wC1 + d.n_off + n : 0;
+            b_m[s] = v ? 1.f : 0.f;
+        } else {
+            const int n = n0 + (tid >> 3) + 32 * s;
+            const bool v = n < d.Nn;
+            b_off[s] = v ? (d.n_off + n) * d.wC1 + (tid & 7) * 4 : 0;
+            b_m[s] = v ? 1.f : 0.f;
+        }
+    }
+    const bool b_allvalid = (n0 + BN <= d.Nn);
 
     const int nkt = (Ktot + BK - 1) / BK;
     const int per = (nkt + splitk - 1) / splitk;
@@ -181,13 +215,50 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
 
     // staging registers
     float4 ra[A_ROWS];
-    bool rav[A_ROWS];
+    float rav[A_ROWS];    // 1.0 / 0.0 validity of each staged A row
     float4 raa, rab;
+    bool ra_plain = false;   // UT: this K-tile's source has no affine and no activation
     float4 rb[B_SLOTS];
-    int rbm[B_SLOTS];     // per-element validity bits of the staged filter values
+    float4 rbm[B_SLOTS];  // generic path: per-element 1.0 / 0.0 validity of the staged filter values
+    const float x_slope = act_slope(d.x.act);
 
     auto load_tile = [&](int kt) {
-        // ---- A (gather view): every load unconditional from a clamped address ----
+        if (UT) {
+            // ---- scalar (wave-uniform) part ----
+            const int kb = kt * BK;
+            const int tap = div32(kb, mg.mC, mg.oneC);
+            const int cch = kb - tap * C;
+            const int ty = div32(tap, mg.mTW, mg.oneTW), tx = tap - ty * d.TW;
+            const bool first = cch < d.x.C0;
+            const int cs = first ? d.x.C0 : d.x.C1;
+            const int cc = first ? cch : cch - d.x.C0;
+            const float* sbase = (first ? d.x.s0 : d.x.s1) + cc;
+            const float* abp = first ? d.x.ab0 : d.x.ab1;
+            const int tapshift = (ty * d.x.W + tx) * cs;
+            ra_plain = (abp == nullptr) && (d.x.act == SSC_ACT_NONE);
+            if (abp != nullptr) {
+                raa = *reinterpret_cast<const float4*>(abp + cc + a_col4 * 4);
+                rab = *reinterpret_cast<const float4*>(abp + cs + cc + a_col4 * 4);
+            } else {
+                raa = make_float4(1.f, 1.f, 1.f, 1.f);
+                rab = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                const int iy = a_iyb[i] + ty, ix = a_ixb[i] + tx;
+                const bool v = a_mv[i] && (unsigned)iy < (unsigned)d.x.H && (unsigned)ix < (unsigned)d.x.W;
+                const int off = v ? (first ? a_off0[i] : a_off1[i]) + tapshift : a_col4 * 4;
+                rav[i] = v ? 1.f : 0.f;
+                ra[i] = *reinterpret_cast<const float4*>(sbase + off);
+            }
+            const int ky = ph.ky0 + ty * d.kstep, kx = ph.kx0 + tx * d.kstep;
+            const float* wtap = (BMODE == 0) ? d.w + ((long)(ky * d.KW + kx) * d.wC0 + cch) * d.wC1
+                                             : d.w + (long)(ky * d.KW + kx) * d.wC0 * d.wC1 + cch;
+#pragma unroll
+            for (int s = 0; s < B_SLOTS; ++s) rb[s] = *reinterpret_cast<const float4*>(wtap + b_off[s]);
+            return;
+        }
+        // ---- generic path: A (gather view), every load unconditional from a clamped address ----
         {
             const int kcol = kt * BK + a_col4 * 4;
             const bool kv = kcol < Ktot;
@@ -204,19 +275,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
                 const int iy = a_iyb[i] + ty, ix = a_ixb[i] + tx;
                 const bool v = kv && a_mv[i] && iy >= 0 && iy < d.x.H && ix >= 0 && ix < d.x.W;
                 const long pix = v ? a_nb[i] + (long)iy * d.x.W + ix : 0;
-                rav[i] = v;
+                rav[i] = v ? 1.f : 0.f;
                 ra[i] = *reinterpret_cast<const float4*>(base + pix * cs);
             }
         }
-        // ---- B (filter) ----
-        if (BMODE == 0) {
-            // KN: tile [BK rows k][BN cols n], n contiguous in memory
-            constexpr int RP = 1024 / BN;
-            const int col4 = tid % (BN / 4);
-            const int n = n0 + col4 * 4;
+        if (BMODE == 0) {           // KN: tile [BK rows k][BN cols n], n contiguous in memory
+            const int n = n0 + (tid % (BN / 4)) * 4;
 #pragma unroll
             for (int s = 0; s < B_SLOTS; ++s) {
-                const int krow = kt * BK + tid / (BN / 4) + RP * s;
+                const int krow = kt * BK + tid / (BN / 4) + B_RP * s;
                 const bool kv = krow < Ktot;
                 const int kk = kv ? krow : 0;
                 const int tp = div32(kk, mg.mC, mg.oneC);
@@ -224,12 +291,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
                 const int tty = div32(tp, mg.mTW, mg.oneTW), ttx = tp - tty * d.TW;
                 const int ky = ph.ky0 + tty * d.kstep, kx = ph.kx0 + ttx * d.kstep;
                 const bool rowv = kv && kc < d.k_real;
-                const int kcs = rowv ? kc : 0;
-                const float* wp = d.w + ((long)(ky * d.KW + kx) * d.wC0 + kcs) * d.wC1 + d.n_off;
+                const float* wp = d.w + ((long)(ky * d.KW + kx) * d.wC0 + (rowv ? kc : 0)) * d.wC1 + d.n_off;
                 if (VECB) {
                     const bool cv = n < d.Nn;       // Nn % 4 == 0: the whole float4 is in or out
                     rb[s] = *reinterpret_cast<const float4*>(wp + (cv ? n : 0));
-                    rbm[s] = (rowv && cv) ? 15 : 0;
+                    const float m = (rowv && cv) ? 1.f : 0.f;
+                    rbm[s] = make_float4(m, m, m, m);
                 } else {
                     const bool v0 = rowv && n + 0 < d.Nn, v1 = rowv && n + 1 < d.Nn;
                     const bool v2 = rowv && n + 2 < d.Nn, v3 = rowv && n + 3 < d.Nn;
@@ -237,11 +304,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
                     rb[s].y = wp[v1 ? n + 1 : 0];
                     rb[s].z = wp[v2 ? n + 2 : 0];
                     rb[s].w = wp[v3 ? n + 3 : 0];
-                    rbm[s] = (v0 ? 1 : 0) | (v1 ? 2 : 0) | (v2 ? 4 : 0) | (v3 ? 8 : 0);
+                    rbm[s] = make_float4(v0 ? 1.f : 0.f, v1 ? 1.f : 0.f, v2 ? 1.f : 0.f, v3 ? 1.f : 0.f);
                 }
             }
-        } else {
-            // NK: tile [BN rows n][BK cols k], k contiguous in memory
+        } else {                    // NK: tile [BN rows n][BK cols k], k contiguous in memory
             const int kc4 = kt * BK + (tid & 7) * 4;
             const bool kvb = kc4 < Ktot;
             const int kk = kvb ? kc4 : 0;
@@ -258,7 +324,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
                 if (VECB) {
                     const bool cv = kc < d.k_real;  // k_real % 4 == 0
                     rb[s] = *reinterpret_cast<const float4*>(wp + (cv ? kc : 0));
-                    rbm[s] = (nv && cv) ? 15 : 0;
+                    const float m = (nv && cv) ? 1.f : 0.f;
+                    rbm[s] = make_float4(m, m, m, m);
                 } else {
                     const bool v0 = nv && kc + 0 < d.k_real, v1 = nv && kc + 1 < d.k_real;
                     const bool v2 = nv && kc + 2 < d.k_real, v3 = nv && kc + 3 < d.k_real;
@@ -266,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
                     rb[s].y = wp[v1 ? kc + 1 : 0];
                     rb[s].z = wp[v2 ? kc + 2 : 0];
                     rb[s].w = wp[v3 ? kc + 3 : 0];
-                    rbm[s] = (v0 ? 1 : 0) | (v1 ? 2 : 0) | (v2 ? 4 : 0) | (v3 ? 8 : 0);
+                    rbm[s] = make_float4(v0 ? 1.f : 0.f, v1 ? 1.f : 0.f, v2 ? 1.f : 0.f, v3 ? 1.f : 0.f);
                 }
             }
         }
@@ -275,29 +342,34 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
     auto store_tile = [&](int buf) {
         float* Ab = As + buf * A_SZ;
         float* Bb = Bs + buf * B_SZ;
+        if (UT && ra_plain) {       // wave-uniform: no norm, no activation -> only the padding mask
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) {
-            const float4 v = xform4(ra[i], raa, rab, d.x.act, rav[i]);
-            float* p = Ab + ((tid >> 3) + 32 * i) * A_LD + a_col4 * 4;
-            p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
-        }
-        if (BMODE == 0) {
-            constexpr int RP = 1024 / BN;
-            const int col4 = tid % (BN / 4);
-#pragma unroll
-            for (int s = 0; s < B_SLOTS; ++s) {
-                const int row = tid / (BN / 4) + RP * s;
-                float4 v;
-                v.x = (rbm[s] & 1) ? rb[s].x : 0.f; v.y = (rbm[s] & 2) ? rb[s].y : 0.f;
-                v.z = (rbm[s] & 4) ? rb[s].z : 0.f; v.w = (rbm[s] & 8) ? rb[s].w : 0.f;
-                *reinterpret_cast<float4*>(Bb + row * B_LD + col4 * 4) = v;
+            for (int i = 0; i < A_ROWS; ++i) {
+                const float4 v = mask4(ra[i], rav[i]);
+                float* p = Ab + ((tid >> 3) + 32 * i) * A_LD + a_col4 * 4;
+                p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < B_SLOTS; ++s) {
+            for (int i = 0; i < A_ROWS; ++i) {
+                const float4 v = xform4(ra[i], raa, rab, x_slope, rav[i]);
+                float* p = Ab + ((tid >> 3) + 32 * i) * A_LD + a_col4 * 4;
+                p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < B_SLOTS; ++s) {
+            float4 v = rb[s];
+            if (UT) {
+                if (!b_allvalid) v = mask4(v, b_m[s]);      // wave-uniform branch
+            } else {
+                v.x *= rbm[s].x; v.y *= rbm[s].y; v.z *= rbm[s].z; v.w *= rbm[s].w;
+            }
+            if (BMODE == 0) {
+                *reinterpret_cast<float4*>(Bb + (tid / (BN / 4) + B_RP * s) * B_LD + (tid % (BN / 4)) * 4) = v;
+            } else {
                 float* p = Bb + ((tid >> 3) + 32 * s) * B_LD + (tid & 7) * 4;
-                p[0] = (rbm[s] & 1) ? rb[s].x : 0.f; p[1] = (rbm[s] & 2) ? rb[s].y : 0.f;
-                p[2] = (rbm[s] & 4) ? rb[s].z : 0.f; p[3] = (rbm[s] & 8) ? rb[s].w : 0.f;
+                p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
             }
         }
     };
@@ -308,6 +380,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
     }
     __syncthreads();
 
+    // main loop: the global loads of K-tile kt+1 are issued before the 64 MFMAs of K-tile kt and written to
+    // the other LDS buffer after them (one barrier per K-tile)
     const int l31 = lane & 31, lhi = lane >> 5;
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -426,6 +500,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     const float* a_base;
     int a_cs;
     gview_src(d.g, a_c, a_base, a_cs);
+    const bool a_plain = ((a_c < d.g.C0 ? d.g.ab0 : d.g.ab1) == nullptr) && d.g.act == SSC_ACT_NONE;
     const int b_col = n0 + (tid % (BN / 4)) * 4;
     const bool b_cv = b_col < Cd;
     const int b_c = b_cv ? b_col : 0;
@@ -434,6 +509,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     const float* b_base;
     int b_cs;
     gview_src(d.d, b_c, b_base, b_cs);
+    const bool b_plain = ((b_c < d.d.C0 ? d.d.ab0 : d.d.ab1) == nullptr) && d.d.act == SSC_ACT_NONE;
+    const int a_iy0 = d.ioff_y + a_ty, a_ix0 = d.ioff_x + a_tx;
 
     const long nkt = (P + BK - 1) / BK;
     const long per = (nkt + splitk - 1) / splitk;
@@ -449,7 +526,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[A_SLOTS], rb[B_SLOTS];
-    bool rav[A_SLOTS], rbv[B_SLOTS];
+    float rav[A_SLOTS], rbv[B_SLOTS];
+    const float g_slope = act_slope(d.g.act), d_slope = act_slope(d.d.act);
 
     auto load_tile = [&](long kt) {
 #pragma unroll
@@ -457,21 +535,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
             const long p = kt * BK + tid / (BM / 4) + A_RP * s;
             const bool pv = a_cv && p < P;
             const long pp = pv ? p : 0;
-            const int n = (int)div64(pp, mg.mPHPW, mg.onePHPW);
-            const int rem = (int)(pp - (long)n * PHW);
-            const int py = (int)div64(rem, mg.mPW, mg.onePW), px = rem - py * d.PW;
-            const int iy = py * d.in_stride + d.ioff_y + a_ty;
-            const int ix = px * d.in_stride + d.ioff_x + a_tx;
-            const bool v = pv && iy >= 0 && iy < d.g.H && ix >= 0 && ix < d.g.W;
+            int n, py, px;
+            if (mg.use32) {     // wave-uniform: numerators fit the 32-bit multiply-high
+                n = (int)__umulhi((unsigned)pp, mg.mPHPW32) + (int)((unsigned)pp & (unsigned)mg.onePHPW);
+                const int rem = (int)pp - n * PHW;
+                py = (int)__umulhi((unsigned)rem, mg.mPW32) + (int)((unsigned)rem & (unsigned)mg.onePW);
+                px = rem - py * d.PW;
+            } else {
+                n = (int)div64(pp, mg.mPHPW, mg.onePHPW);
+                const int rem = (int)(pp - (long)n * PHW);
+                py = (int)div64(rem, mg.mPW, mg.onePW);
+                px = rem - py * d.PW;
+            }
+            const int iy = py * d.in_stride + a_iy0;
+            const int ix = px * d.in_stride + a_ix0;
+            const bool v = pv && (unsigned)iy < (unsigned)d.g.H && (unsigned)ix < (unsigned)d.g.W;
             const long pix = v ? ((long)n * d.g.H + iy) * d.g.W + ix : 0;
-            rav[s] = v;
+            rav[s] = v ? 1.f : 0.f;
             ra[s] = *reinterpret_cast<const float4*>(a_base + pix * a_cs);
         }
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
             const long p = kt * BK + tid / (BN / 4) + B_RP * s;
             const bool v = b_cv && p < P;   // D lattice == its own pixel grid (d.d.H==PH, d.d.W==PW)
-            rbv[s] = v;
+            rbv[s] = v ? 1.f : 0.f;
             rb[s] = *reinterpret_cast<const float4*>(b_base + (v ? p : 0) * b_cs);
         }
     };
@@ -481,12 +568,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
 #pragma unroll
         for (int s = 0; s < A_SLOTS; ++s) {
             const int row = tid / (BM / 4) + A_RP * s;
-            *reinterpret_cast<float4*>(Ab + row * A_LD + (tid % (BM / 4)) * 4) = xform4(ra[s], aa, ab, d.g.act, rav[s]);
+            *reinterpret_cast<float4*>(Ab + row * A_LD + (tid % (BM / 4)) * 4) =
+                a_plain ? mask4(ra[s], rav[s]) : xform4(ra[s], aa, ab, g_slope, rav[s]);
         }
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
             const int row = tid / (BN / 4) + B_RP * s;
-            *reinterpret_cast<float4*>(Bb + row * B_LD + (tid % (BN / 4)) * 4) = xform4(rb[s], ba, bb, d.d.act, rbv[s]);
+            *reinterpret_cast<float4*>(Bb + row * B_LD + (tid % (BN / 4)) * 4) =
+                b_plain ? mask4(rb[s], rbv[s]) : xform4(rb[s], ba, bb, d_slope, rbv[s]);
         }
     };
 
@@ -569,7 +658,7 @@ static int num_cu() {
     return g_num_cu;
 }
 
-template <int WM, int WN, int SM, int SN, int BMODE, bool VECB>
+template <int WM, int WN, int SM, int SN, int BMODE, bool VECB, bool UT>
 static int launch_fwd_v(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
     constexpr int A_SZ = BM * (BK + 1);
@@ -577,7 +666,8 @@ static int launch_fwd_v(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hip
     constexpr size_t lds = 2 * (A_SZ + B_SZ) * sizeof(float) + BM * sizeof(long);
     const long M = (long)d.NB * d.PH * d.PW;
     const int C = d.x.C0 + d.x.C1;
-    const Magics mg = make_magics((unsigned)C, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW);
+    const Magics mg = make_magics((unsigned)C, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW,
+                                  (unsigned long)M);
     const int Ktot = d.TH * d.TW * C;
     const int nkt = (Ktot + BK - 1) / BK;
     const long mt = (M + BM - 1) / BM;
@@ -599,12 +689,12 @@ static int launch_fwd_v(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hip
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB, UT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
-    hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk);
+    hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB, UT>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk);
     if (splitk > 1) {
         const int thr = 256;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
@@ -618,8 +708,14 @@ static int launch_fwd(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hipSt
     // float4 filter loads need 16-byte aligned, fully in-range groups of 4
     const bool vec = (BMODE == 0) ? (((d.wC1 | d.n_off) & 3) == 0 && (d.Nn & 3) == 0)
                                   : ((d.wC1 & 3) == 0 && (d.k_real & 3) == 0);
-    return vec ? launch_fwd_v<WM, WN, SM, SN, BMODE, true>(d, ws, ws_bytes, st)
-               : launch_fwd_v<WM, WN, SM, SN, BMODE, false>(d, ws, ws_bytes, st);
+    // uniform-tap fast path: every 32-wide K-tile inside one tap and one source, no channel padding
+    const int C = d.x.C0 + d.x.C1;
+    const bool ut = vec && (C % BK) == 0 && (d.x.C0 % BK) == 0 && d.k_real == C &&
+                    (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x7fffffffL &&
+                    (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
+    if (ut) return launch_fwd_v<WM, WN, SM, SN, BMODE, true, true>(d, ws, ws_bytes, st);
+    return vec ? launch_fwd_v<WM, WN, SM, SN, BMODE, true, false>(d, ws, ws_bytes, st)
+               : launch_fwd_v<WM, WN, SM, SN, BMODE, false, false>(d, ws, ws_bytes, st);
 }
 
 // tile configuration ids: 0 = 128x128, 1 = 64x128 (few rows), 2 = 128x64, 3 = 128x32
@@ -680,7 +776,8 @@ static int launch_wgrad(const ssc_wgrad_desc& d, float* ws, int64_t ws_bytes, hi
     const int Cg = d.g.C0 + d.g.C1;
     const int Mtot = d.TH * d.TW * Cg;
     const long P = (long)d.NB * d.PH * d.PW;
-    const Magics mg = make_magics((unsigned)Cg, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW);
+    const Magics mg = make_magics((unsigned)Cg, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW,
+                                  (unsigned long)P);
     const long nkt = (P + BK - 1) / BK;
     const int mt = (Mtot + BM - 1) / BM;
     const int nt = (d.Nn + BN - 1) / BN;

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libsketchycolor_hip.so')
+LIB_PATH = os.environ.get('SSC_LIB_PATH') or os.path.join(_HERE, 'lib', 'libsketchycolor_hip.so')
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 ACT_MIU = 3     # only for the pointwise kernels, never on load
@@ -183,7 +183,8 @@ def _run_conv(d):
     e0.record()
     check(lib().ssc_conv_forward(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_forward')
     e1.record()
-    PROFILE.append((_kernel_name('ssc_conv_forward_kernel_name', d), flops, e0, e1))
+    PROFILE.append((_kernel_name('ssc_conv_forward_kernel_name', d), flops, e0, e1,
+                    (d.NB * d.PH * d.PW * d.nphase, d.Nn, d.TH * d.TW * d.k_real)))
 
 
 def _run_wgrad(d):
@@ -196,7 +197,8 @@ def _run_wgrad(d):
     e0.record()
     check(lib().ssc_conv_wgrad(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_wgrad')
     e1.record()
-    PROFILE.append((_kernel_name('ssc_conv_wgrad_kernel_name', d), flops, e0, e1))
+    PROFILE.append((_kernel_name('ssc_conv_wgrad_kernel_name', d), flops, e0, e1,
+                    (d.TH * d.TW * d.Cg_real, d.Nn, d.NB * d.PH * d.PW)))
 
 
 def _out_geom(out, coff):
