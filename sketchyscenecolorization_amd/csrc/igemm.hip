@@ -658,8 +658,48 @@ static int num_cu() {
     return g_num_cu;
 }
 
+// Tile configurations.  `res` = workgroups resident per CU (LDS-limited), `penalty` = relative cost of the
+// staging instructions per MFMA (fp32 MFMA does not overlap VALU on gfx950).
+struct TileCfg { int id, BM, BN, res; double penalty; };
+static const TileCfg FWD_CFGS[4] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.10}, {2, 128, 64, 3, 1.04}, {3, 128, 32, 3, 1.25}};
+static const TileCfg WG_CFGS[5] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.08}, {2, 128, 64, 3, 1.08}, {3, 64, 64, 4, 1.2},
+                                   {4, 128, 32, 4, 1.3}};
+
+// Makespan model of one launch: `blocks` equal workgroups of `w` MFMA-cycles each on ncu CUs that hold `res`
+// of them at a time and are matrix-pipe bound (co-resident workgroups share the pipe).  Split-K by s divides w
+// and multiplies the block count, at the price of writing + re-reading s partial copies of the output.
+static double makespan(long blocks, double w, int res, int ncu) {
+    const long slots = (long)ncu * res;
+    const long full = blocks / slots, rem = blocks % slots;
+    return (double)(full * res + (rem + ncu - 1) / ncu) * w;
+}
+
+struct Plan { int cfg; int splitk; double cost; };
+
+static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long M, long N, long nphase, long nkt,
+                        long out_elems, int64_t ws_bytes, bool have_ws) {
+    const int ncu = num_cu();
+    Plan best = {-1, 1, 1e300};
+    for (int c = 0; c < ncfg; ++c) {
+        if (!allowed[c]) continue;
+        const TileCfg& t = cfgs[c];
+        const long mt = (M + t.BM - 1) / t.BM, nt = (N + t.BN - 1) / t.BN;
+        const long blocks = mt * nt * nphase;
+        const double wfull = (double)nkt * 16.0 * (t.BM / 32) * (t.BN / 32) / 4.0 * 64.0 * t.penalty;  // cycles
+        for (int sk = 1; sk <= 16; ++sk) {
+            if (sk > 1 && (!have_ws || nkt / sk < 4 || (int64_t)sk * out_elems * 4 > ws_bytes)) break;
+            const long per = (nkt + sk - 1) / sk;
+            if ((nkt + per - 1) / per != sk) continue;      // would leave empty trailing splits
+            double cost = makespan(blocks * sk, wfull * (double)per / (double)nkt, t.res, ncu) + 2500.0;
+            if (sk > 1) cost += 2.0 * sk * (double)out_elems * 4.0 / 1500.0 + 6000.0;   // slab traffic + reduce launch
+            if (cost < best.cost) best = {c, sk, cost};
+        }
+    }
+    return best;
+}
+
 template <int WM, int WN, int SM, int SN, int BMODE, bool VECB, bool UT>
-static int launch_fwd_v(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hipStream_t st) {
+static int launch_fwd_v(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
     constexpr int A_SZ = BM * (BK + 1);
     constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * (BK + 1);
@@ -668,33 +708,18 @@ static int launch_fwd_v(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hip
     const int C = d.x.C0 + d.x.C1;
     const Magics mg = make_magics((unsigned)C, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW,
                                   (unsigned long)M);
-    const int Ktot = d.TH * d.TW * C;
-    const int nkt = (Ktot + BK - 1) / BK;
     const long mt = (M + BM - 1) / BM;
     const int nt = (d.Nstore + BN - 1) / BN;
-    const long blocks = mt * nt * d.nphase;
-    // split-K when the grid cannot fill the chip (2 workgroups per CU resident)
-    int splitk = 1;
     const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
-    const int target = 2 * num_cu();
-    if (ws != nullptr && blocks < target && nkt >= 8) {
-        splitk = (int)((target + blocks - 1) / blocks);
-        if (splitk > nkt / 4) splitk = nkt / 4;
-        if (splitk > 32) splitk = 32;
-        while (splitk > 1 && (int64_t)splitk * out_count * (int64_t)sizeof(float) > ws_bytes) --splitk;
-        if (splitk < 1) splitk = 1;
-        // avoid empty trailing splits
-        const int per = (nkt + splitk - 1) / splitk;
-        splitk = (nkt + per - 1) / per;
-    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB, UT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
-    hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB, UT>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk);
+    hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB, UT>), grid, dim3(256), lds, st, d, mg, ws,
+                       out_count, splitk);
     if (splitk > 1) {
         const int thr = 256;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
@@ -704,7 +729,7 @@ static int launch_fwd_v(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hip
 }
 
 template <int WM, int WN, int SM, int SN, int BMODE>
-static int launch_fwd(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hipStream_t st) {
+static int launch_fwd(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st) {
     // float4 filter loads need 16-byte aligned, fully in-range groups of 4
     const bool vec = (BMODE == 0) ? (((d.wC1 | d.n_off) & 3) == 0 && (d.Nn & 3) == 0)
                                   : ((d.wC1 & 3) == 0 && (d.k_real & 3) == 0);
@@ -713,18 +738,19 @@ static int launch_fwd(const ssc_conv_desc& d, float* ws, int64_t ws_bytes, hipSt
     const bool ut = vec && (C % BK) == 0 && (d.x.C0 % BK) == 0 && d.k_real == C &&
                     (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x7fffffffL &&
                     (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
-    if (ut) return launch_fwd_v<WM, WN, SM, SN, BMODE, true, true>(d, ws, ws_bytes, st);
-    return vec ? launch_fwd_v<WM, WN, SM, SN, BMODE, true, false>(d, ws, ws_bytes, st)
-               : launch_fwd_v<WM, WN, SM, SN, BMODE, false, false>(d, ws, ws_bytes, st);
+    if (ut) return launch_fwd_v<WM, WN, SM, SN, BMODE, true, true>(d, splitk, ws, st);
+    return vec ? launch_fwd_v<WM, WN, SM, SN, BMODE, true, false>(d, splitk, ws, st)
+               : launch_fwd_v<WM, WN, SM, SN, BMODE, false, false>(d, splitk, ws, st);
 }
 
-// tile configuration ids: 0 = 128x128, 1 = 64x128 (few rows), 2 = 128x64, 3 = 128x32
-static int select_fwd_cfg(const ssc_conv_desc& d) {
+static Plan plan_fwd(const ssc_conv_desc& d, int64_t ws_bytes, bool have_ws) {
     const long M = (long)d.NB * d.PH * d.PW;
-    const bool smallM = M <= 2304;   // few row tiles: use the 64-row tile for more workgroups
-    if (d.Nstore > 64) return smallM ? 1 : 0;
-    if (d.Nstore > 32) return 2;
-    return 3;
+    const int C = d.x.C0 + d.x.C1;
+    const long nkt = ((long)d.TH * d.TW * C + BK - 1) / BK;
+    // column tile no wider than needed: <=32 -> 128x32, <=64 -> 128x64, else 128x128 / 64x128 / 128x64
+    const bool allowed[4] = {d.Nstore > 64, d.Nstore > 64, d.Nstore > 32, d.Nstore <= 32};
+    return plan_launch(FWD_CFGS, 4, allowed, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,
+                       have_ws);
 }
 
 static void copy_name(const char* src, char* dst, int len) {
@@ -737,7 +763,8 @@ extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, 
     static const char* names[2][4] = {
         {"conv_fwd<128x128,KN>", "conv_fwd<64x128,KN>", "conv_fwd<128x64,KN>", "conv_fwd<128x32,KN>"},
         {"conv_fwd<128x128,NK>", "conv_fwd<64x128,NK>", "conv_fwd<128x64,NK>", "conv_fwd<128x32,NK>"}};
-    copy_name(names[dp->bmode ? 1 : 0][select_fwd_cfg(*dp)], buf, len);
+    const Plan p = plan_fwd(*dp, (int64_t)1 << 40, true);
+    copy_name(names[dp->bmode ? 1 : 0][p.cfg < 0 ? 0 : p.cfg], buf, len);
     return 0;
 }
 
@@ -749,28 +776,27 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
     if (d.nphase == 4 && (d.TH != 2 || d.TW != 2 || d.KH != 4 || d.KW != 4 || d.kstep != -2 || d.out_stride != 2 ||
                           d.in_stride != 1))
         return -3;
-    // split-K partial slabs cover the whole output; with 4 phases every phase writes a disjoint
-    // quarter of each slab, so unwritten entries must not exist: require all phases present (true).
-    const int cfg = select_fwd_cfg(d);
+    const Plan p = plan_fwd(d, ws_bytes, ws != nullptr);
+    if (p.cfg < 0) return -4;
     if (d.bmode == 0) {
-        switch (cfg) {
-            case 0: return launch_fwd<2, 2, 2, 2, 0>(d, ws, ws_bytes, st);
-            case 1: return launch_fwd<2, 2, 1, 2, 0>(d, ws, ws_bytes, st);
-            case 2: return launch_fwd<2, 2, 2, 1, 0>(d, ws, ws_bytes, st);
-            default: return launch_fwd<4, 1, 1, 1, 0>(d, ws, ws_bytes, st);
+        switch (p.cfg) {
+            case 0: return launch_fwd<2, 2, 2, 2, 0>(d, p.splitk, ws, st);
+            case 1: return launch_fwd<2, 2, 1, 2, 0>(d, p.splitk, ws, st);
+            case 2: return launch_fwd<2, 2, 2, 1, 0>(d, p.splitk, ws, st);
+            default: return launch_fwd<4, 1, 1, 1, 0>(d, p.splitk, ws, st);
         }
     } else {
-        switch (cfg) {
-            case 0: return launch_fwd<2, 2, 2, 2, 1>(d, ws, ws_bytes, st);
-            case 1: return launch_fwd<2, 2, 1, 2, 1>(d, ws, ws_bytes, st);
-            case 2: return launch_fwd<2, 2, 2, 1, 1>(d, ws, ws_bytes, st);
-            default: return launch_fwd<4, 1, 1, 1, 1>(d, ws, ws_bytes, st);
+        switch (p.cfg) {
+            case 0: return launch_fwd<2, 2, 2, 2, 1>(d, p.splitk, ws, st);
+            case 1: return launch_fwd<2, 2, 1, 2, 1>(d, p.splitk, ws, st);
+            case 2: return launch_fwd<2, 2, 2, 1, 1>(d, p.splitk, ws, st);
+            default: return launch_fwd<4, 1, 1, 1, 1>(d, p.splitk, ws, st);
         }
     }
 }
 
 template <int WM, int WN, int SM, int SN>
-static int launch_wgrad(const ssc_wgrad_desc& d, float* ws, int64_t ws_bytes, hipStream_t st) {
+static int launch_wgrad(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
     constexpr size_t lds = 2 * (BK * BM + BK * BN) * sizeof(float);
     const int Cg = d.g.C0 + d.g.C1;
@@ -778,26 +804,13 @@ static int launch_wgrad(const ssc_wgrad_desc& d, float* ws, int64_t ws_bytes, hi
     const long P = (long)d.NB * d.PH * d.PW;
     const Magics mg = make_magics((unsigned)Cg, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW,
                                   (unsigned long)P);
-    const long nkt = (P + BK - 1) / BK;
     const int mt = (Mtot + BM - 1) / BM;
     const int nt = (d.Nn + BN - 1) / BN;
-    const long blocks = (long)mt * nt;
     const long out_count = (long)d.TH * d.TW * d.Cg_real * d.ldc;
-    int splitk = 1;
-    const int target = 3 * num_cu();
-    if (ws != nullptr && blocks < target && nkt >= 8) {
-        long s = (target + blocks - 1) / blocks;
-        if (s > nkt / 4) s = nkt / 4;
-        if (s > 256) s = 256;
-        while (s > 1 && s * out_count * (long)sizeof(float) > ws_bytes) --s;
-        if (s < 1) s = 1;
-        const long per = (nkt + s - 1) / s;
-        splitk = (int)((nkt + per - 1) / per);
-    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<WM, WN, SM, SN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)splitk);
@@ -810,18 +823,44 @@ static int launch_wgrad(const ssc_wgrad_desc& d, float* ws, int64_t ws_bytes, hi
     return (int)hipGetLastError();
 }
 
-// 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
-static int select_wgrad_cfg(const ssc_wgrad_desc& d) {
-    const int Mtot = d.TH * d.TW * (d.g.C0 + d.g.C1);
-    if (d.Nn > 64) return Mtot > 64 ? 0 : 1;
-    if (d.Nn > 32) return Mtot > 64 ? 2 : 3;
-    return 4;
+// split over the pixel (K) dimension: many more choices than the forward form, so search a wider range
+static Plan plan_wgrad(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws) {
+    const int Cg = d.g.C0 + d.g.C1;
+    const long Mtot = (long)d.TH * d.TW * Cg;
+    const long P = (long)d.NB * d.PH * d.PW;
+    const long nkt = (P + BK - 1) / BK;
+    const long out_elems = (long)d.TH * d.TW * d.Cg_real * d.ldc;
+    bool allowed[5];
+    allowed[0] = d.Nn > 64 && Mtot > 64;
+    allowed[1] = d.Nn > 64 && Mtot <= 64;
+    allowed[2] = d.Nn > 32 && d.Nn <= 64 && Mtot > 64;
+    allowed[3] = d.Nn > 32 && d.Nn <= 64 && Mtot <= 64;
+    allowed[4] = d.Nn <= 32;
+    const int ncu = num_cu();
+    Plan best = {-1, 1, 1e300};
+    for (int c = 0; c < 5; ++c) {
+        if (!allowed[c]) continue;
+        const TileCfg& t = WG_CFGS[c];
+        const long mt = (Mtot + t.BM - 1) / t.BM, nt = (d.Nn + t.BN - 1) / t.BN;
+        const long blocks = mt * nt;
+        const double wfull = (double)nkt * 16.0 * (t.BM / 32) * (t.BN / 32) / 4.0 * 64.0 * t.penalty;
+        for (long sk = 1; sk <= 512; sk = (sk < 16 ? sk + 1 : sk + sk / 8)) {
+            if (sk > 1 && (!have_ws || nkt / sk < 4 || (int64_t)sk * out_elems * 4 > ws_bytes)) break;
+            const long per = (nkt + sk - 1) / sk;
+            if ((nkt + per - 1) / per != sk) continue;
+            double cost = makespan(blocks * sk, wfull * (double)per / (double)nkt, t.res, ncu) + 2500.0;
+            if (sk > 1) cost += 2.0 * sk * (double)out_elems * 4.0 / 1500.0 + 6000.0;
+            if (cost < best.cost) best = {c, (int)sk, cost};
+        }
+    }
+    return best;
 }
 
 extern "C" int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* dp, char* buf, int len) {
     static const char* names[5] = {"conv_wgrad<128x128>", "conv_wgrad<64x128>", "conv_wgrad<128x64>",
                                    "conv_wgrad<64x64>", "conv_wgrad<128x32>"};
-    copy_name(names[select_wgrad_cfg(*dp)], buf, len);
+    const Plan p = plan_wgrad(*dp, (int64_t)1 << 40, true);
+    copy_name(names[p.cfg < 0 ? 0 : p.cfg], buf, len);
     return 0;
 }
 
@@ -833,11 +872,13 @@ extern "C" int ssc_conv_wgrad(const ssc_wgrad_desc* dp, float* ws, int64_t ws_by
     // the filter-gradient slab is dense [TH*TW*Cg_real][ldc]; rows/cols skipped by the kernel
     // (padding channels) do not exist in it, so every slab entry is written when ldc == Nn.
     if (d.ldc != d.Nn) return -3;
-    switch (select_wgrad_cfg(d)) {
-        case 0: return launch_wgrad<2, 2, 2, 2>(d, ws, ws_bytes, st);
-        case 1: return launch_wgrad<1, 4, 2, 1>(d, ws, ws_bytes, st);
-        case 2: return launch_wgrad<2, 2, 2, 1>(d, ws, ws_bytes, st);
-        case 3: return launch_wgrad<2, 2, 1, 1>(d, ws, ws_bytes, st);
-        default: return launch_wgrad<4, 1, 1, 1>(d, ws, ws_bytes, st);
+    const Plan p = plan_wgrad(d, ws_bytes, ws != nullptr);
+    switch (p.cfg) {
+        case 0: return launch_wgrad<2, 2, 2, 2>(d, p.splitk, ws, st);
+        case 1: return launch_wgrad<1, 4, 2, 1>(d, p.splitk, ws, st);
+        case 2: return launch_wgrad<2, 2, 2, 1>(d, p.splitk, ws, st);
+        case 3: return launch_wgrad<2, 2, 1, 1>(d, p.splitk, ws, st);
+        case 4: return launch_wgrad<4, 1, 1, 1>(d, p.splitk, ws, st);
+        default: return -4;
     }
 }
