@@ -171,9 +171,10 @@ int ssc_gen_output_grad(const float* gen, int ldg, const float* img, int ldi, co
                         float coef, double* loss_acc, float* dpre, void* stream);
 /* ly.l2_regularizer: loss_acc += rate*sum(w^2)/2; grad += rate*w   (mru.py:55,60) */
 int ssc_l2_reg(const float* w, int64_t n, float rate, double* loss_acc, float* grad, void* stream);
-/* tf.train.AdamOptimizer dense apply (graph_single.py:588); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host */
-int ssc_adam_tf(float* var, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
-                float eps, float gscale, void* stream);
+/* tf.train.AdamOptimizer dense apply (graph_single.py:588); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host, or read
+ * from the device scalar lr_dev when it is not NULL (so a captured hipGraph can be replayed with a new step size) */
+int ssc_adam_tf(float* var, const float* grad, float* m, float* v, int64_t n, float lr_t, const float* lr_dev,
+                float beta1, float beta2, float eps, float gscale, void* stream);
 /* spectral_normed_weight, one power iteration (sn.py:12-52) and its full gradient */
 int ssc_sn_forward(const float* W, const float* u, int m, int n, float* v, float* u_new, float* wbar, float* aux,
                    void* stream);

@@ -158,8 +158,9 @@ extern "C" int ssc_l2_reg(const float* w, int64_t n, float rate, double* loss_ac
 // g = gscale*grad; m = b1*m + (1-b1)*g (m may be NULL when b1 == 0); v = b2*v + (1-b2)*g^2;
 // var -= lr_t * m / (sqrt(v) + eps)      -- eps outside the bias-corrected sqrt, lr_t from the host
 __global__ void adam_tf_kernel(float* __restrict__ var, const float* __restrict__ grad, float* __restrict__ m,
-                               float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps,
-                               float gscale) {
+                               float* __restrict__ v, long n, float lr_t, const float* __restrict__ lr_dev, float b1,
+                               float b2, float eps, float gscale) {
+    if (lr_dev != nullptr) lr_t = *lr_dev;      // step size kept in device memory (graph replay)
     long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (; i + 3 < n; i += stride) {
@@ -187,14 +188,14 @@ __global__ void adam_tf_kernel(float* __restrict__ var, const float* __restrict_
     }
 }
 
-extern "C" int ssc_adam_tf(float* var, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
-                           float beta2, float eps, float gscale, void* stream) {
+extern "C" int ssc_adam_tf(float* var, const float* grad, float* m, float* v, int64_t n, float lr_t,
+                           const float* lr_dev, float beta1, float beta2, float eps, float gscale, void* stream) {
     if (n & 3) return -1;   // flat parameter buffers are padded to 4 floats
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, var, grad, m, v,
-                       (long)n, lr_t, beta1, beta2, eps, gscale);
+                       (long)n, lr_t, lr_dev, beta1, beta2, eps, gscale);
     return CHECK_LAUNCH();
 }
 

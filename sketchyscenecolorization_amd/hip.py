@@ -90,7 +90,7 @@ SIGNATURES = {
     'ssc_acgan_loss': [_P, _P, _I, _I, _I, _F, _P, _P, _P],
     'ssc_gen_output_grad': [_P, _I, _P, _I, _P, _I, _L, _F, _P, _P, _P],
     'ssc_l2_reg': [_P, _L, _F, _P, _P, _P],
-    'ssc_adam_tf': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P],
+    'ssc_adam_tf': [_P, _P, _P, _P, _L, _F, _P, _F, _F, _F, _F, _P],
     'ssc_sn_forward': [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     'ssc_sn_backward': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P],
     'ssc_axpy': [_P, _P, _F, _L, _P],

@@ -165,16 +165,17 @@ class ParamStore(object):
 
 
 class Buffers(object):
-    """Named activation buffers, allocated once per shape and reused across iterations."""
+    """Named activation buffers, allocated once per (name, shape) and never freed, so device pointers
+    recorded in a captured hipGraph stay valid while other shapes (caption lengths, batch sizes) come and go."""
 
     def __init__(self, device='cuda'):
         self.device = device
         self._b = {}
 
     def get(self, name, shape, dtype=torch.float32, zero_on_alloc=False):
-        shape = tuple(int(s) for s in shape)
-        t = self._b.get(name)
-        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
-            t = (torch.zeros if zero_on_alloc else torch.empty)(shape, dtype=dtype, device=self.device)
-            self._b[name] = t
+        key = (name, tuple(int(s) for s in shape), dtype)
+        t = self._b.get(key)
+        if t is None:
+            t = (torch.zeros if zero_on_alloc else torch.empty)(key[1], dtype=dtype, device=self.device)
+            self._b[key] = t
         return t

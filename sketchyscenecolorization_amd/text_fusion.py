@@ -30,25 +30,42 @@ class TextFusion(object):
         self.s = store
         self.b = bufs
 
+    def prepare(self, text, tag='g'):
+        """Host side of the caption branch: which steps run at all, time-major token ids and the per-sample
+        skip mask, uploaded to (static) device buffers.  Kept apart from ``forward`` so that a captured
+        hipGraph of the step contains no host->device copy."""
+        B = self.b
+        text = np.asarray(text.cpu() if isinstance(text, torch.Tensor) else text).astype(np.int32)
+        N = text.shape[0]
+        text = text.reshape(N, -1)
+        steps = [t for t in range(text.shape[1]) if (text[:, t] != 0).any()]
+        S = len(steps)
+        prep = {'S': S, 'N': N}
+        if S > 0:
+            tok_np = np.ascontiguousarray(text[:, steps].T).reshape(-1)        # time-major [S*N]
+            tok = B.get(tag + '/tf/tok', (S * N,), torch.int32)
+            tok.copy_(torch.from_numpy(tok_np))
+            mask = B.get(tag + '/tf/mask', (S, N), torch.int32)
+            mask.copy_(torch.from_numpy((tok_np != 0).astype(np.int32)).view(S, N))
+            prep.update(tok=tok, mask=mask)
+        return prep
+
     def forward(self, e5, ab5, text, tag='g'):
-        """e5 raw [N,h,w,C] (+ folded norm ab5), text int [N,T] on the HOST -> feat [N,h,w,C]."""
+        """e5 raw [N,h,w,C] (+ folded norm ab5), text int [N,T] on the HOST (or a ``prepare`` result)
+        -> feat [N,h,w,C]."""
         s, B = self.s, self.b
         N, hh, ww, C = e5.shape
         P = hh * ww
         R = N * P
-        text = np.asarray(text.cpu() if isinstance(text, torch.Tensor) else text).astype(np.int32).reshape(N, -1)
-        steps = [t for t in range(text.shape[1]) if (text[:, t] != 0).any()]
-        S = len(steps)
+        prep = text if isinstance(text, dict) else self.prepare(text, tag)
+        S = prep['S']
+        assert prep['N'] == N
         ctx = {'N': N, 'P': P, 'C': C, 'S': S, 'tag': tag, 'shape': (N, hh, ww, C)}
         feat = B.get(tag + '/tf/feat', (N, hh, ww, C))
         if S == 0:      # every caption is all padding: relu(atanh(0)) = 0 (SURVEY appendix B.5)
             hip.fill(feat, 0.0)
             return feat, ctx
-        tok_np = np.ascontiguousarray(text[:, steps].T).reshape(-1)        # time-major [S*N]
-        tok = B.get(tag + '/tf/tok', (S * N,), torch.int32)
-        tok.copy_(torch.from_numpy(tok_np), non_blocking=True)
-        mask = B.get(tag + '/tf/mask', (S, N), torch.int32)
-        mask.copy_(torch.from_numpy((tok_np != 0).astype(np.int32)).view(S, N), non_blocking=True)
+        tok, mask = prep['tok'], prep['mask']
         E = s['generator/TextLSTM/embedding']
         Kw, bw = s[PFX_W + 'kernel'], s[PFX_W + 'bias']
         Ka, ba = s[PFX_A + 'kernel'], s[PFX_A + 'bias']

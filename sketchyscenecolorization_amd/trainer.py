@@ -26,7 +26,7 @@ from .pix2pix import Pix2PixDiscriminator, Pix2PixGenerator
 
 class Pix2PixTrainer(object):
     def __init__(self, img=192, vocab_size=58, lstm_hybrid=True, lr_g=2e-4, lr_d=1e-4, max_iter_step=100000,
-                 seed=0, sn=True, process_group=None, device='cuda'):
+                 seed=0, sn=True, process_group=None, device='cuda', use_graphs=False):
         if not torch.cuda.is_available():
             raise RuntimeError('Pix2PixTrainer needs an MI355X (HIP) device: there is no CPU fallback')
         hip.lib()
@@ -42,6 +42,12 @@ class Pix2PixTrainer(object):
         g = self.store.generator.offsets
         self._g_sections = self._sections(g)
         self._sn_pending = None
+        # hipGraph replay of whole D-/G-steps (the ~550 launches of a step are host-bound otherwise):
+        # a step shape is run eagerly the first time, captured the second time, replayed afterwards
+        self.use_graphs = bool(use_graphs)
+        self._capturing = False
+        self._graphs, self._seen, self._static = {}, set(), {}
+        self.lr_dev = torch.zeros(2, dtype=torch.float32, device=device)     # Adam step sizes [G, D]
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -65,12 +71,54 @@ class Pix2PixTrainer(object):
     def _allreduce_wait(self):
         self.reducer.wait()
 
-    def _adam(self, scope, lr):
+    def _adam_prepare(self, scope, idx, lr):
+        """Host part of the optimizer step: advance t, put lr_t = lr*sqrt(1-b2^t)/(1-b1^t) in device memory."""
         scope.adam_t += 1
         t = scope.adam_t
         lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
-        hip.call('ssc_adam_tf', scope.flat, scope.grad, None, scope.adam_v, scope.numel, float(lr_t), self.beta1,
-                 self.beta2, self.eps, 1.0 / self.world)
+        self.lr_dev[idx:idx + 1].fill_(float(lr_t))
+
+    def _adam_launch(self, scope, idx):
+        hip.call('ssc_adam_tf', scope.flat, scope.grad, None, scope.adam_v, scope.numel, 0.0,
+                 self.lr_dev[idx:idx + 1], self.beta1, self.beta2, self.eps, 1.0 / self.world)
+
+    def _run_step(self, kind, batch, counter):
+        """Eager, capture or replay of one D-/G-step."""
+        scope, idx, lr = ((self.store.discriminator, 1, self.lr_d) if kind == 'd' else
+                          (self.store.generator, 0, self.lr_g))
+        impl = self._d_impl if kind == 'd' else self._g_impl
+        if not self.use_graphs or hip.PROFILE is not None:
+            self._adam_prepare(scope, idx, lr * self.decay(counter))
+            return impl(batch)
+        # static inputs: graphs replay fixed device addresses
+        N, _, H, W = batch['sketches'].shape
+        skey = (kind, N, H, W)
+        st = self._static.get(skey)
+        if st is None:
+            st = {k: torch.empty_like(v) for k, v in batch.items() if isinstance(v, torch.Tensor)}
+            self._static[skey] = st
+        for k, v in st.items():
+            v.copy_(batch[k])
+        sbatch = dict(st)
+        sbatch['text'] = self.G.text.prepare(batch['text'], 'g') if self.G.lstm_hybrid else batch['text']
+        S = sbatch['text']['S'] if isinstance(sbatch['text'], dict) else -1
+        key = skey + (S,)
+        self._adam_prepare(scope, idx, lr * self.decay(counter))
+        g = self._graphs.get(key)
+        if g is None:
+            if key not in self._seen:       # first time: eager (allocates buffers, sets kernel attributes)
+                self._seen.add(key)
+                return impl(sbatch)
+            g = torch.cuda.CUDAGraph()
+            self._capturing = True
+            try:
+                with torch.cuda.graph(g):
+                    impl(sbatch)
+            finally:
+                self._capturing = False
+            self._graphs[key] = g
+        g.replay()
+        return self.loss[1:2] if kind == 'd' else self.loss[0:1]
 
     def _pack_fake(self, batch):
         B = self.bufs
@@ -83,16 +131,23 @@ class Pix2PixTrainer(object):
     # ------------------------------------------------------------------ steps
     def d_step(self, batch, counter=0):
         """One discriminator update; returns the device scalar loss_d (a view of self.loss)."""
+        return self._run_step('d', batch, counter)
+
+    def _d_impl(self, batch):
         loss_d = self.d_gradients(batch)
-        self.apply_d(counter)
+        self._apply_d_launch()
         return loss_d
 
     def apply_d(self, counter=0):
         """optim_d.apply_gradients on the (all-reduced) discriminator gradients."""
+        self._adam_prepare(self.store.discriminator, 1, self.lr_d * self.decay(counter))
+        self._apply_d_launch()
+
+    def _apply_d_launch(self):
         sc = self.store.discriminator
         self._allreduce_async(sc.grad, 0, sc.numel)
         self._allreduce_wait()
-        self._adam(sc, self.lr_d * self.decay(counter))
+        self._adam_launch(sc, 1)
 
     def d_gradients(self, batch):
         """loss_d and d loss_d / d discriminator variables (compute_gradients, graph_single.py:309-312)."""
@@ -126,14 +181,21 @@ class Pix2PixTrainer(object):
 
     def g_step(self, batch, counter=0):
         """One generator update (+ spectral-norm u assignment); returns the device scalar loss_g."""
+        return self._run_step('g', batch, counter)
+
+    def _g_impl(self, batch):
         loss_g = self.g_gradients(batch)
-        self.apply_g(counter)
+        self._apply_g_launch()
         return loss_g
 
     def apply_g(self, counter=0):
         """optim_g.apply_gradients under control_dependencies(spectral-norm u assigns)."""
+        self._adam_prepare(self.store.generator, 0, self.lr_g * self.decay(counter))
+        self._apply_g_launch()
+
+    def _apply_g_launch(self):
         self._allreduce_wait()
-        self._adam(self.store.generator, self.lr_g * self.decay(counter))
+        self._adam_launch(self.store.generator, 0)
         if self.D.sn and self._sn_pending is not None:
             self.store['discriminator/fully_connected/u'].copy_(self._sn_pending)
             self._sn_pending = None

@@ -112,3 +112,21 @@ def test_two_iterations_match_oracle_training():
     # Adam with beta1=0 moves every weight by ~lr per step regardless of gradient scale, so a
     # gradient whose sign flips under fp32 noise shifts a weight by up to 2*lr: bound by a few lr.
     assert worst[1] < 1e-3, worst
+
+
+def test_hipgraph_replay_matches_eager():
+    """Steps run eagerly (1st), captured (2nd) and replayed (3rd+) must equal the all-eager trainer."""
+    from sketchyscenecolorization_amd.synthetic import synthetic_batch
+    from sketchyscenecolorization_amd.trainer import Pix2PixTrainer
+    a = Pix2PixTrainer(img=64, seed=5, max_iter_step=50)
+    b = Pix2PixTrainer(img=64, seed=5, max_iter_step=50, use_graphs=True)
+    bd, bg = synthetic_batch(2, 11, 64), synthetic_batch(2, 12, 64)
+    bd2 = synthetic_batch(2, 13, 64)
+    for it in range(5):
+        d_in = bd if it != 3 else bd2          # new data through the same captured graph (if same caption steps)
+        la = (float(a.d_step(d_in, it)), float(a.g_step(bg, it)))
+        lb = (float(b.d_step(d_in, it)), float(b.g_step(bg, it)))
+        assert abs(la[0] - lb[0]) < 1e-4 * max(1.0, abs(la[0])) and abs(la[1] - lb[1]) < 1e-4 * max(1.0, abs(la[1])), (it, la, lb)
+    assert len(b._graphs) >= 2
+    worst = max(float((a.store[n] - b.store[n]).abs().max()) for n in a.store.names())
+    assert worst < 1e-3, worst
