@@ -661,7 +661,9 @@ static int num_cu() {
 // Tile configurations.  `res` = workgroups resident per CU (LDS-limited), `penalty` = relative cost of the
 // staging instructions per MFMA (fp32 MFMA does not overlap VALU on gfx950).
 struct TileCfg { int id, BM, BN, res; double penalty; };
-static const TileCfg FWD_CFGS[4] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.10}, {2, 128, 64, 3, 1.04}, {3, 128, 32, 3, 1.25}};
+// penalties from the measured instruction mix: ~16 VALU per staged A row-float4 (bounds + transform), ~3 per
+// filter float4, 4 cycles each, against 64 cycles per MFMA: (MFMA + VALU) / MFMA, normalised to 128x128
+static const TileCfg FWD_CFGS[4] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.03}, {2, 128, 64, 3, 1.11}, {3, 128, 32, 3, 1.33}};
 static const TileCfg WG_CFGS[5] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.08}, {2, 128, 64, 3, 1.08}, {3, 64, 64, 4, 1.2},
                                    {4, 128, 32, 4, 1.3}};
 
