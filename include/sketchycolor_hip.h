@@ -102,6 +102,9 @@ int ssc_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
 /* implicit GEMM (igemm.hip).  ws: split-K slab workspace (may be NULL). */
 int ssc_conv_forward(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, void* stream);
 int ssc_conv_wgrad(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void* stream);
+/* direct (vector-ALU, LDS patch) form for <= 4 output channels; ssc_conv_forward dispatches to it (narrow.hip) */
+int ssc_conv_narrow_supported(const ssc_conv_desc* d);
+int ssc_conv_narrow_forward(const ssc_conv_desc* d, void* stream);
 /* name of the tile configuration the launcher picks for a descriptor (host only; for profiling) */
 int ssc_conv_forward_kernel_name(const ssc_conv_desc* d, char* buf, int len);
 int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* d, char* buf, int len);
@@ -133,7 +136,7 @@ int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, const float* 
 /* --- caption branch (text_lstm.hip): encode_feat_with_text, models_collection.py:150-248 --- */
 /* tf.nn.embedding_lookup (:182) and its (dense) gradient; tok rows are time-major [T*N] */
 int ssc_embedding_gather(const float* table, const int* tok, int rows, int C, float* out, void* stream);
-int ssc_embedding_scatter_add(float* dtable, const int* tok, int rows, int C, const float* g, void* stream);
+int ssc_embedding_scatter_add(float* dtable, int vocab, const int* tok, int rows, int C, const float* g, void* stream);
 /* tf.nn.l2_normalize over channels (:202,216); z = a*x+b when ab != NULL; ss[row] = sum z^2 */
 int ssc_row_l2norm_fwd(const float* x, int ldx, const float* ab, int64_t M, int C, float* y, float* ss, void* stream);
 int ssc_row_l2norm_bwd(const float* y, const float* ss, const float* dy, int64_t M, int C, float* dz, int accumulate,

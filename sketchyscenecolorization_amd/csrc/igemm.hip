@@ -762,6 +762,10 @@ static void copy_name(const char* src, char* dst, int len) {
 }
 
 extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, int len) {
+    if (ssc_conv_narrow_supported(dp)) {
+        copy_name(dp->nphase == 4 ? "narrow_fwd<transposed>" : "narrow_fwd<conv>", buf, len);
+        return 0;
+    }
     static const char* names[2][4] = {
         {"conv_fwd<128x128,KN>", "conv_fwd<64x128,KN>", "conv_fwd<128x64,KN>", "conv_fwd<128x32,KN>"},
         {"conv_fwd<128x128,NK>", "conv_fwd<64x128,NK>", "conv_fwd<128x64,NK>", "conv_fwd<128x32,NK>"}};
@@ -778,6 +782,7 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
     if (d.nphase == 4 && (d.TH != 2 || d.TW != 2 || d.KH != 4 || d.KW != 4 || d.kstep != -2 || d.out_stride != 2 ||
                           d.in_stride != 1))
         return -3;
+    if (ssc_conv_narrow_supported(dp)) return ssc_conv_narrow_forward(dp, stream);   // <= 4 output channels
     const Plan p = plan_fwd(d, ws_bytes, ws != nullptr);
     if (p.cfg < 0) return -4;
     if (d.bmode == 0) {

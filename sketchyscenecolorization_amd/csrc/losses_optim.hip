@@ -225,14 +225,18 @@ __global__ __launch_bounds__(256) void sn_forward_kernel(const float* __restrict
     const float inva = 1.f / (ra + 1e-12f);
     for (int i = tid; i < m; i += 256) v[i] *= inva;
     __syncthreads();
-    // b[j] = sum_i v[i] W[i][j]  : wave w handles rows w, w+4, ...; lane = column
+    // b[j] = sum_i v[i] W[i][j]  : wave w handles rows w, w+4, ...; lane = column; the four partial sums are
+    // combined in a fixed order (no atomics: results are reproducible run to run)
+    __shared__ float bpart[4][64];
     {
         const int lane = tid & 63, wave = tid >> 6;
         float acc = 0.f;
         if (lane < n)
             for (int i = wave; i < m; i += 4) acc += v[i] * W[(long)i * n + lane];
-        if (lane < n) atomicAdd(&bsh[lane], acc);
+        bpart[wave][lane] = acc;
     }
+    __syncthreads();
+    if (tid < 64) bsh[tid] = (bpart[0][tid] + bpart[1][tid]) + (bpart[2][tid] + bpart[3][tid]);
     __syncthreads();
     float bb = (tid < n) ? bsh[tid] * bsh[tid] : 0.f;
     const float t2 = block_sum_256(bb, sh);

@@ -1,0 +1,225 @@
+// narrow.hip -- convolutions with very few output channels (<= 4): the generator's last transposed conv
+// (128 -> 3, models_collection.py:529-534), the PatchGAN logit conv (512 -> 1, :834-835) and the data
+// gradient of the discriminator's first conv w.r.t. the 3 generated channels.
+//
+// On the MFMA tile kernel these waste >90 % of a 32-column tile (measured 1.4-7 TFLOP/s).  Here they are a
+// direct convolution on the vector ALUs: a workgroup stages a (16+halo)^2 input patch in LDS ONCE per 32-channel
+// chunk -- the folded norm + activation is applied once per input element instead of once per tap -- together
+// with the filter slice, and each lane owns one lattice point (all 4 sub-pixel phases of it for the transposed
+// form), reading the patch with conflict-free ds_read_b128 and the filter as LDS broadcasts.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sketchycolor_hip.h"
+
+#define NT 16            // lattice tile edge (16x16 = 256 lanes)
+#define NCH 32           // channels per chunk
+#define NPAD 36          // floats per patch pixel (32 + 4: odd multiple of 16 B -> conflict-free b128 reads)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float nr_act(float v, int act) {
+    if (act == SSC_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == SSC_ACT_LRELU) return fmaxf(v, 0.2f * v);
+    return v;
+}
+
+// MODE 0: conv form, nphase == 1, in_stride == 1.   MODE 1: k=4 s=2 transposed form (4 phases).
+template <int MODE, int NOUT>
+__global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int C = d.x.C0 + d.x.C1;
+    const int PYD = (MODE == 1) ? NT + 2 : (NT - 1) + d.TH;
+    const int PXD = (MODE == 1) ? NT + 2 : (NT - 1) + d.TW;
+    const int NTAP = d.KH * d.KW;
+    float* patch = smem;                         // [PYD*PXD][NPAD]
+    float* wl = smem + PYD * PXD * NPAD;         // [NTAP][NOUT][NCH]
+
+    const int tid = threadIdx.x;
+    const int ly = tid >> 4, lx = tid & 15;
+    const int nimg = blockIdx.z;
+    const int py0 = blockIdx.y * NT, px0 = blockIdx.x * NT;
+    // input coordinate of patch element (0,0)
+    const int iy0 = (MODE == 1) ? py0 - 1 : py0 + d.ioff_y;
+    const int ix0 = (MODE == 1) ? px0 - 1 : px0 + d.ioff_x;
+
+    // accumulators are float2 (even / odd channel pairs) so that the compiler emits packed v_pk_fma_f32:
+    // two FMAs per vector instruction
+    constexpr int NPH = (MODE == 1) ? 4 : 1;
+    f32x2 acc[NPH][NOUT];
+#pragma unroll
+    for (int p = 0; p < NPH; ++p)
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) acc[p][n] = (f32x2){0.f, 0.f};
+
+    // staging registers: all global loads of a chunk are issued before the first one is consumed
+    constexpr int MAXE = 12;            // ceil(19*19*8 / 256) patch float4 per thread
+    constexpr int MAXW = (16 * NOUT * NCH + 255) / 256;      // filter floats per thread (<= 16 taps)
+    const int c4s = (tid & 7) * 4;      // fixed per thread: 256 % 8 == 0
+    float4 rv[MAXE];
+    bool ok[MAXE];
+    float4 ra = make_float4(1.f, 1.f, 1.f, 1.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    float rw[MAXW];
+    const int nwl = NTAP * NOUT * NCH;
+    auto load_chunk = [&](int cb) {
+        const bool first = cb < d.x.C0;
+        const float* src = first ? d.x.s0 : d.x.s1;
+        const int cs = first ? d.x.C0 : d.x.C1;
+        const int cc = first ? cb : cb - d.x.C0;
+        const float* abp = first ? d.x.ab0 : d.x.ab1;
+        ra = make_float4(1.f, 1.f, 1.f, 1.f);
+        rb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (abp != nullptr) {
+            ra = *reinterpret_cast<const float4*>(abp + cc + c4s);
+            rb = *reinterpret_cast<const float4*>(abp + cs + cc + c4s);
+        }
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int pos = (tid >> 3) + 32 * q;
+            const int pr = pos / PXD, pc = pos - pr * PXD;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            ok[q] = pos < PYD * PXD && (unsigned)iy < (unsigned)d.x.H && (unsigned)ix < (unsigned)d.x.W;
+            const long off = ok[q] ? (((long)nimg * d.x.H + iy) * d.x.W + ix) * cs : 0;
+            rv[q] = *reinterpret_cast<const float4*>(src + off + cc + c4s);
+        }
+#pragma unroll
+        for (int q = 0; q < MAXW; ++q) {
+            const int e = tid + 256 * q;
+            const int k = e & (NCH - 1);
+            const int n = (e / NCH) % NOUT;
+            const int tap = e / (NCH * NOUT);
+            const bool v = e < nwl && n < d.Nn && cb + k < d.k_real;
+            const long idx = (d.bmode == 0) ? ((long)tap * d.wC0 + cb + k) * d.wC1 + d.n_off + n
+                                            : ((long)tap * d.wC0 + d.n_off + n) * d.wC1 + cb + k;
+            const float w = d.w[v ? idx : 0];
+            rw[q] = v ? w : 0.f;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int pos = (tid >> 3) + 32 * q;
+            if (pos < PYD * PXD) {
+                float4 v = rv[q];
+                v.x = nr_act(fmaf(ra.x, v.x, rb.x), d.x.act); v.y = nr_act(fmaf(ra.y, v.y, rb.y), d.x.act);
+                v.z = nr_act(fmaf(ra.z, v.z, rb.z), d.x.act); v.w = nr_act(fmaf(ra.w, v.w, rb.w), d.x.act);
+                if (!ok[q]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(patch + pos * NPAD + c4s) = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MAXW; ++q) {
+            const int e = tid + 256 * q;
+            if (e < nwl) wl[e] = rw[q];
+        }
+    };
+
+    for (int cb = 0; cb < C; cb += NCH) {
+        // (prefetching the next chunk across the accumulate phase was measured slower: the 48 staging registers
+        // held live across it cost more occupancy than the hidden latency buys)
+        load_chunk(cb);
+        store_chunk();
+        __syncthreads();
+        // ---- accumulate ----
+        if (MODE == 1) {
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const int ry = ph >> 1, rx = ph & 1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ty = t >> 1, tx = t & 1;
+                    const float* xp = patch + ((ly + ry + ty) * PXD + lx + rx + tx) * NPAD;
+                    const float* wp = wl + ((3 - ry - 2 * ty) * 4 + (3 - rx - 2 * tx)) * NOUT * NCH;
+#pragma unroll
+                    for (int c4 = 0; c4 < NCH; c4 += 4) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(xp + c4);
+#pragma unroll
+                        for (int n = 0; n < NOUT; ++n) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(wp + n * NCH + c4);
+                            acc[ph][n] = __builtin_elementwise_fma(x.xy, w.xy, acc[ph][n]);
+                            acc[ph][n] = __builtin_elementwise_fma(x.zw, w.zw, acc[ph][n]);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int ty = 0; ty < d.TH; ++ty) {
+                for (int tx = 0; tx < d.TW; ++tx) {
+                    const float* xp = patch + ((ly + ty) * PXD + lx + tx) * NPAD;
+                    const int ky = d.ky0 + ty * d.kstep, kx = d.kx0 + tx * d.kstep;
+                    const float* wp = wl + (ky * d.KW + kx) * NOUT * NCH;
+#pragma unroll
+                    for (int c4 = 0; c4 < NCH; c4 += 4) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(xp + c4);
+#pragma unroll
+                        for (int n = 0; n < NOUT; ++n) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(wp + n * NCH + c4);
+                            acc[0][n] = __builtin_elementwise_fma(x.xy, w.xy, acc[0][n]);
+                            acc[0][n] = __builtin_elementwise_fma(x.zw, w.zw, acc[0][n]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const int py = py0 + ly, px = px0 + lx;
+    if (py >= d.PH || px >= d.PW) return;
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+        const int oy = (MODE == 1) ? 2 * py + (ph >> 1) : py * d.out_stride + d.ooff_y;
+        const int ox = (MODE == 1) ? 2 * px + (ph & 1) : px * d.out_stride + d.ooff_x;
+        float* o = d.out + (((long)nimg * d.OH + oy) * d.OW + ox) * d.ldc;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            if (n >= d.Nstore) break;
+            float v = 0.f;          // columns in [Nn, Nstore) are channel padding: written as 0
+            if (n < NOUT && n < d.Nn) {
+                v = acc[ph][n < NOUT ? n : 0].x + acc[ph][n < NOUT ? n : 0].y;
+                if (d.bias != nullptr) v += d.bias[n];
+                if (d.epi == 1) v = tanhf(v);
+                if (d.accumulate) v += o[n];
+            }
+            o[n] = v;
+        }
+    }
+}
+
+extern "C" int ssc_conv_narrow_supported(const ssc_conv_desc* dp) {
+    const ssc_conv_desc& d = *dp;
+    const int C = d.x.C0 + d.x.C1;
+    if (d.Nn > 4 || d.Nstore > 4) return 0;
+    if ((C % NCH) != 0 || (d.x.C0 % NCH) != 0 || d.k_real != C) return 0;
+    if (d.nphase == 4) return (d.TH == 2 && d.TW == 2 && d.KH == 4 && d.KW == 4) ? 1 : 0;
+    if (d.nphase != 1 || d.in_stride != 1 || d.TH > 4 || d.TW > 4 || d.KH * d.KW > 16) return 0;
+    return 1;
+}
+
+template <int MODE>
+static int launch_narrow(const ssc_conv_desc& d, hipStream_t st) {
+    const int PYD = (MODE == 1) ? NT + 2 : (NT - 1) + d.TH;
+    const int PXD = (MODE == 1) ? NT + 2 : (NT - 1) + d.TW;
+    const int nout = d.Nn < 1 ? 1 : d.Nn;       // accumulators per phase (1..4)
+    const size_t lds = ((size_t)PYD * PXD * NPAD + (size_t)d.KH * d.KW * nout * NCH) * sizeof(float);
+    dim3 grid((d.PW + NT - 1) / NT, (d.PH + NT - 1) / NT, d.NB);
+#define NARROW_LAUNCH(NO)                                                                                          \
+    {                                                                                                              \
+        static bool attr = false;                                                                                  \
+        if (!attr) {                                                                                               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_fwd_kernel<MODE, NO>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                      \
+            attr = true;                                                                                           \
+        }                                                                                                          \
+        hipLaunchKernelGGL((narrow_fwd_kernel<MODE, NO>), grid, dim3(256), lds, st, d);                            \
+    }
+    if (nout == 1) NARROW_LAUNCH(1) else if (nout == 2) NARROW_LAUNCH(2) else if (nout == 3) NARROW_LAUNCH(3) else NARROW_LAUNCH(4)
+#undef NARROW_LAUNCH
+    return (int)hipGetLastError();
+}
+
+extern "C" int ssc_conv_narrow_forward(const ssc_conv_desc* dp, void* stream) {
+    if (!ssc_conv_narrow_supported(dp)) return -1;
+    return dp->nphase == 4 ? launch_narrow<1>(*dp, (hipStream_t)stream) : launch_narrow<0>(*dp, (hipStream_t)stream);
+}

@@ -31,14 +31,18 @@ __global__ void embedding_gather_kernel(const float* __restrict__ table, const i
     *reinterpret_cast<float4*>(out + (long)r * C + c) = *reinterpret_cast<const float4*>(table + (long)tok[r] * C + c);
 }
 
+// Deterministic form of the sparse embedding gradient: thread (v, c) of the (small) table scans the token list
+// in order and adds the rows that hit vocabulary entry v; pad tokens (id 0) never reach the table because
+// tf.cond skips the lookup's consumer.  blockIdx.y = vocabulary row.
 __global__ void embedding_scatter_add_kernel(float* __restrict__ dtable, const int* __restrict__ tok, int rows, int C,
                                              const float* __restrict__ g) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)rows * C) return;
-    const int r = (int)(i / C), c = (int)(i - (long)r * C);
-    const int t = tok[r];
-    if (t == 0) return;   // pad steps never touch the table (tf.cond skips the lookup's consumer)
-    atomicAdd(dtable + (long)t * C + c, g[i]);
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y;
+    if (c >= C || v == 0) return;
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r)
+        if (tok[r] == v) acc += g[(long)r * C + c];
+    dtable[(long)v * C + c] += acc;
 }
 
 extern "C" int ssc_embedding_gather(const float* table, const int* tok, int rows, int C, float* out, void* stream) {
@@ -49,10 +53,9 @@ extern "C" int ssc_embedding_gather(const float* table, const int* tok, int rows
     return CHECK_LAUNCH();
 }
 
-extern "C" int ssc_embedding_scatter_add(float* dtable, const int* tok, int rows, int C, const float* g,
+extern "C" int ssc_embedding_scatter_add(float* dtable, int vocab, const int* tok, int rows, int C, const float* g,
                                          void* stream) {
-    const long tot = (long)rows * C;
-    hipLaunchKernelGGL(embedding_scatter_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(embedding_scatter_add_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)vocab), dim3(256), 0,
                        (hipStream_t)stream, dtable, tok, rows, C, g);
     return CHECK_LAUNCH();
 }

@@ -66,6 +66,8 @@ SIGNATURES = {
     'ssc_device_info': [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, _I],
     'ssc_conv_forward': [C.POINTER(ConvDesc), _P, _L, _P],
     'ssc_conv_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
+    'ssc_conv_narrow_supported': [C.POINTER(ConvDesc)],
+    'ssc_conv_narrow_forward': [C.POINTER(ConvDesc), _P],
     'ssc_conv_forward_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, _I],
     'ssc_conv_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, _I],
     'ssc_nchw_to_nhwc': [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -74,7 +76,7 @@ SIGNATURES = {
     'ssc_bn_stats': [_P, _L, _I, _I, _P, _P, _F, _P, _P, _P, _L, _P],
     'ssc_bn_act_backward': [_P, _L, _I, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _L, _P],
     'ssc_embedding_gather': [_P, _P, _I, _I, _P, _P],
-    'ssc_embedding_scatter_add': [_P, _P, _I, _I, _P, _P],
+    'ssc_embedding_scatter_add': [_P, _I, _P, _I, _I, _P, _P],
     'ssc_row_l2norm_fwd': [_P, _I, _P, _L, _I, _P, _P, _P],
     'ssc_row_l2norm_bwd': [_P, _P, _P, _L, _I, _P, _I, _P],
     'ssc_lstm_pointwise_fwd': [_P, _P, _P, _I, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P],

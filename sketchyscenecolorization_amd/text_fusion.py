@@ -195,7 +195,7 @@ class TextFusion(object):
         hip.matmul_nt(dEW, Kw[0:C], demb, accumulate=True)
         hip.call('ssc_group_rowsum', dEW, G4, 1, S * N, G4, gbw, 0)
         hip.fill(gE, 0.0)
-        hip.call('ssc_embedding_scatter_add', gE, ctx['tok'], S * N, C, demb)
+        hip.call('ssc_embedding_scatter_add', gE, gE.shape[0], ctx['tok'], S * N, C, demb)
         dy5 = B.get(tag + '/tfb/dy5', (R, C))
         hip.call('ssc_row_l2norm_bwd', ctx['vis'], ctx['vis_ss'], dvis, R, C, dy5, 0)
         return dy5
