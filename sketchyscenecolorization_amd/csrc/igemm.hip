@@ -664,7 +664,7 @@ struct TileCfg { int id, BM, BN, res; double penalty; };
 // penalties from the measured instruction mix: ~16 VALU per staged A row-float4 (bounds + transform), ~3 per
 // filter float4, 4 cycles each, against 64 cycles per MFMA: (MFMA + VALU) / MFMA, normalised to 128x128
 static const TileCfg FWD_CFGS[4] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.03}, {2, 128, 64, 3, 1.11}, {3, 128, 32, 3, 1.33}};
-static const TileCfg WG_CFGS[5] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.08}, {2, 128, 64, 3, 1.08}, {3, 64, 64, 4, 1.2},
+static const TileCfg WG_CFGS[5] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.00}, {2, 128, 64, 3, 1.10}, {3, 64, 64, 4, 1.2},
                                    {4, 128, 32, 4, 1.3}};
 
 // Makespan model of one launch: `blocks` equal workgroups of `w` MFMA-cycles each on ncu CUs that hold `res`
@@ -673,7 +673,14 @@ static const TileCfg WG_CFGS[5] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.08}
 static double makespan(long blocks, double w, int res, int ncu) {
     const long slots = (long)ncu * res;
     const long full = blocks / slots, rem = blocks % slots;
-    return (double)(full * res + (rem + ncu - 1) / ncu) * w;
+    double t = (double)(full * res + (rem + ncu - 1) / ncu) * w;
+    // a lone wave per SIMD cannot hide its own LDS / barrier / load waits (measured: 1 workgroup per CU runs
+    // ~25 % below 3 per CU at equal work)
+    const long per_cu = (blocks + ncu - 1) / ncu;
+    const long occ = per_cu < res ? per_cu : res;
+    if (occ <= 1) t *= 1.30;
+    else if (occ == 2) t *= 1.08;
+    return t;
 }
 
 struct Plan { int cfg; int splitk; double cost; };
@@ -839,8 +846,8 @@ static Plan plan_wgrad(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws) 
     const long out_elems = (long)d.TH * d.TW * d.Cg_real * d.ldc;
     bool allowed[5];
     allowed[0] = d.Nn > 64 && Mtot > 64;
-    allowed[1] = d.Nn > 64 && Mtot <= 64;
-    allowed[2] = d.Nn > 32 && d.Nn <= 64 && Mtot > 64;
+    allowed[1] = d.Nn > 64;                     // 64 gathered columns x 128: the gathered side is the costly one
+    allowed[2] = d.Nn > 32 && Mtot > 64;
     allowed[3] = d.Nn > 32 && d.Nn <= 64 && Mtot <= 64;
     allowed[4] = d.Nn <= 32;
     const int ncu = num_cu();
