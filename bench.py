@@ -139,8 +139,18 @@ def main():
             name, (fl, sec, cnt) = dom
             tot_sec = sum(v[1] for v in agg.values())
             ach = fl / sec / 1e12
+            traffic = None      # HBM bytes per launch from the committed PMC passes (same command, --no-graphs)
+            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            if os.path.exists(tpath) and args.batch == 32 and args.img == 192:
+                with open(tpath) as f:
+                    tk = json.load(f)['kernels'].get(name)
+                if tk:
+                    traffic = tk['hbm_bytes_per_launch']
             out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                               'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                               'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, '
+                                               'profiles/r01_pmc_traffic.json)',
+                               'flop_per_launch': fl / cnt,
                                'launches': cnt, 'avg_launch_ms': sec / cnt * 1e3,
                                'igemm_ms_per_step': tot_sec / prof_steps * 1e3,
                                'events': ('timed region (eager launches)' if args.no_graphs else
