@@ -27,6 +27,7 @@ extern "C" {
 #define SSC_ACT_NONE 0
 #define SSC_ACT_RELU 1   /* tf.nn.relu                 models_collection.py:518,531 */
 #define SSC_ACT_LRELU 2  /* tf.maximum(0.2*x, x)       models_collection.py:51-53   */
+#define SSC_ACT_TANH 3   /* only for ssc_affine_act / ssc_residual_merge outputs, never on load */
 
 /*
  * A "gather view": one or two NHWC tensors seen as a single [N,H,W,C0+C1]
@@ -42,8 +43,9 @@ typedef struct ssc_gview {
     const float* ab1;  /* [2][C1]: a then b for s1; NULL = identity */
     int32_t C0, C1;    /* both multiples of 4 */
     int32_t H, W;
-    int32_t act;
-    int32_t _pad;
+    int32_t act;       /* activation of s0 (and of s1 when act1 < 0) */
+    int32_t act1;      /* activation of s1, or -1 = same as act (residual generators concatenate an already
+                          activated block output with a raw+norm+lrelu encoder tensor, models_collection.py:660-664) */
 } ssc_gview;
 
 /*
@@ -115,6 +117,14 @@ int ssc_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int ldc
 /* dst[n,c,hw] = src[n,hw,coff+c] */
 int ssc_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, int ldc, int coff, void* stream);
 int ssc_fill(float* dst, float value, int64_t n, void* stream);
+/* out[r, c] = act(ab[c]*x[r, c] + ab[ldab + c])  (ab may be NULL): materialises a normalised tensor (final
+ * tanh(batchnorm(.)), models_collection.py:664-667) or re-strides a channel-padded one (ldx != ldo) */
+int ssc_affine_act(const float* x, int ldx, const float* ab, int ldab, int act, float* out, int ldo, int64_t M, int C,
+                   void* stream);
+/* bottleneck_residual_{en,de,pu} 'block_add' (residual_util.py:103-109, 138-146, 165-167):
+ * out = act(a1*x1+b1 + (ab2 ? a2*x2+b2 : x2)) */
+int ssc_residual_merge(const float* x1, const float* ab1, const float* x2, const float* ab2, int act, float* out,
+                       int64_t M, int C, void* stream);
 
 /* --- batch-statistics norm (tf.nn.moments + tf.nn.batch_normalization,
  *     models_collection.py:36-46) --- */

@@ -120,14 +120,15 @@ def image_encoder_pix2pix(p, x):
     return outs
 
 
-def encode_feat_with_text(p, visual_encoded, vocab_indices):
-    """models_collection.py:150-248, per-sample loop, op order as written."""
+def encode_feat_with_text(p, visual_encoded, vocab_indices, scope='generator/TextLSTM'):
+    """models_collection.py:150-248, per-sample loop, op order as written (the BG module's copy,
+    bg_colorization_main.py:117-214, is the same graph under scope 'mLSTM_G')."""
     n, c, vh, vw = visual_encoded.shape
-    emb = p['generator/TextLSTM/embedding']
-    kw = p['generator/TextLSTM/RNN/WLSTM/multi_rnn_cell/cell_0/basic_lstm_cell/kernel']
-    bw = p['generator/TextLSTM/RNN/WLSTM/multi_rnn_cell/cell_0/basic_lstm_cell/bias']
-    ka = p['generator/TextLSTM/RNN/ALSTM/multi_rnn_cell/cell_0/basic_lstm_cell/kernel']
-    ba = p['generator/TextLSTM/RNN/ALSTM/multi_rnn_cell/cell_0/basic_lstm_cell/bias']
+    emb = p[scope + '/embedding']
+    kw = p[scope + '/RNN/WLSTM/multi_rnn_cell/cell_0/basic_lstm_cell/kernel']
+    bw = p[scope + '/RNN/WLSTM/multi_rnn_cell/cell_0/basic_lstm_cell/bias']
+    ka = p[scope + '/RNN/ALSTM/multi_rnn_cell/cell_0/basic_lstm_cell/kernel']
+    ba = p[scope + '/RNN/ALSTM/multi_rnn_cell/cell_0/basic_lstm_cell/bias']
     outs = []
     for i in range(n):
         vis = visual_encoded[i:i + 1].permute(0, 2, 3, 1)           # [1,h,w,C]

@@ -300,6 +300,71 @@ extern "C" int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, co
     return CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------ materialising helpers
+__device__ __forceinline__ float act_any(float v, int act) {
+    if (act == SSC_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == SSC_ACT_LRELU) return fmaxf(v, 0.2f * v);
+    if (act == SSC_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+__global__ void affine_act_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ ab, int ldab, int act,
+                                  float* __restrict__ out, int ldo, long M, int C) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = M * C, stride = (long)gridDim.x * blockDim.x;
+    for (; i < tot; i += stride) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        float v = x[r * ldx + c];
+        if (ab != nullptr) v = fmaf(ab[c], v, ab[ldab + c]);
+        out[r * ldo + c] = act_any(v, act);
+    }
+}
+
+extern "C" int ssc_affine_act(const float* x, int ldx, const float* ab, int ldab, int act, float* out, int ldo,
+                              int64_t M, int C, void* stream) {
+    long blocks = ((long)M * C + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, ab, ldab, act, out,
+                       ldo, (long)M, C);
+    return CHECK_LAUNCH();
+}
+
+__global__ void residual_merge_kernel(const float* __restrict__ x1, const float* __restrict__ ab1,
+                                      const float* __restrict__ x2, const float* __restrict__ ab2, int act,
+                                      float* __restrict__ out, long M, int C) {
+    const int cg = C / 4;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = M * cg, stride = (long)gridDim.x * blockDim.x;
+    for (; i < tot; i += stride) {
+        const long r = i / cg;
+        const int c = (int)(i - r * cg) * 4;
+        const float4 a1 = *reinterpret_cast<const float4*>(ab1 + c), b1 = *reinterpret_cast<const float4*>(ab1 + C + c);
+        const float4 u = *reinterpret_cast<const float4*>(x1 + r * C + c);
+        float4 v = *reinterpret_cast<const float4*>(x2 + r * C + c);
+        if (ab2 != nullptr) {
+            const float4 a2 = *reinterpret_cast<const float4*>(ab2 + c), b2 = *reinterpret_cast<const float4*>(ab2 + C + c);
+            v.x = fmaf(a2.x, v.x, b2.x); v.y = fmaf(a2.y, v.y, b2.y); v.z = fmaf(a2.z, v.z, b2.z); v.w = fmaf(a2.w, v.w, b2.w);
+        }
+        float4 o;
+        o.x = act_any(fmaf(a1.x, u.x, b1.x) + v.x, act); o.y = act_any(fmaf(a1.y, u.y, b1.y) + v.y, act);
+        o.z = act_any(fmaf(a1.z, u.z, b1.z) + v.z, act); o.w = act_any(fmaf(a1.w, u.w, b1.w) + v.w, act);
+        *reinterpret_cast<float4*>(out + r * C + c) = o;
+    }
+}
+
+extern "C" int ssc_residual_merge(const float* x1, const float* ab1, const float* x2, const float* ab2, int act,
+                                  float* out, int64_t M, int C, void* stream) {
+    if (C & 3) return -1;
+    long blocks = ((long)M * (C / 4) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(residual_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, ab1, x2, ab2,
+                       act, out, (long)M, C);
+    return CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ info
 extern "C" int ssc_version(void) { return 100; }
 

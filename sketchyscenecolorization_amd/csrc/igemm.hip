@@ -218,9 +218,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
     float rav[A_ROWS];    // 1.0 / 0.0 validity of each staged A row
     float4 raa, rab;
     bool ra_plain = false;   // UT: this K-tile's source has no affine and no activation
+    float ra_slope = 1.f;    // activation slope of the source this K-tile reads
     float4 rb[B_SLOTS];
     float4 rbm[B_SLOTS];  // generic path: per-element 1.0 / 0.0 validity of the staged filter values
-    const float x_slope = act_slope(d.x.act);
+    const float x_slope0 = act_slope(d.x.act), x_slope1 = act_slope(d.x.act1 >= 0 ? d.x.act1 : d.x.act);
 
     auto load_tile = [&](int kt) {
         if (UT) {
@@ -235,7 +236,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
             const float* sbase = (first ? d.x.s0 : d.x.s1) + cc;
             const float* abp = first ? d.x.ab0 : d.x.ab1;
             const int tapshift = (ty * d.x.W + tx) * cs;
-            ra_plain = (abp == nullptr) && (d.x.act == SSC_ACT_NONE);
+            const int src_act = (!first && d.x.act1 >= 0) ? d.x.act1 : d.x.act;
+            ra_slope = act_slope(src_act);
+            ra_plain = (abp == nullptr) && (src_act == SSC_ACT_NONE);
             if (abp != nullptr) {
                 raa = *reinterpret_cast<const float4*>(abp + cc + a_col4 * 4);
                 rab = *reinterpret_cast<const float4*>(abp + cs + cc + a_col4 * 4);
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
             const int c = kk - tap * C;
             const int ty = div32(tap, mg.mTW, mg.oneTW), tx = tap - ty * d.TW;
             gview_affine4(d.x, c, raa, rab);
+            ra_slope = c < d.x.C0 ? x_slope0 : x_slope1;
             const float* base;
             int cs;
             gview_src(d.x, c, base, cs);
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
         } else {
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
-                const float4 v = xform4(ra[i], raa, rab, x_slope, rav[i]);
+                const float4 v = xform4(ra[i], raa, rab, ra_slope, rav[i]);
                 float* p = Ab + ((tid >> 3) + 32 * i) * A_LD + a_col4 * 4;
                 p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
             }
@@ -500,7 +504,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     const float* a_base;
     int a_cs;
     gview_src(d.g, a_c, a_base, a_cs);
-    const bool a_plain = ((a_c < d.g.C0 ? d.g.ab0 : d.g.ab1) == nullptr) && d.g.act == SSC_ACT_NONE;
+    const int a_act = (a_c >= d.g.C0 && d.g.act1 >= 0) ? d.g.act1 : d.g.act;
+    const bool a_plain = ((a_c < d.g.C0 ? d.g.ab0 : d.g.ab1) == nullptr) && a_act == SSC_ACT_NONE;
     const int b_col = n0 + (tid % (BN / 4)) * 4;
     const bool b_cv = b_col < Cd;
     const int b_c = b_cv ? b_col : 0;
@@ -509,7 +514,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     const float* b_base;
     int b_cs;
     gview_src(d.d, b_c, b_base, b_cs);
-    const bool b_plain = ((b_c < d.d.C0 ? d.d.ab0 : d.d.ab1) == nullptr) && d.d.act == SSC_ACT_NONE;
+    const int b_act = (b_c >= d.d.C0 && d.d.act1 >= 0) ? d.d.act1 : d.d.act;
+    const bool b_plain = ((b_c < d.d.C0 ? d.d.ab0 : d.d.ab1) == nullptr) && b_act == SSC_ACT_NONE;
     const int a_iy0 = d.ioff_y + a_ty, a_ix0 = d.ioff_x + a_tx;
 
     const long nkt = (P + BK - 1) / BK;
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
 
     float4 ra[A_SLOTS], rb[B_SLOTS];
     float rav[A_SLOTS], rbv[B_SLOTS];
-    const float g_slope = act_slope(d.g.act), d_slope = act_slope(d.d.act);
+    const float g_slope = act_slope(a_act), d_slope = act_slope(b_act);
 
     auto load_tile = [&](long kt) {
 #pragma unroll

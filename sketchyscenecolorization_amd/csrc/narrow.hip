@@ -61,12 +61,14 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d) 
     float4 ra = make_float4(1.f, 1.f, 1.f, 1.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
     float rw[MAXW];
     const int nwl = NTAP * NOUT * NCH;
+    int cur_act = d.x.act;
     auto load_chunk = [&](int cb) {
         const bool first = cb < d.x.C0;
         const float* src = first ? d.x.s0 : d.x.s1;
         const int cs = first ? d.x.C0 : d.x.C1;
         const int cc = first ? cb : cb - d.x.C0;
         const float* abp = first ? d.x.ab0 : d.x.ab1;
+        cur_act = (!first && d.x.act1 >= 0) ? d.x.act1 : d.x.act;
         ra = make_float4(1.f, 1.f, 1.f, 1.f);
         rb = make_float4(0.f, 0.f, 0.f, 0.f);
         if (abp != nullptr) {
@@ -101,8 +103,8 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d) 
             const int pos = (tid >> 3) + 32 * q;
             if (pos < PYD * PXD) {
                 float4 v = rv[q];
-                v.x = nr_act(fmaf(ra.x, v.x, rb.x), d.x.act); v.y = nr_act(fmaf(ra.y, v.y, rb.y), d.x.act);
-                v.z = nr_act(fmaf(ra.z, v.z, rb.z), d.x.act); v.w = nr_act(fmaf(ra.w, v.w, rb.w), d.x.act);
+                v.x = nr_act(fmaf(ra.x, v.x, rb.x), cur_act); v.y = nr_act(fmaf(ra.y, v.y, rb.y), cur_act);
+                v.z = nr_act(fmaf(ra.z, v.z, rb.z), cur_act); v.w = nr_act(fmaf(ra.w, v.w, rb.w), cur_act);
                 if (!ok[q]) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(patch + pos * NPAD + c4s) = v;
             }

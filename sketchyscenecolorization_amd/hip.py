@@ -12,14 +12,13 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSC_LIB_PATH') or os.path.join(_HERE, 'lib', 'libsketchycolor_hip.so')
 
-ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
-ACT_MIU = 3     # only for the pointwise kernels, never on load
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3     # TANH only for materialising kernels, never on load
 
 
 class GView(C.Structure):
     _fields_ = [('s0', C.c_void_p), ('s1', C.c_void_p), ('ab0', C.c_void_p), ('ab1', C.c_void_p),
                 ('C0', C.c_int32), ('C1', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
-                ('act', C.c_int32), ('_pad', C.c_int32)]
+                ('act', C.c_int32), ('act1', C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -73,6 +72,8 @@ SIGNATURES = {
     'ssc_nchw_to_nhwc': [_P, _P, _I, _I, _I, _I, _I, _P],
     'ssc_nhwc_to_nchw': [_P, _P, _I, _I, _I, _I, _I, _P],
     'ssc_fill': [_P, _F, _L, _P],
+    'ssc_affine_act': [_P, _I, _P, _I, _I, _P, _I, _L, _I, _P],
+    'ssc_residual_merge': [_P, _P, _P, _P, _I, _P, _L, _I, _P],
     'ssc_bn_stats': [_P, _L, _I, _I, _P, _P, _F, _P, _P, _P, _L, _P],
     'ssc_bn_act_backward': [_P, _L, _I, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _L, _P],
     'ssc_embedding_gather': [_P, _P, _I, _I, _P, _P],
@@ -142,9 +143,9 @@ def workspace(nbytes=256 << 20):
 class View(object):
     """Host-side mirror of ssc_gview: NHWC tensor(s) + folded norm + activation."""
 
-    def __init__(self, s0, s1=None, ab0=None, act=ACT_NONE, ab1=None):
+    def __init__(self, s0, s1=None, ab0=None, act=ACT_NONE, ab1=None, act1=-1):
         assert s0.dim() == 4 and s0.is_contiguous()
-        self.s0, self.s1, self.ab0, self.ab1, self.act = s0, s1, ab0, ab1, act
+        self.s0, self.s1, self.ab0, self.ab1, self.act, self.act1 = s0, s1, ab0, ab1, act, act1
         self.N, self.H, self.W, self.C0 = s0.shape
         self.C1 = 0
         if s1 is not None:
@@ -160,7 +161,7 @@ class View(object):
         g.s1 = self.s1.data_ptr() if self.s1 is not None else None
         g.ab0 = self.ab0.data_ptr() if self.ab0 is not None else None
         g.ab1 = self.ab1.data_ptr() if self.ab1 is not None else None
-        g.C0, g.C1, g.H, g.W, g.act = self.C0, self.C1, self.H, self.W, self.act
+        g.C0, g.C1, g.H, g.W, g.act, g.act1 = self.C0, self.C1, self.H, self.W, self.act, self.act1
         return g
 
 
@@ -208,14 +209,26 @@ def _out_geom(out, coff):
     return out.data_ptr() + 4 * coff, out.shape[1], out.shape[2], out.shape[3]
 
 
-def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, accumulate=False):
-    """tf.pad + tf.nn.conv2d(VALID): x View, w [KH,KW,Cin_real,Cout] -> out[..., coff:coff+Cout]."""
+def same_pad_before(size, k, stride):
+    """TF SAME padding rule: pad_before = total // 2, the extra element goes after (bottom/right)."""
+    out = -(-size // stride)
+    return max((out - 1) * stride + k - size, 0) // 2
+
+
+def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, accumulate=False, same=False):
+    """tf.pad + tf.nn.conv2d(VALID): x View, w [KH,KW,Cin_real,Cout] -> out[..., coff:coff+Cout].
+    same=True: tf.nn.conv2d(padding='SAME') -- output ceil(in/stride), asymmetric pad (mru.py:125, conv_ex)."""
     KH, KW, ci, co = w.shape
     d = ConvDesc()
     d.x = x.c()
     d.w, d.bias = w.data_ptr(), (bias.data_ptr() if bias is not None else None)
     d.out, OH, OW, ldc = _out_geom(out, coff)
-    d.NB, d.PH, d.PW = x.N, (x.H + 2 * pad - KH) // stride + 1, (x.W + 2 * pad - KW) // stride + 1
+    if same:
+        d.NB, d.PH, d.PW = x.N, -(-x.H // stride), -(-x.W // stride)
+        pad = same_pad_before(x.H, KH, stride)
+        assert pad == same_pad_before(x.W, KW, stride)
+    else:
+        d.NB, d.PH, d.PW = x.N, (x.H + 2 * pad - KH) // stride + 1, (x.W + 2 * pad - KW) // stride + 1
     assert (OH, OW) == (d.PH, d.PW), ((OH, OW), (d.PH, d.PW))
     d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x, d.nphase = KH, KW, stride, -pad, -pad, 1
     d.ky0, d.kx0, d.kstep = 0, 0, 1
@@ -230,7 +243,7 @@ def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, 
 def deconv_forward(x, f, out, coff=0, nstore=None, epi=0):
     """tf.nn.conv2d_transpose(k=4, s=2, SAME): x View [N,H,W,Cin], f [4,4,Cout,Cin] -> out [N,2H,2W,*]."""
     KH, KW, co, ci = f.shape
-    assert KH == 4 and KW == 4 and ci == x.C
+    assert KH == 4 and KW == 4 and ci <= x.C        # ci < x.C: 3-channel tensors padded to 4 (BG region branch)
     d = ConvDesc()
     d.x = x.c()
     d.w, d.bias = f.data_ptr(), None

@@ -31,13 +31,17 @@ def reset_default_graph():
 def get_trainer(block_type='Pix2Pix', vocab_size=58, img=192, seed=0, **kw):
     """The tower (variables + activation buffers + optimizer slots) of the 'default graph',
     created on first use like tf.get_variable."""
-    if block_type != 'Pix2Pix':
-        raise NotImplementedError('block_type %r: only the Pix2Pix variant is built in this round; MRU/Residual '
-                                  'follow (SURVEY.md section 7, step 7)' % block_type)
-    from ..trainer import Pix2PixTrainer
+    if block_type not in ('Pix2Pix', 'Residual'):
+        raise NotImplementedError('block_type %r: Pix2Pix (train + infer) and Residual (infer) are built; MRU '
+                                  'follows (SURVEY.md section 7, step 7)' % block_type)
     key = (block_type, vocab_size, img)
     if key not in _REGISTRY:
-        _REGISTRY[key] = Pix2PixTrainer(img=img, vocab_size=vocab_size, seed=seed, sn=Config.sn, **kw)
+        if block_type == 'Pix2Pix':
+            from ..trainer import Pix2PixTrainer
+            _REGISTRY[key] = Pix2PixTrainer(img=img, vocab_size=vocab_size, seed=seed, sn=Config.sn, **kw)
+        else:
+            from ..residual import ResidualTower
+            _REGISTRY[key] = ResidualTower(img=img, vocab_size=vocab_size, seed=seed)
     return _REGISTRY[key]
 
 
@@ -101,16 +105,31 @@ def discriminate_pix2pix(discrim_inputs, discrim_targets, num_classes, labels=No
     return disc, c['logits'].clone()
 
 
+def generate_residual(z, text_vocab_indices, LSTM_hybrid, output_channel, num_classes, vocab_size, reuse=False,
+                      data_format='NCHW', labels=None, scope_name=None, noise_vec=None):
+    """models_collection.py:579-672: ResNet-50-style [3,4,6,3] bottleneck U-Net generator (forward)."""
+    assert data_format == 'NCHW' and output_channel == 3
+    z = _as_device(z)
+    n, _, h, w = z.shape
+    tower = get_trainer('Residual', vocab_size, h)
+    if noise_vec is None:
+        noise_vec = torch.randn(n, 256, device='cuda')
+    noise_vec = _as_device(noise_vec)
+    text = text_vocab_indices.cpu().numpy() if isinstance(text_vocab_indices, torch.Tensor) else np.asarray(text_vocab_indices)
+    assert text.shape[0] == n
+    tower.G.lstm_hybrid = bool(LSTM_hybrid)
+    return tower.generate(z, text, noise_vec), noise_vec
+
+
 def _not_built(name):
     def f(*a, **k):
-        raise NotImplementedError('%s: only the Pix2Pix variant (--block_type Pix2Pix) is built in this round; '
-                                  'MRU/Residual follow (SURVEY.md section 7, step 7)' % name)
+        raise NotImplementedError('%s is not built yet: Pix2Pix (train + infer) and the Residual generator (infer) '
+                                  'are; MRU and discriminate_residual follow (SURVEY.md section 7, step 7)' % name)
     return f
 
 
 generate_mru = _not_built('generate_mru')
 discriminate_mru = _not_built('discriminate_mru')
-generate_residual = _not_built('generate_residual')
 discriminate_residual = _not_built('discriminate_residual')
 
 generator_mru = generate_mru

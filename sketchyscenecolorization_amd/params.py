@@ -59,6 +59,74 @@ def pix2pix_param_specs(vocab_size=58, img=192, num_classes=NUM_CLASSES, size=SI
     return g, d, nontrainable
 
 
+RESIDUAL_UNITS = (3, 4, 6, 3)       # models_collection.py:607, bg_colorization_main.py:315
+
+
+def residual_generator_specs(kind='fg', vocab_size=None, img=None, size=SIZE, seg_classes=3):
+    """(name, shape, init) of the bottleneck-residual generators in graph-creation order.
+
+    kind='fg': ``generate_residual`` (models_collection.py:541-672, blocks residual_util.py:81-171);
+    kind='bg': ``create_residual_generator`` (bg_colorization_main.py:302-420) -- same blocks, 1024-channel
+    bottleneck, 'mLSTM_G' caption cells, no noise head, 3-channel region branch, norms under '.../batchnorm'."""
+    fg = kind == 'fg'
+    vocab_size = vocab_size if vocab_size is not None else (58 if fg else 18)
+    img = img if img is not None else (192 if fg else 768)
+    top = size * 8 if fg else size * 16
+    enc_c = [size, size * 2, size * 4, size * 8, top]
+    out = []
+    filt, zeros, ones = ('normal', 0.0, 0.02), ('zeros',), ('normal', 1.0, 0.02)
+
+    def bn(pre, c):
+        out.append((pre + '/offset', (c,), zeros))
+        out.append((pre + '/scale', (c,), ones))
+
+    def unit(pre, first, shape_first, c4, cout, shortcut=None):
+        out.append((pre + '/block_1/%s/filter' % first, shape_first, filt)); bn(pre + '/block_1/batchnorm', c4)
+        out.append((pre + '/block_2/conv_ex/filter', (3, 3, c4, c4), filt)); bn(pre + '/block_2/batchnorm', c4)
+        out.append((pre + '/block_3/conv_ex/filter', (1, 1, c4, cout), filt)); bn(pre + '/block_3/batchnorm', cout)
+        if shortcut is not None:
+            out.append((pre + '/block_add/%s/filter' % first, shortcut, filt)); bn(pre + '/block_add/batchnorm', cout)
+
+    def lstm(scope, c):
+        out.append((scope + '/embedding', (vocab_size, c), ('uniform', -0.08, 0.08)))
+        for cell, rows in (('WLSTM', 2 * c), ('ALSTM', 4 * c)):
+            base = scope + '/RNN/%s/multi_rnn_cell/cell_0/basic_lstm_cell/' % cell
+            out.append((base + 'kernel', (rows, 4 * c), ('glorot',)))
+            out.append((base + 'bias', (4 * c,), zeros))
+
+    top_bn = (lambda pre: pre) if fg else (lambda pre: pre + '/batchnorm')
+    out.append(('generator/encoder_1/conv_ex/filter', (7, 7, 3, size), filt)); bn(top_bn('generator/encoder_1'), size)
+    for k in range(2, 6):
+        cin, co = enc_c[k - 2], enc_c[k - 1]
+        unit('generator/encoder_%d_0' % k, 'conv', (4, 4, cin, co // 4), co // 4, co, (4, 4, cin, co))
+        for u in range(1, RESIDUAL_UNITS[k - 2]):
+            unit('generator/encoder_%d_%d' % (k, u), 'conv_ex', (4, 4, co, co // 4), co // 4, co)
+    if fg:
+        lstm('generator/TextLSTM', top)
+        hw = img // 32
+        out.append(('generator/fully_connected/weights', (256, top // 8 * hw * hw), ('glorot',)))
+        out.append(('generator/fully_connected/biases', (top // 8 * hw * hw,), zeros))
+    else:
+        lstm('generator/mLSTM_G', top)
+        out.append(('generator/region_br_projection/conv_ex/filter', (1, 1, top, seg_classes), filt))
+        bn('generator/region_br_projection/batchnorm', seg_classes)
+    dec_out = {5: size * 8, 4: size * 4, 3: size * 2, 2: size}
+    for k in (5, 4, 3, 2):
+        cin = (top + (top // 8 if fg else 0)) if k == 5 else dec_out[k + 1] + enc_c[k - 1]
+        co = dec_out[k]
+        unit('generator/decoder_%d_0' % k, 'deconv', (4, 4, co // 4, cin), co // 4, co, (4, 4, co, cin))
+        for u in range(1, RESIDUAL_UNITS[k - 2]):
+            unit('generator/decoder_%d_%d' % (k, u), 'conv_ex', (4, 4, co, co // 4), co // 4, co)
+        if not fg:
+            out.append(('generator/region_br_%d/deconv/filter' % k, (4, 4, seg_classes, seg_classes), filt))
+            bn('generator/region_br_%d/batchnorm' % k, seg_classes)
+    out.append(('generator/decoder_1/deconv/filter', (4, 4, 3, size * 2), filt)); bn(top_bn('generator/decoder_1'), 3)
+    if not fg:
+        out.append(('generator/region_br_1/deconv/filter', (4, 4, seg_classes, seg_classes), filt))
+        bn('generator/region_br_1/batchnorm', seg_classes)
+    return out
+
+
 def _init_tensor(shape, init, gen):
     kind = init[0]
     if kind == 'zeros':
@@ -105,9 +173,16 @@ class ParamStore(object):
     """All variables of one model instance (generator + discriminator + non-trainables)."""
 
     def __init__(self, block_type='Pix2Pix', vocab_size=58, img=192, device='cuda', seed=0):
-        if block_type != 'Pix2Pix':
-            raise NotImplementedError('block_type %r: only the Pix2Pix variant is built so far' % block_type)
-        g, d, nt = pix2pix_param_specs(vocab_size, img)
+        if block_type == 'Pix2Pix':
+            g, d, nt = pix2pix_param_specs(vocab_size, img)
+        elif block_type == 'Residual':      # generator only so far (inference); discriminate_residual is not built
+            g, d, nt = residual_generator_specs('fg', vocab_size, img), [], []
+        elif block_type == 'BG':            # Background_Colorization generator (BASELINE config 5), forward only
+            g, d, nt = residual_generator_specs('bg', vocab_size, img), [], []
+        else:
+            raise NotImplementedError('block_type %r: Pix2Pix (train+infer) and Residual/BG (generator forward) '
+                                      'are built so far' % block_type)
+        self.block_type = block_type
         self.device = device
         self.generator = Scope('generator', g, device)
         self.discriminator = Scope('discriminator', d, device)

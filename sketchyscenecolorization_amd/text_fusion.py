@@ -21,14 +21,18 @@ import torch
 
 from . import hip
 
-PFX_W = 'generator/TextLSTM/RNN/WLSTM/multi_rnn_cell/cell_0/basic_lstm_cell/'
-PFX_A = 'generator/TextLSTM/RNN/ALSTM/multi_rnn_cell/cell_0/basic_lstm_cell/'
+CELL = '/RNN/%s/multi_rnn_cell/cell_0/basic_lstm_cell/'
 
 
 class TextFusion(object):
-    def __init__(self, store, bufs):
+    def __init__(self, store, bufs, scope='generator/TextLSTM'):
+        """scope: 'generator/TextLSTM' (FG, models_collection.py:159) or 'generator/mLSTM_G' (BG,
+        bg_colorization_main.py:117-214 -- the same cell pair with C=1024 on the 24x24 bottleneck)."""
         self.s = store
         self.b = bufs
+        self.emb_name = scope + '/embedding'
+        self.pfx_w = scope + CELL % 'WLSTM'
+        self.pfx_a = scope + CELL % 'ALSTM'
 
     def prepare(self, text, tag='g'):
         """Host side of the caption branch: which steps run at all, time-major token ids and the per-sample
@@ -66,9 +70,9 @@ class TextFusion(object):
             hip.fill(feat, 0.0)
             return feat, ctx
         tok, mask = prep['tok'], prep['mask']
-        E = s['generator/TextLSTM/embedding']
-        Kw, bw = s[PFX_W + 'kernel'], s[PFX_W + 'bias']
-        Ka, ba = s[PFX_A + 'kernel'], s[PFX_A + 'bias']
+        E = s[self.emb_name]
+        Kw, bw = s[self.pfx_w + 'kernel'], s[self.pfx_w + 'bias']
+        Ka, ba = s[self.pfx_a + 'kernel'], s[self.pfx_a + 'bias']
         G4 = 4 * C
 
         vis = B.get(tag + '/tf/vis', (R, C))
@@ -125,13 +129,13 @@ class TextFusion(object):
         s, B = self.s, self.b
         N, P, C, S, tag = ctx['N'], ctx['P'], ctx['C'], ctx['S'], ctx['tag']
         R, G4 = N * P, 4 * C
-        gE, gKw, gbw = s.grad('generator/TextLSTM/embedding'), s.grad(PFX_W + 'kernel'), s.grad(PFX_W + 'bias')
-        gKa, gba = s.grad(PFX_A + 'kernel'), s.grad(PFX_A + 'bias')
+        gE, gKw, gbw = s.grad(self.emb_name), s.grad(self.pfx_w + 'kernel'), s.grad(self.pfx_w + 'bias')
+        gKa, gba = s.grad(self.pfx_a + 'kernel'), s.grad(self.pfx_a + 'bias')
         if S == 0:
             for g in (gE, gKw, gbw, gKa, gba):
                 hip.fill(g, 0.0)
             return None
-        Kw, Ka = s[PFX_W + 'kernel'], s[PFX_A + 'kernel']
+        Kw, Ka = s[self.pfx_w + 'kernel'], s[self.pfx_a + 'kernel']
         ca, ha, acts_a, mask = ctx['ca'], ctx['ha'], ctx['acts_a'], ctx['mask']
         dh = B.get(tag + '/tfb/dh0', (R, C))
         dh2 = B.get(tag + '/tfb/dh1', (R, C))
