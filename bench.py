@@ -44,8 +44,77 @@ def cpu_baseline(img, n=4):
                       '(oracle/pix2pix.py), %.1f s' % (n, img, img, dt)}
 
 
+def run_forward_workload(args):
+    """Secondary workloads (not the headline metric): generator-only forward passes.
+      fg_infer  : BASELINE configs[1], Pix2Pix generator inference, batch 16, 192x192
+      fg_resid  : the same for --block_type Residual
+      bg768     : BASELINE configs[4], Background_Colorization 768x768 residual generator, batch 4."""
+    from sketchyscenecolorization_amd import hip
+    from sketchyscenecolorization_amd.params import Buffers, ParamStore
+    wl = args.workload
+    torch.manual_seed(0)
+    if wl == 'bg768':
+        from sketchyscenecolorization_amd.residual import ResidualGenerator
+        n, img = (args.batch if args.batch != 32 else 4), (args.img if args.img != 192 else 768)
+        store = ParamStore('BG', 18, img, 'cuda', 0)
+        gen = ResidualGenerator(store, Buffers('cuda'), 'bg')
+        x = torch.rand(n, img, img, 3, device='cuda') * 2 - 1
+        text = torch.randint(1, 18, (n, 8), dtype=torch.int32).numpy()
+        step = lambda: gen.forward(x, text, None, 'bg')
+        flop_img, name = 439.6e9, 'Background_Colorization create_residual_generator forward'
+    else:
+        n, img = (args.batch if args.batch != 32 else 16), args.img
+        z = torch.rand(n, 3, img, img, device='cuda') * 2 - 1
+        text = torch.randint(1, 58, (n, 15), dtype=torch.int32).numpy()
+        nv = torch.randn(n, 256, device='cuda')
+        if wl == 'fg_resid':
+            from sketchyscenecolorization_amd.residual import ResidualGenerator
+            store = ParamStore('Residual', 58, img, 'cuda', 0)
+            gen = ResidualGenerator(store, Buffers('cuda'), 'fg')
+            flop_img, name = 21.1e9, 'Foreground generate_residual forward'
+        else:
+            from sketchyscenecolorization_amd.pix2pix import Pix2PixGenerator
+            store = ParamStore('Pix2Pix', 58, img, 'cuda', 0)
+            gen = Pix2PixGenerator(store, Buffers('cuda'))
+            flop_img, name = 10.84e9, 'Foreground generate_pix2pix forward'
+        step = lambda: gen.forward(z, text, nv, 'g')
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = []
+    hip.PROFILE = prof
+    step()
+    torch.cuda.synchronize()
+    hip.PROFILE = None
+    agg = {}
+    for kname, fl, e0, e1, _shape in prof:
+        a = agg.setdefault(kname, [0.0, 0.0, 0])
+        a[0] += fl
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    tot = sum(v[1] for v in agg.values())
+    ms = dt / args.steps * 1e3
+    out = {'metric': 'generator forward images/sec', 'value': n * args.steps / dt, 'unit': 'images/sec', 'n_gpus': 1,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+           'config': {'workload': '%s, %dx%d, batch %d' % (name, img, img, n), 'launch': 'eager'},
+           'step_tflops_as_written': flop_img * n / (ms * 1e-3) / 1e12,
+           'step_frac_of_fp32_peak': flop_img * n / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+           'igemm_ms_per_step': tot * 1e3,
+           'per_kernel': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] * 1e3, 'launches_per_step': v[2]}
+                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', default='train', choices=['train', 'fg_infer', 'fg_resid', 'bg768'],
+                    help='train = the headline metric (default); the others are secondary forward-only workloads')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
@@ -57,6 +126,10 @@ def main():
     ap.add_argument('--prof-steps', type=int, default=2, help='eager, HIP-event-instrumented steps for the roofline leg')
     args = ap.parse_args()
 
+    if args.workload != 'train':
+        assert int(os.environ.get('WORLD_SIZE', 1)) == 1, 'forward workloads are single-GPU'
+        torch.cuda.set_device(0)
+        return run_forward_workload(args)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
