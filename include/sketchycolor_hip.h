@@ -28,6 +28,7 @@ extern "C" {
 #define SSC_ACT_RELU 1   /* tf.nn.relu                 models_collection.py:518,531 */
 #define SSC_ACT_LRELU 2  /* tf.maximum(0.2*x, x)       models_collection.py:51-53   */
 #define SSC_ACT_TANH 3   /* only for ssc_affine_act / ssc_residual_merge outputs, never on load */
+#define SSC_ACT_MIU 4    /* miu_relu (x + sqrt(0.09 + x^2))/2, models_collection.py:63-65; pointwise kernels only */
 
 /*
  * A "gather view": one or two NHWC tensors seen as a single [N,H,W,C0+C1]
@@ -74,7 +75,7 @@ typedef struct ssc_conv_desc {
     int32_t Nstore;       /* columns stored (>= Nn; extra ones are written 0) */
     int32_t OH, OW, ldc;
     int32_t out_stride, ooff_y, ooff_x; /* oy = py*out_stride + ooff_y */
-    int32_t epi;          /* 0 none, 1 tanh (models_collection.py:533) */
+    int32_t epi;          /* 0 none, 1 tanh (models_collection.py:533), 2 lrelu 0.2 (MRU gates, mru.py:407-413) */
     int32_t accumulate;   /* 1: out += result */
 } ssc_conv_desc;
 
@@ -117,6 +118,40 @@ int ssc_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int ldc
 /* dst[n,c,hw] = src[n,hw,coff+c] */
 int ssc_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, int ldc, int coff, void* stream);
 int ssc_fill(float* dst, float value, int64_t n, void* stream);
+/* ---- MRU blocks (mru.py:353-461 mru_conv_block_v3, :527-591 mru_deconv_block_v2), NHWC fp32 -------------------- */
+/* mean_pool (mru.py:15-19): out[n, y, x, c] = mean of the 2x2 block */
+int ssc_mean_pool2(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int C, void* stream);
+/* conditional batch norm (models_collection.py:22-35): stats = [mean(C); rstd(C)] (ssc_bn_stats), scale_m/offset_m
+ * [n_labels, C]; abn[n] = [a(C); b(C)] with a = scale[label_n]*rstd, b = offset[label_n] - mean*a */
+int ssc_cbn_fold(const float* stats, const float* scale_m, const float* offset_m, const int32_t* labels, int N, int C,
+                 float* abn, void* stream);
+/* mnmx[n] = [min(C); max(C)] over the P = H*W rows of sample n (tf.reduce_min/max(axis=[2,3]), mru.py:414-415) */
+int ssc_minmax_hw(const float* x, int ld, int N, int P, int C, float* mnmx, float* workspace, int64_t workspace_bytes,
+                  void* stream);
+/* channel-concat writer: out[row, :] = [part0 | part1 | part2], each part = act(a*x+b) (per-sample a,b when
+ * ab_sample_stride != 0), optionally read through a nearest 2x upsample (mru.py:22-28) and multiplied by a min-max
+ * normalised gate (rg * ht, mru.py:571) */
+typedef struct {
+    const float* x;
+    const float* ab;      /* NULL or [a(C); b(C)] (+ n*ab_sample_stride) */
+    const float* gate;    /* NULL or raw gate [N,H,W,C] */
+    const float* mnmx;    /* [N,2,C] when gate != NULL */
+    int32_t ld, C, ab_sample_stride, act, upsample, _pad;
+} ssc_cat_part;
+typedef struct {
+    ssc_cat_part p[3];
+    float* out;
+    int32_t nparts, ldo, N, H, W, _pad;
+} ssc_cat_desc;
+int ssc_concat_parts(const ssc_cat_desc* d, void* stream);
+/* out = ht + (rg - min)/(max - min) * img      (mru.py:422) */
+int ssc_mru_gate_merge(const float* ht, const float* rg, const float* mnmx, const float* img, float* out, int N,
+                       int64_t P, int C, void* stream);
+/* out = hp*(1 - z) + miu(a2*h2+b2)*z, z = (zg - min)/(max - min), hp = ht_ab ? miu(a*ht+b) : ht, ht read at
+ * (y/2, x/2) when ht_lowres      (mru.py:583-589) */
+int ssc_mru_blend(const float* ht, const float* ht_ab, int ht_lowres, const float* h2, const float* h2_ab,
+                  const float* zg, const float* mnmx, float* out, int N, int H, int W, int C, void* stream);
+
 /* out[r, c] = act(ab[c]*x[r, c] + ab[ldab + c])  (ab may be NULL): materialises a normalised tensor (final
  * tanh(batchnorm(.)), models_collection.py:664-667) or re-strides a channel-padded one (ldx != ldo) */
 int ssc_affine_act(const float* x, int ldx, const float* ab, int ldab, int act, float* out, int ldo, int64_t M, int C,

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libsketchycolor_hip.so')
-SOURCES = ['igemm.hip', 'narrow.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip']
+SOURCES = ['igemm.hip', 'narrow.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip', 'mru_ops.hip']
 
 
 def _hipcc():

@@ -432,6 +432,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
                 if (final_pass) {
                     if (d.bias != nullptr && col < d.Nn) v += d.bias[col];
                     if (d.epi == 1) v = tanhf(v);
+                    else if (d.epi == 2) v = fmaxf(v, 0.2f * v);
                     if (d.accumulate) v += *o;
                 }
                 *o = v;
@@ -452,6 +453,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_st
     for (int s = 0; s < splitk; ++s) v += slabs[(long)s * slab_stride + i];
     if (bias != nullptr && col < Nn) v += bias[col];
     if (epi == 1) v = tanhf(v);
+    else if (epi == 2) v = fmaxf(v, 0.2f * v);
     if (accumulate) v += out[i];
     out[i] = v;
 }

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d) 
                 v = acc[ph][n < NOUT ? n : 0].x + acc[ph][n < NOUT ? n : 0].y;
                 if (d.bias != nullptr) v += d.bias[n];
                 if (d.epi == 1) v = tanhf(v);
+                else if (d.epi == 2) v = fmaxf(v, 0.2f * v);
                 if (d.accumulate) v += o[n];
             }
             o[n] = v;

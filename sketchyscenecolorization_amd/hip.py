@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSC_LIB_PATH') or os.path.join(_HERE, 'lib', 'libsketchycolor_hip.so')
 
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3     # TANH only for materialising kernels, never on load
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_MIU = 0, 1, 2, 3, 4     # TANH / MIU: pointwise kernels only, never on load
 
 
 class GView(C.Structure):
@@ -97,9 +97,26 @@ SIGNATURES = {
     'ssc_sn_forward': [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     'ssc_sn_backward': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P],
     'ssc_axpy': [_P, _P, _F, _L, _P],
+    'ssc_mean_pool2': [_P, _I, _P, _I, _I, _I, _I, _I, _P],
+    'ssc_cbn_fold': [_P, _P, _P, _P, _I, _I, _P, _P],
+    'ssc_minmax_hw': [_P, _I, _I, _I, _I, _P, _P, _L, _P],
+    'ssc_concat_parts': [_P, _P],
+    'ssc_mru_gate_merge': [_P, _P, _P, _P, _P, _I, _L, _I, _P],
+    'ssc_mru_blend': [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'ssc_fc_small_fwd': [_P, _P, _P, _I, _I, _I, _P, _P],
     'ssc_fc_small_bwd': [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
 }
+
+
+class CatPart(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('ab', C.c_void_p), ('gate', C.c_void_p), ('mnmx', C.c_void_p),
+                ('ld', C.c_int32), ('C', C.c_int32), ('ab_sample_stride', C.c_int32), ('act', C.c_int32),
+                ('upsample', C.c_int32), ('_pad', C.c_int32)]
+
+
+class CatDesc(C.Structure):
+    _fields_ = [('p', CatPart * 3), ('out', C.c_void_p), ('nparts', C.c_int32), ('ldo', C.c_int32),
+                ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('_pad', C.c_int32)]
 
 
 def _declare(l):
@@ -424,6 +441,37 @@ def call(name, *args):
         else:
             conv.append(a)
     check(getattr(lib(), name)(*conv, stream_ptr()), name)
+
+
+def concat_parts(out, parts):
+    """out [N,H,W,ldo] <- channel concat of up to three parts; part = dict(x=tensor [N,h,w,ld], C=real channels,
+    ab=None | [2C] | [N,2C], act=ACT_*, upsample=bool, gate=None | (raw gate [N,H,W,C], mnmx [N,2,C]))."""
+    N, H, W, ldo = out.shape
+    d = CatDesc()
+    d.out, d.nparts, d.ldo, d.N, d.H, d.W = out.data_ptr(), len(parts), ldo, N, H, W
+    tot = 0
+    for k, q in enumerate(parts):
+        x = q['x']
+        cp = d.p[k]
+        cp.x, cp.ld, cp.C = x.data_ptr(), x.shape[-1], q.get('C', x.shape[-1])
+        ab = q.get('ab')
+        cp.ab = ab.data_ptr() if ab is not None else None
+        cp.ab_sample_stride = 2 * cp.C if (ab is not None and ab.dim() == 2) else 0
+        cp.act, cp.upsample = q.get('act', ACT_NONE), int(bool(q.get('upsample', False)))
+        assert x.shape[1] * (2 if cp.upsample else 1) == H
+        g = q.get('gate')
+        cp.gate, cp.mnmx = (g[0].data_ptr(), g[1].data_ptr()) if g is not None else (None, None)
+        assert g is None or g[0].shape[-1] == cp.C
+        tot += cp.C
+    assert tot <= ldo
+    check(lib().ssc_concat_parts(C.byref(d), stream_ptr()), 'ssc_concat_parts')
+
+
+def minmax_hw(x4d, mnmx):
+    """mnmx [N,2,C] <- per-sample per-channel min / max over H*W of x4d [N,H,W,C]."""
+    n, h, w, c = x4d.shape
+    ws = workspace()
+    check(lib().ssc_minmax_hw(ptr(x4d), c, n, h * w, c, ptr(mnmx), ptr(ws), ws.numel() * 4, stream_ptr()), 'minmax_hw')
 
 
 def bn_stats_view(x4d, scale, offset, ab, stats, eps=1e-5):

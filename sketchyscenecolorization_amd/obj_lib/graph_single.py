@@ -67,8 +67,11 @@ def build_single_graph(images, sketches, images_d, image_data_class_id, image_da
     tr = models.get_trainer(block_type, vocab_size, sk.shape[2])
     tr.G.lstm_hybrid = bool(LSTM_hybrid)
     if not training:
-        b = _batch(None, sk, None, None, None, text_vocab_indiceses, noise_vec)
-        gen = tr.generate(b['sketches'], b['text'], b['noise_vec'])
+        b = _batch(None, sk, None, image_data_class_id, None, text_vocab_indiceses, noise_vec)
+        if block_type == 'MRU':     # class-conditional norms (models_collection.py:80-82, 270-272)
+            gen = tr.generate(b['sketches'], b['text'], b['noise_vec'], labels=b['class_id'])
+        else:
+            gen = tr.generate(b['sketches'], b['text'], b['noise_vec'])
         return [gen, _value(images), sk]
     b = _batch(images, sk, images_d, image_data_class_id, image_data_class_id_d, text_vocab_indiceses, noise_vec)
     loss_d = float(tr.d_gradients(b))

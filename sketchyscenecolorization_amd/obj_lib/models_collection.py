@@ -31,17 +31,19 @@ def reset_default_graph():
 def get_trainer(block_type='Pix2Pix', vocab_size=58, img=192, seed=0, **kw):
     """The tower (variables + activation buffers + optimizer slots) of the 'default graph',
     created on first use like tf.get_variable."""
-    if block_type not in ('Pix2Pix', 'Residual'):
-        raise NotImplementedError('block_type %r: Pix2Pix (train + infer) and Residual (infer) are built; MRU '
-                                  'follows (SURVEY.md section 7, step 7)' % block_type)
+    if block_type not in ('Pix2Pix', 'Residual', 'MRU'):
+        raise NotImplementedError('block_type %r' % block_type)
     key = (block_type, vocab_size, img)
     if key not in _REGISTRY:
         if block_type == 'Pix2Pix':
             from ..trainer import Pix2PixTrainer
             _REGISTRY[key] = Pix2PixTrainer(img=img, vocab_size=vocab_size, seed=seed, sn=Config.sn, **kw)
-        else:
+        elif block_type == 'Residual':
             from ..residual import ResidualTower
             _REGISTRY[key] = ResidualTower(img=img, vocab_size=vocab_size, seed=seed)
+        else:
+            from ..mru import MRUTower
+            _REGISTRY[key] = MRUTower(img=img, vocab_size=vocab_size, seed=seed)
     return _REGISTRY[key]
 
 
@@ -121,14 +123,32 @@ def generate_residual(z, text_vocab_indices, LSTM_hybrid, output_channel, num_cl
     return tower.generate(z, text, noise_vec), noise_vec
 
 
+def generate_mru(z, text_vocab_indices, LSTM_hybrid, output_channel, num_classes, vocab_size, reuse=False,
+                 data_format='NCHW', labels=None, scope_name=None, noise_vec=None):
+    """models_collection.py:251-377: the MRU generator (forward).  ``labels`` = class ids [N] select the rows of
+    the conditional norms (the reference passes them through ``normalizer_params_*['labels']``, :80-82, 270-272)."""
+    assert data_format == 'NCHW' and output_channel == 3
+    if labels is None:
+        raise ValueError('generate_mru needs labels (image_data_class_id): its norms are class-conditional')
+    z = _as_device(z)
+    n, _, h, w = z.shape
+    tower = get_trainer('MRU', vocab_size, h)
+    if noise_vec is None:
+        noise_vec = torch.randn(n, 256, device='cuda')
+    noise_vec = _as_device(noise_vec)
+    text = text_vocab_indices.cpu().numpy() if isinstance(text_vocab_indices, torch.Tensor) else np.asarray(text_vocab_indices)
+    assert text.shape[0] == n
+    tower.G.lstm_hybrid = bool(LSTM_hybrid)
+    return tower.generate(z, text, noise_vec, labels=_as_device(labels, torch.int32)), noise_vec
+
+
 def _not_built(name):
     def f(*a, **k):
-        raise NotImplementedError('%s is not built yet: Pix2Pix (train + infer) and the Residual generator (infer) '
-                                  'are; MRU and discriminate_residual follow (SURVEY.md section 7, step 7)' % name)
+        raise NotImplementedError('%s is not built yet: Pix2Pix (train + infer) and the MRU / Residual generators (infer) '
+                                  'are; the MRU / Residual discriminators follow (SURVEY.md section 7, step 7)' % name)
     return f
 
 
-generate_mru = _not_built('generate_mru')
 discriminate_mru = _not_built('discriminate_mru')
 discriminate_residual = _not_built('discriminate_residual')
 

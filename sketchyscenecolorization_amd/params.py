@@ -127,10 +127,69 @@ def residual_generator_specs(kind='fg', vocab_size=None, img=None, size=SIZE, se
     return out
 
 
+MRU_ENC_UNITS = [(1, 8, 64), (2, 64, 128), (3, 128, 256), (4, 256, 512)]
+MRU_DEC_UNITS = [(0, 512, 384, 67), (2, 384, 256, 131), (4, 256, 128, 67), (6, 128, 128, 11), (8, 128, 64, 3)]
+
+
+def mru_generator_specs(vocab_size=58, img=192, num_classes=NUM_CLASSES):
+    """(name, shape, init) of generate_mru / image_encoder_mru (models_collection.py:68-147, 251-377; blocks
+    mru.py:353-461, 527-591) in graph-creation order.  TF uniquifies the default conv scope ('Conv', 'Conv_1', ...);
+    biases (TF shape (1,C,1,1)) are stored flat; conditional-norm tables are [num_classes, C]
+    (models_collection.py:29-31: offset zeros, scale ones)."""
+    out = []
+    filt, zeros, ones = ('normal', 0.0, 0.02), ('zeros',), ('ones',)
+
+    def conv(pre, k, cin, cout, norm=False, bias_init=zeros):
+        out.append((pre + '/weights', (k, k, cin, cout), filt))
+        out.append((pre + '/biases', (cout,), bias_init))
+        if norm:
+            cbn(pre, cout)
+
+    def cbn(pre, c):
+        out.append((pre + '/offset', (num_classes, c), zeros))
+        out.append((pre + '/scale', (num_classes, c), ones))
+
+    conv('generator/Conv', 7, 3, 8)
+    for u, ch, d in MRU_ENC_UNITS:
+        pre = 'generator/mru_conv_unit_t_%d_layer_0' % u
+        cbn(pre + '/norm_activation_in', ch)
+        conv(pre + '/update_gate', 3, ch + 3, ch, bias_init=('const', 0.5))     # mru.py:360
+        conv(pre + '/Conv', 3, 3, ch)
+        cbn(pre + '/norm_activation_merge_1', ch)
+        conv(pre + '/Conv_1', 3, ch, d, norm=True)
+        conv(pre + '/Conv_2', 3, d, d)
+        if ch != d:
+            conv(pre + '/Conv_3', 1, ch, d)
+    cbn('generator/mru_conv_unit_last_norm', 512)
+    c = 512
+    out.append(('generator/TextLSTM/embedding', (vocab_size, c), ('uniform', -0.08, 0.08)))
+    for cell, rows in (('WLSTM', 2 * c), ('ALSTM', 4 * c)):
+        base = 'generator/TextLSTM/RNN/%s/multi_rnn_cell/cell_0/basic_lstm_cell/' % cell
+        out.append((base + 'kernel', (rows, 4 * c), ('glorot',)))
+        out.append((base + 'bias', (4 * c,), zeros))
+    hw = img // 16
+    out.append(('generator/fully_connected/weights', (256, 64 * hw * hw), ('glorot',)))
+    out.append(('generator/fully_connected/biases', (64 * hw * hw,), zeros))
+    for u, ch, d, ci in MRU_DEC_UNITS:
+        pre = 'generator/mru_deconv_unit_t_%d_layer_0' % u
+        conv(pre + '/Conv', 3, ch + ci, ch)
+        conv(pre + '/Conv_1', 3, ch + ci, d)
+        conv(pre + '/Conv_2', 3, ch + ci, d, norm=True)
+        conv(pre + '/Conv_3', 3, d, d, norm=True)
+        if ch != d:
+            conv(pre + '/Conv_4', 1, ch, d, norm=True)
+    conv('generator/Conv_1', 7, 64, 3)
+    return out
+
+
 def _init_tensor(shape, init, gen):
     kind = init[0]
     if kind == 'zeros':
         return torch.zeros(shape)
+    if kind == 'ones':
+        return torch.ones(shape)
+    if kind == 'const':
+        return torch.full(shape, float(init[1]))
     if kind == 'normal':
         return torch.randn(shape, generator=gen) * init[2] + init[1]
     if kind == 'uniform':
@@ -177,10 +236,12 @@ class ParamStore(object):
             g, d, nt = pix2pix_param_specs(vocab_size, img)
         elif block_type == 'Residual':      # generator only so far (inference); discriminate_residual is not built
             g, d, nt = residual_generator_specs('fg', vocab_size, img), [], []
+        elif block_type == 'MRU':           # generator only so far (inference); discriminate_mru is not built
+            g, d, nt = mru_generator_specs(vocab_size, img), [], []
         elif block_type == 'BG':            # Background_Colorization generator (BASELINE config 5), forward only
             g, d, nt = residual_generator_specs('bg', vocab_size, img), [], []
         else:
-            raise NotImplementedError('block_type %r: Pix2Pix (train+infer) and Residual/BG (generator forward) '
+            raise NotImplementedError('block_type %r: Pix2Pix (train+infer) and MRU/Residual/BG (generator forward) '
                                       'are built so far' % block_type)
         self.block_type = block_type
         self.device = device

@@ -26,7 +26,24 @@ def test_param_registry_matches_reference_counts():
     assert float(st['generator/encoder_2/offset'].abs().max()) == 0.0
     assert float(st['generator/TextLSTM/embedding'].abs().max()) <= 0.08
     with pytest.raises(NotImplementedError):
-        ParamStore('MRU', 58, 192, device='cpu')
+        ParamStore('NoSuchBlock', 58, 192, device='cpu')
+
+
+def test_generator_registries_match_oracle_shapes_and_reference_counts():
+    """Variable names / shapes / order of the MRU, Residual and BG generators."""
+    from oracle import mru as OM
+    from oracle import residual as OR
+    from sketchyscenecolorization_amd.params import ParamStore, mru_generator_specs, residual_generator_specs
+    for specs, shapes, count in ((mru_generator_specs(), OM.generator_shapes(), 30306499),
+                                 (residual_generator_specs('fg'), OR.generator_shapes('fg'), 43516550),
+                                 (residual_generator_specs('bg'), OR.generator_shapes('bg'), 79839866)):
+        assert [n for n, _, _ in specs] == list(shapes.keys())
+        assert all(tuple(s) == tuple(shapes[n]) for n, s, _ in specs)
+        assert sum(int(np.prod(s)) for _, s, _ in specs) == count
+    st = ParamStore('MRU', 58, 64, device='cpu', seed=0)
+    assert float(st['generator/mru_conv_unit_t_1_layer_0/update_gate/biases'].min()) == 0.5      # mru.py:360
+    assert float(st['generator/mru_conv_unit_t_1_layer_0/Conv_1/scale'].min()) == 1.0
+    assert st['generator/mru_deconv_unit_t_0_layer_0/Conv_2/weights'].shape == (3, 3, 579, 384)
 
 
 def test_state_dict_roundtrip_and_tf_names(tmp_path):
