@@ -48,6 +48,7 @@ def run_forward_workload(args):
     """Secondary workloads (not the headline metric): generator-only forward passes.
       fg_infer  : BASELINE configs[1], Pix2Pix generator inference, batch 16, 192x192
       fg_resid  : the same for --block_type Residual
+      fg_mru    : the same for the default --block_type MRU (configs[1] 'MRU second')
       bg768     : BASELINE configs[4], Background_Colorization 768x768 residual generator, batch 4."""
     from sketchyscenecolorization_amd import hip
     from sketchyscenecolorization_amd.params import Buffers, ParamStore
@@ -67,7 +68,13 @@ def run_forward_workload(args):
         z = torch.rand(n, 3, img, img, device='cuda') * 2 - 1
         text = torch.randint(1, 58, (n, 15), dtype=torch.int32).numpy()
         nv = torch.randn(n, 256, device='cuda')
-        if wl == 'fg_resid':
+        if wl == 'fg_mru':
+            from sketchyscenecolorization_amd.mru import MRUGenerator
+            store = ParamStore('MRU', 58, img, 'cuda', 0)
+            gen = MRUGenerator(store, Buffers('cuda'))
+            labels = torch.randint(0, 25, (n,), dtype=torch.int32, device='cuda')
+            flop_img, name = 62.6e9, 'Foreground generate_mru forward'
+        elif wl == 'fg_resid':
             from sketchyscenecolorization_amd.residual import ResidualGenerator
             store = ParamStore('Residual', 58, img, 'cuda', 0)
             gen = ResidualGenerator(store, Buffers('cuda'), 'fg')
@@ -77,7 +84,7 @@ def run_forward_workload(args):
             store = ParamStore('Pix2Pix', 58, img, 'cuda', 0)
             gen = Pix2PixGenerator(store, Buffers('cuda'))
             flop_img, name = 10.84e9, 'Foreground generate_pix2pix forward'
-        step = lambda: gen.forward(z, text, nv, 'g')
+        step = (lambda: gen.forward(z, text, labels, nv, 'g')) if wl == 'fg_mru' else (lambda: gen.forward(z, text, nv, 'g'))
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize()
@@ -113,7 +120,7 @@ def run_forward_workload(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='train', choices=['train', 'fg_infer', 'fg_resid', 'bg768'],
+    ap.add_argument('--workload', default='train', choices=['train', 'fg_infer', 'fg_resid', 'fg_mru', 'bg768'],
                     help='train = the headline metric (default); the others are secondary forward-only workloads')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)

@@ -231,15 +231,18 @@ def get_losses(p, images, image_gens, class_id, class_id_d, real_disc, fake_disc
 
 
 def build_single_graph(p, images, sketches, images_d, class_id, class_id_d, text, noise_vec, training=True,
-                       lstm_hybrid=True):
-    """One tower: forward, both losses and both gradient sets (autograd)."""
+                       lstm_hybrid=True, generator=None, discriminator=None):
+    """One tower: forward, both losses and both gradient sets (autograd).  ``generator`` / ``discriminator``
+    default to the Pix2Pix pair; oracle.residual passes its own (graph_single.py:244-262 picks them by block_type)."""
+    generator = generator or generate_pix2pix
+    discriminator = discriminator or discriminate_pix2pix
     if not training:
         with torch.no_grad():
-            return generate_pix2pix(p, sketches, text, noise_vec, lstm_hybrid), images, sketches
+            return generator(p, sketches, text, noise_vec, lstm_hybrid), images, sketches
     q = OrderedDict((k, v.detach().clone().requires_grad_(not k.endswith('/u'))) for k, v in p.items())
-    gen = generate_pix2pix(q, sketches, text, noise_vec, lstm_hybrid)
-    real_disc, real_logit, u_new = discriminate_pix2pix(q, sketches, images_d, return_u=True)
-    fake_disc, fake_logit = discriminate_pix2pix(q, sketches, gen)
+    gen = generator(q, sketches, text, noise_vec, lstm_hybrid)
+    real_disc, real_logit, u_new = discriminator(q, sketches, images_d, return_u=True)
+    fake_disc, fake_logit = discriminator(q, sketches, gen)
     loss_g, loss_d, parts = get_losses(q, images, gen, class_id, class_id_d, real_disc, fake_disc,
                                        real_logit, fake_logit)
     g_names = trainable(q, 'generator')
@@ -256,7 +259,7 @@ def build_single_graph(p, images, sketches, images_d, class_id, class_id_d, text
             'real_logit': real_logit.detach(), 'fake_logit': fake_logit.detach()}
 
 
-def build_single_graph_f64(p, **batch):
+def build_single_graph_f64(p, generator=None, discriminator=None, **batch):
     """The same restatement evaluated in float64: the arbiter when two fp32 paths disagree
     (batch-stat-norm gradients are ill-conditioned: fp32 torch differs from fp64 by up to ~7e-3)."""
     old = torch.get_default_dtype()
@@ -264,7 +267,7 @@ def build_single_graph_f64(p, **batch):
     try:
         p64 = OrderedDict((k, v.double()) for k, v in p.items())
         b64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
-        return build_single_graph(p64, **b64)
+        return build_single_graph(p64, generator=generator, discriminator=discriminator, **b64)
     finally:
         torch.set_default_dtype(old)
 
@@ -278,9 +281,9 @@ class TrainState(object):
         self.t_d = 0
 
 
-def d_step(p, st, batch, lr_d, counter, max_iter):
+def d_step(p, st, batch, lr_d, counter, max_iter, **nets):
     """sess.run([opt_d, loss_d]) (main_procedure.py:202-216)."""
-    r = build_single_graph(p, **batch)
+    r = build_single_graph(p, **batch, **nets)
     st.t_d += 1
     lr = lr_d * T.lr_decay(counter, max_iter)
     for k, g in r['grad_d'].items():
@@ -288,10 +291,10 @@ def d_step(p, st, batch, lr_d, counter, max_iter):
     return r
 
 
-def g_step(p, st, batch, lr_g, counter, max_iter):
+def g_step(p, st, batch, lr_g, counter, max_iter, **nets):
     """sess.run([opt_g, loss_g, ...]); SN ``u`` assigns run with opt_g
     (graph_single.py:178-210).  Forward uses the pre-update ``u``."""
-    r = build_single_graph(p, **batch)
+    r = build_single_graph(p, **batch, **nets)
     st.t_g += 1
     lr = lr_g * T.lr_decay(counter, max_iter)
     for k, g in r['grad_g'].items():

@@ -99,12 +99,29 @@ def generator_shapes(kind, vocab_size=None, img=None, size=64, seg_classes=3):
     return s
 
 
-def init_params(kind, seed=0, **kw):
+def discriminator_shapes(size=64, num_classes=25):
+    """discriminate_residual (models_collection.py:844-893): 5 stride-2 encoder bottlenecks, a 4x4 s1 SAME patch
+    head and the spectral-normed class head on layer_4's mean."""
+    s = OrderedDict()
+    chans = [(6, size), (size, size * 2), (size * 2, size * 4), (size * 4, size * 8), (size * 8, size * 8)]
+    for k, (ci, co) in enumerate(chans, start=1):
+        _en_shapes(s, 'discriminator/layer_%d' % k, ci, co)
+    s['discriminator/layer_5/conv_ex/filter'] = (4, 4, size * 8, 1)
+    s['discriminator/fully_connected/weights'] = (size * 8, num_classes)
+    s['discriminator/fully_connected/biases'] = (num_classes,)
+    s['discriminator/fully_connected/u'] = (1, num_classes)
+    return s
+
+
+def init_params(kind, seed=0, with_discriminator=False, **kw):
     """Reference initialisers: filters N(0,0.02), scale N(1,0.02), offset 0, embedding U(-0.08,0.08),
     LSTM kernels / FC weights glorot-uniform, biases 0."""
     g = torch.Generator().manual_seed(seed)
     p = OrderedDict()
-    for name, shp in generator_shapes(kind, **kw).items():
+    shapes = generator_shapes(kind, **kw)
+    if with_discriminator:
+        shapes.update(discriminator_shapes())
+    for name, shp in shapes.items():
         leaf = name.rsplit('/', 1)[1]
         if leaf == 'filter':
             p[name] = torch.randn(shp, generator=g) * 0.02
@@ -117,6 +134,11 @@ def init_params(kind, seed=0, **kw):
         elif leaf in ('kernel', 'weights'):
             lim = math.sqrt(6.0 / (shp[0] + shp[1]))
             p[name] = torch.rand(shp, generator=g) * 2 * lim - lim
+        elif leaf == 'u':           # sn.py:18 truncated normal, non-trainable
+            u = torch.randn(shp, generator=g)
+            while bool((u.abs() > 2).any()):
+                u = torch.where(u.abs() > 2, torch.randn(shp, generator=g), u)
+            p[name] = u
         else:
             raise ValueError(name)
     return p
@@ -168,6 +190,38 @@ def _encoder(p, x, bn1):
             out = bottleneck_residual_pu(p, 'generator/encoder_%d_%d' % (k, u), out, True)
         layers.append(out)
     return layers
+
+
+def discriminate_residual(p, discrim_inputs, discrim_targets, sn=True, return_u=False):
+    """models_collection.py:844-893 (Config.sn=True: only the class head's weights are spectral-normed)."""
+    x = torch.cat([discrim_inputs, discrim_targets], dim=1)
+    layers = []
+    for k in range(1, 5):
+        x = bottleneck_residual_en(p, 'discriminator/layer_%d' % k, x, 2)
+        layers.append(x)
+    rectified = x
+    convolved = bottleneck_residual_en(p, 'discriminator/layer_5', rectified, 2)
+    disc = T.conv2d_same(convolved, p['discriminator/layer_5/conv_ex/filter'], 1)
+    img = rectified.mean(dim=(2, 3))
+    w = p['discriminator/fully_connected/weights']
+    u_new = None
+    if sn:
+        w, u_new = T.spectral_normed_weight(w, p['discriminator/fully_connected/u'])
+    logits = img @ w + p['discriminator/fully_connected/biases']
+    if return_u:
+        return disc, logits, u_new
+    return disc, logits
+
+
+def build_single_graph(p, **batch):
+    """One Residual tower (graph_single.py:221-314 with block_type='Residual'): losses + both gradient sets."""
+    from .pix2pix import build_single_graph as bsg
+    return bsg(p, generator=generate_residual, discriminator=discriminate_residual, **batch)
+
+
+def build_single_graph_f64(p, **batch):
+    from .pix2pix import build_single_graph_f64 as bsg64
+    return bsg64(p, generator=generate_residual, discriminator=discriminate_residual, **batch)
 
 
 def generate_residual(p, z, text_vocab_indices, noise_vec, lstm_hybrid=True, return_all=False):

@@ -276,10 +276,11 @@ def deconv_forward(x, f, out, coff=0, nstore=None, epi=0):
     _run_conv(d)
 
 
-def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=None):
-    """Gradient of conv (k=4, pad 1) w.r.t. its input channels [n_off, n_off+nn): dy View -> out [N,Hin,Win,*]."""
+def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=None, accumulate=False):
+    """Gradient of a conv w.r.t. its input channels [n_off, n_off+nn): dy View -> out [N,Hin,Win,*].
+    stride 2: the k=4 pad-1 conv (4 sub-pixel phases).  stride 1: any square kernel, ``pad`` = padding before
+    (SAME: (k-1)//2, the extra element after), input size taken from ``out``."""
     KH, KW, ci, co = w.shape
-    assert KH == 4 and KW == 4 and pad == 1
     nn = ci - n_off if nn is None else nn
     d = ConvDesc()
     d.x = dy.c()
@@ -287,24 +288,24 @@ def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=No
     d.out, OH, OW, ldc = _out_geom(out, 0)
     d.NB = dy.N
     if stride == 2:
-        assert (OH, OW) == (2 * dy.H, 2 * dy.W)
+        assert KH == 4 and KW == 4 and pad == 1 and (OH, OW) == (2 * dy.H, 2 * dy.W)
         d.PH, d.PW, d.TH, d.TW, d.in_stride, d.nphase, d.kstep, d.out_stride = dy.H, dy.W, 2, 2, 1, 4, -2, 2
         d.ky0 = d.kx0 = 0
         d.ioff_y = d.ioff_x = 0
     else:
-        assert stride == 1 and (OH, OW) == (dy.H + 1, dy.W + 1)
-        d.PH, d.PW, d.TH, d.TW, d.in_stride, d.nphase, d.kstep, d.out_stride = OH, OW, 4, 4, 1, 1, -1, 1
-        d.ky0 = d.kx0 = 3
-        d.ioff_y = d.ioff_x = -2
-    d.KH, d.KW, d.wC0, d.wC1, d.bmode = 4, 4, ci, co, 1
+        assert stride == 1 and KH == KW and abs(OH + 2 * pad - KH + 1 - dy.H) <= 1, (OH, dy.H, KH, pad)
+        d.PH, d.PW, d.TH, d.TW, d.in_stride, d.nphase, d.kstep, d.out_stride = OH, OW, KH, KW, 1, 1, -1, 1
+        d.ky0 = d.kx0 = KH - 1
+        d.ioff_y = d.ioff_x = pad - (KH - 1)
+    d.KH, d.KW, d.wC0, d.wC1, d.bmode = KH, KW, ci, co, 1
     d.k_real = co if k_real is None else k_real
     d.n_off, d.Nn, d.Nstore = n_off, nn, (nstore if nstore is not None else nn)
     d.OH, d.OW, d.ldc, d.ooff_y, d.ooff_x = OH, OW, ldc, 0, 0
-    d.epi, d.accumulate = 0, 0
+    d.epi, d.accumulate = 0, int(accumulate)
     _run_conv(d)
 
 
-def deconv_dgrad(dy, f, out, n_off=0, nn=None):
+def deconv_dgrad(dy, f, out, n_off=0, nn=None, accumulate=False):
     """Gradient of the k=4 s=2 transposed conv w.r.t. its input channels: a stride-2 conv of dy with f as HWIO."""
     KH, KW, co, ci = f.shape
     nn = ci - n_off if nn is None else nn
@@ -319,7 +320,7 @@ def deconv_dgrad(dy, f, out, n_off=0, nn=None):
     d.KH, d.KW, d.wC0, d.wC1, d.bmode, d.k_real = 4, 4, co, ci, 0, co
     d.n_off, d.Nn, d.Nstore = n_off, nn, nn
     d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 1, 0, 0
-    d.epi, d.accumulate = 0, 0
+    d.epi, d.accumulate = 0, int(accumulate)
     _run_conv(d)
 
 

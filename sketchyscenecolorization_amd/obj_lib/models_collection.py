@@ -35,12 +35,10 @@ def get_trainer(block_type='Pix2Pix', vocab_size=58, img=192, seed=0, **kw):
         raise NotImplementedError('block_type %r' % block_type)
     key = (block_type, vocab_size, img)
     if key not in _REGISTRY:
-        if block_type == 'Pix2Pix':
-            from ..trainer import Pix2PixTrainer
-            _REGISTRY[key] = Pix2PixTrainer(img=img, vocab_size=vocab_size, seed=seed, sn=Config.sn, **kw)
-        elif block_type == 'Residual':
-            from ..residual import ResidualTower
-            _REGISTRY[key] = ResidualTower(img=img, vocab_size=vocab_size, seed=seed)
+        if block_type in ('Pix2Pix', 'Residual'):
+            from ..trainer import GanTrainer
+            _REGISTRY[key] = GanTrainer(img=img, vocab_size=vocab_size, seed=seed, sn=Config.sn,
+                                        block_type=block_type, **kw)
         else:
             from ..mru import MRUTower
             _REGISTRY[key] = MRUTower(img=img, vocab_size=vocab_size, seed=seed)
@@ -88,23 +86,33 @@ def generate_pix2pix(z, text_vocab_indices, LSTM_hybrid, output_channel, num_cla
     return g.output_nchw(ctx), noise_vec
 
 
-def discriminate_pix2pix(discrim_inputs, discrim_targets, num_classes, labels=None, reuse=False,
-                         data_format='NCHW', scope_name=None):
-    """models_collection.py:789-841: PatchGAN logits [N,1,h-2.. ] + spectral-normed class logits."""
+def _discriminate(block_type, discrim_inputs, discrim_targets, reuse, data_format, scope_name):
     assert data_format == 'NCHW'
     if type(discrim_targets) is list:
         discrim_targets = discrim_targets[-1]
     a, b = _as_device(discrim_inputs), _as_device(discrim_targets)
     n, _, h, w = a.shape
-    store, bufs = get_store('Pix2Pix', 58, h)
-    xd = bufs.get((scope_name or 'discriminator') + '/api_xd', (n, h, w, 8), zero_on_alloc=True)
+    tr = get_trainer(block_type, 58, h)
+    xd = tr.bufs.get((scope_name or 'discriminator') + '/api_xd', (n, h, w, 8), zero_on_alloc=True)
     hip.nchw_to_nhwc(a, xd, 0)
     hip.nchw_to_nhwc(b, xd, 3)
-    d = Pix2PixDiscriminator(store, bufs, Config.sn)
-    sn = d.prepare_sn()
-    c = d.forward(xd, sn, (scope_name or 'discriminator') + ('/reuse' if reuse else ''))
+    tr.D.sn = bool(Config.sn)
+    sn = tr.D.prepare_sn()
+    c = tr.D.forward(xd, sn, (scope_name or 'discriminator') + ('/reuse' if reuse else ''))
     disc = c['disc'][..., 0:1].permute(0, 3, 1, 2).contiguous()
     return disc, c['logits'].clone()
+
+
+def discriminate_pix2pix(discrim_inputs, discrim_targets, num_classes, labels=None, reuse=False,
+                         data_format='NCHW', scope_name=None):
+    """models_collection.py:789-841: PatchGAN logits [N,1,h,w] + spectral-normed class logits [N,25]."""
+    return _discriminate('Pix2Pix', discrim_inputs, discrim_targets, reuse, data_format, scope_name)
+
+
+def discriminate_residual(discrim_inputs, discrim_targets, num_classes, labels=None, reuse=False,
+                          data_format='NCHW', scope_name=None):
+    """models_collection.py:844-893: five stride-2 bottlenecks -> patch logits [N,1,h/32,w/32] + class logits."""
+    return _discriminate('Residual', discrim_inputs, discrim_targets, reuse, data_format, scope_name)
 
 
 def generate_residual(z, text_vocab_indices, LSTM_hybrid, output_channel, num_classes, vocab_size, reuse=False,
@@ -144,13 +152,12 @@ def generate_mru(z, text_vocab_indices, LSTM_hybrid, output_channel, num_classes
 
 def _not_built(name):
     def f(*a, **k):
-        raise NotImplementedError('%s is not built yet: Pix2Pix (train + infer) and the MRU / Residual generators (infer) '
-                                  'are; the MRU / Residual discriminators follow (SURVEY.md section 7, step 7)' % name)
+        raise NotImplementedError('%s is not built yet: Pix2Pix, Residual (train + infer) and the MRU generator (infer) '
+                                  'and Residual (train + infer) are; the MRU discriminator / training follow' % name)
     return f
 
 
 discriminate_mru = _not_built('discriminate_mru')
-discriminate_residual = _not_built('discriminate_residual')
 
 generator_mru = generate_mru
 discriminator_mru = discriminate_mru

@@ -127,6 +127,24 @@ def residual_generator_specs(kind='fg', vocab_size=None, img=None, size=SIZE, se
     return out
 
 
+def residual_discriminator_specs(num_classes=NUM_CLASSES, size=SIZE):
+    """discriminate_residual (models_collection.py:844-893): (trainable specs, non-trainable specs)."""
+    out = []
+    filt, zeros, ones = ('normal', 0.0, 0.02), ('zeros',), ('normal', 1.0, 0.02)
+    chans = [(6, size), (size, size * 2), (size * 2, size * 4), (size * 4, size * 8), (size * 8, size * 8)]
+    for k, (ci, co) in enumerate(chans, start=1):
+        pre = 'discriminator/layer_%d' % k
+        for blk, shape, c in (('block_1/conv', (4, 4, ci, co // 4), co // 4), ('block_2/conv_ex', (3, 3, co // 4, co // 4), co // 4),
+                              ('block_3/conv_ex', (1, 1, co // 4, co), co), ('block_add/conv', (4, 4, ci, co), co)):
+            out.append(('%s/%s/filter' % (pre, blk), shape, filt))
+            out.append(('%s/%s/batchnorm/offset' % (pre, blk.split('/')[0]), (c,), zeros))
+            out.append(('%s/%s/batchnorm/scale' % (pre, blk.split('/')[0]), (c,), ones))
+    out.append(('discriminator/layer_5/conv_ex/filter', (4, 4, size * 8, 1), filt))
+    out.append(('discriminator/fully_connected/weights', (size * 8, num_classes), ('glorot',)))
+    out.append(('discriminator/fully_connected/biases', (num_classes,), zeros))
+    return out, [('discriminator/fully_connected/u', (1, num_classes), ('truncated_normal',))]
+
+
 MRU_ENC_UNITS = [(1, 8, 64), (2, 64, 128), (3, 128, 256), (4, 256, 512)]
 MRU_DEC_UNITS = [(0, 512, 384, 67), (2, 384, 256, 131), (4, 256, 128, 67), (6, 128, 128, 11), (8, 128, 64, 3)]
 
@@ -234,8 +252,9 @@ class ParamStore(object):
     def __init__(self, block_type='Pix2Pix', vocab_size=58, img=192, device='cuda', seed=0):
         if block_type == 'Pix2Pix':
             g, d, nt = pix2pix_param_specs(vocab_size, img)
-        elif block_type == 'Residual':      # generator only so far (inference); discriminate_residual is not built
-            g, d, nt = residual_generator_specs('fg', vocab_size, img), [], []
+        elif block_type == 'Residual':
+            g = residual_generator_specs('fg', vocab_size, img)
+            d, nt = residual_discriminator_specs()
         elif block_type == 'MRU':           # generator only so far (inference); discriminate_mru is not built
             g, d, nt = mru_generator_specs(vocab_size, img), [], []
         elif block_type == 'BG':            # Background_Colorization generator (BASELINE config 5), forward only

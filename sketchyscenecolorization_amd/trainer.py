@@ -24,16 +24,27 @@ from .params import Buffers, ParamStore
 from .pix2pix import Pix2PixDiscriminator, Pix2PixGenerator
 
 
-class Pix2PixTrainer(object):
+class GanTrainer(object):
+    """One tower for ``block_type`` 'Pix2Pix' or 'Residual' (graph_single.py:244-262 picks the generator /
+    discriminator pair by block type; losses, optimizer and the step protocol are shared)."""
+
     def __init__(self, img=192, vocab_size=58, lstm_hybrid=True, lr_g=2e-4, lr_d=1e-4, max_iter_step=100000,
-                 seed=0, sn=True, process_group=None, device='cuda', use_graphs=False):
+                 seed=0, sn=True, process_group=None, device='cuda', use_graphs=False, block_type='Pix2Pix'):
         if not torch.cuda.is_available():
-            raise RuntimeError('Pix2PixTrainer needs an MI355X (HIP) device: there is no CPU fallback')
+            raise RuntimeError('GanTrainer needs an MI355X (HIP) device: there is no CPU fallback')
         hip.lib()
-        self.store = ParamStore('Pix2Pix', vocab_size, img, device, seed)
+        self.block_type = block_type
+        self.store = ParamStore(block_type, vocab_size, img, device, seed)
         self.bufs = Buffers(device)
-        self.G = Pix2PixGenerator(self.store, self.bufs, lstm_hybrid)
-        self.D = Pix2PixDiscriminator(self.store, self.bufs, sn)
+        if block_type == 'Pix2Pix':
+            self.G = Pix2PixGenerator(self.store, self.bufs, lstm_hybrid)
+            self.D = Pix2PixDiscriminator(self.store, self.bufs, sn)
+        elif block_type == 'Residual':
+            from .residual import ResidualDiscriminator, ResidualGenerator
+            self.G = ResidualGenerator(self.store, self.bufs, 'fg', lstm_hybrid)
+            self.D = ResidualDiscriminator(self.store, self.bufs, sn)
+        else:
+            raise NotImplementedError('training for block_type %r is not built' % block_type)
         self.lr_g, self.lr_d, self.max_iter_step = lr_g, lr_d, max_iter_step
         self.beta1, self.beta2, self.eps = 0.0, 0.9, 1e-8     # graph_single.py:588
         self.loss = torch.zeros(2, dtype=torch.float64, device=device)   # [loss_g, loss_d], summed in double
@@ -245,3 +256,6 @@ class Pix2PixTrainer(object):
         """Inference path of build_single_graph (training=False): NCHW in, NCHW out."""
         ctx = self.G.forward(sketches, text, noise_vec, 'g')
         return self.G.output_nchw(ctx)
+
+
+Pix2PixTrainer = GanTrainer     # the name the first round used

@@ -71,6 +71,30 @@ def test_obj_lib_api_inference_and_gradients():
     assert np.isfinite(lg) and np.isfinite(ld)
     names = [n for _, n in grad_g]
     assert 'generator/encoder_1/conv/filter' in names and len(grad_d) == 13
-    with pytest.raises(NotImplementedError):
-        graph_single.build_single_graph(b['images'], b['sketches'], None, b['class_id'], None, b['text'], batch_size=2,
-                                        training=False, LSTM_hybrid=True, vocab_size=58, block_type='MRU')
+    with pytest.raises(NotImplementedError):        # MRU / Residual: generator inference only so far
+        graph_single.build_single_graph(b['images'], b['sketches'], b['images_d'], b['class_id'], b['class_id_d'],
+                                        b['text'], batch_size=2, training=True, LSTM_hybrid=True, vocab_size=58,
+                                        block_type='MRU')
+
+
+@pytest.mark.parametrize('bt', ['MRU', 'Residual'])
+def test_cli_inference_default_block_types(tmp_path, monkeypatch, bt):
+    """--mode inference with the reference's default block type (MRU, what Pipeline_utils/fg_color_utils.py runs)
+    and with Residual, restoring a snapshot keyed by the TF variable names."""
+    from PIL import Image, ImageDraw
+    import obj_colorization_main as cli
+    from sketchyscenecolorization_amd.obj_lib.main_procedure import save_checkpoint
+    from sketchyscenecolorization_amd.params import ParamStore
+    monkeypatch.chdir(tmp_path)
+    ts = '2018-01-02-03-04-05'
+    run = os.path.join('outputs', ts)
+    save_checkpoint(ParamStore(bt, 58, 64, 'cuda', seed=3), os.path.join(run, 'snapshot'), 'model_9.ckpt', 9)
+    os.makedirs('examples')
+    im = Image.new('L', (256, 256), 255)
+    ImageDraw.Draw(im).rectangle([40, 120, 220, 190], outline=0, width=3)
+    im.save('examples/bus.png')
+    args = ['--mode', 'inference', '-rf', ts, '-si', '1', '--infer_name', 'bus.png', '--instruction',
+            'the bus is orange with gray windows']
+    cli.main(args + ([] if bt == 'MRU' else ['-bt', bt]))
+    o = np.array(Image.open(os.path.join(run, 'inference_results', 'bus_output.png')))
+    assert o.shape == (64, 64, 3) and o.dtype == np.uint8 and o.std() > 0

@@ -75,4 +75,146 @@ def test_api_generator_residual_matches_tower():
     img, nv2 = models.generator_residual(z, text, True, 3, 25, 58, noise_vec=nv)
     assert img.shape == (2, 3, 64, 64) and torch.isfinite(img).all() and float(img.abs().max()) <= 1.0
     with pytest.raises(NotImplementedError):
-        models.discriminator_residual(z, z, 25)
+        models.discriminator_mru(z, z, 25)
+
+
+# --------------------------------------------------------------------------- Residual training path
+def _make_trainer(n, img, seed=0):
+    from oracle import pix2pix as O
+    from oracle import residual as R
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    p = R.init_params('fg', seed=seed, with_discriminator=True, img=img)
+    tr = GanTrainer(img=img, seed=seed + 1, block_type='Residual')
+    tr.store.load_dict(p)
+    b = O.synthetic_batch(n, seed=4321 + n, img=img)
+    dev = {k: (v.cuda() if k != 'text' else v.numpy()) for k, v in b.items()}
+    return p, tr, b, dev
+
+
+def test_residual_discriminator_forward_parity():
+    from oracle import residual as R
+    from sketchyscenecolorization_amd import hip
+    p, tr, b, dev = _make_trainer(2, 64)
+    disc, logits = R.discriminate_residual(p, b['sketches'], b['images_d'])
+    xd = torch.zeros(2, 64, 64, 8, device='cuda')
+    hip.nchw_to_nhwc(dev['sketches'], xd, 0)
+    hip.nchw_to_nhwc(dev['images_d'], xd, 3)
+    sn = tr.D.prepare_sn()
+    c = tr.D.forward(xd, sn, 'dr')
+    assert c['disc'].shape[:3] == (2, 1, 1) or c['disc'].shape[1] == disc.shape[2]
+    assert float((c['disc'][..., 0].cpu() - disc[:, 0]).abs().max()) < 1e-3
+    assert float((c['logits'].cpu() - logits).abs().max()) < 1e-3
+
+
+def _grad_errors(get, ref_grads):
+    """Per-variable relative L2 and max errors vs the float64 reference."""
+    l2s, mxs = {}, {}
+    for name, g in ref_grads.items():
+        a = get(name).detach().cpu().double()
+        l2s[name] = float((a - g).norm() / max(float(g.norm()), 1e-30))
+        mxs[name] = float((a - g).abs().max() / max(float(g.abs().max()), 1e-30))
+    return l2s, mxs
+
+
+def _check_grads(scope, ref64, ref32):
+    """~100 chained batch-statistics norms (some over as few as 8 samples) make single gradient entries flip with
+    fp32 rounding: the torch-CPU fp32 restatement itself is up to 4e-2 (L2) / 1.4e-1 (max) away from its float64
+    evaluation for the worst variable, and 2.4e-2 for the MEDIAN generator variable (one flipped relu in the
+    discriminator moves everything upstream).  End-to-end criteria are therefore relative to that fp32 CPU path:
+    median L2 <= max(3e-3, 1.5x CPU median), worst variable <= max(floor, 2x CPU worst).  The exact formulas of every
+    block's backward are pinned separately, in a well-conditioned setting, by test_bottleneck_blocks_backward."""
+    l2, mx = _grad_errors(lambda n: scope.g[n], ref64)
+    c_l2, c_mx = _grad_errors(lambda n: ref32[n], ref64)
+    med, c_med = float(np.median(list(l2.values()))), float(np.median(list(c_l2.values())))
+    worst = max(l2.items(), key=lambda kv: kv[1])
+    worst_mx = max(mx.items(), key=lambda kv: kv[1])
+    assert med < max(3e-3, 1.5 * c_med), (med, c_med)
+    assert worst[1] < max(3e-3, 2 * max(c_l2.values())), (worst, max(c_l2.values()))
+    assert worst_mx[1] < max(3e-2, 2 * max(c_mx.values())), (worst_mx, max(c_mx.values()))
+
+
+@pytest.mark.parametrize('n,img', [(2, 64), (2, 192)])
+def test_residual_train_step_gradients_parity(n, img):
+    """loss_d / loss_g and every gradient of one Residual tower vs float64 autograd on the oracle."""
+    from oracle import residual as R
+    p, tr, b, dev = _make_trainer(n, img)
+    r = R.build_single_graph_f64(p, **b)
+    r32 = R.build_single_graph(p, **b)
+    ld = tr.d_step(dev, counter=0)
+    assert abs(float(ld) - float(r['loss_d'])) < 1e-4 * max(1.0, abs(float(r['loss_d'])))
+    _check_grads(tr.store.discriminator, r['grad_d'], r32['grad_d'])
+    tr.store.load_dict(p)
+    lg = tr.g_step(dev, counter=0)
+    assert abs(float(lg) - float(r['loss_g'])) < 1e-4 * max(1.0, abs(float(r['loss_g'])))
+    _check_grads(tr.store.generator, r['grad_g'], r32['grad_g'])
+
+
+@pytest.mark.parametrize('kind', ['de_pu', 'en_pu'])
+def test_bottleneck_blocks_backward(kind):
+    """One projection bottleneck + one identity bottleneck, forward and hand-written backward, against float64
+    autograd on the oracle's blocks: 2x16x16 positions per channel keep the norms well conditioned, so every
+    gradient (filters, scales, offsets, both concatenated inputs) must agree to 1e-4 relative L2."""
+    from oracle import residual as R
+    from sketchyscenecolorization_amd.hip import ACT_LRELU, ACT_RELU
+    from sketchyscenecolorization_amd.params import Buffers, ParamStore
+    from sketchyscenecolorization_amd.residual import ResidualGenerator, _Val
+    g = torch.Generator().manual_seed(3)
+    p = R.init_params('fg', seed=2, img=64)
+    store = ParamStore('Residual', 58, 64, 'cuda', 0)
+    store.load_dict(p)
+    gen = ResidualGenerator(store, Buffers('cuda'), 'fg')
+    if kind == 'de_pu':
+        pre0, pre1, c0, c1, cout, hw, act = 'generator/decoder_3_0', 'generator/decoder_3_1', 256, 256, 128, 8, ACT_RELU
+    else:
+        pre0, pre1, c0, c1, cout, hw, act = 'generator/encoder_3_0', 'generator/encoder_3_1', 128, 0, 256, 32, ACT_LRELU
+    xa = torch.randn(2, c0, hw, hw, generator=g)
+    xb = torch.randn(2, c1, hw, hw, generator=g) if c1 else None
+    # ---- float64 reference
+    q = {k: v.double().requires_grad_(True) for k, v in p.items() if k.startswith(pre0) or k.startswith(pre1)}
+    xa64 = xa.double().requires_grad_(True)
+    xb64 = xb.double().requires_grad_(True) if c1 else None
+    if kind == 'de_pu':
+        o = R.bottleneck_residual_de(q, pre0, torch.cat([xa64, xb64], 1))
+        o = R.bottleneck_residual_pu(q, pre1, o, False)
+    else:
+        o = R.bottleneck_residual_en(q, pre0, xa64, 2)
+        o = R.bottleneck_residual_pu(q, pre1, o, True)
+    gout = torch.randn(o.shape, generator=g)
+    names = list(q.keys())
+    inputs = [xa64] + ([xb64] if c1 else [])
+    grads = torch.autograd.grad((o * gout.double()).sum(), [q[k] for k in names] + inputs)
+    # ---- HIP
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    va = _Val(nhwc(xa))
+    srcs = (va, _Val(nhwc(xb))) if c1 else (va,)
+    gen._tape = []
+    if kind == 'de_pu':
+        o1 = gen._de('t', pre0, srcs, cout)
+    else:
+        o1 = gen._en('t', pre0, srcs, cout)
+    o2 = gen._pu('t', pre1, o1, act)
+    assert float((o2.t.cpu().permute(0, 3, 1, 2) - o.detach().float()).abs().max()) < 1e-4
+    gen._gdone = {}
+    slot, _ = gen._gslot(o2.t)
+    slot.copy_(nhwc(gout))
+    for rec in reversed(gen._tape):
+        gen._block_backward(rec, gen._gget(rec['out']))
+    worst = ('', 0.0)
+    for name, gr in zip(names, grads[:len(names)]):
+        a = store.grad(name).cpu().double()
+        e = float((a - gr).norm() / gr.norm())
+        worst = max(worst, (name, e), key=lambda kv: kv[1])
+    for src, gr in zip(srcs, grads[len(names):]):
+        a = gen._gget(src.t).cpu().double().permute(0, 3, 1, 2)
+        e = float((a - gr).norm() / gr.norm())
+        worst = max(worst, ('input', e), key=lambda kv: kv[1])
+    assert worst[1] < 1e-4, worst
+
+
+def test_residual_cli_train_smoke(tmp_path, monkeypatch):
+    import os
+    import obj_colorization_main as cli
+    monkeypatch.chdir(tmp_path)
+    cli.main(['--mode', 'train', '-bt', 'Residual', '-si', '1', '-bs', '2', '-mi', '3', '-smf', '2', '-swf', '1'])
+    run = os.path.join('outputs', sorted(os.listdir('outputs'))[0])
+    assert os.path.exists(os.path.join(run, 'snapshot', 'model_1.ckpt-1'))
