@@ -127,6 +127,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (reference --batch_size is per GPU)')
     ap.add_argument('--img', type=int, default=192)
+    ap.add_argument('--block-type', default='Pix2Pix', choices=['Pix2Pix', 'Residual'],
+                    help='train workload: Pix2Pix = the headline metric; Residual = secondary (108.8 GFLOP/img-iteration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-graphs', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
@@ -152,9 +154,9 @@ def main():
 
     from sketchyscenecolorization_amd import hip
     from sketchyscenecolorization_amd.synthetic import synthetic_batch
-    from sketchyscenecolorization_amd.trainer import Pix2PixTrainer
+    from sketchyscenecolorization_amd.trainer import GanTrainer
 
-    tr = Pix2PixTrainer(img=args.img, seed=0, process_group=pg, use_graphs=not args.no_graphs)
+    tr = GanTrainer(img=args.img, seed=0, process_group=pg, use_graphs=not args.no_graphs, block_type=args.block_type)
     bd = synthetic_batch(args.batch, 1234 + rank, args.img)
     bg = synthetic_batch(args.batch, 5678 + rank, args.img)
 
@@ -195,16 +197,17 @@ def main():
         global_batch = args.batch * world
         ms = dt / args.steps * 1e3
         value = global_batch * args.steps / dt
-        flops_step = (4 * F_G + 8 * F_D) * args.batch       # per GPU, as-written reference FLOPs
+        f_g, f_d = (F_G, F_D) if args.block_type == 'Pix2Pix' else (21.1e9, 3.05e9)
+        flops_step = (4 * f_g + 8 * f_d) * args.batch       # per GPU, as-written reference FLOPs
         out = {'metric': 'train images/sec (192x192, gen+disc fwd+bwd)', 'value': value, 'unit': 'images/sec',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32',
                'data': 'synthetic',
-               'config': {'workload': 'Foreground_Instance_Colorization Pix2Pix GAN train step '
+               'config': {'workload': 'Foreground_Instance_Colorization ' + args.block_type + ' GAN train step '
                                       '(D-step + G-step, TF-Adam), %dx%d, batch %d per GPU' % (args.img, args.img,
                                                                                              args.batch),
                           'global_batch': global_batch, 'parallelism': 'dp%d' % world,
-                          'block_type': 'Pix2Pix', 'loss_g': loss_g, 'loss_d': loss_d,
+                          'block_type': args.block_type, 'loss_g': loss_g, 'loss_d': loss_d,
                           'launch': 'eager' if args.no_graphs else 'hipGraph replay'},
                'step_tflops_as_written': flops_step / (ms * 1e-3) / 1e12,
                'step_frac_of_fp32_peak': flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
@@ -221,7 +224,7 @@ def main():
             ach = fl / sec / 1e12
             traffic = None      # HBM bytes per launch from the committed PMC passes (same command, --no-graphs)
             tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-            if os.path.exists(tpath) and args.batch == 32 and args.img == 192:
+            if os.path.exists(tpath) and args.batch == 32 and args.img == 192 and args.block_type == 'Pix2Pix':
                 with open(tpath) as f:
                     tk = json.load(f)['kernels'].get(name)
                 if tk:
@@ -239,7 +242,7 @@ def main():
                                'per_kernel': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / prof_steps * 1e3,
                                                   'launches_per_step': v[2] / prof_steps}
                                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.block_type == 'Pix2Pix':
             out['cpu_baseline'] = cpu_baseline(args.img)
         print(json.dumps(out))
     if world > 1:
