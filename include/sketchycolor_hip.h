@@ -28,6 +28,8 @@ extern "C" {
 #define SSC_ACT_RELU 1   /* tf.nn.relu                 models_collection.py:518,531 */
 #define SSC_ACT_LRELU 2  /* tf.maximum(0.2*x, x)       models_collection.py:51-53   */
 #define SSC_ACT_TANH 3   /* only for ssc_affine_act / ssc_residual_merge outputs, never on load */
+#define SSC_ACT_PRELU 5  /* tf.maximum(leak*x, x) with a trainable scalar leak (models_collection.py:56-60); ssc_concat_parts only,
+                            the part's `ab` pointer then addresses the leak */
 #define SSC_ACT_MIU 4    /* miu_relu (x + sqrt(0.09 + x^2))/2, models_collection.py:63-65; pointwise kernels only */
 
 /*
@@ -149,6 +151,38 @@ int ssc_mru_gate_merge(const float* ht, const float* rg, const float* mnmx, cons
                        int64_t P, int C, void* stream);
 /* out = hp*(1 - z) + miu(a2*h2+b2)*z, z = (zg - min)/(max - min), hp = ht_ab ? miu(a*ht+b) : ht, ht read at
  * (y/2, x/2) when ht_lowres      (mru.py:583-589) */
+/* ---- their backward passes ---- */
+/* out[c] (+)= sum_r x[r, c]: bias gradients */
+int ssc_colsum(const float* x, int ld, int64_t M, int C, float* out, int accumulate, float* workspace,
+               int64_t workspace_bytes, void* stream);
+/* dst[r, 0:C] (+)= src[r, 0:C] with independent row strides (splitting a concat gradient) */
+int ssc_strided_copy(const float* src, int lds, float* dst, int ldd, int64_t M, int C, int accumulate, void* stream);
+/* out (+)= scale * (sum of each 2x2 block): gradient of the nearest upsample (scale 1) / forward mean_pool (0.25) */
+int ssc_pool2(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int C, float scale, int accumulate,
+              void* stream);
+/* backward of y = act(cond_batchnorm(x)) (act = SSC_ACT_MIU or NONE): dx (+)= ..., table gradients
+ * dscale_m/doffset_m [n_labels, C] (may be NULL).  gy rows have stride ldg (a channel slice of a concat gradient). */
+int ssc_cbn_act_backward(const float* x, const float* abn, const float* stats, const float* scale_m,
+                         const int32_t* labels, int n_labels, const float* gy, int ldg, int act, int N, int P, int C,
+                         float* dx, int lddx, int accumulate_dx, float* dscale_m, float* doffset_m,
+                         int accumulate_params, float* workspace, int64_t workspace_bytes, void* stream);
+/* backward of prelu: dx (+)= gy * (leak*x >= x ? leak : 1) (dx may be NULL), dleak (+)= sum gy*x over that set */
+int ssc_prelu_backward(const float* x, int ldx, const float* leak, const float* gy, int ldg, int64_t M, int C, float* dx,
+                       int lddx, int accumulate_dx, float* dleak, int accumulate_leak, float* workspace,
+                       int64_t workspace_bytes, void* stream);
+/* backward of r = (g - min)/(max - min) with g = lrelu(pre) stored: dpre from gr = d loss / d r (TF tie rule) */
+int ssc_minmax_gate_backward(const float* g, const float* mnmx, const float* gr, int N, int P, int C, float* dpre,
+                             float* workspace, int64_t workspace_bytes, void* stream);
+/* ht_plus = ht + r*img: gr = g*img, gimg = g*r */
+int ssc_mru_gate_merge_backward(const float* ghtp, const float* rg, const float* mnmx, const float* img, float* gr,
+                                float* gimg, int N, int64_t P, int C, void* stream);
+/* out = hp*(1-z) + h*z: ghp = g*(1-z), gh = g*z, gz = g*(h - hp) (arguments as ssc_mru_blend) */
+int ssc_mru_blend_backward(const float* gout, const float* ht, const float* ht_ab, int ht_lowres, const float* h2,
+                           const float* h2_ab, const float* zg, const float* mnmx, float* ghp, float* gh, float* gz,
+                           int N, int H, int W, int C, void* stream);
+/* G[:, 0:C] = d loss / d (r * up(ht)): gr = G*up(ht); G[:, 0:C] <- G*r in place */
+int ssc_mru_in2_gate_backward(float* G, int ldG, const float* rg, const float* mnmx, const float* ht_low, float* gr,
+                              int N, int H, int W, int C, void* stream);
 int ssc_mru_blend(const float* ht, const float* ht_ab, int ht_lowres, const float* h2, const float* h2_ab,
                   const float* zg, const float* mnmx, float* out, int N, int H, int W, int C, void* stream);
 
@@ -228,6 +262,13 @@ int ssc_sn_forward(const float* W, const float* u, int m, int n, float* v, float
                    void* stream);
 int ssc_sn_backward(const float* W, const float* u, const float* v, const float* u_new, const float* aux,
                     const float* G, int m, int n, float* dW, int accumulate, float* scratch, void* stream);
+/* the same for weights of any size (every conv / FC weight of the MRU discriminator): multi-workgroup, two-stage
+ * fixed-order reductions.  forward workspace >= 64*n floats; backward workspace >= 1024+n floats, scratch m floats */
+int ssc_sn_forward_any(const float* W, const float* u, int m, int n, float* v, float* u_new, float* wbar, float* aux,
+                       float* workspace, int64_t workspace_bytes, void* stream);
+int ssc_sn_backward_any(const float* W, const float* u, const float* v, const float* u_new, const float* aux,
+                        const float* G, int m, int n, float* dW, int accumulate, float* scratch, float* workspace,
+                        int64_t workspace_bytes, void* stream);
 int ssc_axpy(float* y, const float* x, float a, int64_t n, void* stream);
 /* fully_connected with <= 64 outputs (class logits, models_collection.py:839): y = x W + b, and its gradients */
 int ssc_fc_small_fwd(const float* x, const float* W, const float* b, int N, int K, int J, float* y, void* stream);

@@ -77,14 +77,59 @@ def generator_shapes(vocab_size=58, img=192, size=SIZE):
     return s
 
 
-def init_params(seed=0, perturb=True, **kw):
+DISC_UNITS = [(1, 8, 128), (2, 128, 256), (3, 256, 512), (4, 512, 768)]          # discriminate_mru, :728-763
+
+
+def _sn_conv(s, pre, k, cin, cout, prelu=False):
+    s[pre + '/weights'] = (k, k, cin, cout)
+    s[pre + '/u'] = (1, cout)                   # sn.py:17-18, created right after the weights, non-trainable
+    s[pre + '/biases'] = (cout,)
+    if prelu:
+        s[pre + '/prelu/param'] = ()            # models_collection.py:56-60, scalar, init 0.2
+
+
+def discriminator_shapes(num_classes=N_LABELS):
+    """discriminate_mru (models_collection.py:676-786), Config.sn=True: every conv / FC weight is spectral-normed
+    (own ``u``), activation prelu (one trainable scalar per use), no norm."""
+    s = OrderedDict()
+    _sn_conv(s, 'discriminator/Conv', 7, 3, 8, prelu=True)
+    for u, ch, d in DISC_UNITS:
+        pre = 'discriminator/mru_conv_unit_t_%d_layer_0' % u
+        s[pre + '/norm_activation_in/prelu/param'] = ()
+        _sn_conv(s, pre + '/update_gate', 3, ch + 3, ch)
+        _sn_conv(s, pre + '/Conv', 3, 3, ch)
+        s[pre + '/norm_activation_merge_1/prelu/param'] = ()
+        _sn_conv(s, pre + '/Conv_1', 3, ch, d, prelu=True)
+        _sn_conv(s, pre + '/Conv_2', 3, d, d)
+        _sn_conv(s, pre + '/Conv_3', 1, ch, d)
+    s['discriminator/mru_conv_unit_last_norm/prelu/param'] = ()
+    _sn_conv(s, 'discriminator/Conv_1', 1, 768, 1)
+    s['discriminator/fully_connected/weights'] = (768, num_classes)
+    s['discriminator/fully_connected/u'] = (1, num_classes)
+    s['discriminator/fully_connected/biases'] = (num_classes,)
+    return s
+
+
+def init_params(seed=0, perturb=True, with_discriminator=False, **kw):
     """Reference initialisers (weights N(0,0.02); biases 0, update_gate 0.5; cond-norm offset 0 / scale 1; LSTM +
     noise FC glorot; embedding U(-0.08,0.08)).  perturb=True additionally jitters biases and the cond-norm tables
     (as training would) so that parity tests exercise the per-label rows and the bias adds."""
     g = torch.Generator().manual_seed(seed)
     p = OrderedDict()
-    for name, shp in generator_shapes(**kw).items():
+    shapes = generator_shapes(**kw)
+    if with_discriminator:
+        shapes.update(discriminator_shapes())
+    for name, shp in shapes.items():
         leaf = name.rsplit('/', 1)[1]
+        if leaf == 'u':             # sn.py:18 truncated normal
+            u = torch.randn(shp, generator=g)
+            while bool((u.abs() > 2).any()):
+                u = torch.where(u.abs() > 2, torch.randn(shp, generator=g), u)
+            p[name] = u
+            continue
+        if leaf == 'param':         # prelu leak
+            p[name] = torch.tensor(0.2) + (torch.randn((), generator=g) * 0.02 if perturb else 0.0)
+            continue
         if leaf == 'weights' and len(shp) == 4:
             p[name] = torch.randn(shp, generator=g) * 0.02
         elif leaf in ('weights', 'kernel'):
@@ -224,3 +269,100 @@ def generate_mru(p, z, text_vocab_indices, labels, noise_vec, lstm_hybrid=True, 
     if return_all:
         return out, {'enc': enc, 'feat': feat, 'noise': noise, 'dec': hts}
     return out
+
+
+# ---------------------------------------------------------------------------
+# discriminator (models_collection.py:676-786) and the training graph
+# ---------------------------------------------------------------------------
+def _prelu(p, scope, x):
+    """models_collection.py:56-60: tf.maximum(leak * x, x), trainable scalar leak."""
+    return torch.maximum(p[scope + '/prelu/param'] * x, x)
+
+
+def _sn_conv2d(p, pre, x, us, stride=1, act=None):
+    w, u_new = T.spectral_normed_weight(p[pre + '/weights'], p[pre + '/u'])
+    us[pre + '/u'] = u_new
+    y = T.conv2d_same(x, w, stride, p[pre + '/biases'])
+    return act(y) if act is not None else y
+
+
+def _d_conv_block(p, pre, inp, ht, d, us):
+    """mru_conv_block_v3 with sn=True, activation prelu, no normaliser."""
+    ch = ht.shape[1]
+    full_inp = torch.cat([_prelu(p, pre + '/norm_activation_in', ht), inp], 1)
+    rg = _minmax(_sn_conv2d(p, pre + '/update_gate', full_inp, us, act=_lrelu))
+    img_new = _sn_conv2d(p, pre + '/Conv', inp, us)
+    ht_new_in = _prelu(p, pre + '/norm_activation_merge_1', ht + rg * img_new)
+    h_new = _sn_conv2d(p, pre + '/Conv_1', ht_new_in, us, act=lambda t: _prelu(p, pre + '/Conv_1', t))
+    h_new = _sn_conv2d(p, pre + '/Conv_2', h_new, us)
+    ht_orig = _sn_conv2d(p, pre + '/Conv_3', ht, us) if ch != d else ht
+    return mean_pool(ht_orig + h_new)
+
+
+def discriminate_mru(p, discrim_inputs, discrim_targets, sn=True, return_u=False):
+    """The sketch (discrim_inputs) is ignored by the reference (:690-700 only pyramids discrim_targets)."""
+    assert sn
+    us = OrderedDict()
+    x_list = [discrim_targets]
+    for _ in range(5):
+        x_list.append(mean_pool(x_list[-1]))
+    x_list = x_list[::-1]
+    ht = _sn_conv2d(p, 'discriminator/Conv', x_list[-1], us, act=lambda t: _prelu(p, 'discriminator/Conv', t))
+    for (u, ch, d), xin in zip(DISC_UNITS, (x_list[-1], x_list[-2], x_list[-3], x_list[-4])):
+        ht = _d_conv_block(p, 'discriminator/mru_conv_unit_t_%d_layer_0' % u, xin, ht, d, us)
+    img = _prelu(p, 'discriminator/mru_conv_unit_last_norm', ht)
+    disc = _sn_conv2d(p, 'discriminator/Conv_1', img, us)
+    w, u_new = T.spectral_normed_weight(p['discriminator/fully_connected/weights'], p['discriminator/fully_connected/u'])
+    us['discriminator/fully_connected/u'] = u_new
+    logits = img.mean(dim=(2, 3)) @ w + p['discriminator/fully_connected/biases']
+    if return_u:
+        return disc, logits, us
+    return disc, logits
+
+
+def regularization_loss(p, scope):
+    """tf.losses.get_regularization_loss(scope): l2_regularizer(1e-5) on every conv weight of the MRU blocks
+    (mru.py:600, 664 -> :381, 545; the decoder's projection conv and the top-level convs have none), 1e-6 on
+    fully_connected weights (mru.py:55); scale * sum(w^2) / 2."""
+    tot = 0.0
+    for k, v in p.items():
+        if not k.startswith(scope + '/') or not k.endswith('/weights'):
+            continue
+        if '/fully_connected/' in k:
+            tot = tot + 1e-6 * (v * v).sum() / 2.0
+        elif '/mru_conv_unit_t_' in k or ('/mru_deconv_unit_t_' in k and not k.endswith('Conv_4/weights')):
+            tot = tot + 1e-5 * (v * v).sum() / 2.0
+    return tot
+
+
+def build_single_graph(p, images, sketches, images_d, class_id, class_id_d, text, noise_vec, lstm_hybrid=True):
+    """One MRU tower (graph_single.py:221-314, block_type='MRU'): both losses and both gradient sets."""
+    from .pix2pix import get_losses
+    q = OrderedDict((k, v.detach().clone().requires_grad_(not k.endswith('/u'))) for k, v in p.items())
+    gen = generate_mru(q, sketches, text, class_id, noise_vec, lstm_hybrid)
+    real_disc, real_logit, us = discriminate_mru(q, sketches, images_d, return_u=True)
+    fake_disc, fake_logit = discriminate_mru(q, sketches, gen)
+    loss_g, loss_d, parts = get_losses(q, images, gen, class_id, class_id_d, real_disc, fake_disc, real_logit,
+                                       fake_logit, reg=regularization_loss)
+    g_names = [k for k in q if k.startswith('generator/')]
+    d_names = [k for k in q if k.startswith('discriminator/') and not k.endswith('/u')]
+    grads_g = torch.autograd.grad(loss_g, [q[k] for k in g_names], retain_graph=True, allow_unused=True)
+    grads_d = torch.autograd.grad(loss_d, [q[k] for k in d_names], allow_unused=True)
+    z = lambda k, g: (g if g is not None else torch.zeros_like(q[k])).detach()
+    return {'loss_g': loss_g.detach(), 'loss_d': loss_d.detach(),
+            'grad_g': OrderedDict((k, z(k, g)) for k, g in zip(g_names, grads_g)),
+            'grad_d': OrderedDict((k, z(k, g)) for k, g in zip(d_names, grads_d)),
+            'gen': gen.detach(), 'u_new': OrderedDict((k, v.detach()) for k, v in us.items()),
+            'real_disc': real_disc.detach(), 'fake_disc': fake_disc.detach(),
+            'real_logit': real_logit.detach(), 'fake_logit': fake_logit.detach()}
+
+
+def build_single_graph_f64(p, **batch):
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        p64 = OrderedDict((k, v.double()) for k, v in p.items())
+        b64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+        return build_single_graph(p64, **b64)
+    finally:
+        torch.set_default_dtype(old)

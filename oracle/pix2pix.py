@@ -214,7 +214,9 @@ def regularization_loss(p, scope):
     return 1e-6 * (w * w).sum() / 2.0
 
 
-def get_losses(p, images, image_gens, class_id, class_id_d, real_disc, fake_disc, real_logit, fake_logit):
+def get_losses(p, images, image_gens, class_id, class_id_d, real_disc, fake_disc, real_logit, fake_logit,
+               reg=None):
+    reg = reg or regularization_loss
     loss_g_gan = T.softplus(-fake_disc).mean()
     loss_d_gan = T.softplus(fake_disc).mean() + T.softplus(-real_disc).mean()
     ce_real = T.sparse_softmax_ce(real_logit, class_id_d)
@@ -223,8 +225,8 @@ def get_losses(p, images, image_gens, class_id, class_id_d, real_disc, fake_disc
     loss_ac_g = 0.5 * T.sparse_softmax_ce(fake_logit, class_id).mean()
     a = (images - image_gens).abs()
     smooth = torch.where(a < 1.0, 0.5 * a ** 2, a - 0.5).mean()
-    loss_g = loss_g_gan + loss_ac_g + 100.0 * smooth + regularization_loss(p, 'generator')
-    loss_d = loss_d_gan + loss_ac_d + regularization_loss(p, 'discriminator')
+    loss_g = loss_g_gan + loss_ac_g + 100.0 * smooth + reg(p, 'generator')
+    loss_d = loss_d_gan + loss_ac_d + reg(p, 'discriminator')
     parts = {'GAN_loss_g': loss_g_gan, 'GAN_loss_d': loss_d_gan, 'ACGAN_loss_g': loss_ac_g,
              'ACGAN_loss_d': loss_ac_d, 'l1_perceptual_loss': smooth}
     return loss_g, loss_d, parts

@@ -315,6 +315,172 @@ extern "C" int ssc_sn_backward(const float* W, const float* u, const float* v, c
     return CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------ spectral norm for weights of any size
+// (every conv / FC weight of the MRU discriminator, mru.py:123, 68; sn.py:12-52).  Same math as the single-block
+// kernels above, split into row-dot / column-dot / scalar stages so a [6912, 768] filter uses the whole chip.
+// All reductions are two-stage with a fixed order (reproducible).
+__global__ void sn_rowdot_kernel(const float* __restrict__ W, const float* __restrict__ x, int m, int n,
+                                 float* __restrict__ out) {         // out[i] = sum_j x[j] W[i][j], one wavefront per row
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    float acc = 0.f;
+    for (int j = lane; j < n; j += 64) acc += x[j] * W[(long)row * n + j];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) out[row] = acc;
+}
+
+__global__ void sn_coldot_partial_kernel(const float* __restrict__ W, const float* __restrict__ v, int m, int n,
+                                         int nsplit, float* __restrict__ part) {   // part[s][j] = sum_{i in s} v[i] W[i][j]
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane, s = blockIdx.y;
+    const int rows = (m + nsplit - 1) / nsplit;
+    const int r0 = s * rows, r1 = min(m, r0 + rows);
+    float acc = 0.f;
+    if (j < n)
+        for (int i = r0 + rl; i < r1; i += 4) acc += v[i] * W[(long)i * n + j];
+    sh[rl][lane] = acc;
+    __syncthreads();
+    if (rl == 0 && j < n) part[(long)s * n + j] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void sn_normalize_v_kernel(float* __restrict__ v, int m, float* __restrict__ aux) {
+    __shared__ float sh[4];
+    __shared__ float sc;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < m; i += 256) ss += v[i] * v[i];
+    const float t = block_sum_256(ss, sh);
+    if (threadIdx.x == 0) { sc = sqrtf(t); aux[1] = sc; }
+    __syncthreads();
+    const float inv = 1.f / (sc + 1e-12f);
+    for (int i = threadIdx.x; i < m; i += 256) v[i] *= inv;
+}
+
+__global__ __launch_bounds__(256) void sn_finish_u_kernel(const float* __restrict__ part, int nsplit, int n,
+                                                          float* __restrict__ u_new, float* __restrict__ aux) {
+    __shared__ float sh[4];
+    __shared__ float sc;
+    float ss = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        float b = 0.f;
+        for (int s = 0; s < nsplit; ++s) b += part[(long)s * n + j];
+        u_new[j] = b;
+        ss += b * b;
+    }
+    const float t = block_sum_256(ss, sh);
+    if (threadIdx.x == 0) {
+        const float rb = sqrtf(t);
+        sc = rb;
+        aux[2] = rb;
+        aux[0] = t / (rb + 1e-12f);      // sigma = b . (b/(|b|+eps))
+    }
+    __syncthreads();
+    const float inv = 1.f / (sc + 1e-12f);
+    for (int j = threadIdx.x; j < n; j += 256) u_new[j] *= inv;
+}
+
+__global__ void sn_scale_kernel(const float* __restrict__ W, const float* __restrict__ aux, long count,
+                                float* __restrict__ wbar) {
+    const float sigma = aux[0];
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) wbar[i] = W[i] / sigma;
+}
+
+extern "C" int ssc_sn_forward_any(const float* W, const float* u, int m, int n, float* v, float* u_new, float* wbar,
+                                  float* aux, float* workspace, int64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int nsplit = (m + 127) / 128;
+    if (nsplit > 64) nsplit = 64;
+    if ((int64_t)nsplit * n * 4 > workspace_bytes) return -2;
+    hipLaunchKernelGGL(sn_rowdot_kernel, dim3((m + 3) / 4), dim3(256), 0, st, W, u, m, n, v);
+    hipLaunchKernelGGL(sn_normalize_v_kernel, dim3(1), dim3(256), 0, st, v, m, aux);
+    hipLaunchKernelGGL(sn_coldot_partial_kernel, dim3((n + 63) / 64, nsplit), dim3(256), 0, st, W, v, m, n, nsplit,
+                       workspace);
+    hipLaunchKernelGGL(sn_finish_u_kernel, dim3(1), dim3(256), 0, st, workspace, nsplit, n, u_new, aux);
+    long blocks = ((long)m * n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sn_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, st, W, aux, (long)m * n, wbar);
+    return CHECK_LAUNCH();
+}
+
+__global__ void sn_dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long count,
+                                      float* __restrict__ part) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) acc += a[i] * b[i];
+    const float t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// gb[j] = dsig * dsds * b_j / rb with dsig = -<G,W>/sigma^2
+__global__ __launch_bounds__(256) void sn_gb_kernel(const float* __restrict__ part, int nparts,
+                                                    const float* __restrict__ u_new, const float* __restrict__ aux,
+                                                    int n, float* __restrict__ gb) {
+    __shared__ float sh[4];
+    __shared__ float sc;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+    const float gw = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) sc = gw;
+    __syncthreads();
+    const float sigma = aux[0], rb = aux[2], eps = 1e-12f;
+    const float dsig = -sc / (sigma * sigma);
+    const float dsds = (rb * rb + 2.f * rb * eps) / ((rb + eps) * (rb + eps));
+    for (int j = threadIdx.x; j < n; j += 256) gb[j] = dsig * dsds * (u_new[j] * (rb + eps)) / rb;
+}
+
+// scratch[i] = gv[i] on entry; ga[i] on exit
+__global__ __launch_bounds__(256) void sn_ga_kernel(float* __restrict__ scratch, const float* __restrict__ v,
+                                                    const float* __restrict__ aux, int m) {
+    __shared__ float sh[4];
+    __shared__ float sc;
+    const float ra = aux[1], eps = 1e-12f;
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < m; i += 256) dot += scratch[i] * v[i] * (ra + eps);
+    const float t = block_sum_256(dot, sh);
+    if (threadIdx.x == 0) sc = t;
+    __syncthreads();
+    const float gvdot = sc;
+    for (int i = threadIdx.x; i < m; i += 256) {
+        const float ai = v[i] * (ra + eps);
+        scratch[i] = scratch[i] / (ra + eps) - gvdot * ai / (ra * (ra + eps) * (ra + eps));
+    }
+}
+
+__global__ void sn_dw_kernel(const float* __restrict__ G, const float* __restrict__ v, const float* __restrict__ gb,
+                             const float* __restrict__ ga, const float* __restrict__ u, const float* __restrict__ aux,
+                             int m, int n, float* __restrict__ dW, int accumulate) {
+    const float sigma = aux[0];
+    const long count = (long)m * n, stride = (long)gridDim.x * blockDim.x;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const int i = (int)(k / n), j = (int)(k - (long)i * n);
+        float d = G[k] / sigma + v[i] * gb[j] + ga[i] * u[j];
+        if (accumulate) d += dW[k];
+        dW[k] = d;
+    }
+}
+
+// dW (+)= G/sigma + v^T gb + ga^T u; workspace >= (1024 + n) floats, scratch m floats
+extern "C" int ssc_sn_backward_any(const float* W, const float* u, const float* v, const float* u_new, const float* aux,
+                                   const float* G, int m, int n, float* dW, int accumulate, float* scratch,
+                                   float* workspace, int64_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int nparts = 1024;
+    if ((int64_t)(nparts + n) * 4 > workspace_bytes) return -2;
+    float* part = workspace;
+    float* gb = workspace + nparts;
+    hipLaunchKernelGGL(sn_dot_partial_kernel, dim3(nparts), dim3(256), 0, st, G, W, (long)m * n, part);
+    hipLaunchKernelGGL(sn_gb_kernel, dim3(1), dim3(256), 0, st, part, nparts, u_new, aux, n, gb);
+    hipLaunchKernelGGL(sn_rowdot_kernel, dim3((m + 3) / 4), dim3(256), 0, st, W, gb, m, n, scratch);
+    hipLaunchKernelGGL(sn_ga_kernel, dim3(1), dim3(256), 0, st, scratch, v, aux, m);
+    long blocks = ((long)m * n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sn_dw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, v, gb, scratch, u, aux, m, n, dW,
+                       accumulate);
+    return CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ flat-buffer helpers
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -149,11 +149,15 @@ __global__ void concat_parts_kernel(ssc_cat_desc d) {
             srow = ((long)n * (d.H / 2) + (y >> 1)) * (d.W / 2) + (x >> 1);
         }
         float v = q.x[srow * q.ld + c];
-        if (q.ab != nullptr) {
-            const float* ab = q.ab + (long)n * q.ab_sample_stride;
-            v = fmaf(ab[c], v, ab[q.C + c]);
+        if (q.act == SSC_ACT_PRELU) {
+            v = fmaxf(q.ab[0] * v, v);       // q.ab points at the scalar leak
+        } else {
+            if (q.ab != nullptr) {
+                const float* ab = q.ab + (long)n * q.ab_sample_stride;
+                v = fmaf(ab[c], v, ab[q.C + c]);
+            }
+            v = mru_act(v, q.act);
         }
-        v = mru_act(v, q.act);
         if (q.gate != nullptr) {
             const float mn = q.mnmx[(long)n * 2 * q.C + c], mx = q.mnmx[(long)n * 2 * q.C + q.C + c];
             v *= (q.gate[row * q.C + c] - mn) / (mx - mn);
@@ -228,5 +232,451 @@ extern "C" int ssc_mru_blend(const float* ht, const float* ht_ab, int ht_lowres,
                              const float* zg, const float* mnmx, float* out, int N, int H, int W, int C, void* stream) {
     hipLaunchKernelGGL(mru_blend_kernel, dim3(grid_for((long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, ht,
                        ht_ab, ht_lowres, h2, h2_ab, zg, mnmx, out, N, H, W, C);
+    return CHECK_LAUNCH();
+}
+
+// =====================================================================================================
+// backward kernels of the MRU blocks
+// =====================================================================================================
+__device__ __forceinline__ float mru_act_grad(float z, int act) {
+    switch (act) {
+        case SSC_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case SSC_ACT_LRELU: return z > 0.f ? 1.f : 0.2f;
+        case SSC_ACT_MIU: return 0.5f * (1.f + z * rsqrtf(0.09f + z * z));
+        default: return 1.f;
+    }
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+__global__ void colsum_partial_kernel(const float* __restrict__ x, int ld, long M, int C, int nsplit,
+                                      float* __restrict__ part) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, s = blockIdx.y;
+    const long rows = (M + nsplit - 1) / nsplit;
+    const long r0 = s * rows, r1 = min(M, r0 + rows);
+    float acc = 0.f;
+    if (c < C)
+        for (long r = r0 + rl; r < r1; r += 4) acc += x[r * ld + c];
+    sh[rl][lane] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) part[(long)s * C + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out,
+                                    int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) acc += part[(long)s * C + c];
+    out[c] = accumulate ? out[c] + acc : acc;
+}
+
+extern "C" int ssc_colsum(const float* x, int ld, int64_t M, int C, float* out, int accumulate, float* workspace,
+                          int64_t workspace_bytes, void* stream) {
+    int nsplit = (int)((M + 511) / 512);
+    if (nsplit > 256) nsplit = 256;
+    if (nsplit < 1) nsplit = 1;
+    if ((int64_t)nsplit * C * 4 > workspace_bytes) return -2;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nsplit), dim3(256), 0, (hipStream_t)stream, x, ld,
+                       (long)M, C, nsplit, workspace);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, nsplit,
+                       C, out, accumulate);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ strided copy / add, 2x2 pooling with scale
+__global__ void strided_copy_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, long M,
+                                    int C, int accumulate) {
+    const long tot = M * C, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        const float v = src[r * lds + c];
+        float* o = dst + r * ldd + c;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+extern "C" int ssc_strided_copy(const float* src, int lds, float* dst, int ldd, int64_t M, int C, int accumulate,
+                                void* stream) {
+    hipLaunchKernelGGL(strided_copy_kernel, dim3(grid_for((long)M * C)), dim3(256), 0, (hipStream_t)stream, src, lds,
+                       dst, ldd, (long)M, C, accumulate);
+    return CHECK_LAUNCH();
+}
+
+__global__ void pool2_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int ldo, int N, int H, int W,
+                             int C, float scale, int accumulate) {
+    const int oh = H / 2, ow = W / 2;
+    const long tot = (long)N * oh * ow * C, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int xo = (int)(r % ow);
+        r /= ow;
+        const int yo = (int)(r % oh);
+        const int n = (int)(r / oh);
+        const float* p = x + (((long)n * H + 2 * yo) * W + 2 * xo) * ldx + c;
+        const float v = (((p[0] + p[(long)W * ldx]) + p[ldx]) + p[(long)W * ldx + ldx]) * scale;
+        float* o = out + (((long)n * oh + yo) * ow + xo) * ldo + c;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+extern "C" int ssc_pool2(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int C, float scale,
+                         int accumulate, void* stream) {
+    if ((H | W) & 1) return -1;
+    hipLaunchKernelGGL(pool2_kernel, dim3(grid_for((long)N * (H / 2) * (W / 2) * C)), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, out, ldo, N, H, W, C, scale, accumulate);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ conditional norm + activation backward
+// y = act(a[n,c]*x + b[n,c]),  a = scale[l_n,c]*rstd[c],  xhat = (x - mean)*rstd
+// pass 1: S1[n,c] = sum_p gz, S2[n,c] = sum_p gz*xhat  (gz = gy*act'(z));   pass 2: tables + k1,k2;   pass 3: dx
+__global__ void cbn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ abn,
+                                       const float* __restrict__ stats, const float* __restrict__ gy, int ldg, int act,
+                                       int P, int C, int nsplit, float* __restrict__ part) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, s = blockIdx.y, n = blockIdx.z;
+    const int rows = (P + nsplit - 1) / nsplit;
+    const int r0 = s * rows, r1 = min(P, r0 + rows);
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C) {
+        const float a = abn[(long)n * 2 * C + c], b = abn[(long)n * 2 * C + C + c];
+        const float mean = stats[c], rstd = stats[C + c];
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const long row = (long)n * P + r;
+            const float xv = x[row * C + c];
+            const float gz = gy[row * ldg + c] * mru_act_grad(fmaf(a, xv, b), act);
+            a1 += gz;
+            a2 += gz * (xv - mean) * rstd;
+        }
+    }
+    s1[rl][lane] = a1;
+    s2[rl][lane] = a2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float* o = part + (((long)n * nsplit + s) * 2) * C + c;
+        o[0] = (s1[0][lane] + s1[1][lane]) + (s1[2][lane] + s1[3][lane]);
+        o[C] = (s2[0][lane] + s2[1][lane]) + (s2[2][lane] + s2[3][lane]);
+    }
+}
+
+// folds the splits -> sn[n][2][C]
+__global__ void cbn_bwd_fold_kernel(const float* __restrict__ part, int nsplit, int N, int C, float* __restrict__ sn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    float a1 = 0.f, a2 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* p = part + (((long)n * nsplit + s) * 2) * C + c;
+        a1 += p[0];
+        a2 += p[C];
+    }
+    sn[(long)n * 2 * C + c] = a1;
+    sn[(long)n * 2 * C + C + c] = a2;
+}
+
+// thread (l, c): table gradients; thread (L, c): k1, k2
+__global__ void cbn_bwd_final_kernel(const float* __restrict__ sn, const float* __restrict__ scale_m,
+                                     const int* __restrict__ labels, int N, int C, int L, float inv_m,
+                                     float* __restrict__ dscale_m, float* __restrict__ doffset_m, int accumulate,
+                                     float* __restrict__ kk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (L + 1) * C) return;
+    const int l = i / C, c = i - l * C;
+    if (l < L) {
+        float ds = 0.f, dof = 0.f;
+        for (int n = 0; n < N; ++n)
+            if (labels[n] == l) {
+                dof += sn[(long)n * 2 * C + c];
+                ds += sn[(long)n * 2 * C + C + c];
+            }
+        if (dscale_m != nullptr) {
+            dscale_m[(long)l * C + c] = accumulate ? dscale_m[(long)l * C + c] + ds : ds;
+            doffset_m[(long)l * C + c] = accumulate ? doffset_m[(long)l * C + c] + dof : dof;
+        }
+    } else {
+        float k1 = 0.f, k2 = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float sc = scale_m[(long)labels[n] * C + c];
+            k1 += sc * sn[(long)n * 2 * C + c];
+            k2 += sc * sn[(long)n * 2 * C + C + c];
+        }
+        kk[c] = k1 * inv_m;
+        kk[C + c] = k2 * inv_m;
+    }
+}
+
+__global__ void cbn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ abn,
+                                     const float* __restrict__ stats, const float* __restrict__ kk,
+                                     const float* __restrict__ gy, int ldg, int act, int N, long P, int C,
+                                     float* __restrict__ dx, int lddx, int accumulate) {
+    const long tot = (long)N * P * C, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const int c = (int)(i % C);
+        const long row = i / C;
+        const int n = (int)(row / P);
+        const float a = abn[(long)n * 2 * C + c], b = abn[(long)n * 2 * C + C + c];
+        const float xv = x[i];
+        const float gz = gy[row * ldg + c] * mru_act_grad(fmaf(a, xv, b), act);
+        const float mean = stats[c], rstd = stats[C + c];
+        const float v = gz * a - rstd * (kk[c] + (xv - mean) * rstd * kk[C + c]);
+        float* o = dx + row * lddx + c;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+extern "C" int ssc_cbn_act_backward(const float* x, const float* abn, const float* stats, const float* scale_m,
+                                    const int32_t* labels, int n_labels, const float* gy, int ldg, int act, int N,
+                                    int P, int C, float* dx, int lddx, int accumulate_dx, float* dscale_m,
+                                    float* doffset_m, int accumulate_params, float* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+    int nsplit = (P + 255) / 256;
+    if (nsplit > 64) nsplit = 64;
+    const int64_t need = ((int64_t)N * nsplit * 2 * C + (int64_t)N * 2 * C + 2 * C) * 4;
+    if (need > workspace_bytes) return -2;
+    float* part = workspace;
+    float* sn = part + (long)N * nsplit * 2 * C;
+    float* kk = sn + (long)N * 2 * C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cbn_bwd_partial_kernel, dim3((C + 63) / 64, nsplit, N), dim3(256), 0, st, x, abn, stats, gy, ldg,
+                       act, P, C, nsplit, part);
+    hipLaunchKernelGGL(cbn_bwd_fold_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, part, nsplit, N, C, sn);
+    hipLaunchKernelGGL(cbn_bwd_final_kernel, dim3(((n_labels + 1) * C + 255) / 256), dim3(256), 0, st, sn, scale_m,
+                       labels, N, C, n_labels, 1.f / ((float)N * (float)P), dscale_m, doffset_m, accumulate_params, kk);
+    hipLaunchKernelGGL(cbn_bwd_apply_kernel, dim3(grid_for((long)N * P * C)), dim3(256), 0, st, x, abn, stats, kk, gy, ldg,
+                       act, N, (long)P, C, dx, lddx, accumulate_dx);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ prelu backward (models_collection.py:56-60)
+// y = max(leak*x, x): the first argument takes the gradient where leak*x >= x (tf.maximum's tie rule)
+__global__ void prelu_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ leak_p,
+                                 const float* __restrict__ gy, int ldg, long M, int C, float* __restrict__ dx, int lddx,
+                                 int accumulate, float* __restrict__ part) {
+    __shared__ float sh[256];
+    const float leak = *leak_p;
+    const long tot = M * C, stride = (long)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        const float xv = x[r * ldx + c], g = gy[r * ldg + c];
+        const bool first = leak * xv >= xv;
+        if (first) acc += g * xv;
+        if (dx != nullptr) {
+            const float v = g * (first ? leak : 1.f);
+            float* o = dx + r * lddx + c;
+            *o = accumulate ? *o + v : v;
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+__global__ void scalar_fold_kernel(const float* __restrict__ part, int n, float* __restrict__ out, int accumulate) {
+    __shared__ float sh[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = accumulate ? *out + sh[0] : sh[0];
+}
+
+extern "C" int ssc_prelu_backward(const float* x, int ldx, const float* leak, const float* gy, int ldg, int64_t M, int C,
+                                  float* dx, int lddx, int accumulate_dx, float* dleak, int accumulate_leak,
+                                  float* workspace, int64_t workspace_bytes, void* stream) {
+    long blocks = ((long)M * C + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    if (blocks * 4 > workspace_bytes) return -2;
+    hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, leak, gy, ldg,
+                       (long)M, C, dx, lddx, accumulate_dx, workspace);
+    hipLaunchKernelGGL(scalar_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, (int)blocks, dleak,
+                       accumulate_leak);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ min-max gate backward (mru.py:414-415, 560-568)
+// r = (g - mn)/(mx - mn), g = lrelu(pre) stored;  given gr: dpre.  reduce_min / reduce_max send their gradient to
+// every position that attains the extremum, divided by the number of ties (TF's _MinOrMaxGrad).
+__global__ void gate_bwd_partial_kernel(const float* __restrict__ g, const float* __restrict__ mnmx,
+                                        const float* __restrict__ gr, int P, int C, int nsplit,
+                                        float* __restrict__ part) {
+    __shared__ float sh[4][4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, s = blockIdx.y, n = blockIdx.z;
+    const int rows = (P + nsplit - 1) / nsplit;
+    const int r0 = s * rows, r1 = min(P, r0 + rows);
+    float A = 0.f, B = 0.f, cmn = 0.f, cmx = 0.f;
+    if (c < C) {
+        const float mn = mnmx[(long)n * 2 * C + c], mx = mnmx[(long)n * 2 * C + C + c];
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const long i = ((long)n * P + r) * C + c;
+            const float gv = g[i], q = gr[i];
+            A += q * (gv - mx);
+            B += q * (gv - mn);
+            cmn += (gv == mn) ? 1.f : 0.f;
+            cmx += (gv == mx) ? 1.f : 0.f;
+        }
+    }
+    sh[0][rl][lane] = A; sh[1][rl][lane] = B; sh[2][rl][lane] = cmn; sh[3][rl][lane] = cmx;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float* o = part + (((long)n * nsplit + s) * 4) * C + c;
+        for (int k = 0; k < 4; ++k) o[(long)k * C] = (sh[k][0][lane] + sh[k][1][lane]) + (sh[k][2][lane] + sh[k][3][lane]);
+    }
+}
+
+__global__ void gate_bwd_fold_kernel(const float* __restrict__ part, const float* __restrict__ mnmx, int nsplit, int N,
+                                     int C, float* __restrict__ coef) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    float A = 0.f, B = 0.f, cmn = 0.f, cmx = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* p = part + (((long)n * nsplit + s) * 4) * C + c;
+        A += p[0]; B += p[C]; cmn += p[2 * (long)C]; cmx += p[3 * (long)C];
+    }
+    const float d = mnmx[(long)n * 2 * C + C + c] - mnmx[(long)n * 2 * C + c];
+    coef[(long)n * 2 * C + c] = A / (d * d) / cmn;          // d loss / d min, per tied position
+    coef[(long)n * 2 * C + C + c] = -B / (d * d) / cmx;     // d loss / d max
+}
+
+__global__ void gate_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ mnmx,
+                                      const float* __restrict__ coef, const float* __restrict__ gr, int N, long P, int C,
+                                      float* __restrict__ dpre) {
+    const long tot = (long)N * P * C, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / (P * C));
+        const float mn = mnmx[(long)n * 2 * C + c], mx = mnmx[(long)n * 2 * C + C + c];
+        const float gv = g[i];
+        float dg = gr[i] / (mx - mn);
+        if (gv == mn) dg += coef[(long)n * 2 * C + c];
+        if (gv == mx) dg += coef[(long)n * 2 * C + C + c];
+        dpre[i] = dg * (gv > 0.f ? 1.f : 0.2f);
+    }
+}
+
+extern "C" int ssc_minmax_gate_backward(const float* g, const float* mnmx, const float* gr, int N, int P, int C,
+                                        float* dpre, float* workspace, int64_t workspace_bytes, void* stream) {
+    int nsplit = (P + 255) / 256;
+    if (nsplit > 64) nsplit = 64;
+    const int64_t need = ((int64_t)N * nsplit * 4 * C + (int64_t)N * 2 * C) * 4;
+    if (need > workspace_bytes) return -2;
+    float* part = workspace;
+    float* coef = part + (long)N * nsplit * 4 * C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gate_bwd_partial_kernel, dim3((C + 63) / 64, nsplit, N), dim3(256), 0, st, g, mnmx, gr, P, C, nsplit,
+                       part);
+    hipLaunchKernelGGL(gate_bwd_fold_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, part, mnmx, nsplit, N, C, coef);
+    hipLaunchKernelGGL(gate_bwd_apply_kernel, dim3(grid_for((long)N * P * C)), dim3(256), 0, st, g, mnmx, coef, gr, N,
+                       (long)P, C, dpre);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ ht_plus = ht + r*img backward: gr = g*img, g_img = g*r
+__global__ void gate_merge_bwd_kernel(const float* __restrict__ ghtp, const float* __restrict__ rg,
+                                      const float* __restrict__ mnmx, const float* __restrict__ img,
+                                      float* __restrict__ gr, float* __restrict__ gimg, int N, long P, int C) {
+    const long tot = (long)N * P * C, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / (P * C));
+        const float mn = mnmx[(long)n * 2 * C + c], mx = mnmx[(long)n * 2 * C + C + c];
+        const float q = ghtp[i];
+        gr[i] = q * img[i];
+        gimg[i] = q * ((rg[i] - mn) / (mx - mn));
+    }
+}
+
+extern "C" int ssc_mru_gate_merge_backward(const float* ghtp, const float* rg, const float* mnmx, const float* img,
+                                           float* gr, float* gimg, int N, int64_t P, int C, void* stream) {
+    hipLaunchKernelGGL(gate_merge_bwd_kernel, dim3(grid_for((long)N * P * C)), dim3(256), 0, (hipStream_t)stream, ghtp,
+                       rg, mnmx, img, gr, gimg, N, (long)P, C);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ blend backward: out = hp*(1-z) + h*z
+// ghp = gout*(1-z) (full resolution), gh = gout*z (w.r.t. miu(a2*h2+b2)), gz = gout*(h - hp) (w.r.t. the normalised gate)
+__global__ void blend_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ ht,
+                                 const float* __restrict__ ht_ab, int ht_lowres, const float* __restrict__ h2,
+                                 const float* __restrict__ h2_ab, const float* __restrict__ zg,
+                                 const float* __restrict__ mnmx, float* __restrict__ ghp, float* __restrict__ gh,
+                                 float* __restrict__ gz, int N, int H, int W, int C) {
+    const long P = (long)H * W;
+    const long tot = (long)N * P * C, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const int c = (int)(i % C);
+        const long row = i / C;
+        const int n = (int)(row / P);
+        long srow = row;
+        if (ht_lowres) {
+            const int pix = (int)(row - (long)n * P);
+            const int y = pix / W, x = pix - y * W;
+            srow = ((long)n * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1);
+        }
+        float hp = ht[srow * C + c];
+        if (ht_ab != nullptr) {
+            const float* ab = ht_ab + (long)n * 2 * C;
+            hp = mru_act(fmaf(ab[c], hp, ab[C + c]), SSC_ACT_MIU);
+        }
+        const float* ab2 = h2_ab + (long)n * 2 * C;
+        const float h = mru_act(fmaf(ab2[c], h2[i], ab2[C + c]), SSC_ACT_MIU);
+        const float mn = mnmx[(long)n * 2 * C + c], mx = mnmx[(long)n * 2 * C + C + c];
+        const float z = (zg[i] - mn) / (mx - mn);
+        const float q = gout[i];
+        ghp[i] = q * (1.f - z);
+        gh[i] = q * z;
+        gz[i] = q * (h - hp);
+    }
+}
+
+extern "C" int ssc_mru_blend_backward(const float* gout, const float* ht, const float* ht_ab, int ht_lowres,
+                                      const float* h2, const float* h2_ab, const float* zg, const float* mnmx,
+                                      float* ghp, float* gh, float* gz, int N, int H, int W, int C, void* stream) {
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid_for((long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, gout,
+                       ht, ht_ab, ht_lowres, h2, h2_ab, zg, mnmx, ghp, gh, gz, N, H, W, C);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ [rg*up(ht) | ...] backward
+// G[:, 0:C] holds d loss / d (r * up(ht)):  gr = G * up(ht);  G[:, 0:C] <- G * r   (in place)
+__global__ void in2_gate_bwd_kernel(float* __restrict__ G, int ldG, const float* __restrict__ rg,
+                                    const float* __restrict__ mnmx, const float* __restrict__ ht_low,
+                                    float* __restrict__ gr, int N, int H, int W, int C) {
+    const long P = (long)H * W;
+    const long tot = (long)N * P * C, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const int c = (int)(i % C);
+        const long row = i / C;
+        const int n = (int)(row / P);
+        const int pix = (int)(row - (long)n * P);
+        const int y = pix / W, x = pix - y * W;
+        const long srow = ((long)n * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1);
+        const float mn = mnmx[(long)n * 2 * C + c], mx = mnmx[(long)n * 2 * C + C + c];
+        const float q = G[row * ldG + c];
+        gr[i] = q * ht_low[srow * C + c];
+        G[row * ldG + c] = q * ((rg[i] - mn) / (mx - mn));
+    }
+}
+
+extern "C" int ssc_mru_in2_gate_backward(float* G, int ldG, const float* rg, const float* mnmx, const float* ht_low,
+                                         float* gr, int N, int H, int W, int C, void* stream) {
+    hipLaunchKernelGGL(in2_gate_bwd_kernel, dim3(grid_for((long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, G,
+                       ldG, rg, mnmx, ht_low, gr, N, H, W, C);
     return CHECK_LAUNCH();
 }

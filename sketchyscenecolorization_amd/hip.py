@@ -12,6 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSC_LIB_PATH') or os.path.join(_HERE, 'lib', 'libsketchycolor_hip.so')
 
+ACT_PRELU = 5       # concat_parts only: the part's ab is the scalar leak
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_MIU = 0, 1, 2, 3, 4     # TANH / MIU: pointwise kernels only, never on load
 
 
@@ -97,11 +98,22 @@ SIGNATURES = {
     'ssc_sn_forward': [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     'ssc_sn_backward': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P],
     'ssc_axpy': [_P, _P, _F, _L, _P],
+    'ssc_sn_forward_any': [_P, _P, _I, _I, _P, _P, _P, _P, _P, _L, _P],
+    'ssc_sn_backward_any': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _L, _P],
     'ssc_mean_pool2': [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     'ssc_cbn_fold': [_P, _P, _P, _P, _I, _I, _P, _P],
     'ssc_minmax_hw': [_P, _I, _I, _I, _I, _P, _P, _L, _P],
     'ssc_concat_parts': [_P, _P],
     'ssc_mru_gate_merge': [_P, _P, _P, _P, _P, _I, _L, _I, _P],
+    'ssc_colsum': [_P, _I, _L, _I, _P, _I, _P, _L, _P],
+    'ssc_strided_copy': [_P, _I, _P, _I, _L, _I, _I, _P],
+    'ssc_pool2': [_P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    'ssc_cbn_act_backward': [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _L, _P],
+    'ssc_prelu_backward': [_P, _I, _P, _P, _I, _L, _I, _P, _I, _I, _P, _I, _P, _L, _P],
+    'ssc_minmax_gate_backward': [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P],
+    'ssc_mru_gate_merge_backward': [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P],
+    'ssc_mru_blend_backward': [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'ssc_mru_in2_gate_backward': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'ssc_mru_blend': [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'ssc_fc_small_fwd': [_P, _P, _P, _I, _I, _I, _P, _P],
     'ssc_fc_small_bwd': [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],

@@ -35,13 +35,9 @@ def get_trainer(block_type='Pix2Pix', vocab_size=58, img=192, seed=0, **kw):
         raise NotImplementedError('block_type %r' % block_type)
     key = (block_type, vocab_size, img)
     if key not in _REGISTRY:
-        if block_type in ('Pix2Pix', 'Residual'):
-            from ..trainer import GanTrainer
-            _REGISTRY[key] = GanTrainer(img=img, vocab_size=vocab_size, seed=seed, sn=Config.sn,
-                                        block_type=block_type, **kw)
-        else:
-            from ..mru import MRUTower
-            _REGISTRY[key] = MRUTower(img=img, vocab_size=vocab_size, seed=seed)
+        from ..trainer import GanTrainer
+        _REGISTRY[key] = GanTrainer(img=img, vocab_size=vocab_size, seed=seed, sn=Config.sn, block_type=block_type,
+                                    **kw)
     return _REGISTRY[key]
 
 
@@ -150,6 +146,12 @@ def generate_mru(z, text_vocab_indices, LSTM_hybrid, output_channel, num_classes
     return tower.generate(z, text, noise_vec, labels=_as_device(labels, torch.int32)), noise_vec
 
 
+def discriminate_mru(discrim_inputs, discrim_targets, num_classes, labels=None, reuse=False,
+                     data_format='NCHW', scope_name=None):
+    """models_collection.py:676-786: MRU discriminator (spectral norm everywhere, prelu; the sketch is unused)."""
+    return _discriminate('MRU', discrim_inputs, discrim_targets, reuse, data_format, scope_name)
+
+
 def _not_built(name):
     def f(*a, **k):
         raise NotImplementedError('%s is not built yet: Pix2Pix, Residual (train + infer) and the MRU generator (infer) '
@@ -157,7 +159,6 @@ def _not_built(name):
     return f
 
 
-discriminate_mru = _not_built('discriminate_mru')
 
 generator_mru = generate_mru
 discriminator_mru = discriminate_mru

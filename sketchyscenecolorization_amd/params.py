@@ -200,6 +200,41 @@ def mru_generator_specs(vocab_size=58, img=192, num_classes=NUM_CLASSES):
     return out
 
 
+MRU_DISC_UNITS = [(1, 8, 128), (2, 128, 256), (3, 256, 512), (4, 512, 768)]
+
+
+def mru_discriminator_specs(num_classes=NUM_CLASSES):
+    """discriminate_mru (models_collection.py:676-786) with Config.sn=True: (trainable specs, non-trainable ``u``
+    specs).  Every conv / FC weight has its own power-iteration vector (sn.py:17-18); prelu leaks are scalars
+    initialised to 0.2 (models_collection.py:56-60)."""
+    out, nt = [], []
+    filt, zeros = ('normal', 0.0, 0.02), ('zeros',)
+
+    def conv(pre, k, cin, cout, prelu=False, bias_init=zeros):
+        out.append((pre + '/weights', (k, k, cin, cout), filt))
+        nt.append((pre + '/u', (1, cout), ('truncated_normal',)))
+        out.append((pre + '/biases', (cout,), bias_init))
+        if prelu:
+            out.append((pre + '/prelu/param', (), ('const', 0.2)))
+
+    conv('discriminator/Conv', 7, 3, 8, prelu=True)
+    for u, ch, d in MRU_DISC_UNITS:
+        pre = 'discriminator/mru_conv_unit_t_%d_layer_0' % u
+        out.append((pre + '/norm_activation_in/prelu/param', (), ('const', 0.2)))
+        conv(pre + '/update_gate', 3, ch + 3, ch, bias_init=('const', 0.5))
+        conv(pre + '/Conv', 3, 3, ch)
+        out.append((pre + '/norm_activation_merge_1/prelu/param', (), ('const', 0.2)))
+        conv(pre + '/Conv_1', 3, ch, d, prelu=True)
+        conv(pre + '/Conv_2', 3, d, d)
+        conv(pre + '/Conv_3', 1, ch, d)
+    out.append(('discriminator/mru_conv_unit_last_norm/prelu/param', (), ('const', 0.2)))
+    conv('discriminator/Conv_1', 1, 768, 1)
+    out.append(('discriminator/fully_connected/weights', (768, num_classes), ('glorot',)))
+    nt.append(('discriminator/fully_connected/u', (1, num_classes), ('truncated_normal',)))
+    out.append(('discriminator/fully_connected/biases', (num_classes,), zeros))
+    return out, nt
+
+
 def _init_tensor(shape, init, gen):
     kind = init[0]
     if kind == 'zeros':
@@ -255,8 +290,9 @@ class ParamStore(object):
         elif block_type == 'Residual':
             g = residual_generator_specs('fg', vocab_size, img)
             d, nt = residual_discriminator_specs()
-        elif block_type == 'MRU':           # generator only so far (inference); discriminate_mru is not built
-            g, d, nt = mru_generator_specs(vocab_size, img), [], []
+        elif block_type == 'MRU':
+            g = mru_generator_specs(vocab_size, img)
+            d, nt = mru_discriminator_specs()
         elif block_type == 'BG':            # Background_Colorization generator (BASELINE config 5), forward only
             g, d, nt = residual_generator_specs('bg', vocab_size, img), [], []
         else:

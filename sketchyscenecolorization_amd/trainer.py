@@ -43,11 +43,16 @@ class GanTrainer(object):
             from .residual import ResidualDiscriminator, ResidualGenerator
             self.G = ResidualGenerator(self.store, self.bufs, 'fg', lstm_hybrid)
             self.D = ResidualDiscriminator(self.store, self.bufs, sn)
+        elif block_type == 'MRU':
+            from .mru import MRUDiscriminator, MRUGenerator
+            self.G = MRUGenerator(self.store, self.bufs, lstm_hybrid)
+            self.D = MRUDiscriminator(self.store, self.bufs, sn)
         else:
             raise NotImplementedError('training for block_type %r is not built' % block_type)
         self.lr_g, self.lr_d, self.max_iter_step = lr_g, lr_d, max_iter_step
         self.beta1, self.beta2, self.eps = 0.0, 0.9, 1e-8     # graph_single.py:588
         self.loss = torch.zeros(2, dtype=torch.float64, device=device)   # [loss_g, loss_d], summed in double
+        self.G.loss_acc, self.D.loss_acc = self.loss[0:1], self.loss[1:2]     # regularisers added inside backward
         self.reducer = GradReducer(process_group)
         self.world = self.reducer.world
         g = self.store.generator.offsets
@@ -131,12 +136,17 @@ class GanTrainer(object):
         g.replay()
         return self.loss[1:2] if kind == 'd' else self.loss[0:1]
 
+    def _g_forward(self, batch, **kw):
+        if self.block_type == 'MRU':        # class-conditional norms (models_collection.py:80-82, 270-272)
+            return self.G.forward(batch['sketches'], batch['text'], batch['class_id'], batch['noise_vec'], 'g', **kw)
+        return self.G.forward(batch['sketches'], batch['text'], batch['noise_vec'], 'g', **kw)
+
     def _pack_fake(self, batch):
         B = self.bufs
         N, _, H, W = batch['sketches'].shape
         xd_f = B.get('xd_fake', (N, H, W, 8), zero_on_alloc=True)
         hip.nchw_to_nhwc(batch['sketches'], xd_f, 0)
-        gctx = self.G.forward(batch['sketches'], batch['text'], batch['noise_vec'], 'g', out=xd_f, out_coff=3)
+        gctx = self._g_forward(batch, out=xd_f, out_coff=3)
         return xd_f, gctx
 
     # ------------------------------------------------------------------ steps
@@ -208,7 +218,10 @@ class GanTrainer(object):
         self._allreduce_wait()
         self._adam_launch(self.store.generator, 0)
         if self.D.sn and self._sn_pending is not None:
-            self.store['discriminator/fully_connected/u'].copy_(self._sn_pending)
+            if hasattr(self.D, 'commit_u'):
+                self.D.commit_u(self._sn_pending)
+            else:
+                self.store['discriminator/fully_connected/u'].copy_(self._sn_pending['u_new'])
             self._sn_pending = None
 
     def g_gradients(self, batch):
@@ -233,7 +246,7 @@ class GanTrainer(object):
         hip.call('ssc_gen_output_grad', xd_f.view(-1)[3:], 8, img4, 4, dgen, 4, N * H * W, 100.0, loss_g, dpre)
         sc = s.generator
         self.G.backward(gctx, dpre, on_section=lambda name: self._section_done(sc, name))
-        self._sn_pending = sn['u_new'] if self.D.sn else None
+        self._sn_pending = sn if self.D.sn else None
         self.last = {'gctx': gctx, 'cf': cf}
         return loss_g
 
@@ -252,9 +265,14 @@ class GanTrainer(object):
         lg = self.g_step(batch_g, counter)
         return lg, ld
 
-    def generate(self, sketches, text, noise_vec):
+    def generate(self, sketches, text, noise_vec, labels=None):
         """Inference path of build_single_graph (training=False): NCHW in, NCHW out."""
-        ctx = self.G.forward(sketches, text, noise_vec, 'g')
+        if self.block_type == 'MRU':
+            if labels is None:
+                raise ValueError('the MRU generator is class-conditional: pass the class ids (image_data_class_id)')
+            ctx = self.G.forward(sketches, text, labels, noise_vec, 'g')
+        else:
+            ctx = self.G.forward(sketches, text, noise_vec, 'g')
         return self.G.output_nchw(ctx)
 
 

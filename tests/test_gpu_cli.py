@@ -71,10 +71,11 @@ def test_obj_lib_api_inference_and_gradients():
     assert np.isfinite(lg) and np.isfinite(ld)
     names = [n for _, n in grad_g]
     assert 'generator/encoder_1/conv/filter' in names and len(grad_d) == 13
-    with pytest.raises(NotImplementedError):        # MRU / Residual: generator inference only so far
-        graph_single.build_single_graph(b['images'], b['sketches'], b['images_d'], b['class_id'], b['class_id_d'],
-                                        b['text'], batch_size=2, training=True, LSTM_hybrid=True, vocab_size=58,
-                                        block_type='MRU')
+    lg, ld, grad_g, grad_d = graph_single.build_single_graph(b['images'], b['sketches'], b['images_d'], b['class_id'],
+                                                             b['class_id_d'], b['text'], batch_size=2, training=True,
+                                                             LSTM_hybrid=True, vocab_size=58, noise_vec=b['noise_vec'])
+    assert np.isfinite(lg) and np.isfinite(ld)      # default block_type = 'MRU'
+    assert 'generator/mru_conv_unit_t_1_layer_0/update_gate/weights' in [n for _, n in grad_g]
 
 
 @pytest.mark.parametrize('bt', ['MRU', 'Residual'])

@@ -61,3 +61,102 @@ def test_api_generator_mru_and_single_graph_inference():
     assert torch.equal(gen, img)
     with pytest.raises(ValueError):
         models.generator_mru(z, text, True, 3, 25, 58)
+    disc, logits = models.discriminator_mru(z, gen, 25)
+    assert disc.shape == (1, 1, 4, 4) and logits.shape == (1, 25)
+
+
+# --------------------------------------------------------------------------- MRU training path
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def _nhwc(t, pad_to=None):
+    t = t.permute(0, 2, 3, 1).contiguous()
+    if pad_to is not None and t.shape[-1] < pad_to:
+        t = torch.cat([t, torch.zeros(t.shape[:-1] + (pad_to - t.shape[-1],))], -1)
+    return t.cuda()
+
+
+@pytest.mark.parametrize('mode', ['gen_conv', 'gen_deconv', 'gen_deconv_noproj', 'disc_conv'])
+def test_mru_blocks_backward(mode):
+    """One MRU block, forward + hand-written backward, against float64 autograd on the oracle's block
+    (well-conditioned sizes): every parameter gradient and every input gradient to 2e-4 relative L2."""
+    from oracle import mru as M
+    from sketchyscenecolorization_amd.mru import MRUDiscriminator, MRUGenerator
+    from sketchyscenecolorization_amd.params import Buffers, ParamStore
+    g = torch.Generator().manual_seed(5)
+    p = M.init_params(3, with_discriminator=True, img=64)
+    store = ParamStore('MRU', 58, 64, 'cuda', 0)
+    store.load_dict(p)
+    bufs = Buffers('cuda')
+    n = 3
+    labels = torch.tensor([4, 17, 4], dtype=torch.int32)
+    if mode == 'gen_conv':
+        pre, ch, d, hw = 'generator/mru_conv_unit_t_2_layer_0', 64, 128, 16
+    elif mode == 'disc_conv':
+        pre, ch, d, hw = 'discriminator/mru_conv_unit_t_2_layer_0', 128, 256, 16
+    elif mode == 'gen_deconv':
+        pre, ch, d, hw, cs = 'generator/mru_deconv_unit_t_4_layer_0', 256, 128, 8, 64
+    else:
+        pre, ch, d, hw, cs = 'generator/mru_deconv_unit_t_6_layer_0', 128, 128, 8, 8
+    q = {k: v.double().requires_grad_(not k.endswith('/u')) for k, v in p.items() if k.startswith(pre)}
+    ht = torch.randn(n, ch, hw, hw, generator=g)
+    ht64 = ht.double().requires_grad_(True)
+    if mode in ('gen_conv', 'disc_conv'):
+        x = torch.rand(n, 3, hw, hw, generator=g) * 2 - 1
+        x64 = x.double().requires_grad_(True)
+        if mode == 'gen_conv':
+            o = M.mru_conv_block_v3(q, pre, x64, ht64, d, labels.long(), 2)
+        else:
+            o = M._d_conv_block(q, pre, x64, ht64, d, {})
+        ins64 = [ht64, x64]
+    else:
+        z = torch.rand(n, 3, 2 * hw, 2 * hw, generator=g) * 2 - 1
+        sk = torch.randn(n, cs, 2 * hw, 2 * hw, generator=g)
+        sk64 = sk.double().requires_grad_(True)
+        o = M.mru_deconv_block_v2(q, pre, torch.cat([z.double(), sk64], 1), ht64, d, labels.long(), 2)
+        ins64 = [ht64, sk64]
+    gout = torch.randn(o.shape, generator=g)
+    names = [k for k in q if not k.endswith('/u')]
+    grads = torch.autograd.grad((o * gout.double()).sum(), [q[k] for k in names] + ins64)
+    ref = dict(zip(names, grads[:len(names)]))
+    # ---- HIP
+    net = MRUDiscriminator(store, bufs) if mode == 'disc_conv' else MRUGenerator(store, bufs)
+    tape = []
+    ht_d = _nhwc(ht)
+    lab_d = labels.cuda()
+    if mode in ('gen_conv', 'disc_conv'):
+        x_d = _nhwc(x, 4)
+        if mode == 'disc_conv':
+            sn = net.prepare_sn()
+            net._sn = sn
+            lab_d = None
+        out = net._conv_block('t', pre, x_d, ht_d, d, lab_d, tape)
+    else:
+        z_d, sk_d = _nhwc(z, 4), _nhwc(sk)
+        out = net._deconv_block('t', pre, z_d, sk_d, ht_d, d, lab_d, tape)
+    assert _rel(out.permute(0, 3, 1, 2), o) < 1e-5
+    net._gdone = {}
+    slot, _ = net._gslot(out)
+    slot.copy_(_nhwc(gout))
+    if mode in ('gen_conv', 'disc_conv'):
+        g_x = torch.zeros_like(x_d)
+        net._conv_block_backward(tape[0], lab_d, True, False, g_x)
+        if mode == 'disc_conv':
+            net.finish_sn_backward(sn)
+        got_inputs = [net._gget(ht_d).permute(0, 3, 1, 2), g_x[..., :3].permute(0, 3, 1, 2)]
+    else:
+        net._deconv_block_backward(tape[0], lab_d)
+        got_inputs = [net._gget(ht_d).permute(0, 3, 1, 2), net._gget(sk_d).permute(0, 3, 1, 2)]
+    worst = ('', 0.0)
+    big = max(float(v.norm()) for v in ref.values())
+    for k in names:
+        got = store.grad(k).reshape(ref[k].shape)
+        if float(ref[k].norm()) < 1e-7 * big:       # e.g. a bias feeding a batch norm: exactly zero gradient
+            assert float(got.norm()) < 1e-4 * big, k
+            continue
+        worst = max(worst, (k, _rel(got, ref[k])), key=lambda kv: kv[1])
+    for i, (a, b) in enumerate(zip(got_inputs, grads[len(names):])):
+        worst = max(worst, ('input%d' % i, _rel(a, b)), key=lambda kv: kv[1])
+    assert worst[1] < 2e-4, worst

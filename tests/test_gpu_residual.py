@@ -74,8 +74,8 @@ def test_api_generator_residual_matches_tower():
     nv = torch.randn(2, 256)
     img, nv2 = models.generator_residual(z, text, True, 3, 25, 58, noise_vec=nv)
     assert img.shape == (2, 3, 64, 64) and torch.isfinite(img).all() and float(img.abs().max()) <= 1.0
-    with pytest.raises(NotImplementedError):
-        models.discriminator_mru(z, z, 25)
+    disc, logits = models.discriminator_residual(z, img, 25)
+    assert disc.shape == (2, 1, 2, 2) and logits.shape == (2, 25)
 
 
 # --------------------------------------------------------------------------- Residual training path
