@@ -160,3 +160,84 @@ def test_mru_blocks_backward(mode):
     for i, (a, b) in enumerate(zip(got_inputs, grads[len(names):])):
         worst = max(worst, ('input%d' % i, _rel(a, b)), key=lambda kv: kv[1])
     assert worst[1] < 2e-4, worst
+
+
+def _make_trainer(n, img, seed=0):
+    from oracle import mru as M
+    from oracle import pix2pix as O
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    p = M.init_params(seed, with_discriminator=True, img=img)
+    tr = GanTrainer(img=img, seed=seed + 1, block_type='MRU')
+    tr.store.load_dict(p)
+    b = O.synthetic_batch(n, seed=987 + n, img=img)
+    dev = {k: (v.cuda() if k != 'text' else v.numpy()) for k, v in b.items()}
+    return p, tr, b, dev
+
+
+def test_mru_discriminator_forward_parity():
+    from oracle import mru as M
+    from sketchyscenecolorization_amd import hip
+    p, tr, b, dev = _make_trainer(2, 64)
+    disc, logits, us = M.discriminate_mru(p, b['sketches'], b['images_d'], return_u=True)
+    xd = torch.zeros(2, 64, 64, 8, device='cuda')
+    hip.nchw_to_nhwc(dev['sketches'], xd, 0)
+    hip.nchw_to_nhwc(dev['images_d'], xd, 3)
+    sn = tr.D.prepare_sn()
+    c = tr.D.forward(xd, sn, 'dr')
+    assert float((c['disc'][..., 0].cpu() - disc[:, 0]).abs().max()) < 1e-3 * max(1.0, float(disc.abs().max()))
+    assert float((c['logits'].cpu() - logits).abs().max()) < 1e-3 * max(1.0, float(logits.abs().max()))
+    for k, u in us.items():
+        assert _rel(sn[k[:-2]]['u_new'], u) < 1e-4, k
+
+
+def _grad_errors(get, ref_grads):
+    """Relative L2 per variable vs float64, the denominator floored at 1e-4 of the largest gradient norm (biases that
+    feed a batch norm have an exactly-zero gradient; scalar prelu leaks can have tiny ones)."""
+    l2s = {}
+    big = max(float(g.norm()) for g in ref_grads.values())
+    for name, g in ref_grads.items():
+        a = get(name).reshape(g.shape).detach().cpu().double()
+        l2s[name] = float((a - g).norm() / max(float(g.norm()), 1e-4 * big))
+    return l2s
+
+
+@pytest.mark.parametrize('n,img,noise', [(2, 64, True), (2, 64, False), (2, 192, False)])
+def test_mru_train_step_gradients_parity(n, img, noise):
+    """loss_d / loss_g and every gradient of one MRU tower vs float64 autograd on the oracle.
+
+    The min-max gates (mru.py:414-415, 560-568) send gradient to the arg-min / arg-max position of every (sample,
+    channel) plane.  On sketches (large flat regions) several positions are within fp32 rounding of the extremum, so
+    WHICH one is selected differs between any two fp32 evaluations -- observed on both sides: HIP 5e-3 vs torch-CPU
+    fp32 5e-5 on one input, HIP 3.5e-5 vs torch-CPU 4e-4 on another -- and one flipped selection shifts every
+    upstream variable by the same relative amount.  The end-to-end bar is therefore loose (median relative L2 < 2e-2
+    on sketches, < 5e-3 on noise images that have no near-ties; a wrong formula gives O(1)); the exact formulas are
+    pinned at 2e-4 by test_mru_blocks_backward."""
+    from oracle import mru as M
+    p, tr, b, dev = _make_trainer(n, img)
+    if noise:
+        b['sketches'] = torch.rand(b['sketches'].shape, generator=torch.Generator().manual_seed(1)) * 2 - 1
+        dev['sketches'] = b['sketches'].cuda()
+    r = M.build_single_graph_f64(p, **b)
+    ld = tr.d_step(dev, counter=0)
+    assert abs(float(ld) - float(r['loss_d'])) < 1e-4 * max(1.0, abs(float(r['loss_d'])))
+    ed = _grad_errors(lambda k: tr.store.discriminator.g[k], r['grad_d'])
+    tr.store.load_dict(p)
+    lg = tr.g_step(dev, counter=0)
+    assert abs(float(lg) - float(r['loss_g'])) < 1e-4 * max(1.0, abs(float(r['loss_g'])))
+    eg = _grad_errors(lambda k: tr.store.generator.g[k], r['grad_g'])
+    med_tol = 5e-3 if noise else 2e-2
+    for e in (ed, eg):
+        assert float(np.median(list(e.values()))) < med_tol, float(np.median(list(e.values())))
+        worst = max(e.items(), key=lambda kv: kv[1])
+        assert worst[1] < 10 * med_tol, worst
+    for k, u in r['u_new'].items():          # the G-step commits every spectral-norm u (graph_single.py:178-210)
+        assert _rel(tr.store[k], u) < 1e-3, k
+
+
+def test_mru_cli_train_smoke(tmp_path, monkeypatch):
+    import os
+    import obj_colorization_main as cli
+    monkeypatch.chdir(tmp_path)
+    cli.main(['--mode', 'train', '-si', '1', '-bs', '2', '-mi', '3', '-smf', '2', '-swf', '1'])     # default -bt MRU
+    run = os.path.join('outputs', sorted(os.listdir('outputs'))[0])
+    assert os.path.exists(os.path.join(run, 'snapshot', 'model_1.ckpt-1'))
