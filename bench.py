@@ -127,8 +127,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (reference --batch_size is per GPU)')
     ap.add_argument('--img', type=int, default=192)
-    ap.add_argument('--block-type', default='Pix2Pix', choices=['Pix2Pix', 'Residual'],
-                    help='train workload: Pix2Pix = the headline metric; Residual = secondary (108.8 GFLOP/img-iteration)')
+    ap.add_argument('--block-type', default='Pix2Pix', choices=['Pix2Pix', 'Residual', 'MRU'],
+                    help='train workload: Pix2Pix = the headline metric; Residual (108.8 GFLOP/img-iteration) and MRU (767) '
+                         'are secondary')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-graphs', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
@@ -197,7 +198,7 @@ def main():
         global_batch = args.batch * world
         ms = dt / args.steps * 1e3
         value = global_batch * args.steps / dt
-        f_g, f_d = (F_G, F_D) if args.block_type == 'Pix2Pix' else (21.1e9, 3.05e9)
+        f_g, f_d = {'Pix2Pix': (F_G, F_D), 'Residual': (21.1e9, 3.05e9), 'MRU': (62.6e9, 64.6e9)}[args.block_type]
         flops_step = (4 * f_g + 8 * f_d) * args.batch       # per GPU, as-written reference FLOPs
         out = {'metric': 'train images/sec (192x192, gen+disc fwd+bwd)', 'value': value, 'unit': 'images/sec',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
