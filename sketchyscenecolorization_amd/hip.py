@@ -138,7 +138,12 @@ def _declare(l):
         fn.restype = C.c_int
 
 
+LAUNCHES = 0        # bumped by every C-ABI call (lets the trainer tell an empty graph segment from a real one)
+
+
 def check(rc, what):
+    global LAUNCHES
+    LAUNCHES += 1
     if rc != 0:
         raise RuntimeError('%s failed with code %d' % (what, rc))
 

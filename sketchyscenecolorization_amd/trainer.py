@@ -14,6 +14,7 @@ of the backward pass has produced them, and the 1/world factor is folded into th
 Adam kernel.
 """
 import math
+import warnings
 
 import numpy as np
 import torch
@@ -29,7 +30,8 @@ class GanTrainer(object):
     discriminator pair by block type; losses, optimizer and the step protocol are shared)."""
 
     def __init__(self, img=192, vocab_size=58, lstm_hybrid=True, lr_g=2e-4, lr_d=1e-4, max_iter_step=100000,
-                 seed=0, sn=True, process_group=None, device='cuda', use_graphs=False, block_type='Pix2Pix'):
+                 seed=0, sn=True, process_group=None, device='cuda', use_graphs=False, block_type='Pix2Pix',
+                 segment_graphs=None):
         if not torch.cuda.is_available():
             raise RuntimeError('GanTrainer needs an MI355X (HIP) device: there is no CPU fallback')
         hip.lib()
@@ -63,6 +65,11 @@ class GanTrainer(object):
         self.use_graphs = bool(use_graphs)
         self._capturing = False
         self._graphs, self._seen, self._static = {}, set(), {}
+        # world > 1: collectives are NOT captured.  A step is captured as a chain of graph segments that end where
+        # the backward pass hands a gradient section to the reducer; replay = segment, eager RCCL all-reduce on the
+        # side stream, next segment, ...  (same overlap as eager mode, no dependence on graph-capturable RCCL).
+        self.segment_graphs = (self.world > 1) if segment_graphs is None else bool(segment_graphs)
+        self._seg = None
         self.lr_dev = torch.zeros(2, dtype=torch.float32, device=device)     # Adam step sizes [G, D]
 
     # ------------------------------------------------------------------ helpers
@@ -82,10 +89,61 @@ class GanTrainer(object):
         return float(max(np.float32(0.2), np.float32(1.0) - c))
 
     def _allreduce_async(self, flat, lo, hi):
-        self.reducer.reduce_async(flat, lo, hi)
+        if self._seg is not None:
+            self._seg_break(('reduce', flat, lo, hi))
+        else:
+            self.reducer.reduce_async(flat, lo, hi)
 
     def _allreduce_wait(self):
-        self.reducer.wait()
+        if self._seg is not None:
+            self._seg_break(('wait',))
+        else:
+            self.reducer.wait()
+
+    # ------------------------------------------------------------------ segmented capture
+    def _seg_begin_graph(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self._seg['pool'])
+        self._seg['cur'], self._seg['mark'] = g, hip.LAUNCHES
+
+    def _seg_end_graph(self):
+        sg = self._seg
+        with warnings.catch_warnings():     # "The CUDA Graph is empty" for a segment between two back-to-back collectives
+            warnings.simplefilter('ignore')
+            sg['cur'].capture_end()
+        if hip.LAUNCHES != sg['mark']:          # segments without a single launch are dropped
+            sg['ops'].append(('graph', sg['cur']))
+        sg['cur'] = None
+
+    def _seg_break(self, op):
+        self._seg_end_graph()
+        self._seg['ops'].append(op)
+        self._seg_begin_graph()
+
+    def _capture_segments(self, impl, sbatch):
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        self._seg = {'ops': [], 'pool': torch.cuda.graph_pool_handle(), 'cur': None, 'mark': 0}
+        self._capturing = True
+        try:
+            with torch.cuda.stream(stream):
+                self._seg_begin_graph()
+                impl(sbatch)
+                self._seg_end_graph()
+        finally:
+            self._capturing = False
+            ops, self._seg = self._seg['ops'], None
+        torch.cuda.current_stream().wait_stream(stream)
+        return ops
+
+    def _replay_segments(self, ops):
+        for op in ops:
+            if op[0] == 'graph':
+                op[1].replay()
+            elif op[0] == 'reduce':
+                self.reducer.reduce_async(op[1], op[2], op[3])
+            else:
+                self.reducer.wait()
 
     def _adam_prepare(self, scope, idx, lr):
         """Host part of the optimizer step: advance t, put lr_t = lr*sqrt(1-b2^t)/(1-b1^t) in device memory."""
@@ -125,15 +183,21 @@ class GanTrainer(object):
             if key not in self._seen:       # first time: eager (allocates buffers, sets kernel attributes)
                 self._seen.add(key)
                 return impl(sbatch)
-            g = torch.cuda.CUDAGraph()
-            self._capturing = True
-            try:
-                with torch.cuda.graph(g):
-                    impl(sbatch)
-            finally:
-                self._capturing = False
+            if self.segment_graphs:
+                g = self._capture_segments(impl, sbatch)
+            else:
+                g = torch.cuda.CUDAGraph()
+                self._capturing = True
+                try:
+                    with torch.cuda.graph(g):
+                        impl(sbatch)
+                finally:
+                    self._capturing = False
             self._graphs[key] = g
-        g.replay()
+        if isinstance(g, list):
+            self._replay_segments(g)
+        else:
+            g.replay()
         return self.loss[1:2] if kind == 'd' else self.loss[0:1]
 
     def _g_forward(self, batch, **kw):

@@ -132,3 +132,37 @@ def test_hipgraph_replay_matches_eager():
     # TF-Adam with beta1=0 moves a weight by ~lr per step whatever the gradient size, so an entry whose gradient
     # sign flips under fp32 summation-order noise may differ by a few lr; every other entry must agree tightly
     assert worst < 4e-3, worst
+
+
+def test_segmented_graphs_with_rccl_world1_match_eager():
+    """The multi-GPU step protocol on one GPU: a 1-rank RCCL process group, steps captured as graph SEGMENTS with the
+    all-reduces issued eagerly on the side stream between them (what world > 1 uses).  Must equal the eager trainer."""
+    import os
+    import torch.distributed as dist
+    from sketchyscenecolorization_amd.synthetic import synthetic_batch
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29531')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        a = GanTrainer(img=64, seed=5, max_iter_step=50)
+        b = GanTrainer(img=64, seed=5, max_iter_step=50, use_graphs=True, segment_graphs=True,
+                       process_group=dist.group.WORLD)
+        b.reducer.world = 2          # exercise the collective calls; a 1-rank all-reduce leaves the data unchanged
+        b.reducer.stream = torch.cuda.Stream()
+        b.world = 1
+        bd, bg = synthetic_batch(2, 11, 64), synthetic_batch(2, 12, 64)
+        for it in range(4):
+            la = (float(a.d_step(bd, it)), float(a.g_step(bg, it)))
+            lb = (float(b.d_step(bd, it)), float(b.g_step(bg, it)))
+            assert abs(la[0] - lb[0]) < 1e-4 * max(1.0, abs(la[0])) and abs(la[1] - lb[1]) < 1e-4 * max(1.0, abs(la[1])), (it, la, lb)
+        segs = [g for g in b._graphs.values() if isinstance(g, list)]
+        assert len(segs) == 2 and all(sum(1 for op in ops if op[0] == 'reduce') >= 1 for ops in segs)
+        assert sum(1 for op in [o for ops in segs for o in ops] if op[0] == 'reduce') == 4      # D: 1, G: 3 sections
+        worst = max(float((a.store[n] - b.store[n]).abs().max()) for n in a.store.names())
+        assert worst < 4e-3, worst
+    finally:
+        if created:
+            dist.destroy_process_group()
