@@ -394,19 +394,35 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
         const float* Ab = As + cur * A_SZ + (wm * SM * 32 + l31) * A_LD + lhi;
         const float* Bb = (BMODE == 0) ? (Bs + cur * B_SZ + lhi * B_LD + wn * SN * 32 + l31)
                                        : (Bs + cur * B_SZ + (wn * SN * 32 + l31) * B_LD + lhi);
+        // LDS -> register operand fetch, software-pipelined by groups of FG k-steps: the ds_reads of group g+1 are
+        // issued before the MFMAs of group g (the compiler otherwise places every read directly in front of its
+        // MFMA pair behind an s_waitcnt lgkmcnt(0), exposing the LDS latency 16 times per K-tile)
+        constexpr int FG = 4, NFG = BK / 2 / FG;
+        float av[2][FG][SM], bv[2][FG][SN];
+        auto fetch = [&](int g, int buf) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float av[SM], bv[SN];
+            for (int q = 0; q < FG; ++q) {
+                const int kk = g * FG + q;
 #pragma unroll
-            for (int i = 0; i < SM; ++i) av[i] = Ab[i * 32 * A_LD + kk * 2];
-#pragma unroll
-            for (int j = 0; j < SN; ++j)
-                bv[j] = (BMODE == 0) ? Bb[kk * 2 * B_LD + j * 32] : Bb[j * 32 * B_LD + kk * 2];
-#pragma unroll
-            for (int i = 0; i < SM; ++i)
+                for (int i = 0; i < SM; ++i) av[buf][q][i] = Ab[i * 32 * A_LD + kk * 2];
 #pragma unroll
                 for (int j = 0; j < SN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    bv[buf][q][j] = (BMODE == 0) ? Bb[kk * 2 * B_LD + j * 32] : Bb[j * 32 * B_LD + kk * 2];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int g = 0; g < NFG; ++g) {
+            if (g + 1 < NFG) fetch(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < FG; ++q)
+#pragma unroll
+                for (int i = 0; i < SM; ++i)
+#pragma unroll
+                    for (int j = 0; j < SN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][q][i], bv[g & 1][q][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) store_tile(cur ^ 1);
         __syncthreads();
@@ -600,18 +616,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
         if (more) load_tile(kt + 1);
         const float* Ab = As + cur * A_SZ + lhi * A_LD + wm * SM * 32 + l31;
         const float* Bb = Bs + cur * B_SZ + lhi * B_LD + wn * SN * 32 + l31;
+        constexpr int FG = 4, NFG = BK / 2 / FG;      // operand fetch pipelined by groups, see conv_fwd_kernel
+        float av[2][FG][SM], bv[2][FG][SN];
+        auto fetch = [&](int g, int buf) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float av[SM], bv[SN];
+            for (int q = 0; q < FG; ++q) {
+                const int kk = g * FG + q;
 #pragma unroll
-            for (int i = 0; i < SM; ++i) av[i] = Ab[kk * 2 * A_LD + i * 32];
+                for (int i = 0; i < SM; ++i) av[buf][q][i] = Ab[kk * 2 * A_LD + i * 32];
 #pragma unroll
-            for (int j = 0; j < SN; ++j) bv[j] = Bb[kk * 2 * B_LD + j * 32];
+                for (int j = 0; j < SN; ++j) bv[buf][q][j] = Bb[kk * 2 * B_LD + j * 32];
+            }
+        };
+        fetch(0, 0);
 #pragma unroll
-            for (int i = 0; i < SM; ++i)
+        for (int g = 0; g < NFG; ++g) {
+            if (g + 1 < NFG) fetch(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < SN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            for (int q = 0; q < FG; ++q)
+#pragma unroll
+                for (int i = 0; i < SM; ++i)
+#pragma unroll
+                    for (int j = 0; j < SN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][q][i], bv[g & 1][q][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) store_tile(cur ^ 1);
         __syncthreads();
