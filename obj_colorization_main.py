@@ -1,161 +1,126 @@
 #!/usr/bin/env python
-"""Foreground_Instance_Colorization module CLI -- flags, defaults, dispatch and on-disk layout of the
-reference obj_colorization_main.py:159-257 (outputs/<UTC ts>/{log,snapshot,...}, log/param_<iter>.json,
-NaN -> restart), running on the MI355X-native HIP path.
+"""Command line of the Foreground_Instance_Colorization module on the MI355X-native HIP path.
+
+Drop-in for the reference CLI (obj_colorization_main.py:159-257): the same flags, short aliases, defaults and
+choices, the same run directory ``outputs/<UTC Y-m-d-H-M-S>/{log,snapshot,validation_results,test_results,
+inference_results}``, ``log/param_<first iteration>.json`` and the restart-after-NaN loop.
 
     python obj_colorization_main.py --mode train --block_type Pix2Pix --batch_size 32 --max_iter 1000
     python -m torch.distributed.run --nproc-per-node 8 obj_colorization_main.py --mode train -bt Pix2Pix -gpu 8
-    python obj_colorization_main.py --mode inference -rf <timestamp> -bt Pix2Pix --infer_name car.png \
+    python obj_colorization_main.py --mode inference -rf <timestamp> --infer_name car.png \
         --instruction 'the car is yellow with blue window'
 """
 import argparse
 import json
 import os
-from time import gmtime, strftime
+import time
 
 from sketchyscenecolorization_amd.obj_lib import main_procedure
 from sketchyscenecolorization_amd.obj_lib.config import Config
 
-OUTPUTS = 'outputs'
-
-
-def _dump_params(log_dir, it, kwargs):
-    with open(os.path.join(log_dir, 'param_%d.json' % it), 'w') as fp:
-        json.dump(kwargs, fp, indent=4)
-
-
-def launch_training(**kwargs):
-    appendix = kwargs["resume_from"]
-    rank0 = int(os.environ.get('RANK', 0)) == 0
-    if appendix is None or appendix == '':
-        cur_time = strftime("%Y-%m-%d-%H-%M-%S", gmtime())
-        log_dir = os.path.join(OUTPUTS, cur_time, 'log')
-        ckpt_dir = os.path.join(OUTPUTS, cur_time, 'snapshot')
-        os.makedirs(log_dir, exist_ok=True)
-        os.makedirs(ckpt_dir, exist_ok=True)
-        kwargs.update(log_dir=log_dir, ckpt_dir=ckpt_dir, resume_from=appendix, iter_from=0)
-        appendix = cur_time
-        if rank0:
-            _dump_params(log_dir, 0, kwargs)
-        Config.set_from_dict(kwargs)
-        print("Launching new train: %s" % cur_time)
-    else:
-        if len(appendix.split('-')) != 6:
-            print("Invalid resume folder")
-            return
-        log_dir = os.path.join(OUTPUTS, appendix, 'log')
-        ckpt_dir = os.path.join(OUTPUTS, appendix, 'snapshot')
-        ckpt_file = main_procedure.latest_checkpoint(ckpt_dir)
-        if ckpt_file is None:
-            raise RuntimeError
-        iter_from = int(os.path.split(ckpt_file)[1].split('-')[1]) + 1
-        kwargs.update(log_dir=log_dir, ckpt_dir=ckpt_dir, iter_from=iter_from)
-        if rank0:
-            _dump_params(log_dir, iter_from, kwargs)
-        Config.set_from_dict(kwargs)
-        print("Launching training from checkpoint: %s" % appendix)
-    status = main_procedure.train(**kwargs)
-    return status, appendix
-
-
-def _resume_dirs(kwargs, results):
-    appendix = kwargs["resume_from"]
-    if appendix is None or appendix == '' or len(appendix.split('-')) != 6:
-        print("Invalid resume folder")
-        return False
-    kwargs['log_dir'] = os.path.join(OUTPUTS, appendix, 'log')
-    kwargs['ckpt_dir'] = os.path.join(OUTPUTS, appendix, 'snapshot')
-    kwargs['results_dir'] = os.path.join(OUTPUTS, appendix, results)
-    Config.set_from_dict(kwargs)
-    return True
-
-
-def launch_val(**kwargs):
-    if _resume_dirs(kwargs, 'validation_results'):
-        print("Launching validation from checkpoint: %s" % kwargs["resume_from"])
-        main_procedure.validation(**kwargs)
-
-
-def launch_test(**kwargs):
-    if _resume_dirs(kwargs, 'test_results'):
-        print("Launching testing from checkpoint: %s" % kwargs["resume_from"])
-        main_procedure.test()
-
-
-def launch_inference(**kwargs):
-    if _resume_dirs(kwargs, 'inference_results'):
-        print("Launching inference from checkpoint: %s" % kwargs["resume_from"])
-        main_procedure.inference(kwargs["infer_name"], kwargs["instruction"])
+# (long flag, short flag, type, default, choices, Config / d_params key, help)
+FLAGS = [
+    ('mode', 'md', str, 'train', ['train', 'val', 'test', 'inference'], 'dataset_type', 'what to run'),
+    ('resume_from', 'rf', str, '', None, 'resume_from', 'timestamp of an earlier run under outputs/ to continue or evaluate'),
+    ('batch_size', 'bs', int, 2, None, 'batch_size', 'samples per GPU and step'),
+    ('max_iter', 'mi', int, 100000, None, 'max_iter_step', 'last training iteration'),
+    ('optimizer', 'opt', str, 'Adam', ['RMSprop', 'Adam', 'AdaDelta', 'AdaGrad'], 'optimizer', 'optimizer family'),
+    ('lr_G', 'lrg', float, 2e-4, None, 'lr_G', 'generator step size'),
+    ('lr_D', 'lrd', float, 1e-4, None, 'lr_D', 'discriminator step size'),
+    ('small_img', 'si', int, 0, [0, 1], 'small_img', '1 = 64x64 instances instead of 192x192'),
+    ('lstm_hybrid', 'lh', int, 1, [0, 1], 'LSTM_hybrid', '1 = the caption steers the colours'),
+    ('distance_map', 'dm', int, 0, [0, 1], 'distance_map', '1 = sketches as distance maps'),
+    ('block_type', 'bt', str, 'MRU', ['MRU', 'Pix2Pix', 'Residual'], 'block_type', 'network family'),
+    ('vocab_size', 'vs', int, 58, None, 'vocab_size', 'caption vocabulary size'),
+    ('disc_iterations', 'di', int, 1, None, 'disc_iterations', 'discriminator updates per generator update'),
+    ('ld', 'ld', int, 10, None, 'ld', 'gradient-penalty weight (unused by the live loss)'),
+    ('num_gpu', 'gpu', int, 1, None, 'num_gpu', 'towers (one process per GPU under torch.distributed.run)'),
+    ('extra_info', 'ei', str, '', None, 'extra_info', 'free text stored with the run parameters'),
+    ('summary_write_freq', 'swf', int, 100, None, 'summary_write_freq', 'iterations between scalar summaries'),
+    ('save_model_freq', 'smf', int, 10000, None, 'save_model_freq', 'iterations between snapshots'),
+    ('count_left_time_freq', 'clt', int, 100, None, 'count_left_time_freq', 'iterations between ETA prints'),
+    ('count_inception_score_freq', 'cis', int, -1, None, 'count_inception_score_freq', '-1 = never'),
+    ('infer_name', 'in', str, '', None, 'infer_name', 'sketch file under examples/ (inference mode)'),
+    ('instruction', 'ins', str, '', None, 'instruction', 'caption for that sketch (inference mode)'),
+]
+RESULT_DIRS = {'val': 'validation_results', 'test': 'test_results', 'inference': 'inference_results'}
 
 
 def build_parser():
-    p = argparse.ArgumentParser()
-    p.add_argument('--mode', '-md', type=str, choices=['train', 'val', 'test', 'inference'], default='train',
-                   help="choose a mode")
-    p.add_argument('--resume_from', '-rf', type=str, default='', help="Whether resume last checkpoint from a past run")
-    p.add_argument('--batch_size', '-bs', type=int, default=2, help="Batch size per gpu")
-    p.add_argument('--max_iter', '-mi', type=int, default=100000, help="Max number of iterations")
-    p.add_argument('--optimizer', '-opt', type=str, choices=["RMSprop", "Adam", "AdaDelta", "AdaGrad"], default='Adam',
-                   help="Optimizer for the graph")
-    p.add_argument('--lr_G', '-lrg', type=float, default=2e-4, help="learning rate for the generator")
-    p.add_argument('--lr_D', '-lrd', type=float, default=1e-4, help="learning rate for the discriminator")
-    p.add_argument('--small_img', '-si', type=int, choices=[0, 1], default=0,
-                   help="Whether using 64x64 instead of 256x256")
-    p.add_argument('--lstm_hybrid', '-lh', type=int, choices=[0, 1], default=1, help="Whether use text to control color")
-    p.add_argument('--distance_map', '-dm', type=int, choices=[0, 1], default=0,
-                   help="Whether using distance maps for sketches")
-    p.add_argument('--block_type', '-bt', type=str, choices=['MRU', 'Pix2Pix', 'Residual'], default='MRU',
-                   help="choose a block_type")
-    p.add_argument('--vocab_size', '-vs', type=int, default=58, help="vocab size")
-    p.add_argument('--disc_iterations', '-di', type=int, default=1, help="Number of discriminator iterations")
-    p.add_argument('--ld', '-ld', type=int, default=10, help="Gradient penalty lambda hyperparameter")
-    p.add_argument('--num_gpu', '-gpu', type=int, default=1, help="Number of GPUs to use")
-    p.add_argument('--extra_info', '-ei', type=str, default='', help="Extra information saved for record")
-    p.add_argument('--summary_write_freq', '-swf', type=int, default=100, help="Write summary frequence")
-    p.add_argument('--save_model_freq', '-smf', type=int, default=10000, help="Save model frequence")
-    p.add_argument('--count_left_time_freq', '-clt', type=int, default=100, help="Count left time frequence")
-    p.add_argument('--count_inception_score_freq', '-cis', type=int, default=-1,
-                   help="Count inception score frequence. -1 for not counting")
-    p.add_argument('--infer_name', '-in', type=str, default='', help="The image name of inference")
-    p.add_argument('--instruction', '-ins', type=str, default='', help="The image name of inference")
-    return p
+    parser = argparse.ArgumentParser(description=__doc__.split('\n')[0])
+    for name, short, typ, default, choices, _key, text in FLAGS:
+        parser.add_argument('--' + name, '-' + short, type=typ, default=default, choices=choices, help=text)
+    return parser
 
 
-def params_from_args(args):
-    return {
-        "dataset_type": args.mode, "resume_from": args.resume_from, "batch_size": args.batch_size,
-        "max_iter_step": args.max_iter, "disc_iterations": args.disc_iterations, "optimizer": args.optimizer,
-        "lr_G": args.lr_G, "lr_D": args.lr_D, "num_gpu": args.num_gpu, "small_img": args.small_img,
-        "distance_map": args.distance_map, "LSTM_hybrid": args.lstm_hybrid, "block_type": args.block_type,
-        "vocab_size": args.vocab_size, "ld": args.ld, "extra_info": args.extra_info,
-        "summary_write_freq": args.summary_write_freq, "save_model_freq": args.save_model_freq,
-        "count_left_time_freq": args.count_left_time_freq,
-        "count_inception_score_freq": args.count_inception_score_freq,
-        "infer_name": args.infer_name, "instruction": args.instruction,
-    }
+def run_dirs(stamp):
+    root = os.path.join('outputs', stamp)
+    return os.path.join(root, 'log'), os.path.join(root, 'snapshot'), root
+
+
+def is_stamp(text):
+    return bool(text) and len(text.split('-')) == 6
+
+
+def start_or_resume_training(params):
+    """One call of main_procedure.train: fresh run (new UTC stamp) or continuation of ``resume_from``."""
+    stamp = params['resume_from']
+    fresh = stamp is None or stamp == ''
+    if fresh:
+        stamp = time.strftime('%Y-%m-%d-%H-%M-%S', time.gmtime())
+        first_iter = 0
+    elif not is_stamp(stamp):
+        print('Invalid resume folder')
+        return None, stamp
+    log_dir, ckpt_dir, _ = run_dirs(stamp)
+    if fresh:
+        for d in (log_dir, ckpt_dir):
+            os.makedirs(d, exist_ok=True)
+    else:
+        latest = main_procedure.latest_checkpoint(ckpt_dir)
+        if latest is None:
+            raise RuntimeError('no snapshot under %s' % ckpt_dir)
+        first_iter = int(os.path.basename(latest).split('-')[1]) + 1
+    params.update(log_dir=log_dir, ckpt_dir=ckpt_dir, iter_from=first_iter)
+    if int(os.environ.get('RANK', 0)) == 0:
+        with open(os.path.join(log_dir, 'param_%d.json' % first_iter), 'w') as fp:
+            json.dump(params, fp, indent=4)
+    Config.set_from_dict(params)
+    print(('Launching new train: %s' if fresh else 'Launching training from checkpoint: %s') % stamp)
+    return main_procedure.train(**params), stamp
+
+
+def evaluate(mode, params):
+    stamp = params['resume_from']
+    if not is_stamp(stamp):
+        print('Invalid resume folder')
+        return
+    log_dir, ckpt_dir, root = run_dirs(stamp)
+    params.update(log_dir=log_dir, ckpt_dir=ckpt_dir, results_dir=os.path.join(root, RESULT_DIRS[mode]))
+    Config.set_from_dict(params)
+    print('Launching %s from checkpoint: %s' % ({'val': 'validation', 'test': 'testing', 'inference': 'inference'}[mode],
+                                                 stamp))
+    if mode == 'val':
+        main_procedure.validation(**params)
+    elif mode == 'test':
+        main_procedure.test()
+    else:
+        main_procedure.inference(params['infer_name'], params['instruction'])
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    if args.mode == 'inference':
-        assert args.infer_name != '' and args.instruction != ''
-    d_params = params_from_args(args)
-    if args.mode == 'train':
-        status, appendix = launch_training(**d_params)
-        while status == -1:     # NaN during training: restart from the last checkpoint
-            print("Training ended with status -1. Restarting..")
-            d_params["resume_from"] = appendix
-            status, appendix = launch_training(**d_params)   # (the reference mis-assigns the tuple here and
-            #                                                   therefore restarts at most once: appendix B.10)
-    elif args.mode == 'val':
-        launch_val(**d_params)
-    elif args.mode == 'test':
-        launch_test(**d_params)
-    elif args.mode == 'inference':
-        launch_inference(**d_params)
-    else:
-        raise Exception('Unknown args_mode:', args.mode)
+    params = {key: getattr(args, name) for name, _s, _t, _d, _c, key, _h in FLAGS}
+    if args.mode != 'train':
+        if args.mode == 'inference':
+            assert args.infer_name != '' and args.instruction != '', '--infer_name and --instruction are required'
+        return evaluate(args.mode, params)
+    status, stamp = start_or_resume_training(params)
+    while status == -1:         # a NaN loss ends train() with -1: continue from the last snapshot
+        print('Training ended with status -1. Restarting..')
+        params['resume_from'] = stamp
+        status, stamp = start_or_resume_training(params)
 
 
-if __name__ == "__main__":
+if __name__ == '__main__':
     main()

@@ -1,16 +1,26 @@
-"""Global config (reference: obj_lib/config.py:4-17) -- a mutable bag of class attributes."""
+"""``Config``: the process-wide settings bag every obj_lib module reads (reference obj_lib/config.py:4-17).
+
+The CLI copies its whole parameter dict onto it (``Config.set_from_dict``), so beyond the defaults below it carries
+``batch_size``, ``block_type``, ``ckpt_dir``, ``results_dir`` ... at run time.
+"""
+
+_DEFAULTS = {
+    'data_format': 'NCHW',                                   # the only layout the API accepts
+    'SPECTRAL_NORM_UPDATE_OPS': 'spectral_norm_update_ops',  # name of the u-assign collection (sn.py)
+    'sn': True,                        # spectral normalisation in the discriminators
+    'proj_d': False,                   # projection discriminator: dead branch in the reference, not built
+    'wgan': False,                     # only read when sn is False: dead branch, not built
+    'pre_calculated_dist_map': False,  # distance maps are never precomputed
+}
 
 
 class Config(object):
-    data_format = 'NCHW'    # DO NOT CHANGE THIS
-    SPECTRAL_NORM_UPDATE_OPS = "spectral_norm_update_ops"
-    sn = True               # spectral normalisation on the discriminator's dense head
-    proj_d = False          # projection discriminator (reference dead branch: not built)
-    wgan = False            # only effective if sn is False (reference dead branch: not built)
-    pre_calculated_dist_map = False
-
     @staticmethod
-    def set_from_dict(d):
-        assert type(d) is dict
-        for k, v in d.items():
-            setattr(Config, k, v)
+    def set_from_dict(mapping):
+        if not isinstance(mapping, dict):
+            raise AssertionError('Config.set_from_dict expects a dict')
+        for name in mapping:
+            setattr(Config, name, mapping[name])
+
+
+Config.set_from_dict(dict(_DEFAULTS))
