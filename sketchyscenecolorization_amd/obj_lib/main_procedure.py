@@ -206,8 +206,12 @@ def _categories():
     return list(CATEGORIES)
 
 
-def _vocab_file():
-    return 'data/vocab.txt' if os.path.exists('data/vocab.txt') else os.path.join(PKG_DIR, 'data', 'vocab.txt')
+def _load_vocab():
+    """data/vocab.txt of the working directory (the reference's location) or the built-in default list."""
+    if os.path.exists('data/vocab.txt'):
+        return load_vocab_dict_from_file('data/vocab.txt')
+    from ..data_processing.default_vocab import default_vocab_dict
+    return default_vocab_dict()
 
 
 def inference(img_name, instruction):
@@ -224,7 +228,7 @@ def inference(img_name, instruction):
     output_folder = Config.results_dir
     print('output_folder:', output_folder)
     os.makedirs(output_folder, exist_ok=True)
-    vocab_dict = load_vocab_dict_from_file(_vocab_file())
+    vocab_dict = _load_vocab()
 
     models.reset_default_graph()
     store, _ = models.get_store(Config.block_type, Config.vocab_size, img_dim[0])
@@ -258,7 +262,7 @@ def test():
     small = Config.small_img != 0
     img_dim = SIZE[small]
     categories = _categories()
-    vocab_dict = load_vocab_dict_from_file(_vocab_file())
+    vocab_dict = _load_vocab()
     os.makedirs(Config.results_dir, exist_ok=True)
     models.reset_default_graph()
     store, _ = models.get_store(Config.block_type, Config.vocab_size, img_dim[0])

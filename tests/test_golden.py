@@ -14,7 +14,8 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 def test_text_processing_matches_reference_goldens():
     from sketchyscenecolorization_amd.data_processing import text_processing as tp
     g = json.load(open(os.path.join(GOLD, 'text_goldens.json')))
-    pkg_vocab = tp.load_vocab_dict_from_file(os.path.join(os.path.dirname(tp.__file__), '..', 'data', 'vocab.txt'))
+    from sketchyscenecolorization_amd.data_processing.default_vocab import default_vocab_dict
+    pkg_vocab = default_vocab_dict()
     assert pkg_vocab == g['vocab'] and len(pkg_vocab) == 58 and pkg_vocab['<pad>'] == 0 and pkg_vocab['<unk>'] == 1
     for case in g['cases']:
         assert tp.preprocess_sentence(case['sentence'], g['vocab'], g['T']) == case['indices'], case['sentence']
