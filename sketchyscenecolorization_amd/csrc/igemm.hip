@@ -700,7 +700,8 @@ static int num_cu() {
 struct TileCfg { int id, BM, BN, res; double penalty; };
 // penalties from the measured instruction mix: ~16 VALU per staged A row-float4 (bounds + transform), ~3 per
 // filter float4, 4 cycles each, against 64 cycles per MFMA: (MFMA + VALU) / MFMA, normalised to 128x128
-static const TileCfg FWD_CFGS[4] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.03}, {2, 128, 64, 3, 1.11}, {3, 128, 32, 3, 1.33}};
+static const TileCfg FWD_CFGS[5] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.03}, {2, 128, 64, 3, 1.11}, {3, 128, 32, 3, 1.33},
+                                    {4, 64, 64, 4, 1.20}};    // 64x64: small-M GEMMs (LSTM steps) that leave CUs under-filled
 static const TileCfg WG_CFGS[5] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.00}, {2, 128, 64, 3, 1.10}, {3, 64, 64, 4, 1.2},
                                    {4, 128, 32, 4, 1.3}};
 
@@ -794,8 +795,8 @@ static Plan plan_fwd(const ssc_conv_desc& d, int64_t ws_bytes, bool have_ws) {
     const int C = d.x.C0 + d.x.C1;
     const long nkt = ((long)d.TH * d.TW * C + BK - 1) / BK;
     // column tile no wider than needed: <=32 -> 128x32, <=64 -> 128x64, else 128x128 / 64x128 / 128x64
-    const bool allowed[4] = {d.Nstore > 64, d.Nstore > 64, d.Nstore > 32, d.Nstore <= 32};
-    return plan_launch(FWD_CFGS, 4, allowed, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,
+    const bool allowed[5] = {d.Nstore > 64, d.Nstore > 64, d.Nstore > 32, d.Nstore <= 32, d.Nstore > 32};
+    return plan_launch(FWD_CFGS, 5, allowed, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,
                        have_ws);
 }
 
@@ -810,9 +811,9 @@ extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, 
         copy_name(dp->nphase == 4 ? "narrow_fwd<transposed>" : "narrow_fwd<conv>", buf, len);
         return 0;
     }
-    static const char* names[2][4] = {
-        {"conv_fwd<128x128,KN>", "conv_fwd<64x128,KN>", "conv_fwd<128x64,KN>", "conv_fwd<128x32,KN>"},
-        {"conv_fwd<128x128,NK>", "conv_fwd<64x128,NK>", "conv_fwd<128x64,NK>", "conv_fwd<128x32,NK>"}};
+    static const char* names[2][5] = {
+        {"conv_fwd<128x128,KN>", "conv_fwd<64x128,KN>", "conv_fwd<128x64,KN>", "conv_fwd<128x32,KN>", "conv_fwd<64x64,KN>"},
+        {"conv_fwd<128x128,NK>", "conv_fwd<64x128,NK>", "conv_fwd<128x64,NK>", "conv_fwd<128x32,NK>", "conv_fwd<64x64,NK>"}};
     const Plan p = plan_fwd(*dp, (int64_t)1 << 40, true);
     copy_name(names[dp->bmode ? 1 : 0][p.cfg < 0 ? 0 : p.cfg], buf, len);
     return 0;
@@ -834,6 +835,7 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
             case 0: return launch_fwd<2, 2, 2, 2, 0>(d, p.splitk, ws, st);
             case 1: return launch_fwd<2, 2, 1, 2, 0>(d, p.splitk, ws, st);
             case 2: return launch_fwd<2, 2, 2, 1, 0>(d, p.splitk, ws, st);
+            case 4: return launch_fwd<2, 2, 1, 1, 0>(d, p.splitk, ws, st);
             default: return launch_fwd<4, 1, 1, 1, 0>(d, p.splitk, ws, st);
         }
     } else {
@@ -841,6 +843,7 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
             case 0: return launch_fwd<2, 2, 2, 2, 1>(d, p.splitk, ws, st);
             case 1: return launch_fwd<2, 2, 1, 2, 1>(d, p.splitk, ws, st);
             case 2: return launch_fwd<2, 2, 2, 1, 1>(d, p.splitk, ws, st);
+            case 4: return launch_fwd<2, 2, 1, 1, 1>(d, p.splitk, ws, st);
             default: return launch_fwd<4, 1, 1, 1, 1>(d, p.splitk, ws, st);
         }
     }

@@ -166,12 +166,30 @@ _ws = {}
 
 
 def workspace(nbytes=256 << 20):
-    dev = torch.cuda.current_device()
-    w = _ws.get(dev)
+    """Split-K / reduction scratch of the CURRENT stream (one buffer per device and stream: kernels of the filter-
+    gradient side stream must not share partial-sum slabs with the main stream)."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    w = _ws.get(key)
     if w is None or w.numel() * 4 < nbytes:
         w = torch.empty(nbytes // 4, dtype=torch.float32, device='cuda')
-        _ws[dev] = w
+        _ws[key] = w
     return w
+
+
+# Filter gradients on a side stream.  In a backward pass the data-gradient chain (dgrad -> norm backward -> dgrad ...)
+# is the critical path; the filter gradient of each layer only consumes what that chain has already produced and its
+# result is not needed before the optimizer.  When the trainer sets WGRAD_STREAM, conv_wgrad / deconv_wgrad launch
+# there (after waiting for everything issued so far on the current stream), so their workgroups fill the CUs that the
+# chain's small layers and kernel tails leave idle; join_wgrad() makes the current stream wait for them.
+WGRAD_STREAM = None
+_wgrad_pending = False
+
+
+def join_wgrad():
+    global _wgrad_pending
+    if _wgrad_pending and WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+    _wgrad_pending = False
 
 
 class View(object):
@@ -224,7 +242,15 @@ def _run_conv(d):
                     (d.NB * d.PH * d.PW * d.nphase, d.Nn, d.TH * d.TW * d.k_real)))
 
 
-def _run_wgrad(d):
+def _run_wgrad(d, side=False):
+    global _wgrad_pending
+    if side and WGRAD_STREAM is not None and PROFILE is None:
+        WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(WGRAD_STREAM):
+            ws = workspace()
+            check(lib().ssc_conv_wgrad(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_wgrad')
+        _wgrad_pending = True
+        return
     ws = workspace()
     if PROFILE is None:
         check(lib().ssc_conv_wgrad(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_wgrad')
@@ -351,7 +377,7 @@ def conv_wgrad(x, dy, w_grad, stride, pad, accumulate=False):
     d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = KH, KW, stride, -pad, -pad
     d.Cg_real, d.Nn, d.ldc, d.accumulate = ci, co, co, int(accumulate)
     assert ci <= x.C and co <= dy.C
-    _run_wgrad(d)
+    _run_wgrad(d, side=True)
 
 
 def deconv_wgrad(x, dy, f_grad, accumulate=False):
@@ -364,7 +390,7 @@ def deconv_wgrad(x, dy, f_grad, accumulate=False):
     d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = 4, 4, 2, -1, -1
     d.Cg_real, d.Nn, d.ldc, d.accumulate = co, ci, ci, int(accumulate)
     assert co <= dy.C and ci == x.C
-    _run_wgrad(d)
+    _run_wgrad(d, side=True)
 
 
 def _mat_view(a, ab=None, act=ACT_NONE):
