@@ -155,6 +155,32 @@ extern "C" int ssc_bn_stats(const float* x, int64_t M, int C, int ldx, const flo
     return CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------ column sums (bias gradients, mru.py:128-132)
+// the float4 row-strided partial kernel above, folded per channel in double by one wavefront
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partial, int nblk, int Cv, int C,
+                                                           float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = lane; b < nblk; b += 64) s += (double)partial[(long)b * 2 * Cv + c];
+    s = wave_sum_d(s);
+    if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+extern "C" int ssc_colsum(const float* x, int ld, int64_t M, int C, float* out, int accumulate, float* workspace,
+                          int64_t workspace_bytes, void* stream) {
+    const int Cv = (C + 3) / 4 * 4;
+    if (Cv > ld || (ld & 3)) return -1;
+    int tcg, rl, nbr, nbc;
+    col_grid(M, Cv, tcg, rl, nbr, nbc);
+    if ((int64_t)nbr * 2 * Cv * (int64_t)sizeof(float) > workspace_bytes) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, x, (long)M, Cv, ld, tcg, workspace);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, nbr, Cv, C, out, accumulate);
+    return CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ norm + activation backward
 struct BnBwdArgs {
     const float* x; long M; int C; int ldx;

@@ -131,38 +131,79 @@ extern "C" int ssc_minmax_hw(const float* x, int ld, int N, int P, int C, float*
 }
 
 // ------------------------------------------------------------------ channel-concat writer
+__device__ __forceinline__ float cat_elem(const ssc_cat_part& q, long srow, long row, int n, int c) {
+    float v = q.x[srow * q.ld + c];
+    if (q.act == SSC_ACT_PRELU) {
+        v = fmaxf(q.ab[0] * v, v);       // q.ab points at the scalar leak
+    } else {
+        if (q.ab != nullptr) {
+            const float* ab = q.ab + (long)n * q.ab_sample_stride;
+            v = fmaf(ab[c], v, ab[q.C + c]);
+        }
+        v = mru_act(v, q.act);
+    }
+    if (q.gate != nullptr) {
+        const float mn = q.mnmx[(long)n * 2 * q.C + c], mx = q.mnmx[(long)n * 2 * q.C + q.C + c];
+        v *= (q.gate[row * q.C + c] - mn) / (mx - mn);
+    }
+    return v;
+}
+
+// one thread per (row, group of 4 output columns).  A group that lies inside one part whose channel count and row
+// stride are multiples of 4 moves as float4 (the common case: the state / gradient tensors); the 3-channel image
+// part and everything after it fall back to per-element code.
 __global__ void concat_parts_kernel(ssc_cat_desc d) {
     const int c0 = d.p[0].C, c1 = c0 + (d.nparts > 1 ? d.p[1].C : 0), ct = c1 + (d.nparts > 2 ? d.p[2].C : 0);
+    const int ng = (ct + 3) / 4;
     const long P = (long)d.H * d.W;
-    const long tot = (long)d.N * P * ct, stride = (long)gridDim.x * blockDim.x;
+    const long tot = (long)d.N * P * ng, stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
-        const int col = (int)(i % ct);
-        const long row = i / ct;
-        const int k = col < c0 ? 0 : (col < c1 ? 1 : 2);
-        const int c = col - (k == 0 ? 0 : (k == 1 ? c0 : c1));
-        const ssc_cat_part& q = d.p[k];
+        const int col = (int)(i % ng) * 4;
+        const long row = i / ng;
         const int n = (int)(row / P);
-        long srow = row;
-        if (q.upsample) {
-            const int pix = (int)(row - (long)n * P);
-            const int y = pix / d.W, x = pix - y * d.W;
-            srow = ((long)n * (d.H / 2) + (y >> 1)) * (d.W / 2) + (x >> 1);
-        }
-        float v = q.x[srow * q.ld + c];
-        if (q.act == SSC_ACT_PRELU) {
-            v = fmaxf(q.ab[0] * v, v);       // q.ab points at the scalar leak
-        } else {
-            if (q.ab != nullptr) {
-                const float* ab = q.ab + (long)n * q.ab_sample_stride;
-                v = fmaf(ab[c], v, ab[q.C + c]);
+        const int pix = (int)(row - (long)n * P);
+        const int py = pix / d.W, px = pix - py * d.W;
+        const long uprow = ((long)n * (d.H / 2) + (py >> 1)) * (d.W / 2) + (px >> 1);
+        const int k = col < c0 ? 0 : (col < c1 ? 1 : 2);
+        const int base = k == 0 ? 0 : (k == 1 ? c0 : c1);
+        const ssc_cat_part& q = d.p[k];
+        const int c = col - base;
+        float* o = d.out + row * d.ldo + col;
+        if (c + 4 <= q.C && ((q.C | q.ld | c) & 3) == 0 && (d.ldo & 3) == 0) {
+            const long srow = q.upsample ? uprow : row;
+            float4 v = *reinterpret_cast<const float4*>(q.x + srow * q.ld + c);
+            if (q.act == SSC_ACT_PRELU) {
+                const float lk = q.ab[0];
+                v.x = fmaxf(lk * v.x, v.x); v.y = fmaxf(lk * v.y, v.y); v.z = fmaxf(lk * v.z, v.z); v.w = fmaxf(lk * v.w, v.w);
+            } else {
+                if (q.ab != nullptr) {
+                    const float* ab = q.ab + (long)n * q.ab_sample_stride;
+                    const float4 a = *reinterpret_cast<const float4*>(ab + c), b = *reinterpret_cast<const float4*>(ab + q.C + c);
+                    v.x = fmaf(a.x, v.x, b.x); v.y = fmaf(a.y, v.y, b.y); v.z = fmaf(a.z, v.z, b.z); v.w = fmaf(a.w, v.w, b.w);
+                }
+                if (q.act != SSC_ACT_NONE) {
+                    v.x = mru_act(v.x, q.act); v.y = mru_act(v.y, q.act); v.z = mru_act(v.z, q.act); v.w = mru_act(v.w, q.act);
+                }
             }
-            v = mru_act(v, q.act);
+            if (q.gate != nullptr) {
+                const float* mm = q.mnmx + (long)n * 2 * q.C;
+                const float4 mn = *reinterpret_cast<const float4*>(mm + c), mx = *reinterpret_cast<const float4*>(mm + q.C + c);
+                const float4 g = *reinterpret_cast<const float4*>(q.gate + row * q.C + c);
+                v.x *= (g.x - mn.x) / (mx.x - mn.x); v.y *= (g.y - mn.y) / (mx.y - mn.y);
+                v.z *= (g.z - mn.z) / (mx.z - mn.z); v.w *= (g.w - mn.w) / (mx.w - mn.w);
+            }
+            *reinterpret_cast<float4*>(o) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int cc = col + e;
+                if (cc >= ct) break;
+                const int kk = cc < c0 ? 0 : (cc < c1 ? 1 : 2);
+                const ssc_cat_part& qq = d.p[kk];
+                const long srow = qq.upsample ? uprow : row;
+                o[e] = cat_elem(qq, srow, row, n, cc - (kk == 0 ? 0 : (kk == 1 ? c0 : c1)));
+            }
         }
-        if (q.gate != nullptr) {
-            const float mn = q.mnmx[(long)n * 2 * q.C + c], mx = q.mnmx[(long)n * 2 * q.C + q.C + c];
-            v *= (q.gate[row * q.C + c] - mn) / (mx - mn);
-        }
-        d.out[row * d.ldo + col] = v;
     }
 }
 
@@ -171,7 +212,7 @@ extern "C" int ssc_concat_parts(const ssc_cat_desc* desc, void* stream) {
     if (d.nparts < 1 || d.nparts > 3) return -1;
     long ct = 0;
     for (int k = 0; k < d.nparts; ++k) ct += d.p[k].C;
-    hipLaunchKernelGGL(concat_parts_kernel, dim3(grid_for((long)d.N * d.H * d.W * ct)), dim3(256), 0,
+    hipLaunchKernelGGL(concat_parts_kernel, dim3(grid_for((long)d.N * d.H * d.W * ((ct + 3) / 4))), dim3(256), 0,
                        (hipStream_t)stream, d);
     return CHECK_LAUNCH();
 }
@@ -245,44 +286,6 @@ __device__ __forceinline__ float mru_act_grad(float z, int act) {
         case SSC_ACT_MIU: return 0.5f * (1.f + z * rsqrtf(0.09f + z * z));
         default: return 1.f;
     }
-}
-
-// ------------------------------------------------------------------ column sums (bias gradients)
-__global__ void colsum_partial_kernel(const float* __restrict__ x, int ld, long M, int C, int nsplit,
-                                      float* __restrict__ part) {
-    __shared__ float sh[4][64];
-    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane, s = blockIdx.y;
-    const long rows = (M + nsplit - 1) / nsplit;
-    const long r0 = s * rows, r1 = min(M, r0 + rows);
-    float acc = 0.f;
-    if (c < C)
-        for (long r = r0 + rl; r < r1; r += 4) acc += x[r * ld + c];
-    sh[rl][lane] = acc;
-    __syncthreads();
-    if (rl == 0 && c < C) part[(long)s * C + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
-}
-
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out,
-                                    int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float acc = 0.f;
-    for (int s = 0; s < nsplit; ++s) acc += part[(long)s * C + c];
-    out[c] = accumulate ? out[c] + acc : acc;
-}
-
-extern "C" int ssc_colsum(const float* x, int ld, int64_t M, int C, float* out, int accumulate, float* workspace,
-                          int64_t workspace_bytes, void* stream) {
-    int nsplit = (int)((M + 511) / 512);
-    if (nsplit > 256) nsplit = 256;
-    if (nsplit < 1) nsplit = 1;
-    if ((int64_t)nsplit * C * 4 > workspace_bytes) return -2;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nsplit), dim3(256), 0, (hipStream_t)stream, x, ld,
-                       (long)M, C, nsplit, workspace);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, nsplit,
-                       C, out, accumulate);
-    return CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------ strided copy / add, 2x2 pooling with scale
