@@ -253,6 +253,19 @@ int ssc_gen_output_grad(const float* gen, int ldg, const float* img, int ldi, co
                         float coef, double* loss_acc, float* dpre, void* stream);
 /* ly.l2_regularizer: loss_acc += rate*sum(w^2)/2; grad += rate*w   (mru.py:55,60) */
 int ssc_l2_reg(const float* w, int64_t n, float rate, double* loss_acc, float* grad, void* stream);
+/* ---- Background_Colorization losses (bg_colorization_main.py:596-627), vanilla GAN on sigmoid(z) ------------------ */
+/* mode 0: loss += scale*sum -log(sigmoid(z)+1e-12); mode 1: -log(1-sigmoid(z)+1e-12); dz = gscale * d/dz (may be NULL) */
+int ssc_bg_gan_loss(const float* z, int64_t n, int mode, float scale, double* loss_acc, float* dz, float gscale,
+                    void* stream);
+/* count[0] = #(labels != 0): the pixels the masked L1 averages over (:612-616) */
+int ssc_count_nonzero_i32(const int32_t* labels, int64_t n, float* count, float* workspace, int64_t workspace_bytes,
+                          void* stream);
+/* img = tanh(pre) [M,3]: loss += l1w * mean_{label != 0} |tgt - img|; dpre [M,4] = (dL1 + dgan [M,4]) * (1 - img^2) */
+int ssc_bg_output_grad(const float* img, const float* tgt, const int32_t* labels, const float* count, float l1w,
+                       const float* dgan, double* loss_acc, float* dpre, int64_t M, void* stream);
+/* region-mask loss (:589-591): loss += w * mean softmax-CE(logits [M,K<=4], labels); dlogits [M, ldg] (pad columns 0) */
+int ssc_seg_ce_loss(const float* logits, int K, const int32_t* labels, int64_t M, float w, double* loss_acc,
+                    float* dlogits, int ldg, void* stream);
 /* tf.train.AdamOptimizer dense apply (graph_single.py:588); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host, or read
  * from the device scalar lr_dev when it is not NULL (so a captured hipGraph can be replayed with a new step size) */
 int ssc_adam_tf(float* var, const float* grad, float* m, float* v, int64_t n, float lr_t, const float* lr_dev,

@@ -278,3 +278,118 @@ def create_residual_generator(p, generator_inputs, vocab_indices, return_all=Fal
     if return_all:
         return img, seg, {'layers': layers, 'feat': feat}
     return img, seg
+
+
+# ---------------------------------------------------------------------------
+# Background_Colorization training graph (bg_colorization_main.py:516-726)
+# ---------------------------------------------------------------------------
+BG_EPS = 1e-12      # bg_colorization_main.py:21
+
+
+def bg_discriminator_shapes(ndf=64):
+    """create_residual_discriminator (:550-580): five stride-2 encoder bottlenecks, sigmoid on the last."""
+    s = OrderedDict()
+    chans = [(6, ndf), (ndf, ndf * 2), (ndf * 2, ndf * 4), (ndf * 4, ndf * 8), (ndf * 8, 1024)]
+    for k, (ci, co) in enumerate(chans, start=1):
+        _en_shapes(s, 'discriminator/layer_%d' % k, ci, co)
+    return s
+
+
+def init_bg_params(seed=0, **kw):
+    """Generator + discriminator of the BG module with the reference initialisers."""
+    p = init_params('bg', seed=seed, **kw)
+    g = torch.Generator().manual_seed(seed + 977)
+    for name, shp in bg_discriminator_shapes().items():
+        leaf = name.rsplit('/', 1)[1]
+        p[name] = (torch.randn(shp, generator=g) * 0.02 if leaf == 'filter' else
+                   torch.randn(shp, generator=g) * 0.02 + 1.0 if leaf == 'scale' else torch.zeros(shp))
+    return p
+
+
+def create_residual_discriminator(p, discrim_inputs, discrim_targets):
+    """NHWC in, sigmoid probabilities [N, H/32, W/32, 1024] NHWC out."""
+    x = torch.cat([discrim_inputs, discrim_targets], dim=3).permute(0, 3, 1, 2)
+    for k in range(1, 6):
+        x = bottleneck_residual_en(p, 'discriminator/layer_%d' % k, x, 2)
+    return torch.sigmoid(x).permute(0, 2, 3, 1)
+
+
+def bg_losses(outputs, region_logits, predict_real, predict_fake, targets, labels_gt, gan_weight=1.0, l1_weight=100.0,
+              seg_weight=100.0):
+    """:596-627.  labels_gt int [N,H,W] in {0 = foreground, 1, 2}; the L1 term averages |t - o| over the pixels with
+    label != 0 (all three channels)."""
+    discrim_loss = (-(torch.log(predict_real + BG_EPS) + torch.log(1 - predict_fake + BG_EPS))).mean()
+    gen_loss_gan = (-torch.log(predict_fake + BG_EPS)).mean()
+    sel = labels_gt.reshape(-1) != 0
+    gen_loss_l1 = (targets - outputs).abs().reshape(-1, outputs.shape[3])[sel].mean()
+    seg = T.sparse_softmax_ce(region_logits.reshape(-1, region_logits.shape[3]), labels_gt.reshape(-1)).mean()
+    gen_loss = gen_loss_gan * gan_weight + gen_loss_l1 * l1_weight + seg * seg_weight
+    return discrim_loss, gen_loss, {'gen_loss_GAN': gen_loss_gan, 'gen_loss_L1': gen_loss_l1, 'region_mask_loss': seg}
+
+
+def bg_build_graph(p, inputs, targets, text, labels_gt):
+    """One evaluation of create_model in train mode: both losses and both gradient sets from ONE forward pass.
+    (The reference builds the generator gradients under control_dependencies([discrim_train]); which discriminator
+    weights its backward ops then read is not defined by the TF1 ref-variable semantics.  This restatement -- and the
+    build -- differentiate both losses at the weights the forward pass used.)"""
+    q = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in p.items())
+    outputs, region_logits = create_residual_generator(q, inputs, text)
+    predict_real = create_residual_discriminator(q, inputs, targets)
+    predict_fake = create_residual_discriminator(q, inputs, outputs)
+    d_loss, g_loss, parts = bg_losses(outputs, region_logits, predict_real, predict_fake, targets, labels_gt)
+    g_names = [k for k in q if k.startswith('generator/')]
+    d_names = [k for k in q if k.startswith('discriminator/')]
+    gg = torch.autograd.grad(g_loss, [q[k] for k in g_names], retain_graph=True, allow_unused=True)
+    gd = torch.autograd.grad(d_loss, [q[k] for k in d_names], allow_unused=True)
+    z = lambda k, g: (g if g is not None else torch.zeros_like(q[k])).detach()
+    return {'discrim_loss': d_loss.detach(), 'gen_loss': g_loss.detach(),
+            'parts': {k: v.detach() for k, v in parts.items()}, 'outputs': outputs.detach(),
+            'region_logits': region_logits.detach(), 'predict_real': predict_real.detach(),
+            'predict_fake': predict_fake.detach(),
+            'grad_g': OrderedDict((k, z(k, g)) for k, g in zip(g_names, gg)),
+            'grad_d': OrderedDict((k, z(k, g)) for k, g in zip(d_names, gd))}
+
+
+def bg_build_graph_f64(p, inputs, targets, text, labels_gt):
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        return bg_build_graph(OrderedDict((k, v.double()) for k, v in p.items()), inputs.double(), targets.double(),
+                              text, labels_gt)
+    finally:
+        torch.set_default_dtype(old)
+
+
+def bg_learning_rate(lr, step, max_steps):
+    """tf.train.polynomial_decay(lr, global_step, decay_steps=round(0.75*max_steps), end=lr/10, power=0.9) (:632-637)."""
+    decay_steps = int(round(max_steps * 0.75))
+    s = min(step, decay_steps)
+    return (lr - lr / 10.0) * (1.0 - s / decay_steps) ** 0.9 + lr / 10.0
+
+
+class BGTrainState(object):
+    def __init__(self, params):
+        self.m = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
+        self.v = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
+        self.t = 0
+
+
+def bg_train_step(p, st, batch, step, lr=2e-4, max_steps=100000, beta1=0.5):
+    """model.train (:641-655): Adam(lr_t, beta1=0.5, beta2=0.999) on both nets; both optimizers have made the same
+    number of steps, so one counter serves."""
+    r = bg_build_graph(p, **batch)
+    st.t += 1
+    lr_t = bg_learning_rate(lr, step, max_steps)
+    for k, g in list(r['grad_d'].items()) + list(r['grad_g'].items()):
+        T.tf_adam_update(p[k], g, st.v[k], st.t, lr_t, beta1=beta1, beta2=0.999, m=st.m[k])
+    return r
+
+
+def bg_synthetic_batch(n=1, img=96, seed=0, t_steps=8, vocab_size=18):
+    g = torch.Generator().manual_seed(seed)
+    inputs = torch.rand(n, img, img, 3, generator=g) * 2 - 1
+    targets = torch.rand(n, img, img, 3, generator=g) * 2 - 1
+    text = torch.zeros(n, t_steps, dtype=torch.int32)
+    text[:, t_steps - 5:] = torch.randint(1, vocab_size, (n, 5), generator=g, dtype=torch.int32)
+    labels = torch.randint(0, 3, (n, img // 8, img // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    return {'inputs': inputs, 'targets': targets, 'text': text, 'labels_gt': labels.to(torch.int32)}

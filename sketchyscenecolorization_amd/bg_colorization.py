@@ -43,3 +43,116 @@ def create_residual_generator(generator_inputs, generator_outputs_channels, voca
     store, bufs, gen = get_tower(x.shape[1], vocab_size, ngf, seg_classes)
     ctx = gen.forward(x, text, None, 'bg')
     return ctx['image'], ctx['region_logits']
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training (create_model in train mode, bg_colorization_main.py:516-726)
+# ---------------------------------------------------------------------------------------------------------------
+class BGTrainer(object):
+    """Generator + residual discriminator of the BG module with the reference's losses and optimizer:
+
+        discrim_loss = mean(-(log(D(x, y) + eps) + log(1 - D(x, G(x)) + eps)))
+        gen_loss     = gan_weight * mean(-log(D(x, G(x)) + eps)) + l1_weight * mean_{label != 0} |y - G(x)|
+                       + seg_weight * mean CE(region logits, labels)
+        Adam(lr_t, beta1 = 0.5, beta2 = 0.999) on both nets, lr_t = polynomial_decay(lr, step, 0.75 * max_steps,
+        lr / 10, power 0.9).
+
+    One ``train_step`` = one ``sess.run(model.train)`` (:898-901): a single forward pass, both gradient sets, both
+    Adam applies.  The reference orders the generator's gradient ops after the discriminator update
+    (control_dependencies, :648) without defining which discriminator weights they read; here both gradients are
+    taken at the weights the forward pass used."""
+
+    def __init__(self, image_size=768, vocab_size=18, ngf=64, ndf=64, seg_classes=3, lr=2e-4, max_steps=100000,
+                 gan_weight=1.0, l1_weight=100.0, seg_weight=100.0, beta1=0.5, seed=0, device='cuda'):
+        if not torch.cuda.is_available():
+            raise RuntimeError('BGTrainer needs an MI355X (HIP) device: there is no CPU fallback')
+        if ngf != 64 or ndf != 64:
+            raise NotImplementedError('the parameter registry is laid out for ngf = ndf = 64')
+        from .residual import BGDiscriminator
+        hip.lib()
+        self.store = ParamStore('BG', vocab_size, image_size, device, seed)
+        self.bufs = Buffers(device)
+        self.G = ResidualGenerator(self.store, self.bufs, 'bg', True, ngf, seg_classes)
+        self.D = BGDiscriminator(self.store, self.bufs, ndf)
+        self.seg = seg_classes
+        self.lr, self.max_steps = lr, max_steps
+        self.w_gan, self.w_l1, self.w_seg = gan_weight, l1_weight, seg_weight
+        self.beta1, self.beta2, self.eps = beta1, 0.999, 1e-8
+        # [discrim_loss, gen_loss, gen_loss_GAN, gen_loss_L1, region_mask_loss] accumulated in double on the device
+        self.losses = torch.zeros(5, dtype=torch.float64, device=device)
+        for sc in (self.store.generator, self.store.discriminator):
+            sc.adam_m = torch.zeros_like(sc.adam_v)
+        self.global_step = 0
+
+    def learning_rate(self, step):
+        decay_steps = int(round(self.max_steps * 0.75))
+        s = min(step, decay_steps)
+        return (self.lr - self.lr / 10.0) * (1.0 - s / decay_steps) ** 0.9 + self.lr / 10.0
+
+    def _pack(self, name, inputs, second):
+        N, H, W, _ = inputs.shape
+        xd = self.bufs.get(name, (N, H, W, 8), zero_on_alloc=True)
+        M = N * H * W
+        hip.call('ssc_strided_copy', inputs, 3, xd, 8, M, 3, 0)
+        hip.call('ssc_strided_copy', second, 3, xd.view(-1)[3:], 8, M, 3, 0)
+        return xd
+
+    def gradients(self, inputs, targets, text, labels_gt):
+        """inputs / targets NHWC [N,H,W,3] in [-1,1], text int [N,T] (host), labels_gt int32 [N,H,W].
+        Fills both flat gradient buffers and ``self.losses``; returns the generator context."""
+        B = self.bufs
+        inputs, targets = inputs.contiguous(), targets.contiguous()
+        labels = labels_gt.to(device=inputs.device, dtype=torch.int32).contiguous()
+        N, H, W, _ = inputs.shape
+        M = N * H * W
+        L = self.losses
+        L.zero_()
+        gctx = self.G.forward(inputs, text, None, 'bg')
+        image, logits = gctx['image'], gctx['region_logits']
+        cr = self.D.forward(self._pack('xd_real', inputs, targets), 'dr')
+        cf = self.D.forward(self._pack('xd_fake', inputs, image), 'df')
+        nz = cr['z'].numel()
+        ws = hip.workspace()
+        # ---- discriminator loss and gradients
+        dz_r, dz_f = B.get('dz_r', cr['z'].shape), B.get('dz_f', cf['z'].shape)
+        hip.call('ssc_bg_gan_loss', cr['z'], nz, 0, 1.0 / nz, L[0:1], dz_r, 1.0 / nz)
+        hip.call('ssc_bg_gan_loss', cf['z'], nz, 1, 1.0 / nz, L[0:1], dz_f, 1.0 / nz)
+        self.D.backward(cr, dz_r, True, False, accumulate=False)
+        self.D.backward(cf, dz_f, True, False, accumulate=True)
+        # ---- generator loss and gradients
+        dz_g = B.get('dz_g', cf['z'].shape)
+        hip.call('ssc_bg_gan_loss', cf['z'], nz, 0, 1.0 / nz, L[2:3], dz_g, self.w_gan / nz)
+        dgan = self.D.backward(cf, dz_g, False, True, accumulate=False)
+        count = B.get('l1_count', (1,))
+        hip.call('ssc_count_nonzero_i32', labels, M, count, ws, ws.numel() * 4)
+        dpre = B.get('dpre', (N, H, W, 4))
+        hip.call('ssc_bg_output_grad', image, targets, labels, count, 1.0, dgan, L[3:4], dpre, M)
+        if self.w_l1 != 1.0:        # the kernel folds the weight into the gradient: run it with the real weight
+            L[3:4].zero_()
+            hip.call('ssc_bg_output_grad', image, targets, labels, count, float(self.w_l1), dgan, L[3:4], dpre, M)
+        dlog = B.get('dlog', (N, H, W, 4), zero_on_alloc=True)
+        hip.call('ssc_seg_ce_loss', logits, self.seg, labels, M, float(self.w_seg), L[4:5], dlog, 4)
+        self.G.backward(gctx, dpre, None, dlogits=dlog)
+        return gctx
+
+    def loss_values(self):
+        """(discrim_loss, gen_loss, gen_loss_GAN, gen_loss_L1, region_mask_loss) as Python floats."""
+        d, _, gan, l1w, segw = [float(v) for v in self.losses.tolist()]
+        l1 = l1w / self.w_l1 if self.w_l1 else 0.0
+        seg = segw / self.w_seg if self.w_seg else 0.0
+        return d, gan * self.w_gan + l1w + segw, gan, l1, seg
+
+    def apply_gradients(self):
+        lr = self.learning_rate(self.global_step)
+        for sc in (self.store.discriminator, self.store.generator):
+            sc.adam_t += 1
+            t = sc.adam_t
+            lr_t = lr * (1.0 - self.beta2 ** t) ** 0.5 / (1.0 - self.beta1 ** t)
+            hip.call('ssc_adam_tf', sc.flat, sc.grad, sc.adam_m, sc.adam_v, sc.numel, float(lr_t), None, self.beta1,
+                     self.beta2, self.eps, 1.0)
+        self.global_step += 1
+
+    def train_step(self, inputs, targets, text, labels_gt):
+        gctx = self.gradients(inputs, targets, text, labels_gt)
+        self.apply_gradients()
+        return gctx

@@ -481,6 +481,135 @@ extern "C" int ssc_sn_backward_any(const float* W, const float* u, const float* 
     return CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------ Background_Colorization losses (bg_colorization_main.py:596-627)
+// vanilla GAN terms on sigmoid(z): mode 0: -log(p + eps)  (real term of the discriminator loss / generator GAN loss),
+// mode 1: -log(1 - p + eps) (fake term of the discriminator loss).  loss_acc += scale * sum;  dz = gscale * d/dz.
+__global__ __launch_bounds__(256) void bg_gan_loss_kernel(const float* __restrict__ z, long n, int mode, float scale,
+                                                           double* __restrict__ loss_acc, float* __restrict__ dz,
+                                                           float gscale) {
+    __shared__ float sh[4];
+    const float eps = 1e-12f;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float p = 1.f / (1.f + expf(-z[i]));
+        const float dp = p * (1.f - p);
+        if (mode == 0) {
+            s += -logf(p + eps);
+            if (dz != nullptr) dz[i] = gscale * (-dp / (p + eps));
+        } else {
+            s += -logf(1.f - p + eps);
+            if (dz != nullptr) dz[i] = gscale * (dp / (1.f - p + eps));
+        }
+    }
+    const float t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_acc, (double)scale * (double)t);
+}
+
+extern "C" int ssc_bg_gan_loss(const float* z, int64_t n, int mode, float scale, double* loss_acc, float* dz,
+                               float gscale, void* stream) {
+    long blocks = (n + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(bg_gan_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, (long)n, mode,
+                       scale, loss_acc, dz, gscale);
+    return CHECK_LAUNCH();
+}
+
+// count[0] = number of labels != 0 (the pixels the L1 term averages over, :612-616)
+__global__ __launch_bounds__(256) void count_nonzero_kernel(const int* __restrict__ labels, long n, float* __restrict__ part) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += labels[i] != 0 ? 1.f : 0.f;
+    const float t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void count_fold_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    const float t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+extern "C" int ssc_count_nonzero_i32(const int32_t* labels, int64_t n, float* count, float* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    const int blocks = 256;
+    if (blocks * 4 > workspace_bytes) return -2;
+    hipLaunchKernelGGL(count_nonzero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, labels, (long)n, workspace);
+    hipLaunchKernelGGL(count_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, blocks, count);
+    return CHECK_LAUNCH();
+}
+
+// generator output: img = tanh(pre) [M,3].  loss_acc += l1w * mean_{label != 0} |t - o|;  dpre[M,4] =
+// (l1 gradient + dgan[M,4]) * (1 - img^2), pad channel 0.
+__global__ __launch_bounds__(256) void bg_output_grad_kernel(const float* __restrict__ img, const float* __restrict__ tgt,
+                                                              const int* __restrict__ labels,
+                                                              const float* __restrict__ count, float l1w,
+                                                              const float* __restrict__ dgan,
+                                                              double* __restrict__ loss_acc, float* __restrict__ dpre,
+                                                              long M) {
+    __shared__ float sh[4];
+    const float denom = count[0] * 3.f;
+    float s = 0.f;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long)gridDim.x * 256) {
+        const bool sel = labels[r] != 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float o = img[r * 3 + c], t = tgt[r * 3 + c];
+            float g = dgan != nullptr ? dgan[r * 4 + c] : 0.f;
+            if (sel) {
+                const float d = t - o;
+                s += fabsf(d);
+                g += l1w / denom * (d > 0.f ? -1.f : (d < 0.f ? 1.f : 0.f));
+            }
+            dpre[r * 4 + c] = g * (1.f - o * o);
+        }
+        dpre[r * 4 + 3] = 0.f;
+    }
+    const float t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_acc, (double)l1w * (double)t / (double)denom);
+}
+
+extern "C" int ssc_bg_output_grad(const float* img, const float* tgt, const int32_t* labels, const float* count,
+                                  float l1w, const float* dgan, double* loss_acc, float* dpre, int64_t M, void* stream) {
+    long blocks = (M + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(bg_output_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, tgt, labels,
+                       count, l1w, dgan, loss_acc, dpre, (long)M);
+    return CHECK_LAUNCH();
+}
+
+// region-mask loss (:589-591): loss_acc += w * mean CE(softmax(logits[r, 0:K]), labels[r]);  dlogits[r, 0:ldg] (pad 0)
+__global__ __launch_bounds__(256) void seg_ce_loss_kernel(const float* __restrict__ logits, int K,
+                                                           const int* __restrict__ labels, long M, float w,
+                                                           double* __restrict__ loss_acc, float* __restrict__ dlogits,
+                                                           int ldg) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const float inv = w / (float)M;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long)gridDim.x * 256) {
+        float z[4], m = -INFINITY;
+        for (int k = 0; k < K; ++k) { z[k] = logits[r * K + k]; m = fmaxf(m, z[k]); }
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) { z[k] = expf(z[k] - m); se += z[k]; }
+        const int y = labels[r];
+        s += -(logits[r * K + y] - m - logf(se));
+        for (int k = 0; k < ldg; ++k) dlogits[r * ldg + k] = k < K ? inv * (z[k] / se - (k == y ? 1.f : 0.f)) : 0.f;
+    }
+    const float t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_acc, (double)inv * (double)t);
+}
+
+extern "C" int ssc_seg_ce_loss(const float* logits, int K, const int32_t* labels, int64_t M, float w, double* loss_acc,
+                               float* dlogits, int ldg, void* stream) {
+    if (K > 4) return -1;
+    long blocks = (M + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(seg_ce_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, K, labels,
+                       (long)M, w, loss_acc, dlogits, ldg);
+    return CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ flat-buffer helpers
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

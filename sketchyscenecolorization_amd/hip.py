@@ -98,6 +98,10 @@ SIGNATURES = {
     'ssc_sn_forward': [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     'ssc_sn_backward': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P],
     'ssc_axpy': [_P, _P, _F, _L, _P],
+    'ssc_bg_gan_loss': [_P, _L, _I, _F, _P, _P, _F, _P],
+    'ssc_count_nonzero_i32': [_P, _L, _P, _P, _L, _P],
+    'ssc_bg_output_grad': [_P, _P, _P, _P, _F, _P, _P, _P, _L, _P],
+    'ssc_seg_ce_loss': [_P, _I, _P, _L, _F, _P, _P, _I, _P],
     'ssc_sn_forward_any': [_P, _P, _I, _I, _P, _P, _P, _P, _P, _L, _P],
     'ssc_sn_backward_any': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _L, _P],
     'ssc_mean_pool2': [_P, _I, _P, _I, _I, _I, _I, _I, _P],
@@ -389,7 +393,7 @@ def deconv_wgrad(x, dy, f_grad, accumulate=False):
     d.NB, d.PH, d.PW = x.N, x.H, x.W
     d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = 4, 4, 2, -1, -1
     d.Cg_real, d.Nn, d.ldc, d.accumulate = co, ci, ci, int(accumulate)
-    assert co <= dy.C and ci == x.C
+    assert co <= dy.C and ci <= x.C      # ci < x.C: 3-channel tensors padded to 4 (BG region branch)
     _run_wgrad(d, side=True)
 
 

@@ -145,6 +145,21 @@ def residual_discriminator_specs(num_classes=NUM_CLASSES, size=SIZE):
     return out, [('discriminator/fully_connected/u', (1, num_classes), ('truncated_normal',))]
 
 
+def bg_discriminator_specs(ndf=SIZE):
+    """create_residual_discriminator (bg_colorization_main.py:550-580): five stride-2 encoder bottlenecks."""
+    out = []
+    filt, zeros, ones = ('normal', 0.0, 0.02), ('zeros',), ('normal', 1.0, 0.02)
+    chans = [(6, ndf), (ndf, ndf * 2), (ndf * 2, ndf * 4), (ndf * 4, ndf * 8), (ndf * 8, 1024)]
+    for k, (ci, co) in enumerate(chans, start=1):
+        pre = 'discriminator/layer_%d' % k
+        for blk, shape, c in (('block_1/conv', (4, 4, ci, co // 4), co // 4), ('block_2/conv_ex', (3, 3, co // 4, co // 4), co // 4),
+                              ('block_3/conv_ex', (1, 1, co // 4, co), co), ('block_add/conv', (4, 4, ci, co), co)):
+            out.append(('%s/%s/filter' % (pre, blk), shape, filt))
+            out.append(('%s/%s/batchnorm/offset' % (pre, blk.split('/')[0]), (c,), zeros))
+            out.append(('%s/%s/batchnorm/scale' % (pre, blk.split('/')[0]), (c,), ones))
+    return out
+
+
 MRU_ENC_UNITS = [(1, 8, 64), (2, 64, 128), (3, 128, 256), (4, 256, 512)]
 MRU_DEC_UNITS = [(0, 512, 384, 67), (2, 384, 256, 131), (4, 256, 128, 67), (6, 128, 128, 11), (8, 128, 64, 3)]
 
@@ -273,6 +288,7 @@ class Scope(object):
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.adam_v = torch.zeros(off, dtype=torch.float32, device=device)
+        self.adam_m = None      # first moment: only optimizers with beta1 != 0 (the BG module) allocate it
         self.adam_t = 0
         self.p = OrderedDict((n, self.flat[o:o + k].view(s)) for n, (o, k, s) in self.offsets.items())
         self.g = OrderedDict((n, self.grad[o:o + k].view(s)) for n, (o, k, s) in self.offsets.items())
@@ -293,8 +309,8 @@ class ParamStore(object):
         elif block_type == 'MRU':
             g = mru_generator_specs(vocab_size, img)
             d, nt = mru_discriminator_specs()
-        elif block_type == 'BG':            # Background_Colorization generator (BASELINE config 5), forward only
-            g, d, nt = residual_generator_specs('bg', vocab_size, img), [], []
+        elif block_type == 'BG':            # Background_Colorization (BASELINE config 5): residual generator + discriminator
+            g, d, nt = residual_generator_specs('bg', vocab_size, img), bg_discriminator_specs(), []
         else:
             raise NotImplementedError('block_type %r: Pix2Pix (train+infer) and MRU/Residual/BG (generator forward) '
                                       'are built so far' % block_type)

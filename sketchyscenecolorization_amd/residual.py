@@ -310,7 +310,9 @@ class ResidualGenerator(_Bottlenecks):
             rp = B.get(tag + '/reg_p', (N, hh, ww, 4), zero_on_alloc=True)
             hip.conv_forward(_view(layers[-1]), s['generator/region_br_projection/conv_ex/filter'], 1, 0, rp, nstore=4,
                              same=True)
-            reg = _Val(rp, self._bn(tag, 'generator/region_br_projection/batchnorm', rp, self.seg)[0], ACT_RELU)
+            abp, stp = self._bn(tag, 'generator/region_br_projection/batchnorm', rp, self.seg)
+            reg = _Val(rp, abp, ACT_RELU, stp, 'generator/region_br_projection/batchnorm')
+            ctx['region'] = [reg]
         dec_out = {5: size * 8, 4: size * 4, 3: size * 2, 2: size}
         n_enc = len(layers)
         for dl, k in enumerate((5, 4, 3, 2)):
@@ -322,12 +324,14 @@ class ResidualGenerator(_Bottlenecks):
             layers.append(o)
             if reg is not None:
                 reg = self._region_up(tag, k, reg)
+                ctx['region'].append(reg)
         # decoder_1: deconv(concat[decoder_2, encoder_1]) + norm + tanh
         d1 = B.get(tag + '/d1', (N, H, W, 4))
         v1 = _view(layers[-1], layers[0])
         hip.deconv_forward(v1, s['generator/decoder_1/deconv/filter'], d1, nstore=4)
         ab1, st1 = self._bn(tag, top_bn('generator/decoder_1'), d1, 3)
-        ctx.update(layers=layers, feat=feat, d1=d1, ab_d1=ab1, st_d1=st1, v1=v1, tape=self._tape)
+        ctx.update(layers=layers, feat=feat, d1=d1, ab_d1=ab1, st_d1=st1, v1=v1, tape=self._tape,
+                   bn_d1=top_bn('generator/decoder_1'))
         if self.fg:
             if out is None:
                 out = B.get(tag + '/gen', (N, H, W, 4), zero_on_alloc=True)
@@ -337,6 +341,7 @@ class ResidualGenerator(_Bottlenecks):
             ctx.update(out=out, out_coff=out_coff)
         else:
             reg = self._region_up(tag, 1, reg)
+            ctx['region'].append(reg)
             image = torch.empty((N, H, W, 3), dtype=torch.float32, device=d1.device)
             hip.call('ssc_affine_act', d1, 4, ab1, 4, ACT_TANH, image, 3, N * H * W, 3)
             logits = torch.empty((N, H, W, self.seg), dtype=torch.float32, device=d1.device)
@@ -349,7 +354,8 @@ class ResidualGenerator(_Bottlenecks):
         N, h, w, _ = reg.t.shape
         r = self.b.get(tag + '/reg_%d' % k, (N, 2 * h, 2 * w, 4), zero_on_alloc=True)
         hip.deconv_forward(_view(reg), self.s['generator/region_br_%d/deconv/filter' % k], r, nstore=4)
-        return _Val(r, self._bn(tag, 'generator/region_br_%d/batchnorm' % k, r, self.seg)[0], ACT_RELU)
+        ab, st = self._bn(tag, 'generator/region_br_%d/batchnorm' % k, r, self.seg)
+        return _Val(r, ab, ACT_RELU, st, 'generator/region_br_%d' % k)
 
     def output_nchw(self, ctx):
         N, H, W = ctx['N'], ctx['H'], ctx['W']
@@ -358,17 +364,19 @@ class ResidualGenerator(_Bottlenecks):
         return o
 
     # ------------------------------------------------------------------ backward (FG)
-    def backward(self, ctx, dpre, on_section=None):
+    def backward(self, ctx, dpre, on_section=None, dlogits=None):
         """dpre [N,H,W,4]: gradient w.r.t. the pre-tanh output (= norm(decoder_1 deconv)).  Writes every generator
-        gradient; ``on_section(name)`` as in Pix2PixGenerator.backward ('decoders', 'text', 'encoders')."""
-        assert self.fg, 'the BG generator is forward-only'
+        gradient; ``on_section(name)`` as in Pix2PixGenerator.backward ('decoders', 'text', 'encoders').
+        BG generator: ``dlogits`` [N,H,W,4] = gradient w.r.t. the region-mask logits (region branch, :331-416)."""
         s, B = self.s, self.b
         done = on_section if on_section is not None else (lambda name: None)
         tag, N = ctx['tag'], ctx['N']
         layers, tape = ctx['layers'], ctx['tape']
         self._gdone = {}
+        if not self.fg:
+            self._region_backward(ctx, dlogits)
         # decoder_1
-        dd1 = self._bn_bwd(tag, 'generator/decoder_1', ctx['d1'], ctx['ab_d1'], ctx['st_d1'], dpre, ACT_NONE, True,
+        dd1 = self._bn_bwd(tag, ctx['bn_d1'], ctx['d1'], ctx['ab_d1'], ctx['st_d1'], dpre, ACT_NONE, True,
                            False, c_real=3)
         f1 = s['generator/decoder_1/deconv/filter']
         hip.deconv_wgrad(ctx['v1'], View(dd1), s.grad('generator/decoder_1/deconv/filter'))
@@ -393,18 +401,43 @@ class ResidualGenerator(_Bottlenecks):
                        hip.same_pad_before(ctx['H'], 7, 2))
         done('encoders')
 
+    def _region_backward(self, ctx, dlogits):
+        """region_br_1 .. region_br_5 and the 1x1 projection (3-channel tensors padded to 4)."""
+        s, B = self.s, self.b
+        tag = ctx['tag']
+        chain = ctx['region']           # [projection, br_5, br_4, br_3, br_2, br_1]
+        g = dlogits
+        for idx in range(len(chain) - 1, 0, -1):
+            cur, prev = chain[idx], chain[idx - 1]
+            dr = self._bn_bwd(tag, cur.pre + '/batchnorm', cur.t, cur.ab, cur.st, g, ACT_RELU, True, False, c_real=self.seg)
+            name = cur.pre + '/deconv/filter'
+            hip.deconv_wgrad(_view(prev), View(dr), s.grad(name))
+            gp = B.get(tag + '/gb/' + cur.pre + '/gin', prev.t.shape, zero_on_alloc=True)
+            hip.deconv_dgrad(View(dr), s[name], gp, n_off=0, nn=self.seg)
+            g = gp
+        proj = chain[0]
+        drp = self._bn_bwd(tag, proj.pre, proj.t, proj.ab, proj.st, g, ACT_RELU, True, False, c_real=self.seg)
+        e5 = ctx['layers'][4]
+        w = s['generator/region_br_projection/conv_ex/filter']
+        hip.conv_wgrad(_view(e5), View(drp), s.grad('generator/region_br_projection/conv_ex/filter'), 1, 0)
+        slot, a = self._gslot(e5.t)
+        hip.conv_dgrad(View(drp), w, 1, 0, slot, k_real=self.seg, accumulate=a)
+
     def _after_decoders(self, ctx, done):
         """Noise head and caption branch, between the decoder and encoder halves of the tape."""
         s, B = self.s, self.b
         tag, N = ctx['tag'], ctx['N']
-        noise, feat = ctx['noise'], ctx['feat']
-        g_noise, g_feat = self._gget(noise), self._gget(feat)
-        P = noise.shape[1] * noise.shape[2]
-        cd = noise.shape[3]
-        dpre_fc = B.get(tag + '/gb/noise_dpre', (N, cd * P))
-        hip.call('ssc_miu_permute_bwd', ctx['noise_pre'], g_noise, N, cd, P, dpre_fc)
-        hip.matmul_tn(ctx['noise_vec'], dpre_fc, s.grad('generator/fully_connected/weights'))
-        hip.call('ssc_group_rowsum', dpre_fc, cd * P, 1, N, cd * P, s.grad('generator/fully_connected/biases'), 0)
+        feat = ctx['feat']
+        g_feat = self._gget(feat)
+        if self.fg:
+            noise = ctx['noise']
+            g_noise = self._gget(noise)
+            P = noise.shape[1] * noise.shape[2]
+            cd = noise.shape[3]
+            dpre_fc = B.get(tag + '/gb/noise_dpre', (N, cd * P))
+            hip.call('ssc_miu_permute_bwd', ctx['noise_pre'], g_noise, N, cd, P, dpre_fc)
+            hip.matmul_tn(ctx['noise_vec'], dpre_fc, s.grad('generator/fully_connected/weights'))
+            hip.call('ssc_group_rowsum', dpre_fc, cd * P, 1, N, cd * P, s.grad('generator/fully_connected/biases'), 0)
         done('decoders')
         e5 = ctx['layers'][4].t
         if self.lstm_hybrid:
@@ -414,14 +447,57 @@ class ResidualGenerator(_Bottlenecks):
                 hip.fill(ge5, 0.0)
             else:
                 ge5 = dy5.view(e5.shape)
-            self._gdone[e5.data_ptr()] = ge5
+            prev = self._gget(e5)           # BG: the region projection already contributed
+            if prev is None:
+                self._gdone[e5.data_ptr()] = ge5
+            else:
+                hip.call('ssc_axpy', prev, ge5, 1.0, ge5.numel())
         else:       # feat IS encoder_5's output: its slot already holds the gradient
             for nm in ('embedding', 'RNN/WLSTM/multi_rnn_cell/cell_0/basic_lstm_cell/kernel',
                        'RNN/WLSTM/multi_rnn_cell/cell_0/basic_lstm_cell/bias',
                        'RNN/ALSTM/multi_rnn_cell/cell_0/basic_lstm_cell/kernel',
                        'RNN/ALSTM/multi_rnn_cell/cell_0/basic_lstm_cell/bias'):
-                hip.fill(s.grad('generator/TextLSTM/' + nm), 0.0)
+                hip.fill(s.grad(self.text.emb_name.rsplit('/', 1)[0] + '/' + nm), 0.0)
         done('text')
+
+
+class BGDiscriminator(_Bottlenecks):
+    """create_residual_discriminator (bg_colorization_main.py:550-580): five stride-2 encoder bottlenecks on
+    concat[inputs, targets]; the sigmoid of the last block's output is the patch prediction [N, H/32, W/32, 1024]
+    (the sigmoid lives in the loss kernel, ``forward`` returns the pre-sigmoid block output)."""
+
+    def __init__(self, store, bufs, ndf=64):
+        self._init_blocks(store, bufs)
+        self.chans = [ndf, ndf * 2, ndf * 4, ndf * 8, 1024]
+        self._tape, self._gdone = [], {}
+
+    def forward(self, xd, tag):
+        """xd NHWC [N,H,W,8] = [inputs(3), targets(3), 0, 0]."""
+        self._tape = []
+        cur = _Val(xd, pre='input')
+        for k in range(1, 6):
+            cur = self._en(tag, 'discriminator/layer_%d' % k, (cur,), self.chans[k - 1])
+        return {'tag': tag, 'N': xd.shape[0], 'xd': xd, 'tape': self._tape, 'z': cur.t}
+
+    def backward(self, ctx, dz, need_params, need_input, accumulate):
+        """dz: gradient w.r.t. the pre-sigmoid output.  Returns d loss / d targets as NHWC [N,H,W,4] if need_input."""
+        B = self.b
+        self._gdone = {}
+        self._gdone[ctx['z'].data_ptr()] = dz
+        dgen = None
+        tape = ctx['tape']
+        for i, rec in enumerate(reversed(tape)):
+            g_out = self._gget(rec['out'])
+            if i == len(tape) - 1:
+                if need_input:
+                    xd = ctx['xd']
+                    dgen = B.get(ctx['tag'] + '/gb/dgen', (ctx['N'], xd.shape[1], xd.shape[2], 4))
+                    self._block_backward(rec, g_out, need_params, accumulate, True, input_slice=(3, 3, dgen, 4))
+                else:
+                    self._block_backward(rec, g_out, need_params, accumulate, False)
+            else:
+                self._block_backward(rec, g_out, need_params, accumulate, True)
+        return dgen
 
 
 class ResidualDiscriminator(_Bottlenecks):
