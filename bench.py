@@ -49,12 +49,25 @@ def run_forward_workload(args):
       fg_infer  : BASELINE configs[1], Pix2Pix generator inference, batch 16, 192x192
       fg_resid  : the same for --block_type Residual
       fg_mru    : the same for the default --block_type MRU (configs[1] 'MRU second')
-      bg768     : BASELINE configs[4], Background_Colorization 768x768 residual generator, batch 4."""
+      bg768     : BASELINE configs[4], Background_Colorization 768x768 residual generator, batch 4
+      bg768_train: one BG training step (batch 1 as in the reference), generator + residual discriminator."""
     from sketchyscenecolorization_amd import hip
     from sketchyscenecolorization_amd.params import Buffers, ParamStore
     wl = args.workload
     torch.manual_seed(0)
-    if wl == 'bg768':
+    if wl == 'bg768_train':
+        from sketchyscenecolorization_amd.bg_colorization import BGTrainer
+        n, img = 1, (args.img if args.img != 192 else 768)      # the reference graph is built for batch 1
+        tr = BGTrainer(image_size=img)
+        x = torch.rand(n, img, img, 3, device='cuda') * 2 - 1
+        y = torch.rand(n, img, img, 3, device='cuda') * 2 - 1
+        text = torch.randint(1, 18, (n, 8), dtype=torch.int32).numpy()
+        lab = torch.randint(0, 3, (n, img, img), dtype=torch.int32, device='cuda')
+        step = lambda: tr.train_step(x, y, text, lab)
+        # FLOP figure: generator only (fwd + bwd = 3 x the 439.6 GFLOP forward of SURVEY 8a A13); the discriminator's
+        # share is not in SURVEY and is left out, so step_tflops_as_written under-counts this workload
+        flop_img, name = 3 * 439.6e9, 'Background_Colorization train step (G + residual D, fwd + bwd + Adam)'
+    elif wl == 'bg768':
         from sketchyscenecolorization_amd.residual import ResidualGenerator
         n, img = (args.batch if args.batch != 32 else 4), (args.img if args.img != 192 else 768)
         store = ParamStore('BG', 18, img, 'cuda', 0)
@@ -120,7 +133,7 @@ def run_forward_workload(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='train', choices=['train', 'fg_infer', 'fg_resid', 'fg_mru', 'bg768'],
+    ap.add_argument('--workload', default='train', choices=['train', 'fg_infer', 'fg_resid', 'fg_mru', 'bg768', 'bg768_train'],
                     help='train = the headline metric (default); the others are secondary forward-only workloads')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)

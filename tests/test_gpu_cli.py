@@ -99,3 +99,24 @@ def test_cli_inference_default_block_types(tmp_path, monkeypatch, bt):
     cli.main(args + ([] if bt == 'MRU' else ['-bt', bt]))
     o = np.array(Image.open(os.path.join(run, 'inference_results', 'bus_output.png')))
     assert o.shape == (64, 64, 3) and o.dtype == np.uint8 and o.std() > 0
+
+
+def test_bg_cli_train_resume_test(tmp_path, monkeypatch):
+    """Background_Colorization CLI on synthetic scenes: train, snapshot, resume, test-mode PNGs."""
+    import bg_colorization_main as bgcli
+    from PIL import Image
+    monkeypatch.chdir(tmp_path)
+    bgcli.main(['--mode', 'train', '--image_size', '64', '--max_steps', '3', '--save_freq', '2', '--progress_freq', '1',
+                '--summary_freq', '1'])
+    stamp = sorted(os.listdir('outputs'))[0]
+    snap = os.path.join('outputs', stamp, 'snapshot')
+    assert os.path.exists(os.path.join(snap, 'snapshot-2')) and os.path.exists(os.path.join(snap, 'snapshot-3'))
+    scal = [json.loads(l) for l in open(os.path.join('outputs', stamp, 'log', 'scalars.jsonl'))]
+    assert len(scal) == 3 and all(np.isfinite(s['gen_loss']) for s in scal)
+    bgcli.main(['--mode', 'train', '--resume_from', stamp, '--image_size', '64', '--max_steps', '4', '--save_freq', '1'])
+    assert os.path.exists(os.path.join(snap, 'snapshot-4'))
+    bgcli.main(['--mode', 'test', '--resume_from', stamp, '--image_size', '64'])
+    res = os.path.join('outputs', stamp, 'results')
+    o = np.array(Image.open(os.path.join(res, 'synthetic_0_outputs.png')))
+    assert o.shape == (64, 64, 3) and o.dtype == np.uint8
+    assert len(glob.glob(os.path.join(res, '*_inputs.png'))) == 8
