@@ -119,6 +119,8 @@ int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* d, char* buf, int len);
 int ssc_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int ldc, int coff, void* stream);
 /* dst[n,c,hw] = src[n,hw,coff+c] */
 int ssc_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, int ldc, int coff, void* stream);
+/* host-side CRC-32C (Castagnoli) of n bytes: TFRecord record framing (tf.TFRecordReader, input_pipeline.py:57-59) */
+uint32_t ssc_crc32c(const uint8_t* data, int64_t n);
 int ssc_fill(float* dst, float value, int64_t n, void* stream);
 /* ---- MRU blocks (mru.py:353-461 mru_conv_block_v3, :527-591 mru_deconv_block_v2), NHWC fp32 -------------------- */
 /* mean_pool (mru.py:15-19): out[n, y, x, c] = mean of the 2x2 block */

@@ -410,3 +410,35 @@ extern "C" int ssc_device_info(int* cu_count, int* wave_size, char* arch, int ar
     }
     return 0;
 }
+
+// ------------------------------------------------------------------ host utility: CRC-32C (Castagnoli)
+// TFRecord framing (tf.TFRecordReader, input_pipeline.py:57-59) protects every record with masked CRC-32C values;
+// the reader in sketchyscenecolorization_amd/tfrecord.py verifies them through this slice-by-8 implementation.
+static uint32_t g_crc_tab[8][256];
+static bool g_crc_ready = false;
+
+static void crc32c_init() {
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0x82f63b78u : 0u);
+        g_crc_tab[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+        for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xff];
+    g_crc_ready = true;
+}
+
+extern "C" uint32_t ssc_crc32c(const uint8_t* data, int64_t n) {
+    if (!g_crc_ready) crc32c_init();
+    uint32_t c = 0xffffffffu;
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const uint32_t lo = c ^ ((uint32_t)data[i] | ((uint32_t)data[i + 1] << 8) | ((uint32_t)data[i + 2] << 16) |
+                                 ((uint32_t)data[i + 3] << 24));
+        c = g_crc_tab[7][lo & 0xff] ^ g_crc_tab[6][(lo >> 8) & 0xff] ^ g_crc_tab[5][(lo >> 16) & 0xff] ^
+            g_crc_tab[4][lo >> 24] ^ g_crc_tab[3][data[i + 4]] ^ g_crc_tab[2][data[i + 5]] ^ g_crc_tab[1][data[i + 6]] ^
+            g_crc_tab[0][data[i + 7]];
+    }
+    for (; i < n; ++i) c = (c >> 8) ^ g_crc_tab[0][(c ^ data[i]) & 0xff];
+    return c ^ 0xffffffffu;
+}

@@ -1,7 +1,9 @@
-"""Host-side helpers of obj_lib/input_pipeline.py that the hot path's callers use
-(:11-15 num_classes, :184-196 split_inputs, :199-257 sketch pre-processing).  The TFRecord queue
-machinery is out of scope: training data comes from
-sketchyscenecolorization_amd.synthetic or from the caller."""
+"""Host side of obj_lib/input_pipeline.py: num_classes (:11-15), the paired TFRecord input queue (:43-154, read
+without TensorFlow through sketchyscenecolorization_amd.tfrecord), split_inputs (:184-196) and the sketch
+pre-processing of the inference path (:199-257)."""
+import os
+import random
+
 import numpy as np
 
 num_classes = 25
@@ -54,3 +56,96 @@ def thicken_drawings(image):
     dil = np.maximum(np.maximum(p[:-1, :-1], p[1:, :-1]), np.maximum(p[:-1, 1:], p[1:, 1:]))
     dil = 255 - dil
     return np.repeat(dil[:, :, None], 3, axis=2).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# paired TFRecord queue (get_paired_input + build_input_queue_paired, :43-154)
+# ---------------------------------------------------------------------------------------------------------------
+SIZE = {True: (64, 64), False: (192, 192)}
+RECORD_HW = 384         # "cannot change": the records hold 384x384x3 uint8 images (:77, 82)
+T_STEPS = 15
+
+
+def decode_paired_example(feat, img_dim, rng, data_format='NCHW', distance_map=False):
+    """One parsed Example -> (image, sketch) float32 in [-1,1] (NCHW), class id, caption indices [15].
+
+    tf.image.resize_images with the TF1 defaults (align_corners=False, no half-pixel centres) maps output pixel i to
+    source coordinate i * (384 / size): for the integer factors 2 (192) and 6 (64) BILINEAR is exactly the source pixel
+    at that coordinate and AREA is the mean of the factor x factor block."""
+    if distance_map:
+        raise NotImplementedError('--distance_map 1 (scipy distance transform of the sketch) is not built')
+    img = np.frombuffer(feat['cartoon_data'][0], dtype=np.uint8).astype(np.float32).reshape(RECORD_HW, RECORD_HW, 3)
+    sk = np.frombuffer(feat['sketch_data'][0], dtype=np.uint8).astype(np.float32).reshape(RECORD_HW, RECORD_HW, 3)
+    size = img_dim[0]
+    if size != RECORD_HW:
+        f = RECORD_HW // size
+        assert f * size == RECORD_HW
+        img = img[::f, ::f]
+        sk = sk.reshape(size, f, size, f, 3).mean(axis=(1, 3))
+    img = (img - img.min()) / (img.max() - img.min() + 1)
+    img = img + rng.uniform(0.0, 1.0 / 256, size=img.shape).astype(np.float32)      # dequantisation noise (:117)
+    img = img * 2.0 - 1.0
+    sk = sk / 255.0 * 2.0 - 1.0
+    if data_format == 'NCHW':
+        img, sk = img.transpose(2, 0, 1), sk.transpose(2, 0, 1)
+    text = np.frombuffer(feat['Text_vocab_indices'][0], dtype=np.uint8).astype(np.int32).reshape(T_STEPS)
+    return (np.ascontiguousarray(img, dtype=np.float32), np.ascontiguousarray(sk, dtype=np.float32),
+            int(feat['Category_id'][0]), text)
+
+
+class PairedQueue(object):
+    """build_input_queue_paired: examples of data/tfrecord/<mode>/* in shuffled order, endlessly (num_epochs=None),
+    through a shuffle buffer of ``min_after_dequeue`` decoded examples (tf.train.maybe_shuffle_batch, :143-148)."""
+
+    def __init__(self, mode, batch_size, data_format='NCHW', distance_map=False, small=False, min_after_dequeue=512,
+                 data_base_dir='data', seed=None):
+        from .. import tfrecord
+        assert mode in ('train', 'val', 'test')
+        data_dir = os.path.join(data_base_dir, 'tfrecord', mode)
+        self.files = sorted(os.path.join(data_dir, f) for f in os.listdir(data_dir)
+                            if os.path.isfile(os.path.join(data_dir, f)))
+        print('build_input_queue_paired from %s: paired file num: %d' % (data_dir, len(self.files)))
+        self.tf, self.batch_size, self.fmt, self.dm = tfrecord, batch_size, data_format, distance_map
+        self.img_dim = SIZE[bool(small)]
+        self.shuffle = mode == 'train'
+        self.min_after = min_after_dequeue if self.shuffle else 0
+        self.rng = random.Random(seed)
+        self.np_rng = np.random.RandomState(self.rng.randrange(2 ** 31))
+        self.buf = []
+        self._it = self._examples()
+
+    def _examples(self):
+        while True:
+            files = list(self.files)
+            if self.shuffle:
+                self.rng.shuffle(files)
+            for path in files:
+                for rec in self.tf.read_records(path):
+                    yield decode_paired_example(self.tf.parse_example(rec), self.img_dim, self.np_rng, self.fmt, self.dm)
+            if not self.shuffle:
+                return
+
+    def _next(self):
+        while len(self.buf) <= self.min_after:
+            try:
+                self.buf.append(next(self._it))
+            except StopIteration:
+                break
+        if not self.buf:
+            raise StopIteration
+        i = self.rng.randrange(len(self.buf)) if self.shuffle else 0
+        return self.buf.pop(i)
+
+    def dequeue(self):
+        """One batch: (images [N,3,h,w], sketches, class ids int32 [N], caption indices int32 [N,15])."""
+        ex = [self._next() for _ in range(self.batch_size)]
+        return (np.stack([e[0] for e in ex]), np.stack([e[1] for e in ex]),
+                np.array([e[2] for e in ex], dtype=np.int32), np.stack([e[3] for e in ex]))
+
+
+def build_input_queue_paired(mode, batch_size, data_format='NCHW', distance_map=False, small=False, one_hot=False,
+                             capacity=8192, min_after_dequeue=512, data_base_dir='data'):
+    """Reference signature (:131-154).  Returns the queue; ``queue.dequeue()`` yields what the reference's seven
+    tensors carry that the model uses (images, sketches, dense labels, caption indices)."""
+    assert mode in ['train'] and not one_hot
+    return PairedQueue(mode, batch_size, data_format, distance_map, small, min_after_dequeue, data_base_dir)

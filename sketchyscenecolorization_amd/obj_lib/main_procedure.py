@@ -82,6 +82,33 @@ class SyntheticQueue(object):
         return f
 
 
+class RecordQueue(object):
+    """The same interface over the reference's TFRecords: queue 1 feeds (images, sketches, class_id, text), an
+    independently shuffled queue 2 the discriminator's real images and labels (main_procedure.py:109-122)."""
+
+    def __init__(self, batch_size, small, which, data_base_dir='data'):
+        from .input_pipeline import PairedQueue
+        self.q = PairedQueue('train', batch_size, Config.data_format, Config.distance_map != 0, small,
+                             data_base_dir=data_base_dir)
+        self.which = which
+        self.cur = None
+
+    def advance(self):
+        images, sketches, class_id, text = self.q.dequeue()
+        dev = lambda a: torch.from_numpy(a).cuda()
+        if self.which == 1:
+            self.cur = {'images': dev(images), 'sketches': dev(sketches), 'class_id': dev(class_id), 'text': text}
+        else:
+            self.cur = {'images_d': dev(images), 'class_id_d': dev(class_id)}
+
+    def field(self, name, advance=False):
+        def f():
+            if advance or self.cur is None:
+                self.advance()
+            return self.cur[name]
+        return f
+
+
 def _write_png(path, arr_uint8):
     from PIL import Image
     Image.fromarray(arr_uint8).save(path)
@@ -125,8 +152,13 @@ def train(**kwargs):
 
     # two INDEPENDENT queues, as in the reference (main_procedure.py:109-122): the discriminator's
     # "real" images are not paired with the sketches it sees
-    q1 = SyntheticQueue(batch_size * num_gpu, img, Config.vocab_size, seed=1234 + 1000 * rank)
-    q2 = SyntheticQueue(batch_size * num_gpu, img, Config.vocab_size, seed=998244 + 1000 * rank)
+    if os.path.isdir(os.path.join('data', 'tfrecord', 'train')):     # the reference's dataset location (:109-122)
+        q1 = RecordQueue(batch_size * num_gpu, small, 1)
+        q2 = RecordQueue(batch_size * num_gpu, small, 2)
+    else:
+        print('data/tfrecord/train not found: training on seeded synthetic batches')
+        q1 = SyntheticQueue(batch_size * num_gpu, img, Config.vocab_size, seed=1234 + 1000 * rank)
+        q2 = SyntheticQueue(batch_size * num_gpu, img, Config.vocab_size, seed=998244 + 1000 * rank)
     opt_g, opt_d, loss_g, loss_d, merged_all = build_multi_tower_graph(
         q1.field('images', advance=True), q1.field('sketches'), q2.field('images_d', advance=True),
         q1.field('class_id'), q2.field('class_id_d'), q1.field('text'),

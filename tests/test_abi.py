@@ -25,6 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert names == set(hip.SIGNATURES), names ^ set(hip.SIGNATURES)
     assert lib.ssc_version() >= 100
+    assert hasattr(lib, 'ssc_crc32c')      # the one non-int entry point (host CRC-32C for the TFRecord reader)
 
 
 def test_struct_layouts_match_header():

@@ -120,3 +120,26 @@ def test_bg_cli_train_resume_test(tmp_path, monkeypatch):
     o = np.array(Image.open(os.path.join(res, 'synthetic_0_outputs.png')))
     assert o.shape == (64, 64, 3) and o.dtype == np.uint8
     assert len(glob.glob(os.path.join(res, '*_inputs.png'))) == 8
+
+
+def test_cli_trains_from_tfrecords(tmp_path, monkeypatch):
+    """--mode train reads data/tfrecord/train (the reference's dataset location) through the TensorFlow-free reader."""
+    import obj_colorization_main as cli
+    from sketchyscenecolorization_amd import tfrecord as tf
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.RandomState(0)
+    os.makedirs('data/tfrecord/train')
+    recs = []
+    for i in range(6):
+        sk = np.full((384, 384, 3), 255, np.uint8)
+        sk[60 * i:60 * i + 6, 40:340] = 0
+        text = np.zeros(15, np.uint8)
+        text[-3:] = [3, 4, 5]
+        recs.append(tf.make_example({'ImageName': b'x.png', 'cartoon_data': rng.randint(0, 256, (384, 384, 3)).astype(np.uint8).tobytes(),
+                                     'sketch_data': sk.tobytes(), 'Category': b'car', 'Category_id': i % 25,
+                                     'Color_text': b'the car is red', 'Text_vocab_indices': text.tobytes()}))
+    tf.write_records('data/tfrecord/train/a.tfrecord', recs)
+    cli.main(['--mode', 'train', '-bt', 'Pix2Pix', '-si', '1', '-bs', '2', '-mi', '2', '-smf', '1', '-swf', '1'])
+    run = os.path.join('outputs', sorted(os.listdir('outputs'))[0])
+    scal = [json.loads(l) for l in open(os.path.join(run, 'log', 'scalars.jsonl'))]
+    assert len(scal) == 2 and all(np.isfinite(s['total_loss/g']) for s in scal)
