@@ -90,7 +90,8 @@ def decode_paired_example(feat, img_dim, rng, data_format='NCHW', distance_map=F
         img, sk = img.transpose(2, 0, 1), sk.transpose(2, 0, 1)
     text = np.frombuffer(feat['Text_vocab_indices'][0], dtype=np.uint8).astype(np.int32).reshape(T_STEPS)
     return (np.ascontiguousarray(img, dtype=np.float32), np.ascontiguousarray(sk, dtype=np.float32),
-            int(feat['Category_id'][0]), text)
+            int(feat['Category_id'][0]), text, feat.get('Category', [b''])[0].decode('utf-8', 'replace'),
+            feat.get('ImageName', [b''])[0].decode('utf-8', 'replace'))
 
 
 class PairedQueue(object):
@@ -136,11 +137,27 @@ class PairedQueue(object):
         i = self.rng.randrange(len(self.buf)) if self.shuffle else 0
         return self.buf.pop(i)
 
-    def dequeue(self):
-        """One batch: (images [N,3,h,w], sketches, class ids int32 [N], caption indices int32 [N,15])."""
-        ex = [self._next() for _ in range(self.batch_size)]
-        return (np.stack([e[0] for e in ex]), np.stack([e[1] for e in ex]),
-                np.array([e[2] for e in ex], dtype=np.int32), np.stack([e[3] for e in ex]))
+    def dequeue(self, with_names=False):
+        """One batch: (images [N,3,h,w], sketches, class ids int32 [N], caption indices int32 [N,15])
+        [+ category names, image names].  Raises StopIteration when a val / test epoch is exhausted."""
+        ex = []
+        for _ in range(self.batch_size):
+            try:
+                ex.append(self._next())
+            except StopIteration:
+                break
+        if len(ex) < self.batch_size:       # tf.train.maybe_batch drops the incomplete final batch
+            raise StopIteration
+        out = (np.stack([e[0] for e in ex]), np.stack([e[1] for e in ex]),
+               np.array([e[2] for e in ex], dtype=np.int32), np.stack([e[3] for e in ex]))
+        return out + ([e[4] for e in ex], [e[5] for e in ex]) if with_names else out
+
+
+def build_input_queue_paired_test(mode, batch_size, data_format='NCHW', distance_map=False, small=False, one_hot=False,
+                                  capacity=8192, data_base_dir='data'):
+    """Reference signature (:157-181): one unshuffled epoch of data/tfrecord/<val|test>."""
+    assert mode in ['test', 'val'] and not one_hot
+    return PairedQueue(mode, batch_size, data_format, distance_map, small, 0, data_base_dir)
 
 
 def build_input_queue_paired(mode, batch_size, data_format='NCHW', distance_map=False, small=False, one_hot=False,

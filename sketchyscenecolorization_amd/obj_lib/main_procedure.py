@@ -326,9 +326,9 @@ def test():
 
 
 def validation(**kwargs):
-    """The reference validates from the data/tfrecord/val queue (main_procedure.py:245-358); with the
-    TFRecord pipeline out of scope this runs one synthetic batch through the restored generator and writes
-    validation_results/with_text/<category>_<name>_{output,target,input}.png."""
+    """The reference validates from the data/tfrecord/val queue (main_procedure.py:245-358): here the
+    restored generator runs over data/tfrecord/val when that directory exists, otherwise over one seeded synthetic
+    batch, and writes validation_results/with_text/<category>_<name>_{output,target,input}.png."""
     small = Config.small_img != 0
     img = SIZE[small][0]
     from ..synthetic import synthetic_batch
@@ -337,15 +337,30 @@ def validation(**kwargs):
     restore_checkpoint(store, latest_checkpoint(Config.ckpt_dir))
     out_dir = os.path.join(Config.results_dir, 'with_text' if Config.LSTM_hybrid != 0 else 'without_text')
     os.makedirs(out_dir, exist_ok=True)
+
+    def run(images_, sketches_, class_id_, text_, stems):
+        gen, images, sketches = build_single_graph(images_, sketches_, None, class_id_, None, text_,
+                                                   batch_size=Config.batch_size, training=False,
+                                                   LSTM_hybrid=Config.LSTM_hybrid != 0, vocab_size=Config.vocab_size,
+                                                   data_format=Config.data_format, distance_map=False,
+                                                   block_type=Config.block_type)
+        for i, stem in enumerate(stems):
+            _write_png(os.path.join(out_dir, stem + '_output.png'), _postprocess(gen)[i])
+            _write_png(os.path.join(out_dir, stem + '_target.png'), _postprocess(images)[i])
+            _write_png(os.path.join(out_dir, stem + '_input.png'), _postprocess(sketches)[i])
+
+    if os.path.isdir(os.path.join('data', 'tfrecord', 'val')):      # the reference's validation set (:262-272)
+        from .input_pipeline import build_input_queue_paired_test
+        q = build_input_queue_paired_test('val', Config.batch_size, data_format=Config.data_format, small=small)
+        while True:
+            try:
+                images, sketches, cls, text, cats, names = q.dequeue(with_names=True)
+            except StopIteration:
+                break
+            run(torch.from_numpy(images).cuda(), torch.from_numpy(sketches).cuda(), torch.from_numpy(cls).cuda(), text,
+                ['%s_%s' % (c, n[:-4] if n.endswith('.png') else n) for c, n in zip(cats, names)])
+        return
     b = synthetic_batch(Config.batch_size, 4321, img, Config.vocab_size)
-    gen, images, sketches = build_single_graph(b['images'], b['sketches'], None, b['class_id'], None, b['text'],
-                                               batch_size=Config.batch_size, training=False,
-                                               LSTM_hybrid=Config.LSTM_hybrid != 0, vocab_size=Config.vocab_size,
-                                               data_format=Config.data_format, distance_map=False,
-                                               block_type=Config.block_type)
     cls = b['class_id'].cpu().numpy()
-    for i in range(Config.batch_size):
-        stem = '%s_%04d' % (CATEGORIES[int(cls[i])], i)
-        _write_png(os.path.join(out_dir, stem + '_output.png'), _postprocess(gen)[i])
-        _write_png(os.path.join(out_dir, stem + '_target.png'), _postprocess(images)[i])
-        _write_png(os.path.join(out_dir, stem + '_input.png'), _postprocess(sketches)[i])
+    run(b['images'], b['sketches'], b['class_id'], b['text'],
+        ['%s_%04d' % (CATEGORIES[int(cls[i])], i) for i in range(Config.batch_size)])

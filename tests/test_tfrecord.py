@@ -67,6 +67,16 @@ def test_paired_queue_decodes_like_the_reference_graph(tmp_path, small):
         assert np.abs(images[b].transpose(1, 2, 0) - ref).max() <= 2.0 / 256 + 1e-6        # + dequantisation noise
         area = sk.reshape(size, f, size, f, 3).mean(axis=(1, 3)) / 255.0 * 2 - 1
         assert np.abs(sketches[b].transpose(1, 2, 0) - area).max() < 1e-6
+    vq = PairedQueue('train', 2, small=small, min_after_dequeue=0, data_base_dir=os.path.join(tmp_path, 'data'), seed=1)
+    vq.shuffle = False                                      # the val / test queue: file order, one epoch, names kept
+    vq._it = vq._examples()
+    got = []
+    while True:
+        try:
+            got += vq.dequeue(with_names=True)[5]
+        except StopIteration:
+            break
+    assert got == ['car_0.png', 'car_1.png', 'car_2.png', 'car_3.png']      # the incomplete last batch is dropped
     seen = set(int(c) for c in cls)
     for _ in range(5):
         seen |= set(int(c) for c in q.dequeue()[2])
