@@ -46,12 +46,34 @@ def latest_checkpoint(ckpt_dir):
     with open(idx) as f:
         line = f.readline()
     name = line.split('"')[1]
-    path = os.path.join(ckpt_dir, name)
-    return path if os.path.exists(path) else None
+    path = os.path.join(ckpt_dir, os.path.basename(name))
+    return path if (os.path.exists(path) or os.path.exists(path + '.index')) else None
 
 
 def restore_checkpoint(store, path):
-    store.load_state_dict(torch.load(path, map_location='cpu'))
+    """Our own snapshots (torch files) or a TensorFlow V2 checkpoint prefix written by tf.train.Saver -- e.g. the
+    authors' released models dropped into outputs/<stamp>/snapshot: variables are matched by their TF names, the
+    Adam second-moment slots ('<var>/Adam_1') and step counts ('beta2_power') are taken over when present."""
+    from .. import tf_checkpoint
+    if not tf_checkpoint.is_tf_checkpoint(path):
+        store.load_state_dict(torch.load(path, map_location='cpu'))
+        return
+    tensors = tf_checkpoint.read_checkpoint(path)
+    store.load_dict(tensors)
+    missing = [n for n in store.names() if n not in tensors]
+    if missing:
+        print('restore_checkpoint: %d variables not in %s (kept at their initial values), e.g. %s'
+              % (len(missing), path, missing[:3]))
+    for sc in (store.generator, store.discriminator):
+        for n, (off, k, _shape) in sc.offsets.items():
+            slot = tensors.get(n + '/Adam_1')
+            if slot is not None and slot.size == k:
+                sc.adam_v[off:off + k].copy_(torch.from_numpy(slot.reshape(-1)))
+    for key, val in tensors.items():        # beta2_power = beta2 ** t of each optimizer (generator built first)
+        if key.split('/')[-1].startswith('beta2_power') and 0.0 < float(val) < 1.0:
+            t = int(round(np.log(float(val)) / np.log(0.9)))
+            sc = store.discriminator if key.split('/')[-1].endswith('_1') else store.generator
+            sc.adam_t = t
 
 
 def print_parameter_count(store, verbose=False):
