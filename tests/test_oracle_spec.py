@@ -136,3 +136,123 @@ def test_lr_decay_schedule():
     assert T.lr_decay(0, 100000) == 1.0
     assert abs(T.lr_decay(50000, 100000) - 0.55) < 1e-6
     assert abs(T.lr_decay(99999, 100000) - 0.2) < 1e-6
+
+
+# --------------------------------------------------------------------------- ops of the MRU / Residual / BG oracles
+def test_mean_pool_upsample_and_area_resize_specs():
+    from oracle import mru as M
+    x = rnd(2, 3, 8, 12, seed=4)
+    t = torch.tensor(x)
+    mp = M.mean_pool(t).numpy()
+    up = M.upsample(t).numpy()
+    for i in range(4):
+        for j in range(6):
+            blk = x[:, :, 2 * i:2 * i + 2, 2 * j:2 * j + 2]
+            assert np.abs(mp[:, :, i, j] - blk.sum(axis=(2, 3)) / 4.0).max() < 1e-12        # mru.py:15-19
+    for i in range(16):
+        for j in range(24):
+            assert np.array_equal(up[:, :, i, j], x[:, :, i // 2, j // 2])                    # concat x4 + depth_to_space(2)
+    assert np.abs(M.mean_pool(M.upsample(t)).numpy() - x).max() < 1e-12
+    sq = rnd(1, 3, 8, 8, seed=5)
+    area = M.image_resize_area(torch.tensor(sq), 2).numpy()                                  # AREA, integer factor 4
+    for i in range(2):
+        for j in range(2):
+            assert np.abs(area[:, :, i, j] - sq[:, :, 4 * i:4 * i + 4, 4 * j:4 * j + 4].mean(axis=(2, 3))).max() < 1e-12
+
+
+def test_conditional_batchnorm_and_minmax_gate_specs():
+    from oracle import mru as M
+    x = rnd(3, 4, 5, 6, seed=6)
+    labels = np.array([2, 0, 2])
+    p = {'s/offset': torch.tensor(rnd(5, 4, seed=7)), 's/scale': torch.tensor(rnd(5, 4, seed=8))}
+    got = M.cond_batchnorm(p, 's', torch.tensor(x), torch.tensor(labels)).numpy()
+    mean = x.mean(axis=(0, 2, 3))
+    var = ((x - mean[None, :, None, None]) ** 2).mean(axis=(0, 2, 3))                        # biased, over N,H,W
+    for n in range(3):
+        for c in range(4):
+            ref = (x[n, c] - mean[c]) / math.sqrt(var[c] + 1e-5) * p['s/scale'][labels[n], c].item() + \
+                p['s/offset'][labels[n], c].item()
+            assert np.abs(got[n, c] - ref).max() < 1e-10
+    g = M._minmax(torch.tensor(x)).numpy()
+    for n in range(3):
+        for c in range(4):
+            lo, hi = x[n, c].min(), x[n, c].max()
+            assert np.abs(g[n, c] - (x[n, c] - lo) / (hi - lo)).max() < 1e-12 and g[n, c].min() == 0.0 and g[n, c].max() == 1.0
+    z = np.linspace(-3, 3, 13)
+    assert np.abs(T.miu_relu(torch.tensor(z)).numpy() - (z + np.sqrt(0.09 + z * z)) / 2).max() < 1e-12
+
+
+def test_bottleneck_blocks_against_loop_spec():
+    """bottleneck_residual_en / pu / de (residual_util.py:81-171) composed from the loop conv above."""
+    from oracle import residual as R
+    rs = np.random.RandomState(9)
+    cin, cout = 8, 16
+    c4 = cout // 4
+
+    def bn(v, scale, offset):
+        m = v.mean(axis=(0, 2, 3), keepdims=True)
+        var = ((v - m) ** 2).mean(axis=(0, 2, 3), keepdims=True)
+        return (v - m) / np.sqrt(var + 1e-5) * scale[None, :, None, None] + offset[None, :, None, None]
+
+    lrelu = lambda v: 0.6 * v + 0.4 * np.abs(v)          # the algebraic form of residual_util.py:45-54
+    p = {}
+    for blk, shape in (('block_1/conv', (4, 4, cin, c4)), ('block_2/conv_ex', (3, 3, c4, c4)),
+                       ('block_3/conv_ex', (1, 1, c4, cout)), ('block_add/conv', (4, 4, cin, cout))):
+        p['e/' + blk + '/filter'] = rs.randn(*shape) * 0.2
+        b = blk.split('/')[0]
+        p['e/%s/batchnorm/scale' % b] = 1 + 0.1 * rs.randn(shape[3])
+        p['e/%s/batchnorm/offset' % b] = 0.1 * rs.randn(shape[3])
+    x = rs.randn(2, cin, 8, 8)
+    y = lrelu(bn(spec_conv(x, p['e/block_1/conv/filter'], 2, (1, 1, 1, 1)), p['e/block_1/batchnorm/scale'],
+                 p['e/block_1/batchnorm/offset']))
+    y = lrelu(bn(spec_conv(y, p['e/block_2/conv_ex/filter'], 1, (1, 1, 1, 1)), p['e/block_2/batchnorm/scale'],
+                 p['e/block_2/batchnorm/offset']))
+    y = bn(spec_conv(y, p['e/block_3/conv_ex/filter'], 1, (0, 0, 0, 0)), p['e/block_3/batchnorm/scale'],
+           p['e/block_3/batchnorm/offset'])
+    sc = bn(spec_conv(x, p['e/block_add/conv/filter'], 2, (1, 1, 1, 1)), p['e/block_add/batchnorm/scale'],
+            p['e/block_add/batchnorm/offset'])
+    ref = lrelu(y + sc)
+    got = R.bottleneck_residual_en({k: torch.tensor(v) for k, v in p.items()}, 'e', torch.tensor(x), 2).numpy()
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-9
+    # identity ("pu") unit, decoder flavour: 4x4 s1 SAME pads (1, 2) -- the asymmetric case
+    q = {}
+    for blk, shape in (('block_1/conv_ex', (4, 4, cout, c4)), ('block_2/conv_ex', (3, 3, c4, c4)),
+                       ('block_3/conv_ex', (1, 1, c4, cout))):
+        q['u/' + blk + '/filter'] = rs.randn(*shape) * 0.2
+        b = blk.split('/')[0]
+        q['u/%s/batchnorm/scale' % b] = 1 + 0.1 * rs.randn(shape[3])
+        q['u/%s/batchnorm/offset' % b] = 0.1 * rs.randn(shape[3])
+    relu = lambda v: np.maximum(v, 0)
+    z = relu(bn(spec_conv(ref, q['u/block_1/conv_ex/filter'], 1, (1, 2, 1, 2)), q['u/block_1/batchnorm/scale'],
+                q['u/block_1/batchnorm/offset']))
+    z = relu(bn(spec_conv(z, q['u/block_2/conv_ex/filter'], 1, (1, 1, 1, 1)), q['u/block_2/batchnorm/scale'],
+                q['u/block_2/batchnorm/offset']))
+    z = bn(spec_conv(z, q['u/block_3/conv_ex/filter'], 1, (0, 0, 0, 0)), q['u/block_3/batchnorm/scale'],
+           q['u/block_3/batchnorm/offset'])
+    ref_pu = relu(z + ref)
+    got_pu = R.bottleneck_residual_pu({k: torch.tensor(v) for k, v in q.items()}, 'u', torch.tensor(ref), False).numpy()
+    assert np.abs(got_pu - ref_pu).max() < 1e-9
+
+
+def test_bg_losses_and_lr_schedule_specs():
+    from oracle import residual as R
+    rs = np.random.RandomState(11)
+    out, tgt = rs.uniform(-1, 1, (1, 4, 4, 3)), rs.uniform(-1, 1, (1, 4, 4, 3))
+    logits = rs.randn(1, 4, 4, 3)
+    pr, pf = rs.uniform(0.05, 0.95, (1, 2, 2, 5)), rs.uniform(0.05, 0.95, (1, 2, 2, 5))
+    labels = rs.randint(0, 3, (1, 4, 4))
+    d, g, parts = R.bg_losses(torch.tensor(out), torch.tensor(logits), torch.tensor(pr), torch.tensor(pf), torch.tensor(tgt),
+                              torch.tensor(labels))
+    d_ref = np.mean(-(np.log(pr + 1e-12) + np.log(1 - pf + 1e-12)))
+    gan_ref = np.mean(-np.log(pf + 1e-12))
+    sel = labels.reshape(-1) != 0
+    l1_ref = np.abs(tgt - out).reshape(-1, 3)[sel].mean()
+    lg = logits.reshape(-1, 3)
+    ce = -(lg[np.arange(16), labels.reshape(-1)] - np.log(np.exp(lg).sum(axis=1)))
+    assert abs(float(d) - d_ref) < 1e-12 and abs(float(parts['gen_loss_GAN']) - gan_ref) < 1e-12
+    assert abs(float(parts['gen_loss_L1']) - l1_ref) < 1e-12 and abs(float(parts['region_mask_loss']) - ce.mean()) < 1e-12
+    assert abs(float(g) - (gan_ref + 100 * l1_ref + 100 * ce.mean())) < 1e-9
+    # tf.train.polynomial_decay(lr, step, 0.75*max, lr/10, power=0.9), clipped at decay_steps
+    assert R.bg_learning_rate(2e-4, 0, 1000) == 2e-4
+    assert abs(R.bg_learning_rate(2e-4, 375, 1000) - ((2e-4 - 2e-5) * 0.5 ** 0.9 + 2e-5)) < 1e-18
+    assert R.bg_learning_rate(2e-4, 750, 1000) == R.bg_learning_rate(2e-4, 999, 1000) == 2e-5
