@@ -268,7 +268,7 @@ def build_single_graph_f64(p, generator=None, discriminator=None, **batch):
     torch.set_default_dtype(torch.float64)
     try:
         p64 = OrderedDict((k, v.double()) for k, v in p.items())
-        b64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+        b64 = {k: (v.double() if torch.is_tensor(v) and v.dtype == torch.float32 else v) for k, v in batch.items()}
         return build_single_graph(p64, generator=generator, discriminator=discriminator, **b64)
     finally:
         torch.set_default_dtype(old)
