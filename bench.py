@@ -28,7 +28,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 F_G, F_D = 10.84e9, 3.55e9         # forward FLOPs per image as written in the reference
 
 
-def cpu_baseline(img, n=4):
+def cpu_baseline(img, n=8):
     """Reference arithmetic on the host CPU: one D-step + one G-step of the torch-fp32 oracle."""
     from oracle import pix2pix as O
     torch.manual_seed(0)
