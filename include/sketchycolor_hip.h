@@ -272,6 +272,11 @@ int ssc_seg_ce_loss(const float* logits, int K, const int32_t* labels, int64_t M
  * from the device scalar lr_dev when it is not NULL (so a captured hipGraph can be replayed with a new step size) */
 int ssc_adam_tf(float* var, const float* grad, float* m, float* v, int64_t n, float lr_t, const float* lr_dev,
                 float beta1, float beta2, float eps, float gscale, void* stream);
+/* the other optimizers get_optimizer offers (graph_single.py:584-593), TF dense-apply formulas: kind 1 RMSProp
+ * (h0 = decay, h1 = momentum, h2 = epsilon; s1 = ms, s2 = mom), 2 Adagrad (s1 = accumulator), 3 Adadelta (h0 = rho,
+ * h2 = epsilon; s1 = accum, s2 = accum_update).  lr is read from device memory; grad is scaled by gscale first. */
+int ssc_optimizer_step(int kind, float* var, const float* grad, float* s1, float* s2, int64_t n, const float* lr_dev,
+                       float h0, float h1, float h2, float gscale, void* stream);
 /* spectral_normed_weight, one power iteration (sn.py:12-52) and its full gradient */
 int ssc_sn_forward(const float* W, const float* u, int m, int n, float* v, float* u_new, float* wbar, float* aux,
                    void* stream);

@@ -141,6 +141,30 @@ def tf_adam_update(var, grad, v, t, lr, beta1=0.0, beta2=0.9, eps=1e-8, m=None):
     return var
 
 
+def tf_rmsprop_update(var, grad, ms, mom, lr, decay=0.9, momentum=0.0, eps=1e-10):
+    """tf.train.RMSPropOptimizer dense apply (graph_single.py:586; ``ms`` starts at ones, ``mom`` at zeros)."""
+    ms.add_((grad * grad - ms) * (1.0 - decay))
+    mom.mul_(momentum).add_(lr * grad / torch.sqrt(ms + eps))
+    var.sub_(mom)
+    return var
+
+
+def tf_adagrad_update(var, grad, acc, lr):
+    """tf.train.AdagradOptimizer dense apply (graph_single.py:592-593; accumulator starts at 0.1)."""
+    acc.add_(grad * grad)
+    var.sub_(lr * grad / torch.sqrt(acc))
+    return var
+
+
+def tf_adadelta_update(var, grad, accum, accum_update, lr, rho=0.95, eps=1e-8):
+    """tf.train.AdadeltaOptimizer dense apply (graph_single.py:590-591; both slots start at zeros)."""
+    accum.mul_(rho).add_(grad * grad, alpha=1.0 - rho)
+    upd = torch.sqrt(accum_update + eps) / torch.sqrt(accum + eps) * grad
+    accum_update.mul_(rho).add_(upd * upd, alpha=1.0 - rho)
+    var.sub_(lr * upd)
+    return var
+
+
 def lr_decay(counter, max_iter_step):
     """graph_single.py:139: max(0.2, 1 - counter/max_iter*0.9) in fp32."""
     c = torch.tensor(float(counter), dtype=torch.float32)

@@ -199,6 +199,51 @@ extern "C" int ssc_adam_tf(float* var, const float* grad, float* m, float* v, in
     return CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------ the other optimizers of get_optimizer (graph_single.py:584-593)
+// kind 1: tf.train.RMSPropOptimizer(lr, decay=h0, momentum=h1, epsilon=h2)  (slots: s1 = ms [init 1], s2 = mom [init 0])
+//         ms += (g*g - ms)*(1-decay); mom = momentum*mom + lr*g*rsqrt(ms + eps); var -= mom
+// kind 2: tf.train.AdagradOptimizer(lr)  (s1 = accumulator [init 0.1]):  acc += g*g; var -= lr*g*rsqrt(acc)
+// kind 3: tf.train.AdadeltaOptimizer(lr, rho=h0, epsilon=h2)  (s1 = accum, s2 = accum_update [init 0]):
+//         accum = rho*accum + (1-rho)*g*g; upd = sqrt(accum_update+eps)*rsqrt(accum+eps)*g;
+//         accum_update = rho*accum_update + (1-rho)*upd*upd; var -= lr*upd
+__global__ void optimizer_step_kernel(int kind, float* __restrict__ var, const float* __restrict__ grad,
+                                      float* __restrict__ s1, float* __restrict__ s2, long n,
+                                      const float* __restrict__ lr_dev, float h0, float h1, float h2, float gscale) {
+    const float lr = *lr_dev;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float g = grad[i] * gscale;
+        if (kind == 1) {
+            const float ms = s1[i] + (g * g - s1[i]) * (1.f - h0);
+            const float mom = h1 * s2[i] + lr * g * rsqrtf(ms + h2);
+            s1[i] = ms;
+            s2[i] = mom;
+            var[i] -= mom;
+        } else if (kind == 2) {
+            const float acc = s1[i] + g * g;
+            s1[i] = acc;
+            var[i] -= lr * g * rsqrtf(acc);
+        } else {
+            const float acc = h0 * s1[i] + (1.f - h0) * g * g;
+            const float upd = sqrtf(s2[i] + h2) * rsqrtf(acc + h2) * g;
+            s1[i] = acc;
+            s2[i] = h0 * s2[i] + (1.f - h0) * upd * upd;
+            var[i] -= lr * upd;
+        }
+    }
+}
+
+extern "C" int ssc_optimizer_step(int kind, float* var, const float* grad, float* s1, float* s2, int64_t n,
+                                  const float* lr_dev, float h0, float h1, float h2, float gscale, void* stream) {
+    if (kind < 1 || kind > 3 || lr_dev == nullptr || s1 == nullptr || (kind != 2 && s2 == nullptr)) return -1;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(optimizer_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, kind, var, grad,
+                       s1, s2, (long)n, lr_dev, h0, h1, h2, gscale);
+    return CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ spectral norm (sn.py:12-52, num_iters = 1)
 // W [m, n] row-major (n <= 64), u [n].  One workgroup.
 //   a = u W^T; v = a/(|a|+eps); b = v W; u' = b/(|b|+eps); sigma = b.u'; Wbar = W/sigma

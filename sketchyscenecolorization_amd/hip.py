@@ -98,6 +98,7 @@ SIGNATURES = {
     'ssc_sn_forward': [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     'ssc_sn_backward': [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P],
     'ssc_axpy': [_P, _P, _F, _L, _P],
+    'ssc_optimizer_step': [_I, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P],
     'ssc_bg_gan_loss': [_P, _L, _I, _F, _P, _P, _F, _P],
     'ssc_count_nonzero_i32': [_P, _L, _P, _P, _L, _P],
     'ssc_bg_output_grad': [_P, _P, _P, _P, _F, _P, _P, _P, _L, _P],

@@ -47,11 +47,14 @@ def _batch(images, sketches, images_d, cls, cls_d, text, noise_vec=None):
 
 
 def get_optimizer(optimizer_name, **kwargs):
-    """graph_single.py:584-593.  Only Adam(beta1=0, beta2=0.9) is a live path in the reference."""
-    if optimizer_name.lower() != 'adam':
-        raise NotImplementedError('--optimizer %s: the reference default (Adam, beta1=0, beta2=0.9) is the only '
-                                  'optimizer built' % optimizer_name)
-    return {'name': 'Adam', 'beta1': 0.0, 'beta2': 0.9}
+    """graph_single.py:584-593: the optimizer family and its fixed hyper-parameters."""
+    table = {'rmsprop': {'name': 'RMSProp', 'decay': 0.9, 'momentum': 0.0, 'epsilon': 1e-10},
+             'adam': {'name': 'Adam', 'beta1': 0.0, 'beta2': 0.9},
+             'adadelta': {'name': 'AdaDelta', 'rho': 0.95, 'epsilon': 1e-8},
+             'adagrad': {'name': 'AdaGrad', 'initial_accumulator_value': 0.1}}
+    if optimizer_name.lower() not in table:
+        raise ValueError('unknown optimizer %r' % optimizer_name)
+    return table[optimizer_name.lower()]
 
 
 def build_single_graph(images, sketches, images_d, image_data_class_id, image_data_class_id_d,
@@ -162,7 +165,7 @@ def build_multi_tower_graph(images, sketches, images_d, image_paired_class_ids, 
         pg, rank, world = dist.group.WORLD, dist.get_rank(), num_gpu
     probe = _value(sketches)
     img = probe.shape[2]
-    tr = models.get_trainer(block_type, vocab_size, img, process_group=pg)
+    tr = models.get_trainer(block_type, vocab_size, img, process_group=pg, optimizer=optimizer)
     tr.G.lstm_hybrid = bool(LSTM_hybrid)
     tr.lr_g, tr.lr_d = learning_rates['generator'], learning_rates['discriminator']
     tr.max_iter_step = max_iter_step

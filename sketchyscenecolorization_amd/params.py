@@ -358,6 +358,8 @@ class ParamStore(object):
         for sc in (self.generator, self.discriminator):
             out['__adam_v__/' + sc.name] = sc.adam_v.detach().cpu()
             out['__adam_t__/' + sc.name] = torch.tensor(sc.adam_t)
+            if sc.adam_m is not None:           # second optimizer slot (Adam beta1 != 0, RMSProp, AdaDelta)
+                out['__adam_m__/' + sc.name] = sc.adam_m.detach().cpu()
         return out
 
     def load_state_dict(self, sd):
@@ -366,6 +368,8 @@ class ParamStore(object):
             if '__adam_v__/' + sc.name in sd:
                 sc.adam_v.copy_(sd['__adam_v__/' + sc.name])
                 sc.adam_t = int(sd['__adam_t__/' + sc.name])
+            if sc.adam_m is not None and '__adam_m__/' + sc.name in sd:
+                sc.adam_m.copy_(sd['__adam_m__/' + sc.name])
 
     def parameter_count(self, scope):
         return sum(k for _, (o, k, s) in self.scope(scope).offsets.items())

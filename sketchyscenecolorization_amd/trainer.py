@@ -31,7 +31,7 @@ class GanTrainer(object):
 
     def __init__(self, img=192, vocab_size=58, lstm_hybrid=True, lr_g=2e-4, lr_d=1e-4, max_iter_step=100000,
                  seed=0, sn=True, process_group=None, device='cuda', use_graphs=False, block_type='Pix2Pix',
-                 segment_graphs=None, overlap_wgrad=None):
+                 segment_graphs=None, overlap_wgrad=None, optimizer='Adam'):
         if not torch.cuda.is_available():
             raise RuntimeError('GanTrainer needs an MI355X (HIP) device: there is no CPU fallback')
         hip.lib()
@@ -53,6 +53,19 @@ class GanTrainer(object):
             raise NotImplementedError('training for block_type %r is not built' % block_type)
         self.lr_g, self.lr_d, self.max_iter_step = lr_g, lr_d, max_iter_step
         self.beta1, self.beta2, self.eps = 0.0, 0.9, 1e-8     # graph_single.py:588
+        # get_optimizer (graph_single.py:584-593): Adam(beta1=0, beta2=0.9) is the CLI default; RMSProp(decay 0.9,
+        # momentum 0, eps 1e-10), AdaGrad and AdaDelta (TF defaults) are selectable.  Slot 1 lives in scope.adam_v.
+        self.optimizer = {'adam': 'adam', 'rmsprop': 'rmsprop', 'adagrad': 'adagrad', 'adadelta': 'adadelta'}.get(
+            optimizer.lower())
+        if self.optimizer is None:
+            raise ValueError('unknown optimizer %r' % optimizer)
+        for sc in (self.store.generator, self.store.discriminator):
+            if self.optimizer == 'rmsprop':
+                sc.adam_v.fill_(1.0)            # the rms slot starts at ones (tf.train.RMSPropOptimizer)
+            elif self.optimizer == 'adagrad':
+                sc.adam_v.fill_(0.1)            # initial_accumulator_value
+            if self.optimizer in ('rmsprop', 'adadelta'):
+                sc.adam_m = torch.zeros_like(sc.adam_v)
         self.loss = torch.zeros(2, dtype=torch.float64, device=device)   # [loss_g, loss_d], summed in double
         self.G.loss_acc, self.D.loss_acc = self.loss[0:1], self.loss[1:2]     # regularisers added inside backward
         self.reducer = GradReducer(process_group)
@@ -154,12 +167,23 @@ class GanTrainer(object):
         """Host part of the optimizer step: advance t, put lr_t = lr*sqrt(1-b2^t)/(1-b1^t) in device memory."""
         scope.adam_t += 1
         t = scope.adam_t
-        lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t) if self.optimizer == 'adam' else lr
         self.lr_dev[idx:idx + 1].fill_(float(lr_t))
 
     def _adam_launch(self, scope, idx):
-        hip.call('ssc_adam_tf', scope.flat, scope.grad, None, scope.adam_v, scope.numel, 0.0,
-                 self.lr_dev[idx:idx + 1], self.beta1, self.beta2, self.eps, 1.0 / self.world)
+        lr_dev, gs = self.lr_dev[idx:idx + 1], 1.0 / self.world
+        if self.optimizer == 'adam':
+            hip.call('ssc_adam_tf', scope.flat, scope.grad, None, scope.adam_v, scope.numel, 0.0, lr_dev, self.beta1,
+                     self.beta2, self.eps, gs)
+        elif self.optimizer == 'rmsprop':
+            hip.call('ssc_optimizer_step', 1, scope.flat, scope.grad, scope.adam_v, scope.adam_m, scope.numel, lr_dev,
+                     0.9, 0.0, 1e-10, gs)
+        elif self.optimizer == 'adagrad':
+            hip.call('ssc_optimizer_step', 2, scope.flat, scope.grad, scope.adam_v, None, scope.numel, lr_dev, 0.0, 0.0,
+                     0.0, gs)
+        else:
+            hip.call('ssc_optimizer_step', 3, scope.flat, scope.grad, scope.adam_v, scope.adam_m, scope.numel, lr_dev,
+                     0.95, 0.0, 1e-8, gs)
 
     def _run_step(self, kind, batch, counter):
         """Eager, capture or replay of one D-/G-step."""

@@ -143,3 +143,14 @@ def test_cli_trains_from_tfrecords(tmp_path, monkeypatch):
     run = os.path.join('outputs', sorted(os.listdir('outputs'))[0])
     scal = [json.loads(l) for l in open(os.path.join(run, 'log', 'scalars.jsonl'))]
     assert len(scal) == 2 and all(np.isfinite(s['total_loss/g']) for s in scal)
+
+
+@pytest.mark.parametrize('opt', ['RMSprop', 'AdaDelta', 'AdaGrad'])
+def test_cli_other_optimizers(tmp_path, monkeypatch, opt):
+    """--optimizer choices of the reference CLI (graph_single.py:584-593) all train."""
+    import obj_colorization_main as cli
+    monkeypatch.chdir(tmp_path)
+    cli.main(['--mode', 'train', '-bt', 'Pix2Pix', '-si', '1', '-bs', '2', '-mi', '2', '-smf', '1', '-swf', '1', '-opt', opt])
+    run = os.path.join('outputs', sorted(os.listdir('outputs'))[0])
+    scal = [json.loads(l) for l in open(os.path.join(run, 'log', 'scalars.jsonl'))]
+    assert len(scal) == 2 and all(np.isfinite(s['total_loss/g']) for s in scal)

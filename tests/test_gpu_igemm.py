@@ -263,3 +263,37 @@ def test_layout_roundtrip():
     back = torch.empty(3, 3, 10, 12, device='cuda')
     hip.nhwc_to_nchw(d, back, coff=3)
     close(back, x)
+
+
+@pytest.mark.parametrize('kind', ['rmsprop', 'adagrad', 'adadelta'])
+def test_other_optimizers_match_tf_formulas(kind):
+    """ssc_optimizer_step vs the TF dense-apply formulas (oracle/tf_ops.py) over three steps."""
+    import torch
+    from oracle import tf_ops as T
+    from sketchyscenecolorization_amd import hip
+    g = torch.Generator().manual_seed(4)
+    n = 1000
+    w = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * 0.3 for _ in range(3)]
+    wd = w.cuda().clone()
+    lr = torch.tensor([1e-3], device='cuda')
+    if kind == 'rmsprop':
+        s1, s2 = torch.ones(n), torch.zeros(n)
+        d1, d2 = s1.cuda().clone(), s2.cuda().clone()
+        for gr in grads:
+            T.tf_rmsprop_update(w, gr, s1, s2, 1e-3)
+            hip.call('ssc_optimizer_step', 1, wd, gr.cuda(), d1, d2, n, lr, 0.9, 0.0, 1e-10, 1.0)
+    elif kind == 'adagrad':
+        s1 = torch.full((n,), 0.1)
+        d1 = s1.cuda().clone()
+        for gr in grads:
+            T.tf_adagrad_update(w, gr, s1, 1e-3)
+            hip.call('ssc_optimizer_step', 2, wd, gr.cuda(), d1, None, n, lr, 0.0, 0.0, 0.0, 1.0)
+    else:
+        s1, s2 = torch.zeros(n), torch.zeros(n)
+        d1, d2 = s1.cuda().clone(), s2.cuda().clone()
+        for gr in grads:
+            T.tf_adadelta_update(w, gr, s1, s2, 1e-3)
+            hip.call('ssc_optimizer_step', 3, wd, gr.cuda(), d1, d2, n, lr, 0.95, 0.0, 1e-8, 1.0)
+    assert float((wd.cpu() - w).abs().max()) < 1e-6
+    assert float((d1.cpu() - s1).abs().max()) < 1e-5 * max(1.0, float(s1.abs().max()))
