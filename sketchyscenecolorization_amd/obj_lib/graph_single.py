@@ -154,8 +154,7 @@ def build_multi_tower_graph(images, sketches, images_d, image_paired_class_ids, 
     Returns (opt_g, opt_d, loss_g, loss_d, summaries) to be fetched through Session.run."""
     models.set_param(data_format=data_format)
     get_optimizer(optimizer)
-    if distance_map:
-        raise NotImplementedError('--distance_map 1 is a dead-but-selectable reference flag (SURVEY appendix B.12)')
+    # distance_map only changes what the input queue feeds (input_pipeline.py:86-96); the graph ignores it
     pg, rank, world = None, 0, 1
     if num_gpu > 1:
         import torch.distributed as dist

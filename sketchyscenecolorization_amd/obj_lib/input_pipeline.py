@@ -72,10 +72,13 @@ def decode_paired_example(feat, img_dim, rng, data_format='NCHW', distance_map=F
     tf.image.resize_images with the TF1 defaults (align_corners=False, no half-pixel centres) maps output pixel i to
     source coordinate i * (384 / size): for the integer factors 2 (192) and 6 (64) BILINEAR is exactly the source pixel
     at that coordinate and AREA is the mean of the factor x factor block."""
-    if distance_map:
-        raise NotImplementedError('--distance_map 1 (scipy distance transform of the sketch) is not built')
     img = np.frombuffer(feat['cartoon_data'][0], dtype=np.uint8).astype(np.float32).reshape(RECORD_HW, RECORD_HW, 3)
     sk = np.frombuffer(feat['sketch_data'][0], dtype=np.uint8).astype(np.float32).reshape(RECORD_HW, RECORD_HW, 3)
+    if distance_map:        # :86-96: binarise at 250, Euclidean distance to the nearest stroke pixel, scaled to [0, 255]
+        from scipy import ndimage
+        sk = np.where(sk < 250, 0.0, 255.0).astype(np.float32)
+        sk = ndimage.distance_transform_edt(sk).astype(np.float32)
+        sk = sk / sk.max() * 255.0
     size = img_dim[0]
     if size != RECORD_HW:
         f = RECORD_HW // size

@@ -81,3 +81,18 @@ def test_paired_queue_decodes_like_the_reference_graph(tmp_path, small):
     for _ in range(5):
         seen |= set(int(c) for c in q.dequeue()[2])
     assert seen == {0, 1, 2, 3, 4}                          # endless, shuffled epochs
+
+
+def test_distance_map_sketches(tmp_path):
+    """--distance_map 1 (input_pipeline.py:86-96): binarise, Euclidean distance transform, scale to [0,255], AREA resize."""
+    from scipy import ndimage
+    from sketchyscenecolorization_amd import tfrecord as tf
+    from sketchyscenecolorization_amd.obj_lib.input_pipeline import decode_paired_example
+    ex, img, sk, text = _example(tf, np.random.RandomState(2), 'car_1.png', 1)
+    _, got, _, _, _, _ = decode_paired_example(tf.parse_example(ex), (192, 192), np.random.RandomState(0), distance_map=True)
+    b = np.where(sk.astype(np.float32) < 250, 0.0, 255.0)
+    d = ndimage.distance_transform_edt(b)
+    d = d / d.max() * 255.0
+    ref = d.reshape(192, 2, 192, 2, 3).mean(axis=(1, 3)) / 255.0 * 2 - 1
+    assert np.abs(got.transpose(1, 2, 0) - ref).max() < 1e-5
+    assert got.min() == -1.0 and got.max() <= 1.0                       # strokes at distance 0
