@@ -252,17 +252,19 @@ def main():
             name, (fl, sec, cnt) = dom
             tot_sec = sum(v[1] for v in agg.values())
             ach = fl / sec / 1e12
-            traffic = None      # HBM bytes per launch from the committed PMC passes (same command, --no-graphs)
-            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            traffic = mfma_busy = valu_busy = None      # from the committed PMC passes (same command, --no-graphs)
+            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_final.json')
             if os.path.exists(tpath) and args.batch == 32 and args.img == 192 and args.block_type == 'Pix2Pix':
                 with open(tpath) as f:
                     tk = json.load(f)['kernels'].get(name)
                 if tk:
                     traffic = tk['hbm_bytes_per_launch']
+                    mfma_busy, valu_busy = tk.get('mfma_busy_frac'), tk.get('valu_busy_frac')
             out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                                'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, '
-                                               'profiles/r01_pmc_traffic.json)',
+                                               'profiles/r01_pmc_final.json)',
+                               'mfma_busy_frac_pmc': mfma_busy, 'valu_busy_frac_pmc': valu_busy,
                                'flop_per_launch': fl / cnt,
                                'launches': cnt, 'avg_launch_ms': sec / cnt * 1e3,
                                'igemm_ms_per_step': tot_sec / prof_steps * 1e3,

@@ -1,0 +1,71 @@
+"""Per-kernel summary of the rocprofv3 --pmc passes (rocpd sqlite, view counters_collection):
+HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM) and MFMA / VALU busy fractions.
+usage: pmc_summary.py <dir with pmc_final_*/p_results.db> <out.json>"""
+import json
+import os
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+def demangled_short(name):
+    # rocpd stores demangled names: "void conv_fwd_kernel<2, 2, 1, 2, 0, true, true>(...)"
+    m = re.match(r'void (conv_fwd_kernel|conv_wgrad_kernel|narrow_fwd_kernel)<([^>]*)>', name)
+    if not m:
+        return None
+    k, args = m.group(1), [a.strip() for a in m.group(2).split(',')]
+    if k == 'conv_fwd_kernel':
+        wm, wn, sm, sn, bm = [int(a) for a in args[:5]]
+        return 'conv_fwd<%dx%d,%s>' % (wm * sm * 32, wn * sn * 32, 'NK' if bm else 'KN')
+    if k == 'conv_wgrad_kernel':
+        wm, wn, sm, sn = [int(a) for a in args[:4]]
+        return 'conv_wgrad<%dx%d>' % (wm * sm * 32, wn * sn * 32)
+    return 'narrow_fwd<%s>' % ('transposed' if int(args[0]) == 1 else 'conv')
+
+
+def collect(db):
+    c = sqlite3.connect(db)
+    out = defaultdict(lambda: defaultdict(list))
+    for name, counter, value in c.execute('select kernel_name, counter_name, value from counters_collection'):
+        s = demangled_short(name)
+        if s:
+            out[s][counter].append(float(value))
+    return out
+
+
+def main(base, dst):
+    res = {'source': 'rocprofv3 --kernel-trace --pmc <one pass each> of `python bench.py --steps 2 --warmup 1 --no-graphs '
+                     '--no-kernel-events` (scripts/run_pmc_final.sh), 1x MI355X, batch 32, 192x192, final round-1 tree',
+           'correction': 'FETCH_SIZE (KB) x2 (gfx950 tallies the 128-B requests of coalesced 16-B/lane reads at 64 B, '
+                         'MI355X_MICROARCH.md section HBM); WRITE_SIZE (KB) as reported',
+           'kernels': {}}
+    fetch = collect(os.path.join(base, 'pmc_final_FETCH_SIZE', 'p_results.db'))
+    write = collect(os.path.join(base, 'pmc_final_WRITE_SIZE', 'p_results.db'))
+    sq = collect(os.path.join(base, 'pmc_final_SQ_VALU_MFMA_BUSY_CYCLES', 'p_results.db'))
+    for k in sorted(set(fetch) | set(sq)):
+        e = {}
+        if k in fetch and k in write:
+            f = sum(fetch[k]['FETCH_SIZE']) / len(fetch[k]['FETCH_SIZE']) * 1024
+            w = sum(write[k]['WRITE_SIZE']) / len(write[k]['WRITE_SIZE']) * 1024
+            e.update(launches_profiled=len(fetch[k]['FETCH_SIZE']), fetch_bytes_per_launch_raw=f,
+                     fetch_bytes_per_launch_corrected=2 * f, write_bytes_per_launch=w, hbm_bytes_per_launch=2 * f + w)
+        if k in sq and sq[k].get('GRBM_GUI_ACTIVE'):
+            tot = lambda n: sum(sq[k].get(n, [0.0]))
+            gui = tot('GRBM_GUI_ACTIVE') / 8.0      # the counter is summed over the 8 XCDs: /8 = shader-clock cycles
+            # SQ_VALU_MFMA_BUSY_CYCLES sums over the 1024 SIMDs (256 CUs x 4) and equals 64 x #MFMA for 32x32x2 f32;
+            # SQ_ACTIVE_INST_VALU counts quad-cycles
+            simd_cycles = gui * 1024
+            e.update(mfma_busy_frac=tot('SQ_VALU_MFMA_BUSY_CYCLES') / simd_cycles if gui else None,
+                     valu_busy_frac=tot('SQ_ACTIVE_INST_VALU') * 4 / simd_cycles if gui else None,
+                     mfma_instructions=tot('SQ_VALU_MFMA_BUSY_CYCLES') / 64.0, valu_instructions=tot('SQ_INSTS_VALU'),
+                     kernel_cycles=gui, launches_profiled_sq=len(sq[k]['GRBM_GUI_ACTIVE']))
+        res['kernels'][k] = e
+    json.dump(res, open(dst, 'w'), indent=1)
+    for k, e in res['kernels'].items():
+        print('%-26s hbm/launch %8.1f MB  mfma_busy %s  valu_busy %s' % (
+            k, e.get('hbm_bytes_per_launch', 0) / 1e6, ('%.3f' % e['mfma_busy_frac']) if e.get('mfma_busy_frac') else '-',
+            ('%.3f' % e['valu_busy_frac']) if e.get('valu_busy_frac') else '-'))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])
