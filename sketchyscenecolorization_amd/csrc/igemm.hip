@@ -495,6 +495,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * A_SZ;
+    // per-pixel decode of the K-tile after next, shared by the whole workgroup: {pixel index of (n, iy0, ix0) in the
+    // gathered tensor, iy0, ix0} with iy0 = py*stride + ioff_y (tap offsets are per-thread constants)
+    int4* ptab = reinterpret_cast<int4*>(smem + 2 * A_SZ + 2 * B_SZ);      // [2][BK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -534,7 +537,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     gview_src(d.d, b_c, b_base, b_cs);
     const int b_act = (b_c >= d.d.C0 && d.d.act1 >= 0) ? d.d.act1 : d.d.act;
     const bool b_plain = ((b_c < d.d.C0 ? d.d.ab0 : d.d.ab1) == nullptr) && b_act == SSC_ACT_NONE;
-    const int a_iy0 = d.ioff_y + a_ty, a_ix0 = d.ioff_x + a_tx;
 
     const long nkt = (P + BK - 1) / BK;
     const long per = (nkt + splitk - 1) / splitk;
@@ -553,11 +555,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     float rav[A_SLOTS], rbv[B_SLOTS];
     const float g_slope = act_slope(a_act), d_slope = act_slope(b_act);
 
-    auto load_tile = [&](long kt) {
-#pragma unroll
-        for (int s = 0; s < A_SLOTS; ++s) {
-            const long p = kt * BK + tid / (BM / 4) + A_RP * s;
-            const bool pv = a_cv && p < P;
+    // one thread per pixel of K-tile `kt` fills ptab[kt & 1] (threads 0..BK-1)
+    auto fill_ptab = [&](long kt) {
+        if (tid < BK) {
+            const long p = kt * BK + tid;
+            const bool pv = p < P;
             const long pp = pv ? p : 0;
             int n, py, px;
             if (mg.use32) {     // wave-uniform: numerators fit the 32-bit multiply-high
@@ -571,10 +573,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
                 py = (int)div64(rem, mg.mPW, mg.onePW);
                 px = rem - py * d.PW;
             }
-            const int iy = py * d.in_stride + a_iy0;
-            const int ix = px * d.in_stride + a_ix0;
-            const bool v = pv && (unsigned)iy < (unsigned)d.g.H && (unsigned)ix < (unsigned)d.g.W;
-            const long pix = v ? ((long)n * d.g.H + iy) * d.g.W + ix : 0;
+            const int iy0 = py * d.in_stride + d.ioff_y, ix0 = px * d.in_stride + d.ioff_x;
+            // an invalid pixel gets coordinates no tap can bring inside the image
+            ptab[(kt & 1) * BK + tid] = make_int4((n * d.g.H + iy0) * d.g.W + ix0, pv ? iy0 : -(1 << 20), ix0, 0);
+        }
+    };
+    const int a_tapoff = a_ty * d.g.W + a_tx;
+    auto load_tile = [&](long kt) {
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) {
+            const int4 e = ptab[(kt & 1) * BK + tid / (BM / 4) + A_RP * s];
+            const int iy = e.y + a_ty, ix = e.z + a_tx;
+            const bool v = a_cv && (unsigned)iy < (unsigned)d.g.H && (unsigned)ix < (unsigned)d.g.W;
+            const long pix = v ? (long)(e.x + a_tapoff) : 0;
             rav[s] = v ? 1.f : 0.f;
             ra[s] = *reinterpret_cast<const float4*>(a_base + pix * a_cs);
         }
@@ -603,6 +614,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
         }
     };
 
+    fill_ptab(kt_begin);
+    fill_ptab(kt_begin + 1);
+    __syncthreads();
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
         store_tile(0);
@@ -613,7 +627,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     int cur = 0;
     for (long kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = (kt + 1) < kt_end;
-        if (more) load_tile(kt + 1);
+        if (more) load_tile(kt + 1);        // reads ptab[(kt+1)&1], published by the previous barrier
+        fill_ptab(kt + 2);                  // overwrites ptab[kt&1], last read before that barrier
         const float* Ab = As + cur * A_SZ + lhi * A_LD + wm * SM * 32 + l31;
         const float* Bb = Bs + cur * B_SZ + lhi * B_LD + wn * SN * 32 + l31;
         constexpr int FG = 4, NFG = BK / 2 / FG;      // operand fetch pipelined by groups, see conv_fwd_kernel
@@ -852,7 +867,7 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
 template <int WM, int WN, int SM, int SN>
 static int launch_wgrad(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
-    constexpr size_t lds = 2 * (BK * BM + BK * BN) * sizeof(float);
+    constexpr size_t lds = 2 * (BK * BM + BK * BN) * sizeof(float) + 2 * BK * sizeof(int4);
     const int Cg = d.g.C0 + d.g.C1;
     const int Mtot = d.TH * d.TW * Cg;
     const long P = (long)d.NB * d.PH * d.PW;
