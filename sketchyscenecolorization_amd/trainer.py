@@ -148,9 +148,17 @@ class GanTrainer(object):
                 self._seg_begin_graph()
                 impl(sbatch)
                 self._seg_end_graph()
+        except Exception:
+            cur = self._seg.get('cur') if self._seg else None
+            if cur is not None:
+                try:
+                    cur.capture_end()
+                except Exception:
+                    pass
+            raise
         finally:
             self._capturing = False
-            ops, self._seg = self._seg['ops'], None
+            ops, self._seg = (self._seg['ops'] if self._seg else []), None
         torch.cuda.current_stream().wait_stream(stream)
         return ops
 
@@ -212,16 +220,25 @@ class GanTrainer(object):
             if key not in self._seen:       # first time: eager (allocates buffers, sets kernel attributes)
                 self._seen.add(key)
                 return impl(sbatch)
-            if self.segment_graphs:
-                g = self._capture_segments(impl, sbatch)
-            else:
-                g = torch.cuda.CUDAGraph()
-                self._capturing = True
-                try:
-                    with torch.cuda.graph(g):
-                        impl(sbatch)
-                finally:
-                    self._capturing = False
+            try:
+                if self.segment_graphs:
+                    g = self._capture_segments(impl, sbatch)
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    self._capturing = True
+                    try:
+                        with torch.cuda.graph(g):
+                            impl(sbatch)
+                    finally:
+                        self._capturing = False
+            except Exception as e:      # never lose a training run to graph capture: fall back to eager launches
+                print('hipGraph capture failed (%r): continuing with eager launches' % (e,))
+                self.use_graphs = False
+                self._seg = None
+                torch.cuda.synchronize()
+                scope.adam_t -= 1       # _adam_prepare ran once for this step already
+                self._adam_prepare(scope, idx, lr * self.decay(counter))
+                return impl(sbatch)
             self._graphs[key] = g
         if isinstance(g, list):
             self._replay_segments(g)
