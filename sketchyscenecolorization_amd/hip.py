@@ -187,6 +187,7 @@ def workspace(nbytes=256 << 20):
 # there (after waiting for everything issued so far on the current stream), so their workgroups fill the CUs that the
 # chain's small layers and kernel tails leave idle; join_wgrad() makes the current stream wait for them.
 WGRAD_STREAM = None
+WGRAD_SIDE_MAX_PIXELS = int(os.environ.get('SSC_WGRAD_SIDE_PIXELS', '0')) or None   # None = every layer
 _wgrad_pending = False
 
 
@@ -249,7 +250,8 @@ def _run_conv(d):
 
 def _run_wgrad(d, side=False):
     global _wgrad_pending
-    if side and WGRAD_STREAM is not None and PROFILE is None:
+    if side and WGRAD_STREAM is not None and PROFILE is None and \
+            (WGRAD_SIDE_MAX_PIXELS is None or d.NB * d.PH * d.PW <= WGRAD_SIDE_MAX_PIXELS):
         WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(WGRAD_STREAM):
             ws = workspace()

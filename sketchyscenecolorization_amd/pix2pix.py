@@ -99,11 +99,15 @@ class Pix2PixGenerator(object):
         hip.nhwc_to_nchw(ctx['out'], o, ctx['out_coff'])
         return o
 
-    def backward(self, ctx, dpre, on_section=None):
+    def backward(self, ctx, dpre, on_section=None, side_stream=None):
         """dpre [N,H,W,4]: gradient w.r.t. the pre-tanh output.  Writes every generator gradient.
         ``on_section(name)`` is called when a contiguous block of the flat gradient buffer is final
-        ('decoders' = noise head + decoders, 'text', 'encoders') so the caller can start its all-reduce."""
+        ('decoders' = noise head + decoders, 'text', 'encoders') so the caller can start its all-reduce.
+        With ``side_stream`` the decoder filter gradients (off the critical path: nothing downstream reads
+        them) are held back and launched on that stream next to the caption branch's BPTT, whose small
+        recurrent GEMMs leave most CUs idle."""
         s, B = self.s, self.b
+        held = []
         done = on_section if on_section is not None else (lambda name: None)
         tag, N = ctx['tag'], ctx['N']
         e, ab, st, d, abd, std, views = ctx['e'], ctx['ab'], ctx['st'], ctx['d'], ctx['abd'], ctx['std'], ctx['views']
@@ -114,7 +118,12 @@ class Pix2PixGenerator(object):
             f = s['generator/decoder_%d/deconv/filter' % k]
             v = views[k]
             dyv = View(gcur)
-            hip.deconv_wgrad(v, dyv, s.grad('generator/decoder_%d/deconv/filter' % k))
+            wg = (lambda v=v, dyv=dyv, k=k:
+                  hip.deconv_wgrad(v, dyv, s.grad('generator/decoder_%d/deconv/filter' % k)))
+            if side_stream is None or not self.lstm_hybrid:
+                wg()
+            else:
+                held.append(wg)
             g0 = B.get(tag + '/gb/d%d_in0' % k, (N, v.H, v.W, v.C0))
             g1 = B.get(tag + '/gb/d%d_in1' % k, (N, v.H, v.W, v.C1))
             hip.deconv_dgrad(dyv, f, g0, n_off=0, nn=v.C0)
@@ -136,11 +145,21 @@ class Pix2PixGenerator(object):
         hip.call('ssc_miu_permute_bwd', ctx['noise_pre'], g_noise, N, cd, P, dpre_fc)
         hip.matmul_tn(ctx['noise_vec'], dpre_fc, s.grad('generator/fully_connected/weights'))
         hip.call('ssc_group_rowsum', dpre_fc, cd * P, 1, N, cd * P, s.grad('generator/fully_connected/biases'), 0)
-        done('decoders')
+        if held:
+            main = torch.cuda.current_stream()
+            side_stream.wait_stream(main)
+            with torch.cuda.stream(side_stream):
+                for wg in held:
+                    wg()
+        else:
+            done('decoders')
         # caption branch -> gradient w.r.t. normalised encoder_5 output
         de5 = B.get(tag + '/gb/de5', e[5].shape)
         if self.lstm_hybrid:
             dy5 = self.text.backward(ctx['tctx'], g_feat)
+            if held:
+                main.wait_stream(side_stream)
+                done('decoders')
             done('text')
             if dy5 is None:
                 hip.fill(de5, 0.0)

@@ -14,6 +14,7 @@ of the backward pass has produced them, and the 1/world factor is folded into th
 Adam kernel.
 """
 import math
+import os
 import warnings
 
 import numpy as np
@@ -86,6 +87,8 @@ class GanTrainer(object):
         # Pix2Pix pair only -- its backward touches a filter gradient again only at the section joins below).
         # OFF by default: measured 25.39 vs 24.77 ms/step (batch 32) -- both kernel families already fill the CUs
         # (66 KB LDS per workgroup), so co-scheduling them only adds contention.
+        if overlap_wgrad is None:
+            overlap_wgrad = os.environ.get('SSC_OVERLAP_WGRAD', '0') == '1'
         self._wgrad_stream = torch.cuda.Stream() if (overlap_wgrad and block_type == 'Pix2Pix') else None
         self._aux_stream = torch.cuda.Stream() if overlap_real else None
         self._seg = None
@@ -386,7 +389,11 @@ class GanTrainer(object):
         dpre = B.get('dpre', (N, H, W, 4))
         hip.call('ssc_gen_output_grad', xd_f.view(-1)[3:], 8, img4, 4, dgen, 4, N * H * W, 100.0, loss_g, dpre)
         sc = s.generator
-        self.G.backward(gctx, dpre, on_section=lambda name: self._section_done(sc, name))
+        if self.block_type == 'Pix2Pix':
+            side = self._aux_stream if hip.PROFILE is None else None
+            self.G.backward(gctx, dpre, on_section=lambda name: self._section_done(sc, name), side_stream=side)
+        else:
+            self.G.backward(gctx, dpre, on_section=lambda name: self._section_done(sc, name))
         self._sn_pending = sn if self.D.sn else None
         self.last = {'gctx': gctx, 'cf': cf}
         return loss_g
