@@ -16,6 +16,7 @@
 // are never written to HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "sketchycolor_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -457,6 +458,259 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// uniform-tap form with the staging of later K-tiles interleaved into the MFMA stream of the same wave
+// ---------------------------------------------------------------------------------------------
+// conv_fwd_kernel alternates phases per wave (issue loads | 32-64 MFMAs | transform + LDS writes | barrier) and relies on
+// the 2-3 co-resident waves of a SIMD being in different phases to keep the matrix pipe fed; measured, the pipe sits at
+// 60-70 %.  Here one K-tile step is a single branch-free block: the registers that hold K-tile kt+1 (loaded one step
+// ago) go to the free LDS buffer and are refilled with the global loads of K-tile kt+2 while the MFMAs of K-tile kt
+// issue, so address arithmetic, memory issue and LDS traffic sit in the 64-cycle shadow of each MFMA.
+//   * no per-step branches: the K-tile index is clamped instead of tested, selects are arithmetic, the filter columns
+//     beyond Nn are zeroed in the epilogue instead of masked every step;
+//   * PLAIN (no folded norm, no activation on any source: every data-gradient launch) is a template flag.
+template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN>
+__global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, const Magics mg,
+                                                       float* __restrict__ slab_base, long slab_stride, int splitk) {
+    constexpr int BM = WM * SM * 32;
+    constexpr int BN = WN * SN * 32;
+    constexpr int A_LD = BK + 1;
+    constexpr int A_SZ = BM * A_LD;
+    constexpr int B_LD = (BMODE == 0) ? BN : (BK + 1);
+    constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * (BK + 1);
+    constexpr int A_ROWS = BM / 32;
+    constexpr int B_SLOTS = BN / 32;
+    constexpr int B_RP = 1024 / BN;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * A_SZ;
+    long* rowpix = reinterpret_cast<long*>(smem + 2 * A_SZ + 2 * B_SZ);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // descriptor fields the K loop needs, in registers (the loop must not go back to the kernarg segment)
+    const float* const xs0 = d.x.s0;
+    const float* const xs1 = d.x.s1;
+    const float* const xab0 = d.x.ab0;
+    const float* const xab1 = d.x.ab1;
+    const float* const wbase = d.w;
+    const int xC0 = d.x.C0, xC1 = d.x.C1, xH = d.x.H, xW = d.x.W;
+    const int TWv = d.TW, kstep = d.kstep, KWv = d.KW, wC0 = d.wC0, wC1 = d.wC1;
+    const float slope0 = act_slope(d.x.act), slope1 = act_slope(d.x.act1 >= 0 ? d.x.act1 : d.x.act);
+
+    const int C = xC0 + xC1;
+    const int Ktot = d.TH * d.TW * C;
+    const long M = (long)d.NB * d.PH * d.PW;
+    const int PHW = d.PH * d.PW;
+    const int phase = blockIdx.z / splitk;
+    const int ks = blockIdx.z % splitk;
+    const FwdPhase ph = fwd_phase(d, phase);
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    const int a_col4 = tid & 7;
+    int a_iyb[A_ROWS], a_ixb[A_ROWS], a_off0[A_ROWS], a_off1[A_ROWS];
+    bool a_mv[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const long m = m0 + row;
+        a_mv[i] = m < M;
+        const long mm = a_mv[i] ? m : 0;
+        const int n = (int)div64(mm, mg.mPHPW, mg.onePHPW);
+        const int rem = (int)(mm - (long)n * PHW);
+        const int py = (int)div64(rem, mg.mPW, mg.onePW), px = rem - py * d.PW;
+        a_iyb[i] = py * d.in_stride + ph.ioff_y;
+        a_ixb[i] = px * d.in_stride + ph.ioff_x;
+        const int pix0 = (n * xH + a_iyb[i]) * xW + a_ixb[i];
+        a_off0[i] = pix0 * xC0 + a_col4 * 4;
+        a_off1[i] = pix0 * xC1 + a_col4 * 4;
+        if (a_col4 == 0)
+            rowpix[row] = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
+    }
+    int b_off[B_SLOTS];
+#pragma unroll
+    for (int s = 0; s < B_SLOTS; ++s) {
+        if (BMODE == 0) {
+            const int n = n0 + (tid % (BN / 4)) * 4;
+            b_off[s] = (n < d.Nn) ? (tid / (BN / 4) + B_RP * s) * wC1 + d.n_off + n : 0;
+        } else {
+            const int n = n0 + (tid >> 3) + 32 * s;
+            b_off[s] = (n < d.Nn) ? (d.n_off + n) * wC1 + (tid & 7) * 4 : 0;
+        }
+    }
+
+    const int nkt = (Ktot + BK - 1) / BK;
+    const int per = (nkt + splitk - 1) / splitk;
+    const int kt_begin = ks * per;
+    const int kt_end = min(nkt, kt_begin + per);
+
+    f32x16 acc[SM][SN];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[A_ROWS];
+    float rav[A_ROWS];
+    float4 raa, rab;
+    float ra_slope = 1.f;
+    float4 rb[B_SLOTS];
+
+    auto issue_loads = [&](int kt) {
+        const int kb = kt * BK;
+        const int tap = div32(kb, mg.mC, mg.oneC);
+        const int cch = kb - tap * C;
+        const int ty = div32(tap, mg.mTW, mg.oneTW), tx = tap - ty * TWv;
+        const bool first = cch < xC0;
+        const int cs = first ? xC0 : xC1;
+        const int cc = first ? cch : cch - xC0;
+        const float* sbase = (first ? xs0 : xs1) + cc;
+        const int tapshift = (ty * xW + tx) * cs;
+        const int fmask = first ? -1 : 0;
+        if (!PLAIN) {
+            const float* abp = first ? xab0 : xab1;
+            const bool has = abp != nullptr;
+            const float* pa = has ? abp + cc + a_col4 * 4 : xs0;       // a valid address either way
+            const float* pb = has ? abp + cs + cc + a_col4 * 4 : xs0;
+            const float4 va = *reinterpret_cast<const float4*>(pa);
+            const float4 vb = *reinterpret_cast<const float4*>(pb);
+            raa = has ? va : make_float4(1.f, 1.f, 1.f, 1.f);
+            rab = has ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra_slope = first ? slope0 : slope1;
+        }
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const int iy = a_iyb[i] + ty, ix = a_ixb[i] + tx;
+            const bool v = a_mv[i] & ((unsigned)iy < (unsigned)xH) & ((unsigned)ix < (unsigned)xW);
+            const int osel = (a_off0[i] & fmask) | (a_off1[i] & ~fmask);    // bit select: a ?: here became a scratch array
+            const int off = v ? osel + tapshift : a_col4 * 4;
+            rav[i] = v ? 1.f : 0.f;
+            ra[i] = *reinterpret_cast<const float4*>(sbase + off);
+        }
+        const int ky = ph.ky0 + ty * kstep, kx = ph.kx0 + tx * kstep;
+        const float* wtap = (BMODE == 0) ? wbase + ((long)(ky * KWv + kx) * wC0 + cch) * wC1
+                                         : wbase + (long)(ky * KWv + kx) * wC0 * wC1 + cch;
+#pragma unroll
+        for (int s = 0; s < B_SLOTS; ++s) rb[s] = *reinterpret_cast<const float4*>(wtap + b_off[s]);
+    };
+
+    auto stage = [&](int buf) {
+        float* Ab = As + buf * A_SZ;
+        float* Bb = Bs + buf * B_SZ;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const float4 v = PLAIN ? mask4(ra[i], rav[i]) : xform4(ra[i], raa, rab, ra_slope, rav[i]);
+            float* p = Ab + ((tid >> 3) + 32 * i) * A_LD + a_col4 * 4;
+            p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+        }
+#pragma unroll
+        for (int s = 0; s < B_SLOTS; ++s) {
+            const float4 v = rb[s];
+            if (BMODE == 0) {
+                *reinterpret_cast<float4*>(Bb + (tid / (BN / 4) + B_RP * s) * B_LD + (tid % (BN / 4)) * 4) = v;
+            } else {
+                float* p = Bb + ((tid >> 3) + 32 * s) * B_LD + (tid & 7) * 4;
+                p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+            }
+        }
+    };
+
+    if (kt_begin < kt_end) {
+        const int last = kt_end - 1;
+        issue_loads(kt_begin);
+        stage(0);
+        issue_loads(min(kt_begin + 1, last));
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const float* Ab = As + cur * A_SZ + (wm * SM * 32 + l31) * A_LD + lhi;
+            const float* Bb = (BMODE == 0) ? (Bs + cur * B_SZ + lhi * B_LD + wn * SN * 32 + l31)
+                                           : (Bs + cur * B_SZ + (wn * SN * 32 + l31) * B_LD + lhi);
+            constexpr int FG = 4, NFG = BK / 2 / FG;
+            float av[2][FG][SM], bv[2][FG][SN];
+            auto fetch = [&](int g, int buf) {
+#pragma unroll
+                for (int q = 0; q < FG; ++q) {
+                    const int kk = g * FG + q;
+#pragma unroll
+                    for (int i = 0; i < SM; ++i) av[buf][q][i] = Ab[i * 32 * A_LD + kk * 2];
+#pragma unroll
+                    for (int j = 0; j < SN; ++j)
+                        bv[buf][q][j] = (BMODE == 0) ? Bb[kk * 2 * B_LD + j * 32] : Bb[j * 32 * B_LD + kk * 2];
+                }
+            };
+            auto mfmas = [&](int g) {
+#pragma unroll
+                for (int q = 0; q < FG; ++q)
+#pragma unroll
+                    for (int i = 0; i < SM; ++i)
+#pragma unroll
+                        for (int j = 0; j < SN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][q][i], bv[g & 1][q][j], acc[i][j], 0, 0, 0);
+            };
+            fetch(0, 0);
+            fetch(1, 1);
+            mfmas(0);
+            stage(cur ^ 1);                         // K-tile kt+1: registers -> the LDS buffer nobody reads now
+            fetch(2, 0);
+            mfmas(1);
+            issue_loads(min(kt + 2, last));         // K-tile kt+2 into the registers just drained
+            fetch(3, 1);
+            mfmas(2);
+            mfmas(3);
+#ifdef SSC_UT_SGB
+            // interleave hint: one MFMA, then a few of the independent staging instructions
+#pragma unroll
+            for (int q = 0; q < NFG * FG * SM * SN; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x220, 1, 0);
+            }
+#endif
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue ----
+    float* outp = (splitk > 1) ? (slab_base + (long)ks * slab_stride) : d.out;
+    const bool final_pass = (splitk == 1);
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * SM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (m0 + row >= M) continue;
+            const long opix = rowpix[row];
+#pragma unroll
+            for (int j = 0; j < SN; ++j) {
+                const int col = n0 + wn * SN * 32 + j * 32 + l31;
+                if (col >= d.Nstore) continue;
+                float v = col < d.Nn ? acc[i][j][r] : 0.f;    // the filter loads of columns >= Nn were not masked
+                float* o = outp + opix * d.ldc + col;
+                if (final_pass) {
+                    if (d.bias != nullptr && col < d.Nn) v += d.bias[col];
+                    if (d.epi == 1) v = tanhf(v);
+                    else if (d.epi == 2) v = fmaxf(v, 0.2f * v);
+                    if (d.accumulate) v += *o;
+                }
+                *o = v;
+            }
+        }
+    }
+}
+
 // sum split-K slabs; applies the epilogue that the partial passes skipped
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splitk,
                                    float* __restrict__ out, long count, int ldc, int Nn, int Nstore,
@@ -790,6 +1044,45 @@ static int launch_fwd_v(const ssc_conv_desc& d, int splitk, float* ws, hipStream
     return (int)hipGetLastError();
 }
 
+static int ut2_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("SSC_UT2");
+        mode = (e != nullptr) ? atoi(e) : 1;
+    }
+    return mode;
+}
+
+template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN>
+static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st) {
+    constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
+    constexpr int A_SZ = BM * (BK + 1);
+    constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * (BK + 1);
+    constexpr size_t lds = 2 * (A_SZ + B_SZ) * sizeof(float) + BM * sizeof(long);
+    const long M = (long)d.NB * d.PH * d.PW;
+    const int C = d.x.C0 + d.x.C1;
+    const Magics mg = make_magics((unsigned)C, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW,
+                                  (unsigned long)M);
+    const long mt = (M + BM - 1) / BM;
+    const int nt = (d.Nstore + BN - 1) / BN;
+    const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
+    hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN>), grid, dim3(256), lds, st, d, mg, ws, out_count,
+                       splitk);
+    if (splitk > 1) {
+        const int thr = 256;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
+                           out_count, splitk, d.out, out_count, d.ldc, d.Nn, d.Nstore, d.bias, d.epi, d.accumulate);
+    }
+    return (int)hipGetLastError();
+}
+
 template <int WM, int WN, int SM, int SN, int BMODE>
 static int launch_fwd(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st) {
     // float4 filter loads need 16-byte aligned, fully in-range groups of 4
@@ -800,6 +1093,12 @@ static int launch_fwd(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t
     const bool ut = vec && (C % BK) == 0 && (d.x.C0 % BK) == 0 && d.k_real == C &&
                     (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x7fffffffL &&
                     (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
+    if (ut && ut2_mode() != 0) {
+        const bool plain0 = d.x.ab0 == nullptr && d.x.act == SSC_ACT_NONE;
+        const bool plain1 = d.x.C1 == 0 || (d.x.ab1 == nullptr && (d.x.act1 >= 0 ? d.x.act1 : d.x.act) == SSC_ACT_NONE);
+        if (plain0 && plain1) return launch_fwd_ut<WM, WN, SM, SN, BMODE, true>(d, splitk, ws, st);
+        return launch_fwd_ut<WM, WN, SM, SN, BMODE, false>(d, splitk, ws, st);
+    }
     if (ut) return launch_fwd_v<WM, WN, SM, SN, BMODE, true, true>(d, splitk, ws, st);
     return vec ? launch_fwd_v<WM, WN, SM, SN, BMODE, true, false>(d, splitk, ws, st)
                : launch_fwd_v<WM, WN, SM, SN, BMODE, false, false>(d, splitk, ws, st);
