@@ -22,6 +22,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BK 32
+#ifndef SSC_UT_SGB
+#define SSC_UT_SGB 1     // sched_group_barrier interleave hints in conv_ut_kernel (+1-2 % over the compiler's own order)
+#endif
 
 // Exact division by a launch-constant through multiply-high (the tile loaders run every K-tile:
 // no integer-division expansions, no branches).
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             fetch(3, 1);
             mfmas(2);
             mfmas(3);
-#ifdef SSC_UT_SGB
+#if SSC_UT_SGB
             // interleave hint: one MFMA, then a few of the independent staging instructions
 #pragma unroll
             for (int q = 0; q < NFG * FG * SM * SN; ++q) {
@@ -731,7 +734,10 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_st
 // ---------------------------------------------------------------------------------------------
 // filter-gradient form
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int SM, int SN>
+// One K-tile step is a single branch-free block, as in conv_ut_kernel: K-tile kt+1 goes from registers to the free LDS
+// buffer and K-tile kt+2 is loaded into the drained registers between the MFMAs of K-tile kt.  GPLAIN / DPLAIN: the
+// gathered / dense view has no folded norm and no activation on any source (decided per launch).
+template <int WM, int WN, int SM, int SN, bool GPLAIN, bool DPLAIN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d, const Magics mg,
                                                           float* __restrict__ slab_base, long slab_stride,
                                                           int splitk) {
@@ -780,7 +786,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     int a_cs;
     gview_src(d.g, a_c, a_base, a_cs);
     const int a_act = (a_c >= d.g.C0 && d.g.act1 >= 0) ? d.g.act1 : d.g.act;
-    const bool a_plain = ((a_c < d.g.C0 ? d.g.ab0 : d.g.ab1) == nullptr) && a_act == SSC_ACT_NONE;
     const int b_col = n0 + (tid % (BN / 4)) * 4;
     const bool b_cv = b_col < Cd;
     const int b_c = b_cv ? b_col : 0;
@@ -790,7 +795,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     int b_cs;
     gview_src(d.d, b_c, b_base, b_cs);
     const int b_act = (b_c >= d.d.C0 && d.d.act1 >= 0) ? d.d.act1 : d.d.act;
-    const bool b_plain = ((b_c < d.d.C0 ? d.d.ab0 : d.d.ab1) == nullptr) && b_act == SSC_ACT_NONE;
 
     const long nkt = (P + BK - 1) / BK;
     const long per = (nkt + splitk - 1) / splitk;
@@ -833,12 +837,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
         }
     };
     const int a_tapoff = a_ty * d.g.W + a_tx;
+    const int gH = d.g.H, gW = d.g.W;
     auto load_tile = [&](long kt) {
 #pragma unroll
         for (int s = 0; s < A_SLOTS; ++s) {
             const int4 e = ptab[(kt & 1) * BK + tid / (BM / 4) + A_RP * s];
             const int iy = e.y + a_ty, ix = e.z + a_tx;
-            const bool v = a_cv && (unsigned)iy < (unsigned)d.g.H && (unsigned)ix < (unsigned)d.g.W;
+            const bool v = a_cv & ((unsigned)iy < (unsigned)gH) & ((unsigned)ix < (unsigned)gW);
             const long pix = v ? (long)(e.x + a_tapoff) : 0;
             rav[s] = v ? 1.f : 0.f;
             ra[s] = *reinterpret_cast<const float4*>(a_base + pix * a_cs);
@@ -846,7 +851,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
             const long p = kt * BK + tid / (BN / 4) + B_RP * s;
-            const bool v = b_cv && p < P;   // D lattice == its own pixel grid (d.d.H==PH, d.d.W==PW)
+            const bool v = b_cv & (p < P);  // D lattice == its own pixel grid (d.d.H==PH, d.d.W==PW)
             rbv[s] = v ? 1.f : 0.f;
             rb[s] = *reinterpret_cast<const float4*>(b_base + (v ? p : 0) * b_cs);
         }
@@ -858,62 +863,77 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
         for (int s = 0; s < A_SLOTS; ++s) {
             const int row = tid / (BM / 4) + A_RP * s;
             *reinterpret_cast<float4*>(Ab + row * A_LD + (tid % (BM / 4)) * 4) =
-                a_plain ? mask4(ra[s], rav[s]) : xform4(ra[s], aa, ab, g_slope, rav[s]);
+                GPLAIN ? mask4(ra[s], rav[s]) : xform4(ra[s], aa, ab, g_slope, rav[s]);
         }
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
             const int row = tid / (BN / 4) + B_RP * s;
             *reinterpret_cast<float4*>(Bb + row * B_LD + (tid % (BN / 4)) * 4) =
-                b_plain ? mask4(rb[s], rbv[s]) : xform4(rb[s], ba, bb, d_slope, rbv[s]);
+                DPLAIN ? mask4(rb[s], rbv[s]) : xform4(rb[s], ba, bb, d_slope, rbv[s]);
         }
     };
 
-    fill_ptab(kt_begin);
-    fill_ptab(kt_begin + 1);
-    __syncthreads();
+    const int l31 = lane & 31, lhi = lane >> 5;
     if (kt_begin < kt_end) {
+        // K-tiles past kt_end (another split's, or past the last pixel: every row masked) are staged but never multiplied
+        fill_ptab(kt_begin);
+        fill_ptab(kt_begin + 1);
+        __syncthreads();
         load_tile(kt_begin);
         store_tile(0);
-    }
-    __syncthreads();
-
-    const int l31 = lane & 31, lhi = lane >> 5;
-    int cur = 0;
-    for (long kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = (kt + 1) < kt_end;
-        if (more) load_tile(kt + 1);        // reads ptab[(kt+1)&1], published by the previous barrier
-        fill_ptab(kt + 2);                  // overwrites ptab[kt&1], last read before that barrier
-        const float* Ab = As + cur * A_SZ + lhi * A_LD + wm * SM * 32 + l31;
-        const float* Bb = Bs + cur * B_SZ + lhi * B_LD + wn * SN * 32 + l31;
-        constexpr int FG = 4, NFG = BK / 2 / FG;      // operand fetch pipelined by groups, see conv_fwd_kernel
-        float av[2][FG][SM], bv[2][FG][SN];
-        auto fetch = [&](int g, int buf) {
-#pragma unroll
-            for (int q = 0; q < FG; ++q) {
-                const int kk = g * FG + q;
-#pragma unroll
-                for (int i = 0; i < SM; ++i) av[buf][q][i] = Ab[kk * 2 * A_LD + i * 32];
-#pragma unroll
-                for (int j = 0; j < SN; ++j) bv[buf][q][j] = Bb[kk * 2 * B_LD + j * 32];
-            }
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int g = 0; g < NFG; ++g) {
-            if (g + 1 < NFG) fetch(g + 1, (g + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < FG; ++q)
-#pragma unroll
-                for (int i = 0; i < SM; ++i)
-#pragma unroll
-                    for (int j = 0; j < SN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][q][i], bv[g & 1][q][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) store_tile(cur ^ 1);
+        load_tile(kt_begin + 1);
+        __syncthreads();                    // every thread has read ptab slots kt_begin, kt_begin + 1
+        fill_ptab(kt_begin + 2);
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (long kt = kt_begin; kt < kt_end; ++kt) {
+            const float* Ab = As + cur * A_SZ + lhi * A_LD + wm * SM * 32 + l31;
+            const float* Bb = Bs + cur * B_SZ + lhi * B_LD + wn * SN * 32 + l31;
+            constexpr int FG = 4, NFG = BK / 2 / FG;
+            float av[2][FG][SM], bv[2][FG][SN];
+            auto fetch = [&](int g, int buf) {
+#pragma unroll
+                for (int q = 0; q < FG; ++q) {
+                    const int kk = g * FG + q;
+#pragma unroll
+                    for (int i = 0; i < SM; ++i) av[buf][q][i] = Ab[kk * 2 * A_LD + i * 32];
+#pragma unroll
+                    for (int j = 0; j < SN; ++j) bv[buf][q][j] = Bb[kk * 2 * B_LD + j * 32];
+                }
+            };
+            auto mfmas = [&](int g) {
+#pragma unroll
+                for (int q = 0; q < FG; ++q)
+#pragma unroll
+                    for (int i = 0; i < SM; ++i)
+#pragma unroll
+                        for (int j = 0; j < SN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][q][i], bv[g & 1][q][j], acc[i][j], 0, 0, 0);
+            };
+            fetch(0, 0);
+            fetch(1, 1);
+            mfmas(0);
+            store_tile(cur ^ 1);            // K-tile kt+1: registers -> the LDS buffer nobody reads now
+            fetch(2, 0);
+            mfmas(1);
+            load_tile(kt + 2);              // reads ptab[(kt+2)&1], published by the previous barrier
+            fill_ptab(kt + 3);              // overwrites ptab[(kt+1)&1], last read before that barrier
+            fetch(3, 1);
+            mfmas(2);
+            mfmas(3);
+#if SSC_UT_SGB
+#pragma unroll
+            for (int q = 0; q < NFG * FG * SM * SN; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x220, 1, 0);
+            }
+#endif
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     float* outp = (splitk > 1) ? (slab_base + (long)ks * slab_stride) : d.out;
@@ -1163,8 +1183,13 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
     }
 }
 
-template <int WM, int WN, int SM, int SN>
-static int launch_wgrad(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
+static bool gview_plain(const ssc_gview& g) {
+    return g.ab0 == nullptr && g.act == SSC_ACT_NONE &&
+           (g.C1 == 0 || (g.ab1 == nullptr && (g.act1 >= 0 ? g.act1 : g.act) == SSC_ACT_NONE));
+}
+
+template <int WM, int WN, int SM, int SN, bool GPLAIN, bool DPLAIN>
+static int launch_wgrad_v(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
     constexpr size_t lds = 2 * (BK * BM + BK * BN) * sizeof(float) + 2 * BK * sizeof(int4);
     const int Cg = d.g.C0 + d.g.C1;
@@ -1177,18 +1202,27 @@ static int launch_wgrad(const ssc_wgrad_desc& d, int splitk, float* ws, hipStrea
     const long out_count = (long)d.TH * d.TW * d.Cg_real * d.ldc;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<WM, WN, SM, SN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<WM, WN, SM, SN, GPLAIN, DPLAIN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)splitk);
-    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, SM, SN>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk);
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, SM, SN, GPLAIN, DPLAIN>), grid, dim3(256), lds, st, d, mg, ws, out_count,
+                       splitk);
     if (splitk > 1) {
         const int thr = 256;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
                            out_count, splitk, d.out, out_count, d.accumulate);
     }
     return (int)hipGetLastError();
+}
+
+template <int WM, int WN, int SM, int SN>
+static int launch_wgrad(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
+    const bool gp = gview_plain(d.g), dp = gview_plain(d.d);
+    if (dp) return gp ? launch_wgrad_v<WM, WN, SM, SN, true, true>(d, splitk, ws, st)
+                      : launch_wgrad_v<WM, WN, SM, SN, false, true>(d, splitk, ws, st);
+    return launch_wgrad_v<WM, WN, SM, SN, false, false>(d, splitk, ws, st);   // the full transform covers a plain side
 }
 
 // split over the pixel (K) dimension: many more choices than the forward form, so search a wider range

@@ -125,7 +125,9 @@ class GanTrainer(object):
     # ------------------------------------------------------------------ segmented capture
     def _seg_begin_graph(self):
         g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=self._seg['pool'])
+        # thread_local: the RCCL watchdog thread polls events while we capture; under the default 'global' mode that
+        # call invalidates the capture (hipErrorStreamCaptureInvalidated, seen intermittently)
+        g.capture_begin(pool=self._seg['pool'], capture_error_mode='thread_local')
         self._seg['cur'], self._seg['mark'] = g, hip.LAUNCHES
 
     def _seg_end_graph(self):
@@ -231,7 +233,7 @@ class GanTrainer(object):
                     g = torch.cuda.CUDAGraph()
                     self._capturing = True
                     try:
-                        with torch.cuda.graph(g):
+                        with torch.cuda.graph(g, capture_error_mode='thread_local'):
                             impl(sbatch)
                     finally:
                         self._capturing = False

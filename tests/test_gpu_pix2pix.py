@@ -136,39 +136,16 @@ def test_hipgraph_replay_matches_eager():
 
 def test_segmented_graphs_with_rccl_world1_match_eager():
     """The multi-GPU step protocol on one GPU: a 1-rank RCCL process group, steps captured as graph SEGMENTS with the
-    all-reduces issued eagerly on the side stream between them (what world > 1 uses).  Must equal the eager trainer."""
+    all-reduces issued eagerly on the side stream between them (what world > 1 uses).  Must equal the eager trainer.
+    Runs in its own interpreter (tests/rccl_world1_check.py): creating and destroying an RCCL communicator inside a
+    process that has already captured and dropped dozens of hipGraphs aborted in ProcessGroupNCCL's teardown."""
     import os
-    import torch.distributed as dist
-    from sketchyscenecolorization_amd.synthetic import synthetic_batch
-    from sketchyscenecolorization_amd.trainer import GanTrainer
-    import socket
-    created = not dist.is_initialized()
-    if created:
-        with socket.socket() as sock:           # any free port: the box may already use the default one
-            sock.bind(('127.0.0.1', 0))
-            port = sock.getsockname()[1]
-        try:
-            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
-                                    device_id=torch.device('cuda', 0))
-        except Exception as e:                  # no RCCL on this box: the protocol itself is covered by the gloo test
-            pytest.skip('cannot create a 1-rank RCCL group here: %r' % (e,))
-    try:
-        a = GanTrainer(img=64, seed=5, max_iter_step=50)
-        b = GanTrainer(img=64, seed=5, max_iter_step=50, use_graphs=True, segment_graphs=True,
-                       process_group=dist.group.WORLD)
-        b.reducer.world = 2          # exercise the collective calls; a 1-rank all-reduce leaves the data unchanged
-        b.reducer.stream = torch.cuda.Stream()
-        b.world = 1
-        bd, bg = synthetic_batch(2, 11, 64), synthetic_batch(2, 12, 64)
-        for it in range(4):
-            la = (float(a.d_step(bd, it)), float(a.g_step(bg, it)))
-            lb = (float(b.d_step(bd, it)), float(b.g_step(bg, it)))
-            assert abs(la[0] - lb[0]) < 1e-4 * max(1.0, abs(la[0])) and abs(la[1] - lb[1]) < 1e-4 * max(1.0, abs(la[1])), (it, la, lb)
-        segs = [g for g in b._graphs.values() if isinstance(g, list)]
-        assert len(segs) == 2 and all(sum(1 for op in ops if op[0] == 'reduce') >= 1 for ops in segs)
-        assert sum(1 for op in [o for ops in segs for o in ops] if op[0] == 'reduce') == 4      # D: 1, G: 3 sections
-        worst = max(float((a.store[n] - b.store[n]).abs().max()) for n in a.store.names())
-        assert worst < 4e-3, worst
-    finally:
-        if created:
-            dist.destroy_process_group()
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, 'rccl_world1_check.py')], capture_output=True, text=True,
+                       timeout=600, cwd=os.path.dirname(here))
+    if 'SKIP' in r.stdout:
+        pytest.skip(r.stdout.strip().splitlines()[-1])
+    # the marker is printed after every check and a device synchronize; communicator teardown is not under test
+    assert 'RCCL_WORLD1_OK' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
