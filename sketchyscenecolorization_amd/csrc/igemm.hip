@@ -472,12 +472,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
 //   * no per-step branches: the K-tile index is clamped instead of tested, selects are arithmetic, the filter columns
 //     beyond Nn are zeroed in the epilogue instead of masked every step;
 //   * PLAIN (no folded norm, no activation on any source: every data-gradient launch) is a template flag.
+#define UT_AV(BM, BN) (!((BM) == 128 && (BN) <= 64))
 template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN>
 __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, const Magics mg,
                                                        float* __restrict__ slab_base, long slab_stride, int splitk) {
     constexpr int BM = WM * SM * 32;
     constexpr int BN = WN * SN * 32;
-    constexpr int A_LD = BK + 1;
+    // AV: A rows padded to 36 floats (16-byte aligned, b128 accesses conflict-free) and the K index of MFMA step kk on
+    // lane half lhi permuted to k = 16*lhi + kk (any bijection works when A and B agree): a lane's 16 A operands of a
+    // K-tile are then contiguous, 4 ds_read_b128 instead of 16 ds_read_b32 per row block, and each staged float4 is one
+    // ds_write_b128.  Not for the 128-row x <=64-column tiles, whose 3 workgroups per CU would no longer fit the LDS.
+    constexpr bool AV = UT_AV(BM, BN);
+    constexpr int A_LD = AV ? BK + 4 : BK + 1;
     constexpr int A_SZ = BM * A_LD;
     constexpr int B_LD = (BMODE == 0) ? BN : (BK + 1);
     constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * (BK + 1);
@@ -613,7 +619,11 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         for (int i = 0; i < A_ROWS; ++i) {
             const float4 v = PLAIN ? mask4(ra[i], rav[i]) : xform4(ra[i], raa, rab, ra_slope, rav[i]);
             float* p = Ab + ((tid >> 3) + 32 * i) * A_LD + a_col4 * 4;
-            p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+            if (AV) {
+                *reinterpret_cast<float4*>(p) = v;
+            } else {
+                p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+            }
         }
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
@@ -635,20 +645,32 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         __syncthreads();
         int cur = 0;
         for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const float* Ab = As + cur * A_SZ + (wm * SM * 32 + l31) * A_LD + lhi;
-            const float* Bb = (BMODE == 0) ? (Bs + cur * B_SZ + lhi * B_LD + wn * SN * 32 + l31)
-                                           : (Bs + cur * B_SZ + (wn * SN * 32 + l31) * B_LD + lhi);
+            // K index of MFMA step kk on this lane half: 2*kk + lhi, or 16*lhi + kk (AV)
+            constexpr int KS = AV ? 1 : 2;              // k stride between consecutive steps
+            const int kl = AV ? lhi * (BK / 2) : lhi;   // k of step 0
+            const float* Ab = As + cur * A_SZ + (wm * SM * 32 + l31) * A_LD + kl;
+            const float* Bb = (BMODE == 0) ? (Bs + cur * B_SZ + kl * B_LD + wn * SN * 32 + l31)
+                                           : (Bs + cur * B_SZ + (wn * SN * 32 + l31) * B_LD + kl);
             constexpr int FG = 4, NFG = BK / 2 / FG;
             float av[2][FG][SM], bv[2][FG][SN];
             auto fetch = [&](int g, int buf) {
+                if (AV) {
+#pragma unroll
+                    for (int i = 0; i < SM; ++i) {
+                        const float4 v = *reinterpret_cast<const float4*>(Ab + i * 32 * A_LD + g * FG);
+                        av[buf][0][i] = v.x; av[buf][1][i] = v.y; av[buf][2][i] = v.z; av[buf][3][i] = v.w;
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < FG; ++q) {
                     const int kk = g * FG + q;
+                    if (!AV) {
 #pragma unroll
-                    for (int i = 0; i < SM; ++i) av[buf][q][i] = Ab[i * 32 * A_LD + kk * 2];
+                        for (int i = 0; i < SM; ++i) av[buf][q][i] = Ab[i * 32 * A_LD + kk * KS];
+                    }
 #pragma unroll
                     for (int j = 0; j < SN; ++j)
-                        bv[buf][q][j] = (BMODE == 0) ? Bb[kk * 2 * B_LD + j * 32] : Bb[j * 32 * B_LD + kk * 2];
+                        bv[buf][q][j] = (BMODE == 0) ? Bb[kk * KS * B_LD + j * 32] : Bb[j * 32 * B_LD + kk * KS];
                 }
             };
             auto mfmas = [&](int g) {
@@ -1016,8 +1038,14 @@ static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long
                         long out_elems, int64_t ws_bytes, bool have_ws) {
     const int ncu = num_cu();
     Plan best = {-1, 1, 1e300};
+    static int force = -2;      // SSC_FWD_CFG=n: tuning aid, restricts the search to tile configuration n where allowed
+    if (force == -2) {
+        const char* e = getenv("SSC_FWD_CFG");
+        force = (e != nullptr) ? atoi(e) : -1;
+    }
     for (int c = 0; c < ncfg; ++c) {
         if (!allowed[c]) continue;
+        if (force >= 0 && c != force && allowed[force]) continue;
         const TileCfg& t = cfgs[c];
         const long mt = (M + t.BM - 1) / t.BM, nt = (N + t.BN - 1) / t.BN;
         const long blocks = mt * nt * nphase;
@@ -1076,7 +1104,7 @@ static int ut2_mode() {
 template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN>
 static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
-    constexpr int A_SZ = BM * (BK + 1);
+    constexpr int A_SZ = BM * (UT_AV(BM, BN) ? BK + 4 : BK + 1);
     constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * (BK + 1);
     constexpr size_t lds = 2 * (A_SZ + B_SZ) * sizeof(float) + BM * sizeof(long);
     const long M = (long)d.NB * d.PH * d.PW;
