@@ -10,11 +10,11 @@ from collections import defaultdict
 
 def demangled_short(name):
     # rocpd stores demangled names: "void conv_fwd_kernel<2, 2, 1, 2, 0, true, true>(...)"
-    m = re.match(r'void (conv_fwd_kernel|conv_wgrad_kernel|narrow_fwd_kernel)<([^>]*)>', name)
+    m = re.match(r'void (conv_fwd_kernel|conv_ut_kernel|conv_wgrad_kernel|narrow_fwd_kernel)<([^>]*)>', name)
     if not m:
         return None
     k, args = m.group(1), [a.strip() for a in m.group(2).split(',')]
-    if k == 'conv_fwd_kernel':
+    if k in ('conv_fwd_kernel', 'conv_ut_kernel'):      # same tile configurations, same report name
         wm, wn, sm, sn, bm = [int(a) for a in args[:5]]
         return 'conv_fwd<%dx%d,%s>' % (wm * sm * 32, wn * sn * 32, 'NK' if bm else 'KN')
     if k == 'conv_wgrad_kernel':
