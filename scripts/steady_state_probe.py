@@ -44,3 +44,8 @@ case('4x4s2 enc2 shape, batch 256', 256, 96, 64, 128, 4, 2, 1, True)
 case('4x4s2 enc2 shape, batch 32', 32, 96, 64, 128, 4, 2, 1, True)
 case('4x4s2 enc4 shape, batch 32', 32, 24, 256, 512, 4, 2, 1, True)
 case('4x4s2 enc5 shape, batch 32', 32, 12, 512, 512, 4, 2, 1, True)
+
+# round quantisation: 64x128 tiles, 3 workgroups per CU -> 768 resident; M = 64 * tiles
+if len(sys.argv) > 1 and sys.argv[1] == 'rounds':
+    for n in (12, 18, 24, 36, 48):
+        case('1x1 K=1024 N=128, %d tiles' % (n * 64 * 64 // 64), n, 64, 1024, 128, 1, 1, 0, True)

@@ -475,7 +475,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
 #define UT_AV(BM, BN) (!((BM) == 128 && (BN) <= 64))
 template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN>
 __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, const Magics mg,
-                                                       float* __restrict__ slab_base, long slab_stride, int splitk) {
+                                                       float* __restrict__ slab_base, long slab_stride, int splitk,
+                                                       int ts_full, int ts_s) {
     constexpr int BM = WM * SM * 32;
     constexpr int BN = WN * SN * 32;
     // AV: A rows padded to 36 floats (16-byte aligned, b128 accesses conflict-free) and the K index of MFMA step kk on
@@ -517,11 +518,37 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     const int Ktot = d.TH * d.TW * C;
     const long M = (long)d.NB * d.PH * d.PW;
     const int PHW = d.PH * d.PW;
-    const int phase = blockIdx.z / splitk;
-    const int ks = blockIdx.z % splitk;
+    // workgroup -> (tile, K range).  Legacy grid: x = row tile, y = column tile, z = phase * splitk + K slice.
+    // Tail split (ts_s > 0, 1-D grid, launches without split-K): tiles [0, ts_full) fill whole rounds of the chip and are
+    // finished in place; each of the remaining tiles -- the partly filled last round -- is cut into ts_s K slices that
+    // together fill that round, written as raw partial tiles [BM][BN] and summed by ts_fixup_kernel.
+    int phase, ks, sk, n0;
+    long m0;
+    float* part = nullptr;
+    if (ts_s > 0) {
+        const int bid = blockIdx.x;
+        int tile;
+        if (bid < ts_full) {
+            tile = bid; ks = 0; sk = 1;
+        } else {
+            const int r = bid - ts_full;
+            const int q = r / ts_s;
+            tile = ts_full + q; ks = r - q * ts_s; sk = ts_s;
+            part = slab_base + (long)r * (BM * BN);
+        }
+        const int mt = (int)((M + BM - 1) / BM), nt = (d.Nstore + BN - 1) / BN;
+        const int rest = tile / mt;
+        m0 = (long)(tile - rest * mt) * BM;
+        phase = rest / nt;
+        n0 = (rest - phase * nt) * BN;
+    } else {
+        phase = blockIdx.z / splitk;
+        ks = blockIdx.z % splitk;
+        sk = splitk;
+        m0 = (long)blockIdx.x * BM;
+        n0 = blockIdx.y * BN;
+    }
     const FwdPhase ph = fwd_phase(d, phase);
-    const long m0 = (long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
 
     const int a_col4 = tid & 7;
     int a_iyb[A_ROWS], a_ixb[A_ROWS], a_off0[A_ROWS], a_off1[A_ROWS];
@@ -556,7 +583,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     }
 
     const int nkt = (Ktot + BK - 1) / BK;
-    const int per = (nkt + splitk - 1) / splitk;
+    const int per = (nkt + sk - 1) / sk;
     const int kt_begin = ks * per;
     const int kt_end = min(nkt, kt_begin + per);
 
@@ -709,8 +736,19 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     }
 
     // ---- epilogue ----
-    float* outp = (splitk > 1) ? (slab_base + (long)ks * slab_stride) : d.out;
-    const bool final_pass = (splitk == 1);
+    if (part != nullptr) {      // tail split: raw partial tile
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * SM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+#pragma unroll
+                for (int j = 0; j < SN; ++j) part[row * BN + wn * SN * 32 + j * 32 + l31] = acc[i][j][r];
+            }
+        return;
+    }
+    float* outp = (ts_s == 0 && splitk > 1) ? (slab_base + (long)ks * slab_stride) : d.out;
+    const bool final_pass = (ts_s > 0) || (splitk == 1);
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
 #pragma unroll
@@ -732,6 +770,49 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                 }
                 *o = v;
             }
+        }
+    }
+}
+
+// tail-split fix-up: one workgroup per tail tile sums its ts_s partial tiles (in slice order) and applies the epilogue
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void ts_fixup_kernel(const ssc_conv_desc d, const Magics mg,
+                                                       const float* __restrict__ parts, int ts_full, int ts_s) {
+    const long M = (long)d.NB * d.PH * d.PW;
+    const int PHW = d.PH * d.PW;
+    const int tile = ts_full + blockIdx.x;
+    const int mt = (int)((M + BM - 1) / BM), nt = (d.Nstore + BN - 1) / BN;
+    const int rest = tile / mt;
+    const long m0 = (long)(tile - rest * mt) * BM;
+    const int phase = rest / nt;
+    const int n0 = (rest - phase * nt) * BN;
+    const FwdPhase ph = fwd_phase(d, phase);
+    const float* base = parts + (long)blockIdx.x * ts_s * (BM * BN);
+    constexpr int C4 = BN / 4;
+    for (int e = threadIdx.x; e < BM * C4; e += 256) {
+        const int row = e / C4, c4 = (e - row * C4) * 4;
+        const long m = m0 + row;
+        if (m >= M) continue;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < ts_s; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)q * (BM * BN) + row * BN + c4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int n = (int)div64(m, mg.mPHPW, mg.onePHPW);
+        const int rem = (int)(m - (long)n * PHW);
+        const int py = (int)div64(rem, mg.mPW, mg.onePW), px = rem - py * d.PW;
+        float* o = d.out + (((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x) * d.ldc;
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = n0 + c4 + q;
+            if (col >= d.Nstore) continue;
+            float v = col < d.Nn ? sv[q] : 0.f;
+            if (d.bias != nullptr && col < d.Nn) v += d.bias[col];
+            if (d.epi == 1) v = tanhf(v);
+            else if (d.epi == 2) v = fmaxf(v, 0.2f * v);
+            if (d.accumulate) v += o[col];
+            o[col] = v;
         }
     }
 }
@@ -1019,6 +1100,19 @@ static const TileCfg WG_CFGS[5] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.00}
 // Makespan model of one launch: `blocks` equal workgroups of `w` MFMA-cycles each on ncu CUs that hold `res`
 // of them at a time and are matrix-pipe bound (co-resident workgroups share the pipe).  Split-K by s divides w
 // and multiplies the block count, at the price of writing + re-reading s partial copies of the output.
+// planner constants, overridable from the environment while tuning (read once)
+static double plan_const(const char* name, double dflt) {
+    static const char* names[8];
+    static double vals[8];
+    static int n = 0;
+    for (int i = 0; i < n; ++i)
+        if (names[i] == name) return vals[i];
+    const char* e = getenv(name);
+    const double v = (e != nullptr) ? atof(e) : dflt;
+    if (n < 8) { names[n] = name; vals[n] = v; ++n; }
+    return v;
+}
+
 static double makespan(long blocks, double w, int res, int ncu) {
     const long slots = (long)ncu * res;
     const long full = blocks / slots, rem = blocks % slots;
@@ -1027,8 +1121,8 @@ static double makespan(long blocks, double w, int res, int ncu) {
     // ~25 % below 3 per CU at equal work)
     const long per_cu = (blocks + ncu - 1) / ncu;
     const long occ = per_cu < res ? per_cu : res;
-    if (occ <= 1) t *= 1.30;
-    else if (occ == 2) t *= 1.08;
+    if (occ <= 1) t *= plan_const("SSC_PLAN_OCC1", 1.30);
+    else if (occ == 2) t *= plan_const("SSC_PLAN_OCC2", 1.08);
     return t;
 }
 
@@ -1055,7 +1149,7 @@ static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long
             const long per = (nkt + sk - 1) / sk;
             if ((nkt + per - 1) / per != sk) continue;      // would leave empty trailing splits
             double cost = makespan(blocks * sk, wfull * (double)per / (double)nkt, t.res, ncu) + 2500.0;
-            if (sk > 1) cost += 2.0 * sk * (double)out_elems * 4.0 / 1500.0 + 6000.0;   // slab traffic + reduce launch
+            if (sk > 1) cost += 2.0 * sk * (double)out_elems * 4.0 / 1500.0 + plan_const("SSC_PLAN_REDUCE", 6000.0);   // slab traffic + reduce launch
             if (cost < best.cost) best = {c, sk, cost};
         }
     }
@@ -1092,6 +1186,18 @@ static int launch_fwd_v(const ssc_conv_desc& d, int splitk, float* ws, hipStream
     return (int)hipGetLastError();
 }
 
+// set by ssc_conv_forward for the launch it is about to make: resident workgroups per CU of the chosen tile, workspace size
+static thread_local int g_launch_res = 2;
+static thread_local int64_t g_launch_ws_bytes = 0;
+static int tail_split_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("SSC_TAIL_SPLIT");
+        mode = (e != nullptr) ? atoi(e) : 1;
+    }
+    return mode;
+}
+
 static int ut2_mode() {
     static int mode = -1;
     if (mode < 0) {
@@ -1120,9 +1226,28 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    // tail split: a launch without split-K whose last round would be partly filled
+    if (splitk == 1 && ws != nullptr && tail_split_mode() != 0) {
+        const long tiles = mt * nt * d.nphase;
+        const long slots = (long)num_cu() * g_launch_res;
+        const long nkt = ((long)d.TH * d.TW * C + BK - 1) / BK;
+        const long full = (tiles / slots) * slots, tail = tiles - full;
+        if (full > 0 && tail > 0 && tail * 4 <= slots * 3) {
+            long s = slots / tail;
+            if (s > 8) s = 8;
+            while (s > 1 && nkt / s < 4) --s;
+            if (s > 1 && (int64_t)tail * s * BM * BN * 4 <= g_launch_ws_bytes && full + tail * s < 0x7fffffffL) {
+                hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN>), dim3((unsigned)(full + tail * s)),
+                                   dim3(256), lds, st, d, mg, ws, out_count, 1, (int)full, (int)s);
+                hipLaunchKernelGGL((ts_fixup_kernel<BM, BN>), dim3((unsigned)tail), dim3(256), 0, st, d, mg, ws, (int)full,
+                                   (int)s);
+                return (int)hipGetLastError();
+            }
+        }
+    }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
     hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN>), grid, dim3(256), lds, st, d, mg, ws, out_count,
-                       splitk);
+                       splitk, 0, 0);
     if (splitk > 1) {
         const int thr = 256;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
@@ -1192,6 +1317,8 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
     if (ssc_conv_narrow_supported(dp)) return ssc_conv_narrow_forward(dp, stream);   // <= 4 output channels
     const Plan p = plan_fwd(d, ws_bytes, ws != nullptr);
     if (p.cfg < 0) return -4;
+    g_launch_res = FWD_CFGS[p.cfg].res;
+    g_launch_ws_bytes = ws_bytes;
     if (d.bmode == 0) {
         switch (p.cfg) {
             case 0: return launch_fwd<2, 2, 2, 2, 0>(d, p.splitk, ws, st);
@@ -1279,7 +1406,7 @@ static Plan plan_wgrad(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws) 
             const long per = (nkt + sk - 1) / sk;
             if ((nkt + per - 1) / per != sk) continue;
             double cost = makespan(blocks * sk, wfull * (double)per / (double)nkt, t.res, ncu) + 2500.0;
-            if (sk > 1) cost += 2.0 * sk * (double)out_elems * 4.0 / 1500.0 + 6000.0;
+            if (sk > 1) cost += 2.0 * sk * (double)out_elems * 4.0 / 1500.0 + plan_const("SSC_PLAN_REDUCE", 6000.0);
             if (cost < best.cost) best = {c, (int)sk, cost};
         }
     }
