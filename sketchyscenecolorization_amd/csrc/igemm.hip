@@ -473,7 +473,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
 //     beyond Nn are zeroed in the epilogue instead of masked every step;
 //   * PLAIN (no folded norm, no activation on any source: every data-gradient launch) is a template flag.
 #define UT_AV(BM, BN) (!((BM) == 128 && (BN) <= 64))
-template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN>
+// KMASK: channel counts that are not multiples of 32 (the MRU concats: 576 + 4, of which 579 real).  K-tiles are then
+// enumerated per (tap, source, 32-channel chunk), mg.mC holding the magic of chunks-per-tap, so a tile still lies inside
+// one tap and one source; the last chunk of a source is partly empty: its A float4s beyond the source's channels are
+// not loaded and its filter rows beyond the real channels are zeroed (the A padding channels need not hold zeros).
+template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN, bool KMASK>
 __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, const Magics mg,
                                                        float* __restrict__ slab_base, long slab_stride, int splitk,
                                                        int ts_full, int ts_s) {
@@ -515,7 +519,9 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     const float slope0 = act_slope(d.x.act), slope1 = act_slope(d.x.act1 >= 0 ? d.x.act1 : d.x.act);
 
     const int C = xC0 + xC1;
-    const int Ktot = d.TH * d.TW * C;
+    const int nch0 = (xC0 + BK - 1) / BK, nch1 = (xC1 + BK - 1) / BK;     // 32-channel chunks per source
+    const int tpt = nch0 + nch1;                                          // K-tiles per tap
+    const int kreal0 = min(xC0, d.k_real), kreal1 = d.k_real - xC0;        // real filter channels of each source
     const long M = (long)d.NB * d.PH * d.PW;
     const int PHW = d.PH * d.PW;
     // workgroup -> (tile, K range).  Legacy grid: x = row tile, y = column tile, z = phase * splitk + K slice.
@@ -570,19 +576,27 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         if (a_col4 == 0)
             rowpix[row] = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
     }
-    int b_off[B_SLOTS];
+    // filter offsets of this thread's float4 slots, split into the part along K (b_k: filter rows of the tile for KN,
+    // element offset along the row for NK) and the rest (b_n), so that KMASK can drop the K part of an empty slot
+    int b_k[B_SLOTS], b_n[B_SLOTS], b_kk[B_SLOTS];     // b_kk: k index inside the tile
 #pragma unroll
     for (int s = 0; s < B_SLOTS; ++s) {
         if (BMODE == 0) {
             const int n = n0 + (tid % (BN / 4)) * 4;
-            b_off[s] = (n < d.Nn) ? (tid / (BN / 4) + B_RP * s) * wC1 + d.n_off + n : 0;
+            const bool nv = n < d.Nn;
+            b_kk[s] = tid / (BN / 4) + B_RP * s;
+            b_k[s] = nv ? b_kk[s] * wC1 : 0;
+            b_n[s] = nv ? d.n_off + n : 0;
         } else {
             const int n = n0 + (tid >> 3) + 32 * s;
-            b_off[s] = (n < d.Nn) ? (d.n_off + n) * wC1 + (tid & 7) * 4 : 0;
+            const bool nv = n < d.Nn;
+            b_kk[s] = (tid & 7) * 4;
+            b_k[s] = nv ? b_kk[s] : 0;
+            b_n[s] = nv ? (d.n_off + n) * wC1 : 0;
         }
     }
 
-    const int nkt = (Ktot + BK - 1) / BK;
+    const int nkt = d.TH * d.TW * tpt;
     const int per = (nkt + sk - 1) / sk;
     const int kt_begin = ks * per;
     const int kt_end = min(nkt, kt_begin + per);
@@ -600,23 +614,27 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     float4 raa, rab;
     float ra_slope = 1.f;
     float4 rb[B_SLOTS];
+    float rbv[B_SLOTS];      // KMASK: 1.0 / 0.0 validity of each staged filter float4
 
     auto issue_loads = [&](int kt) {
-        const int kb = kt * BK;
-        const int tap = div32(kb, mg.mC, mg.oneC);
-        const int cch = kb - tap * C;
+        const int tap = div32(kt, mg.mC, mg.oneC);      // mC: magic of tpt
+        const int chunk = kt - tap * tpt;
         const int ty = div32(tap, mg.mTW, mg.oneTW), tx = tap - ty * TWv;
-        const bool first = cch < xC0;
+        const bool first = chunk < nch0;
         const int cs = first ? xC0 : xC1;
-        const int cc = first ? cch : cch - xC0;
+        const int cc = (first ? chunk : chunk - nch0) * BK;     // channel offset inside the source
+        const int cch = first ? cc : xC0 + cc;                  // channel offset inside the filter's K rows
+        const int kreal = (first ? kreal0 : kreal1) - cc;       // real channels left in this source from cc on
+        const int cchf = (!KMASK || kreal > 0) ? cch : 0;       // a chunk without real channels reads (and drops) row 0
         const float* sbase = (first ? xs0 : xs1) + cc;
         const int tapshift = (ty * xW + tx) * cs;
         const int fmask = first ? -1 : 0;
         if (!PLAIN) {
             const float* abp = first ? xab0 : xab1;
             const bool has = abp != nullptr;
-            const float* pa = has ? abp + cc + a_col4 * 4 : xs0;       // a valid address either way
-            const float* pb = has ? abp + cs + cc + a_col4 * 4 : xs0;
+            const bool hc = has & (!KMASK || cc + a_col4 * 4 < cs);     // KMASK: no table entries beyond the source
+            const float* pa = hc ? abp + cc + a_col4 * 4 : xs0;       // a valid address either way
+            const float* pb = hc ? abp + cs + cc + a_col4 * 4 : xs0;
             const float4 va = *reinterpret_cast<const float4*>(pa);
             const float4 vb = *reinterpret_cast<const float4*>(pb);
             raa = has ? va : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -626,17 +644,26 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             const int iy = a_iyb[i] + ty, ix = a_ixb[i] + tx;
-            const bool v = a_mv[i] & ((unsigned)iy < (unsigned)xH) & ((unsigned)ix < (unsigned)xW);
+            const bool v = a_mv[i] & ((unsigned)iy < (unsigned)xH) & ((unsigned)ix < (unsigned)xW) &
+                           (!KMASK || cc + a_col4 * 4 < cs);
             const int osel = (a_off0[i] & fmask) | (a_off1[i] & ~fmask);    // bit select: a ?: here became a scratch array
             const int off = v ? osel + tapshift : a_col4 * 4;
             rav[i] = v ? 1.f : 0.f;
             ra[i] = *reinterpret_cast<const float4*>(sbase + off);
         }
         const int ky = ph.ky0 + ty * kstep, kx = ph.kx0 + tx * kstep;
-        const float* wtap = (BMODE == 0) ? wbase + ((long)(ky * KWv + kx) * wC0 + cch) * wC1
-                                         : wbase + (long)(ky * KWv + kx) * wC0 * wC1 + cch;
+        const float* wtap = (BMODE == 0) ? wbase + ((long)(ky * KWv + kx) * wC0 + cchf) * wC1
+                                         : wbase + (long)(ky * KWv + kx) * wC0 * wC1 + cchf;
 #pragma unroll
-        for (int s = 0; s < B_SLOTS; ++s) rb[s] = *reinterpret_cast<const float4*>(wtap + b_off[s]);
+        for (int s = 0; s < B_SLOTS; ++s) {
+            if (KMASK) {
+                const bool bv = b_kk[s] < kreal;        // k_real % 4 == 0 for NK: the float4 is all in or all out
+                rbv[s] = bv ? 1.f : 0.f;
+                rb[s] = *reinterpret_cast<const float4*>(wtap + (bv ? b_k[s] : 0) + b_n[s]);
+            } else {
+                rb[s] = *reinterpret_cast<const float4*>(wtap + b_k[s] + b_n[s]);
+            }
+        }
     };
 
     auto stage = [&](int buf) {
@@ -654,7 +681,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         }
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
-            const float4 v = rb[s];
+            const float4 v = KMASK ? mask4(rb[s], rbv[s]) : rb[s];
             if (BMODE == 0) {
                 *reinterpret_cast<float4*>(Bb + (tid / (BN / 4) + B_RP * s) * B_LD + (tid % (BN / 4)) * 4) = v;
             } else {
@@ -1198,6 +1225,34 @@ static int tail_split_mode() {
     return mode;
 }
 
+// uniform-tap fast path: every 32-wide K-tile inside one tap and one source, no channel padding; float4 filter loads
+// need 16-byte aligned, fully in-range groups of 4
+static bool fwd_is_ut(const ssc_conv_desc& d) {
+    const bool vec = (d.bmode == 0) ? (((d.wC1 | d.n_off) & 3) == 0 && (d.Nn & 3) == 0)
+                                    : ((d.wC1 & 3) == 0 && (d.k_real & 3) == 0);
+    const int C = d.x.C0 + d.x.C1;
+    return vec && (C % BK) == 0 && (d.x.C0 % BK) == 0 && d.k_real == C &&
+           (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x7fffffffL &&
+           (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
+}
+
+// chunked uniform-tap form (conv_ut_kernel<KMASK>): vector filter loads possible and at most 20 % of the K-tiles' width
+// wasted on the partly empty last chunk of each source
+static bool fwd_is_utg(const ssc_conv_desc& d) {
+    const bool vec = (d.bmode == 0) ? (((d.wC1 | d.n_off) & 3) == 0 && (d.Nn & 3) == 0)
+                                    : ((d.wC1 & 3) == 0 && (d.k_real & 3) == 0);
+    const int C = d.x.C0 + d.x.C1;
+    const int padded = ((d.x.C0 + BK - 1) / BK + (d.x.C1 + BK - 1) / BK) * BK;
+    static int off = -1;
+    if (off < 0) {
+        const char* e = getenv("SSC_UTG");
+        off = (e != nullptr && e[0] == '0') ? 1 : 0;
+    }
+    return !off && vec && d.k_real >= 1 && d.k_real <= C && padded * 5 <= C * 6 &&
+           (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x7fffffffL &&
+           (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
+}
+
 static int ut2_mode() {
     static int mode = -1;
     if (mode < 0) {
@@ -1207,7 +1262,7 @@ static int ut2_mode() {
     return mode;
 }
 
-template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN>
+template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN, bool KMASK>
 static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
     constexpr int A_SZ = BM * (UT_AV(BM, BN) ? BK + 4 : BK + 1);
@@ -1215,14 +1270,15 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
     constexpr size_t lds = 2 * (A_SZ + B_SZ) * sizeof(float) + BM * sizeof(long);
     const long M = (long)d.NB * d.PH * d.PW;
     const int C = d.x.C0 + d.x.C1;
-    const Magics mg = make_magics((unsigned)C, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW,
+    const int tpt = (d.x.C0 + BK - 1) / BK + (d.x.C1 + BK - 1) / BK;       // K-tiles per tap (mg.mC divides by it)
+    const Magics mg = make_magics((unsigned)tpt, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW,
                                   (unsigned long)M);
     const long mt = (M + BM - 1) / BM;
     const int nt = (d.Nstore + BN - 1) / BN;
     const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KMASK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
@@ -1230,14 +1286,14 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
     if (splitk == 1 && ws != nullptr && tail_split_mode() != 0) {
         const long tiles = mt * nt * d.nphase;
         const long slots = (long)num_cu() * g_launch_res;
-        const long nkt = ((long)d.TH * d.TW * C + BK - 1) / BK;
+        const long nkt = (long)d.TH * d.TW * tpt;
         const long full = (tiles / slots) * slots, tail = tiles - full;
         if (full > 0 && tail > 0 && tail * 4 <= slots * 3) {
             long s = slots / tail;
             if (s > 8) s = 8;
             while (s > 1 && nkt / s < 4) --s;
             if (s > 1 && (int64_t)tail * s * BM * BN * 4 <= g_launch_ws_bytes && full + tail * s < 0x7fffffffL) {
-                hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN>), dim3((unsigned)(full + tail * s)),
+                hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KMASK>), dim3((unsigned)(full + tail * s)),
                                    dim3(256), lds, st, d, mg, ws, out_count, 1, (int)full, (int)s);
                 hipLaunchKernelGGL((ts_fixup_kernel<BM, BN>), dim3((unsigned)tail), dim3(256), 0, st, d, mg, ws, (int)full,
                                    (int)s);
@@ -1246,7 +1302,7 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
         }
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
-    hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN>), grid, dim3(256), lds, st, d, mg, ws, out_count,
+    hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KMASK>), grid, dim3(256), lds, st, d, mg, ws, out_count,
                        splitk, 0, 0);
     if (splitk > 1) {
         const int thr = 256;
@@ -1261,16 +1317,15 @@ static int launch_fwd(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t
     // float4 filter loads need 16-byte aligned, fully in-range groups of 4
     const bool vec = (BMODE == 0) ? (((d.wC1 | d.n_off) & 3) == 0 && (d.Nn & 3) == 0)
                                   : ((d.wC1 & 3) == 0 && (d.k_real & 3) == 0);
-    // uniform-tap fast path: every 32-wide K-tile inside one tap and one source, no channel padding
-    const int C = d.x.C0 + d.x.C1;
-    const bool ut = vec && (C % BK) == 0 && (d.x.C0 % BK) == 0 && d.k_real == C &&
-                    (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x7fffffffL &&
-                    (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
-    if (ut && ut2_mode() != 0) {
+    const bool ut = fwd_is_ut(d);
+    if ((ut || fwd_is_utg(d)) && ut2_mode() != 0) {
         const bool plain0 = d.x.ab0 == nullptr && d.x.act == SSC_ACT_NONE;
         const bool plain1 = d.x.C1 == 0 || (d.x.ab1 == nullptr && (d.x.act1 >= 0 ? d.x.act1 : d.x.act) == SSC_ACT_NONE);
-        if (plain0 && plain1) return launch_fwd_ut<WM, WN, SM, SN, BMODE, true>(d, splitk, ws, st);
-        return launch_fwd_ut<WM, WN, SM, SN, BMODE, false>(d, splitk, ws, st);
+        const bool plain = plain0 && plain1;
+        if (ut) return plain ? launch_fwd_ut<WM, WN, SM, SN, BMODE, true, false>(d, splitk, ws, st)
+                             : launch_fwd_ut<WM, WN, SM, SN, BMODE, false, false>(d, splitk, ws, st);
+        return plain ? launch_fwd_ut<WM, WN, SM, SN, BMODE, true, true>(d, splitk, ws, st)
+                     : launch_fwd_ut<WM, WN, SM, SN, BMODE, false, true>(d, splitk, ws, st);
     }
     if (ut) return launch_fwd_v<WM, WN, SM, SN, BMODE, true, true>(d, splitk, ws, st);
     return vec ? launch_fwd_v<WM, WN, SM, SN, BMODE, true, false>(d, splitk, ws, st)
@@ -1280,7 +1335,9 @@ static int launch_fwd(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t
 static Plan plan_fwd(const ssc_conv_desc& d, int64_t ws_bytes, bool have_ws) {
     const long M = (long)d.NB * d.PH * d.PW;
     const int C = d.x.C0 + d.x.C1;
-    const long nkt = ((long)d.TH * d.TW * C + BK - 1) / BK;
+    long nkt = ((long)d.TH * d.TW * C + BK - 1) / BK;
+    if (ut2_mode() != 0 && (fwd_is_ut(d) || fwd_is_utg(d)))       // conv_ut_kernel walks whole chunks per tap and source
+        nkt = (long)d.TH * d.TW * ((d.x.C0 + BK - 1) / BK + (d.x.C1 + BK - 1) / BK);
     // column tile no wider than needed: <=32 -> 128x32, <=64 -> 128x64, else 128x128 / 64x128 / 128x64
     const bool allowed[5] = {d.Nstore > 64, d.Nstore > 64, d.Nstore > 32, d.Nstore <= 32, d.Nstore > 32};
     return plan_launch(FWD_CFGS, 5, allowed, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,

@@ -80,6 +80,46 @@ def test_conv_forward_padded_channels_and_cout1():
     assert float(out1[..., 1:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('c0,c1,real1,co,k,same,act', [
+    (576, 4, 3, 384, 3, True, 1),      # the MRU concat [h, sketch]: 580 channels, 579 real (mru.py:452-470)
+    (160, 8, 8, 128, 4, False, 2),     # two sources, neither a multiple of 32
+    (200, 0, 0, 64, 3, True, 0),       # one source, last chunk 8 of 32 channels
+])
+def test_conv_forward_channel_chunks(c0, c1, real1, co, k, same, act):
+    """Channel counts that are not multiples of 32 run the chunked uniform-tap kernel (conv_ut_kernel<KMASK>): the K loop
+    walks (tap, source, 32-channel chunk), the partly empty last chunk of a source must contribute nothing -- whatever
+    the padding channels hold (finite garbage here) and although the filter has no rows for them."""
+    hip = _hip()
+    n, h = 2, 14
+    xa = rnd(n, c0, h, h, seed=21)
+    parts = [xa]
+    if c1:
+        xb = rnd(n, c1, h, h, seed=22)
+        parts.append(xb[:, :real1])
+    x = torch.cat(parts, 1)
+    ci = x.shape[1]
+    w = rnd(k, k, ci, co, seed=23, std=0.03)
+    ab = torch.cat([1.0 + 0.1 * rnd(c0, seed=24), 0.2 * rnd(c0, seed=25)])
+    xin = torch.cat([act_ref(xa * ab[:c0].view(1, -1, 1, 1) + ab[c0:].view(1, -1, 1, 1), act)] + parts[1:], 1)
+    if same:
+        ref = torch.nn.functional.conv2d(xin, w.permute(3, 2, 0, 1), padding=k // 2)
+    else:
+        ref = T.conv2d_valid_pad(xin, w, 2, 1)
+    oh = ref.shape[2]
+    s1 = None
+    if c1:
+        s1 = nhwc(xb).clone()
+        s1[..., real1:] = 1.0e3                 # padding channels: the kernel may not rely on zeros there
+        s1 = s1.cuda()
+    out = torch.full((n, oh, oh, co), float('nan'), device='cuda')
+    v = hip.View(nhwc(xa).cuda(), s1, ab.cuda(), act, None, 0)
+    if same:
+        hip.conv_forward(v, w.cuda(), 1, 0, out, same=True)
+    else:
+        hip.conv_forward(v, w.cuda(), 2, 1, out)
+    close(nchw(out), ref)
+
+
 def test_conv_forward_splitk_small_m():
     hip = _hip()
     n, h, ci, co = 2, 12, 512, 512
