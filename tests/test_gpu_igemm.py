@@ -120,6 +120,38 @@ def test_conv_forward_channel_chunks(c0, c1, real1, co, k, same, act):
     close(nchw(out), ref)
 
 
+def test_large_launches_tail_split():
+    """Launches with more tiles than the chip holds at once (1152-1536 tiles of 64x128 on 768 resident workgroups): the
+    partly filled last round is cut into K slices and summed by ts_fixup_kernel (igemm.hip, tail split), for the plain
+    grid, the 4 sub-pixel phases of the transposed conv, and the accumulating data-gradient epilogue.  Reference:
+    torch's own convolutions on the GPU (fp32)."""
+    import torch.nn.functional as F
+    hip = _hip()
+    torch.backends.cudnn.allow_tf32 = False
+    # conv 3x3 SAME, M = 8*96*96 = 73728 -> 1152 row tiles
+    x = rnd(8, 32, 96, 96, seed=41).cuda()
+    w = rnd(3, 3, 32, 128, seed=42, std=0.05).cuda()
+    ref = F.conv2d(torch.relu(x), w.permute(3, 2, 0, 1), padding=1)
+    out = torch.full((8, 96, 96, 128), float('nan'), device='cuda')
+    hip.conv_forward(hip.View(nhwc(x), None, None, 1), w, 1, 0, out, same=True)
+    close(nchw(out), ref)
+    # transposed conv k=4 s=2: 4 phases x (8*48*48 / 64) = 1152 tiles
+    xd = rnd(8, 64, 48, 48, seed=43).cuda()
+    f = rnd(4, 4, 128, 64, seed=44, std=0.05).cuda()
+    refd = F.conv_transpose2d(xd, f.permute(3, 2, 0, 1), stride=2, padding=1)
+    outd = torch.full((8, 96, 96, 128), float('nan'), device='cuda')
+    hip.deconv_forward(hip.View(nhwc(xd)), f, outd)
+    close(nchw(outd), refd)
+    # data gradient of a stride-1 conv, accumulated onto an existing tensor
+    w2 = rnd(3, 3, 128, 64, seed=47, std=0.05).cuda()
+    dy = rnd(8, 64, 96, 96, seed=45).cuda()
+    base = rnd(8, 96, 96, 128, seed=46).cuda()
+    refg = F.conv_transpose2d(dy, w2.permute(3, 2, 0, 1), padding=1)
+    dx = base.clone()
+    hip.conv_dgrad(hip.View(nhwc(dy)), w2, 1, 1, dx, accumulate=True)
+    close(nchw(dx - base), refg)
+
+
 def test_conv_forward_splitk_small_m():
     hip = _hip()
     n, h, ci, co = 2, 12, 512, 512
