@@ -21,6 +21,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// narrow.hip
+int ssc_conv_narrow_forward_ws(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, void* stream, int* csplit_out);
+
 #define BK 32
 #ifndef SSC_UT_SGB
 #define SSC_UT_SGB 1     // sched_group_barrier interleave hints in conv_ut_kernel (+1-2 % over the compiler's own order)
@@ -1371,7 +1374,15 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
     if (d.nphase == 4 && (d.TH != 2 || d.TW != 2 || d.KH != 4 || d.KW != 4 || d.kstep != -2 || d.out_stride != 2 ||
                           d.in_stride != 1))
         return -3;
-    if (ssc_conv_narrow_supported(dp)) return ssc_conv_narrow_forward(dp, stream);   // <= 4 output channels
+    if (ssc_conv_narrow_supported(dp)) {        // <= 4 output channels
+        int csplit = 1;
+        const int rc = ssc_conv_narrow_forward_ws(dp, ws, ws_bytes, stream, &csplit);
+        if (rc != 0 || csplit == 1) return rc;
+        const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + 255) / 256)), dim3(256), 0, st, ws, out_count,
+                           csplit, d.out, out_count, d.ldc, d.Nn, d.Nstore, d.bias, d.epi, d.accumulate);
+        return (int)hipGetLastError();
+    }
     const Plan p = plan_fwd(d, ws_bytes, ws != nullptr);
     if (p.cfg < 0) return -4;
     g_launch_res = FWD_CFGS[p.cfg].res;

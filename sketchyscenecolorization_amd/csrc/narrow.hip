@@ -26,7 +26,8 @@ __device__ __forceinline__ float nr_act(float v, int act) {
 
 // MODE 0: conv form, nphase == 1, in_stride == 1.   MODE 1: k=4 s=2 transposed form (4 phases).
 template <int MODE, int NOUT>
-__global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d) {
+__global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d, float* __restrict__ slabs,
+                                                         long slab_stride, int csplit) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int C = d.x.C0 + d.x.C1;
     const int PYD = (MODE == 1) ? NT + 2 : (NT - 1) + d.TH;
@@ -37,7 +38,10 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d) 
 
     const int tid = threadIdx.x;
     const int ly = tid >> 4, lx = tid & 15;
-    const int nimg = blockIdx.z;
+    // csplit > 1: the channel chunks are divided among csplit workgroups per tile (few lattice tiles, many channels: the
+    // PatchGAN logit conv is 128 tiles x 512 channels); each writes its raw partial sums to slab `cslice`
+    const int nimg = blockIdx.z / csplit;
+    const int cslice = blockIdx.z - nimg * csplit;
     const int py0 = blockIdx.y * NT, px0 = blockIdx.x * NT;
     // input coordinate of patch element (0,0)
     const int iy0 = (MODE == 1) ? py0 - 1 : py0 + d.ioff_y;
@@ -116,7 +120,10 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d) 
         }
     };
 
-    for (int cb = 0; cb < C; cb += NCH) {
+    const int nchunk = C / NCH;
+    const int cper = (nchunk + csplit - 1) / csplit;
+    const int cb_begin = cslice * cper * NCH, cb_end = min(C, cb_begin + cper * NCH);
+    for (int cb = cb_begin; cb < cb_end; cb += NCH) {
         // (prefetching the next chunk across the accumulate phase was measured slower: the 48 staging registers
         // held live across it cost more occupancy than the hidden latency buys)
         load_chunk(cb);
@@ -173,13 +180,18 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d) 
     for (int ph = 0; ph < NPH; ++ph) {
         const int oy = (MODE == 1) ? 2 * py + (ph >> 1) : py * d.out_stride + d.ooff_y;
         const int ox = (MODE == 1) ? 2 * px + (ph & 1) : px * d.out_stride + d.ooff_x;
-        float* o = d.out + (((long)nimg * d.OH + oy) * d.OW + ox) * d.ldc;
+        const long opix = (((long)nimg * d.OH + oy) * d.OW + ox) * d.ldc;
+        float* o = (csplit > 1) ? slabs + (long)cslice * slab_stride + opix : d.out + opix;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             if (n >= d.Nstore) break;
             float v = 0.f;          // columns in [Nn, Nstore) are channel padding: written as 0
             if (n < NOUT && n < d.Nn) {
                 v = acc[ph][n < NOUT ? n : 0].x + acc[ph][n < NOUT ? n : 0].y;
+                if (csplit > 1) {   // bias, activation and accumulation belong to the reduce pass
+                    o[n] = v;
+                    continue;
+                }
                 if (d.bias != nullptr) v += d.bias[n];
                 if (d.epi == 1) v = tanhf(v);
                 else if (d.epi == 2) v = fmaxf(v, 0.2f * v);
@@ -201,12 +213,24 @@ extern "C" int ssc_conv_narrow_supported(const ssc_conv_desc* dp) {
 }
 
 template <int MODE>
-static int launch_narrow(const ssc_conv_desc& d, hipStream_t st) {
+static int launch_narrow(const ssc_conv_desc& d, hipStream_t st, float* ws, int64_t ws_bytes, int* csplit_out) {
     const int PYD = (MODE == 1) ? NT + 2 : (NT - 1) + d.TH;
     const int PXD = (MODE == 1) ? NT + 2 : (NT - 1) + d.TW;
     const int nout = d.Nn < 1 ? 1 : d.Nn;       // accumulators per phase (1..4)
     const size_t lds = ((size_t)PYD * PXD * NPAD + (size_t)d.KH * d.KW * nout * NCH) * sizeof(float);
     dim3 grid((d.PW + NT - 1) / NT, (d.PH + NT - 1) / NT, d.NB);
+    // channel split when the lattice alone gives the chip too few workgroups (conv form only)
+    int csplit = 1;
+    const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
+    if (MODE == 0 && ws != nullptr && csplit_out != nullptr) {
+        const long wgs = (long)grid.x * grid.y * grid.z;
+        const int nchunk = (d.x.C0 + d.x.C1) / NCH;
+        while (csplit < 8 && wgs * csplit < 512 && nchunk / (csplit * 2) >= 2 &&
+               (int64_t)(csplit * 2) * out_count * 4 <= ws_bytes)
+            csplit *= 2;
+    }
+    if (csplit_out != nullptr) *csplit_out = csplit;
+    grid.z *= csplit;
 #define NARROW_LAUNCH(NO)                                                                                          \
     {                                                                                                              \
         static bool attr = false;                                                                                  \
@@ -215,7 +239,7 @@ static int launch_narrow(const ssc_conv_desc& d, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                      \
             attr = true;                                                                                           \
         }                                                                                                          \
-        hipLaunchKernelGGL((narrow_fwd_kernel<MODE, NO>), grid, dim3(256), lds, st, d);                            \
+        hipLaunchKernelGGL((narrow_fwd_kernel<MODE, NO>), grid, dim3(256), lds, st, d, ws, out_count, csplit);     \
     }
     if (nout == 1) NARROW_LAUNCH(1) else if (nout == 2) NARROW_LAUNCH(2) else if (nout == 3) NARROW_LAUNCH(3) else NARROW_LAUNCH(4)
 #undef NARROW_LAUNCH
@@ -224,5 +248,14 @@ static int launch_narrow(const ssc_conv_desc& d, hipStream_t st) {
 
 extern "C" int ssc_conv_narrow_forward(const ssc_conv_desc* dp, void* stream) {
     if (!ssc_conv_narrow_supported(dp)) return -1;
-    return dp->nphase == 4 ? launch_narrow<1>(*dp, (hipStream_t)stream) : launch_narrow<0>(*dp, (hipStream_t)stream);
+    return dp->nphase == 4 ? launch_narrow<1>(*dp, (hipStream_t)stream, nullptr, 0, nullptr)
+                           : launch_narrow<0>(*dp, (hipStream_t)stream, nullptr, 0, nullptr);
+}
+
+// with a workspace: may split the channels (csplit_out > 1); the caller then sums the csplit slabs of the workspace
+// (slab stride = NB*OH*OW*ldc floats) and applies bias / activation / accumulation (slab_reduce_kernel in igemm.hip)
+int ssc_conv_narrow_forward_ws(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, void* stream, int* csplit_out) {
+    if (!ssc_conv_narrow_supported(dp)) return -1;
+    return dp->nphase == 4 ? launch_narrow<1>(*dp, (hipStream_t)stream, ws, ws_bytes, csplit_out)
+                           : launch_narrow<0>(*dp, (hipStream_t)stream, ws, ws_bytes, csplit_out);
 }

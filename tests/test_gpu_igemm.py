@@ -78,6 +78,15 @@ def test_conv_forward_padded_channels_and_cout1():
     hip.conv_forward(hip.View(nhwc(x).cuda()), w1.cuda(), 1, 1, out1, nstore=4)
     close(out1[..., 0], ref1[:, 0])
     assert float(out1[..., 1:].abs().max()) == 0.0
+    # the PatchGAN logit conv: few lattice tiles, 512 channels -> channel-split narrow kernel + slab reduce, with bias
+    xl = rnd(n, 512, 13, 13, seed=9)
+    wl = rnd(4, 4, 512, 1, seed=10, std=0.02)
+    bias = torch.tensor([0.25])
+    refl = T.conv2d_valid_pad(T.lrelu(xl, 0.2), wl, 1, 1) + 0.25
+    outl = torch.full((n, 12, 12, 4), float('nan'), device='cuda')
+    hip.conv_forward(hip.View(nhwc(xl).cuda(), None, None, 2), wl.cuda(), 1, 1, outl, nstore=4, bias=bias.cuda())
+    close(outl[..., 0], refl[:, 0])
+    assert float(outl[..., 1:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize('c0,c1,real1,co,k,same,act', [
