@@ -1093,14 +1093,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splitk,
-                                    float* __restrict__ out, long count, int accumulate) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+// Sum of the split-K slabs of a filter gradient.  Small filters (1x1 / 3x3 convs of the residual blocks: 10^4-10^5
+// elements) are split hundreds of ways over the pixels, so one thread per element would leave a few dozen workgroups
+// walking hundreds of slabs each: L threads share an element (slabs s, s+L, ...) and combine through LDS in a fixed order.
+template <int L>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splitk,
+                                                           float* __restrict__ out, long count, int accumulate) {
+    constexpr int EPB = 256 / L;        // elements per block
+    __shared__ float part[256];
+    const int e = threadIdx.x % EPB, ls = threadIdx.x / EPB;
+    const long i = (long)blockIdx.x * EPB + e;
     float v = 0.f;
-    for (int s = 0; s < splitk; ++s) v += slabs[(long)s * slab_stride + i];
-    if (accumulate) v += out[i];
-    out[i] = v;
+    if (i < count)
+        for (int s = ls; s < splitk; s += L) v += slabs[(long)s * slab_stride + i];
+    if (L > 1) {
+        part[threadIdx.x] = v;
+        __syncthreads();
+        if (ls == 0)
+            for (int l = 1; l < L; ++l) v += part[l * EPB + e];
+    }
+    if (ls == 0 && i < count) {
+        if (accumulate) v += out[i];
+        out[i] = v;
+    }
+}
+
+static void launch_wgrad_reduce(const float* ws, long count, int splitk, float* out, int accumulate, hipStream_t st) {
+    if (count >= 262144 || splitk < 8) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, count,
+                           splitk, out, count, accumulate);
+    } else if (count >= 65536 || splitk < 32) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, st, ws, count, splitk,
+                           out, count, accumulate);
+    } else {
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((count + 15) / 16)), dim3(256), 0, st, ws, count, splitk,
+                           out, count, accumulate);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1432,11 +1460,7 @@ static int launch_wgrad_v(const ssc_wgrad_desc& d, int splitk, float* ws, hipStr
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)splitk);
     hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, SM, SN, GPLAIN, DPLAIN>), grid, dim3(256), lds, st, d, mg, ws, out_count,
                        splitk);
-    if (splitk > 1) {
-        const int thr = 256;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
-                           out_count, splitk, d.out, out_count, d.accumulate);
-    }
+    if (splitk > 1) launch_wgrad_reduce(ws, out_count, splitk, d.out, d.accumulate, st);
     return (int)hipGetLastError();
 }
 
