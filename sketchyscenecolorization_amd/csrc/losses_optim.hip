@@ -679,8 +679,17 @@ __global__ __launch_bounds__(256) void fc_small_fwd_kernel(const float* __restri
     __shared__ float sh[256];
     const int n = blockIdx.x, j = threadIdx.x & 63, kl = threadIdx.x >> 6;
     float acc = 0.f;
-    if (j < J)
-        for (int k = kl; k < K; k += 4) acc += x[(long)n * K + k] * W[(long)k * J + j];
+    if (j < J) {
+        // 8 independent partial sums: the loop is latency-bound (32 workgroups on the chip), the loads must overlap
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = kl;
+        for (; k + 28 < K; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] = fmaf(x[(long)n * K + k + 4 * u], W[(long)(k + 4 * u) * J + j], a8[u]);
+        }
+        for (; k < K; k += 4) a8[0] = fmaf(x[(long)n * K + k], W[(long)k * J + j], a8[0]);
+        acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    }
     sh[threadIdx.x] = acc;
     __syncthreads();
     if (kl == 0 && j < J)

@@ -293,12 +293,22 @@ __global__ __launch_bounds__(256) void act_mean_hw_kernel(const float* __restric
     if (c < C) {
         const float a = ab != nullptr ? ab[c] : 1.f, b = ab != nullptr ? ab[C + c] : 0.f;
         const float* p = x + (long)n * P * C + c;
-        for (int q = rl; q < P; q += 4) {
-            float v = fmaf(a, p[(long)q * C], b);
-            if (act == SSC_ACT_RELU) v = fmaxf(v, 0.f);
-            else if (act == SSC_ACT_LRELU) v = fmaxf(v, 0.2f * v);
-            s += v;
+        const float slope = act == SSC_ACT_RELU ? 0.f : (act == SSC_ACT_LRELU ? 0.2f : 1.f);   // act(t) = max(t, slope*t)
+        // 8 independent partial sums so that the strided loads overlap (256 workgroups, each a serial walk over P)
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int q = rl;
+        for (; q + 28 < P; q += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float v = fmaf(a, p[(long)(q + 4 * u) * C], b);
+                s8[u] += fmaxf(v, slope * v);
+            }
         }
+        for (; q < P; q += 4) {
+            const float v = fmaf(a, p[(long)q * C], b);
+            s8[0] += fmaxf(v, slope * v);
+        }
+        s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
     sh[threadIdx.x] = s;
     __syncthreads();
