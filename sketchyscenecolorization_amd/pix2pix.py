@@ -25,6 +25,10 @@ class Pix2PixGenerator(object):
     def __init__(self, store, bufs, lstm_hybrid=True):
         self.s, self.b = store, bufs
         self.lstm_hybrid = bool(lstm_hybrid)
+        # set by the trainer: side stream for the image-independent half of the caption branch, forward / backward.
+        # (Backward only when no gradient section ends a graph segment in between: the fork must be joined inside it.)
+        self.text_stream = None
+        self.text_stream_bwd = None
         self.text = TextFusion(store, bufs)
 
     def forward(self, sketches, text, noise_vec, tag='g', out=None, out_coff=0):
@@ -32,10 +36,14 @@ class Pix2PixGenerator(object):
         Writes tanh output into ``out[..., out_coff:out_coff+3]`` (NHWC) and returns the context."""
         s, B = self.s, self.b
         N, _, H, W = sketches.shape
+        chans = [None, 64, 128, 256, 512, 512]
+        tstream = self.text_stream if hip.PROFILE is None else None     # per-kernel timing runs everything in line
+        if self.lstm_hybrid and tstream is not None:
+            # the caption's word LSTM does not see the image: start it next to the encoder convolutions
+            text = self.text.start_words(text, chans[5], tag, tstream)
         xs = B.get(tag + '/xs', (N, H, W, 4), zero_on_alloc=True)
         hip.nchw_to_nhwc(sketches, xs, 0)
         e, ab, st = [None] * 6, [None] * 6, [None] * 6
-        chans = [None, 64, 128, 256, 512, 512]
         h = H
         for k in range(1, 6):
             h //= 2
@@ -155,12 +163,17 @@ class Pix2PixGenerator(object):
             done('decoders')
         # caption branch -> gradient w.r.t. normalised encoder_5 output
         de5 = B.get(tag + '/gb/de5', e[5].shape)
+        text_pending = False
         if self.lstm_hybrid:
-            dy5 = self.text.backward(ctx['tctx'], g_feat)
+            tstream = self.text_stream_bwd if hip.PROFILE is None else None
+            dy5 = self.text.backward(ctx['tctx'], g_feat, side_stream=tstream)
             if held:
                 main.wait_stream(side_stream)
                 done('decoders')
-            done('text')
+            if tstream is None:
+                done('text')
+            else:
+                text_pending = True     # its word-branch gradients are still being computed next to the encoder backward
             if dy5 is None:
                 hip.fill(de5, 0.0)
                 hip.fill(s.grad('generator/encoder_5/scale'), 0.0)
@@ -198,6 +211,9 @@ class Pix2PixGenerator(object):
                                     g2=_rows(g_skip[1]), act2=ACT_RELU)
             gcur = dx
         hip.conv_wgrad(View(ctx['xs']), View(gcur), s.grad('generator/encoder_1/conv/filter'), 2, 1)
+        if text_pending:
+            self.text.join_backward()
+            done('text')
         done('encoders')
 
 

@@ -54,37 +54,20 @@ class TextFusion(object):
             prep.update(tok=tok, mask=mask)
         return prep
 
-    def forward(self, e5, ab5, text, tag='g'):
-        """e5 raw [N,h,w,C] (+ folded norm ab5), text int [N,T] on the HOST (or a ``prepare`` result)
-        -> feat [N,h,w,C]."""
+    def _words_forward(self, prep, C, tag):
+        """The part of the branch that does not see the image: embedding, word LSTM over the S live steps, and the two
+        word-dependent terms of the multimodal gates for every step (one GEMM each)."""
         s, B = self.s, self.b
-        N, hh, ww, C = e5.shape
-        P = hh * ww
-        R = N * P
-        prep = text if isinstance(text, dict) else self.prepare(text, tag)
-        S = prep['S']
-        assert prep['N'] == N
-        ctx = {'N': N, 'P': P, 'C': C, 'S': S, 'tag': tag, 'shape': (N, hh, ww, C)}
-        feat = B.get(tag + '/tf/feat', (N, hh, ww, C))
-        if S == 0:      # every caption is all padding: relu(atanh(0)) = 0 (SURVEY appendix B.5)
-            hip.fill(feat, 0.0)
-            return feat, ctx
+        S, N = prep['S'], prep['N']
         tok, mask = prep['tok'], prep['mask']
         E = s[self.emb_name]
         Kw, bw = s[self.pfx_w + 'kernel'], s[self.pfx_w + 'bias']
-        Ka, ba = s[self.pfx_a + 'kernel'], s[self.pfx_a + 'bias']
+        Ka = s[self.pfx_a + 'kernel']
         G4 = 4 * C
-
-        vis = B.get(tag + '/tf/vis', (R, C))
-        vis_ss = B.get(tag + '/tf/vis_ss', (R,))
-        hip.call('ssc_row_l2norm_fwd', e5, C, ab5, R, C, vis, vis_ss)
-        Gv = B.get(tag + '/tf/Gv', (R, G4))
-        hip.matmul(vis, Ka[0:C], Gv, bias=ba)
         emb = B.get(tag + '/tf/emb', (S * N, C))
         hip.call('ssc_embedding_gather', E, tok, S * N, C, emb)
         EW = B.get(tag + '/tf/EW', (S * N, G4))
         hip.matmul(emb, Kw[0:C], EW, bias=bw)
-
         # ---- word LSTM (state [c,h], batch rows) ----
         cw = B.get(tag + '/tf/cw', (S + 1, N, C))
         hw = B.get(tag + '/tf/hw', (S + 1, N, C))
@@ -102,6 +85,50 @@ class TextFusion(object):
         Rall = B.get(tag + '/tf/Rall', (S * N, G4))
         hip.matmul(emb, Ka[C:2 * C], Rall)
         hip.matmul(lang, Ka[2 * C:3 * C], Rall, accumulate=True)
+        return {'emb': emb, 'cw': cw, 'hw': hw, 'acts_w': acts_w, 'lang': lang, 'lang_ss': lang_ss, 'Rall': Rall}
+
+    def start_words(self, text, C, tag, stream):
+        """Run the image-independent part on ``stream`` now, so that its chain of small recurrent GEMMs overlaps the
+        encoder convolutions; ``forward`` joins it.  Returns the ``prepare`` result to pass as ``text``."""
+        prep = text if isinstance(text, dict) else self.prepare(text, tag)
+        if prep['S'] > 0 and stream is not None and 'words' not in prep:
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                words = self._words_forward(prep, C, tag)
+            prep = dict(prep, words=words, words_stream=stream)
+        return prep
+
+    def forward(self, e5, ab5, text, tag='g'):
+        """e5 raw [N,h,w,C] (+ folded norm ab5), text int [N,T] on the HOST (or a ``prepare`` result)
+        -> feat [N,h,w,C]."""
+        s, B = self.s, self.b
+        N, hh, ww, C = e5.shape
+        P = hh * ww
+        R = N * P
+        prep = text if isinstance(text, dict) else self.prepare(text, tag)
+        S = prep['S']
+        assert prep['N'] == N
+        ctx = {'N': N, 'P': P, 'C': C, 'S': S, 'tag': tag, 'shape': (N, hh, ww, C)}
+        feat = B.get(tag + '/tf/feat', (N, hh, ww, C))
+        if S == 0:      # every caption is all padding: relu(atanh(0)) = 0 (SURVEY appendix B.5)
+            hip.fill(feat, 0.0)
+            return feat, ctx
+        tok, mask = prep['tok'], prep['mask']
+        Ka, ba = s[self.pfx_a + 'kernel'], s[self.pfx_a + 'bias']
+        G4 = 4 * C
+
+        vis = B.get(tag + '/tf/vis', (R, C))
+        vis_ss = B.get(tag + '/tf/vis_ss', (R,))
+        hip.call('ssc_row_l2norm_fwd', e5, C, ab5, R, C, vis, vis_ss)
+        Gv = B.get(tag + '/tf/Gv', (R, G4))
+        hip.matmul(vis, Ka[0:C], Gv, bias=ba)
+        words = prep.get('words')
+        if words is None:
+            words = self._words_forward(prep, C, tag)
+        elif prep.get('words_stream') is not None:      # started earlier on a side stream (start_words): join it
+            torch.cuda.current_stream().wait_stream(prep['words_stream'])
+        emb, cw, hw, acts_w, lang, lang_ss, Rall = (words[k] for k in ('emb', 'cw', 'hw', 'acts_w', 'lang', 'lang_ss',
+                                                                        'Rall'))
 
         # ---- multimodal LSTM (state per spatial position) ----
         ca = B.get(tag + '/tf/ca', (S + 1, R, C))
@@ -122,10 +149,20 @@ class TextFusion(object):
                    acts_w=acts_w, ca=ca, ha=ha, acts_a=acts_a, feat=feat, Gv=Gv)
         return feat, ctx
 
-    def backward(self, ctx, g_feat):
+    def join_backward(self):
+        """Make the current stream wait for the word-branch gradients that ``backward`` left on a side stream."""
+        if self._bwd_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._bwd_stream)
+            self._bwd_stream = None
+
+    _bwd_stream = None
+
+    def backward(self, ctx, g_feat, side_stream=None):
         """g_feat [N,h,w,C]: gradient w.r.t. the fused feature.  Fills the TextLSTM parameter
         gradients and returns the gradient w.r.t. the *normalised* encoder_5 output [R,C]
-        (None when no step ran)."""
+        (None when no step ran).  With ``side_stream`` everything downstream of the multimodal BPTT that the image
+        path does not need (word-term filter gradients, word LSTM BPTT, embedding gradient: a chain of small GEMMs)
+        runs there; the caller must ``join_backward()`` before it reads the TextLSTM gradients."""
         s, B = self.s, self.b
         N, P, C, S, tag = ctx['N'], ctx['P'], ctx['C'], ctx['S'], ctx['tag']
         R, G4 = N * P, 4 * C
@@ -163,6 +200,23 @@ class TextFusion(object):
         hip.matmul_tn(ctx['vis'], dGv, gKa[0:C])
         dvis = B.get(tag + '/tfb/dvis', (R, C))
         hip.matmul_nt(dGv, Ka[0:C], dvis)
+        dy5 = B.get(tag + '/tfb/dy5', (R, C))
+        hip.call('ssc_row_l2norm_bwd', ctx['vis'], ctx['vis_ss'], dvis, R, C, dy5, 0)
+        if side_stream is not None:
+            side_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side_stream):
+                self._backward_words(ctx, dR, gE, gKw, gbw, gKa)
+            self._bwd_stream = side_stream
+        else:
+            self._backward_words(ctx, dR, gE, gKw, gbw, gKa)
+        return dy5
+
+    def _backward_words(self, ctx, dR, gE, gKw, gbw, gKa):
+        s, B = self.s, self.b
+        N, C, S, tag = ctx['N'], ctx['C'], ctx['S'], ctx['tag']
+        G4 = 4 * C
+        Kw, Ka = s[self.pfx_w + 'kernel'], s[self.pfx_a + 'kernel']
+        mask = ctx['mask']
         hip.matmul_tn(ctx['emb'], dR, gKa[C:2 * C])
         hip.matmul_tn(ctx['lang'], dR, gKa[2 * C:3 * C])
         demb = B.get(tag + '/tfb/demb', (S * N, C))
@@ -200,6 +254,3 @@ class TextFusion(object):
         hip.call('ssc_group_rowsum', dEW, G4, 1, S * N, G4, gbw, 0)
         hip.fill(gE, 0.0)
         hip.call('ssc_embedding_scatter_add', gE, gE.shape[0], ctx['tok'], S * N, C, demb)
-        dy5 = B.get(tag + '/tfb/dy5', (R, C))
-        hip.call('ssc_row_l2norm_bwd', ctx['vis'], ctx['vis_ss'], dvis, R, C, dy5, 0)
-        return dy5
