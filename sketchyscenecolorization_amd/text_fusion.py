@@ -178,26 +178,20 @@ class TextFusion(object):
         dh2 = B.get(tag + '/tfb/dh1', (R, C))
         dc = B.get(tag + '/tfb/dc0', (R, C))
         dc2 = B.get(tag + '/tfb/dc1', (R, C))
-        dg = B.get(tag + '/tfb/dg', (R, G4))
-        dGv = B.get(tag + '/tfb/dGv', (R, G4))
+        dg_all = B.get(tag + '/tfb/dg_all', (S, R, G4))      # gate gradients of every step: the filter gradient and the
+        dGv = B.get(tag + '/tfb/dGv', (R, G4))              # per-sample row sums are batched over the steps afterwards
         dR = B.get(tag + '/tfb/dR', (S * N, G4))
         hip.call('ssc_squash_bwd', ha[S], ctx['feat'], g_feat, R * C, dh)
         hip.fill(dc, 0.0)
         hip.fill(dGv, 0.0)
-        first = True
         for i in range(S - 1, -1, -1):
-            hip.call('ssc_lstm_pointwise_bwd', dh, dc, acts_a[i], ca[i], ca[i + 1], mask[i], P, R, C, dg, dc2, dh2, dGv)
-            hip.call('ssc_group_rowsum', dg, G4, N, P, G4, dR[i * N:(i + 1) * N], 0)
-            if i > 0:       # h_a[0] = 0: no contribution, and nothing upstream of it
-                hip.matmul_tn(ha[i], dg, gKa[3 * C:4 * C], accumulate=not first)
-                first = False
-                hip.matmul_nt(dg, Ka[3 * C:4 * C], dh2, accumulate=True)
+            # the sequential chain: pointwise backward, then dh_{i-1} += dg_i Kh^T
+            hip.call('ssc_lstm_pointwise_bwd', dh, dc, acts_a[i], ca[i], ca[i + 1], mask[i], P, R, C, dg_all[i], dc2, dh2,
+                     dGv)
+            if i > 0:       # h_a[0] = 0: nothing upstream of it
+                hip.matmul_nt(dg_all[i], Ka[3 * C:4 * C], dh2, accumulate=True)
             dh, dh2 = dh2, dh
             dc, dc2 = dc2, dc
-        if first:
-            hip.fill(gKa[3 * C:4 * C], 0.0)
-        hip.call('ssc_group_rowsum', dGv, G4, 1, R, G4, gba, 0)
-        hip.matmul_tn(ctx['vis'], dGv, gKa[0:C])
         dvis = B.get(tag + '/tfb/dvis', (R, C))
         hip.matmul_nt(dGv, Ka[0:C], dvis)
         dy5 = B.get(tag + '/tfb/dy5', (R, C))
@@ -205,18 +199,30 @@ class TextFusion(object):
         if side_stream is not None:
             side_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side_stream):
-                self._backward_words(ctx, dR, gE, gKw, gbw, gKa)
+                self._backward_words(ctx, dR, dGv, gE, gKw, gbw, gKa, gba)
             self._bwd_stream = side_stream
         else:
-            self._backward_words(ctx, dR, gE, gKw, gbw, gKa)
+            self._backward_words(ctx, dR, dGv, gE, gKw, gbw, gKa, gba)
         return dy5
 
-    def _backward_words(self, ctx, dR, gE, gKw, gbw, gKa):
+    def _backward_words(self, ctx, dR, dGv, gE, gKw, gbw, gKa, gba):
+        """Everything the image path does not wait for: the filter gradients of the multimodal cell (batched over the
+        steps), the word-term gradients, the word LSTM BPTT and the embedding gradient."""
         s, B = self.s, self.b
         N, C, S, tag = ctx['N'], ctx['C'], ctx['S'], ctx['tag']
         G4 = 4 * C
         Kw, Ka = s[self.pfx_w + 'kernel'], s[self.pfx_a + 'kernel']
         mask = ctx['mask']
+        P, R = ctx['P'], ctx['N'] * ctx['P']
+        ha, dg_all = ctx['ha'], B.get(tag + '/tfb/dg_all', (S, R, G4))
+        hip.call('ssc_group_rowsum', dGv, G4, 1, R, G4, gba, 0)
+        hip.matmul_tn(ctx['vis'], dGv, gKa[0:C])
+        # batched over the steps: dR_i = per-sample sums of dg_i over the positions; dKh = sum_i h_{i-1}^T dg_i
+        hip.call('ssc_group_rowsum', dg_all, G4, S * N, P, G4, dR, 0)
+        if S > 1:
+            hip.matmul_tn(ha[1:S].reshape((S - 1) * R, C), dg_all[1:S].reshape((S - 1) * R, G4), gKa[3 * C:4 * C])
+        else:
+            hip.fill(gKa[3 * C:4 * C], 0.0)
         hip.matmul_tn(ctx['emb'], dR, gKa[C:2 * C])
         hip.matmul_tn(ctx['lang'], dR, gKa[2 * C:3 * C])
         demb = B.get(tag + '/tfb/demb', (S * N, C))
