@@ -302,25 +302,27 @@ class GanTrainer(object):
     def _d_gradients(self, batch):
         B, s = self.bufs, self.store
         N, _, H, W = batch['sketches'].shape
-        sn = self.D.prepare_sn()
         xd_r = B.get('xd_real', (N, H, W, 8), zero_on_alloc=True)
 
-        def real_branch():
+        def real_branch(sn):
             hip.nchw_to_nhwc(batch['sketches'], xd_r, 0)
             hip.nchw_to_nhwc(batch['images_d'], xd_r, 3)
             return self.D.forward(xd_r, sn, 'dr')
 
         if self._aux_stream is not None and hip.PROFILE is None:
-            # D(real) does not depend on the generator: run it on a second stream so that its full-size launches fill
-            # the CUs the generator's caption branch (a chain of small GEMMs) leaves idle
+            # D(real) does not depend on the generator: run it (and the spectral-norm power iterations in front of it) on a
+            # second stream so that its full-size launches fill the CUs the generator's caption branch (a chain of small
+            # GEMMs) leaves idle
             self._aux_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._aux_stream):
-                cr = real_branch()
+                sn = self.D.prepare_sn()
+                cr = real_branch(sn)
             xd_f, gctx = self._pack_fake(batch)
             torch.cuda.current_stream().wait_stream(self._aux_stream)
         else:
+            sn = self.D.prepare_sn()
             xd_f, gctx = self._pack_fake(batch)
-            cr = real_branch()
+            cr = real_branch(sn)
         cf = self.D.forward(xd_f, sn, 'df')
         loss_d = self.loss[1:2]
         loss_d.zero_()
@@ -378,8 +380,20 @@ class GanTrainer(object):
     def _g_gradients(self, batch):
         B, s = self.bufs, self.store
         N, _, H, W = batch['sketches'].shape
-        xd_f, gctx = self._pack_fake(batch)
-        sn = self.D.prepare_sn()
+        if self._aux_stream is not None and hip.PROFILE is None:
+            # the spectral-norm power iterations and the target image's layout change do not depend on the generator
+            self._aux_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._aux_stream):
+                sn = self.D.prepare_sn()
+                img4 = B.get('img4', (N, H, W, 4), zero_on_alloc=True)
+                hip.nchw_to_nhwc(batch['images'], img4, 0)
+            xd_f, gctx = self._pack_fake(batch)
+            torch.cuda.current_stream().wait_stream(self._aux_stream)
+        else:
+            xd_f, gctx = self._pack_fake(batch)
+            sn = self.D.prepare_sn()
+            img4 = B.get('img4', (N, H, W, 4), zero_on_alloc=True)
+            hip.nchw_to_nhwc(batch['images'], img4, 0)
         cf = self.D.forward(xd_f, sn, 'df')
         loss_g = self.loss[0:1]
         loss_g.zero_()
@@ -390,8 +404,6 @@ class GanTrainer(object):
         dlog_f = B.get('dlog_f', (N, K))
         hip.call('ssc_acgan_loss', cf['logits'], batch['class_id'], N, K, 0, 0.5, loss_g, dlog_f)
         dgen = self.D.backward(cf, dl5_f, dlog_f, sn, False, True, accumulate=False)
-        img4 = B.get('img4', (N, H, W, 4), zero_on_alloc=True)
-        hip.nchw_to_nhwc(batch['images'], img4, 0)
         dpre = B.get('dpre', (N, H, W, 4))
         hip.call('ssc_gen_output_grad', xd_f.view(-1)[3:], 8, img4, 4, dgen, 4, N * H * W, 100.0, loss_g, dpre)
         sc = s.generator
