@@ -1487,8 +1487,16 @@ static Plan plan_wgrad(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws) 
     allowed[4] = d.Nn <= 32;
     const int ncu = num_cu();
     Plan best = {-1, 1, 1e300};
+    static int force_cfg = -2, force_sk = -2;       // SSC_WG_CFG / SSC_WG_SPLITK: tuning aids
+    if (force_cfg == -2) {
+        const char* e = getenv("SSC_WG_CFG");
+        force_cfg = (e != nullptr) ? atoi(e) : -1;
+        e = getenv("SSC_WG_SPLITK");
+        force_sk = (e != nullptr) ? atoi(e) : -1;
+    }
     for (int c = 0; c < 5; ++c) {
         if (!allowed[c]) continue;
+        if (force_cfg >= 0 && c != force_cfg && allowed[force_cfg]) continue;
         const TileCfg& t = WG_CFGS[c];
         const long mt = (Mtot + t.BM - 1) / t.BM, nt = (d.Nn + t.BN - 1) / t.BN;
         const long blocks = mt * nt;
@@ -1499,6 +1507,7 @@ static Plan plan_wgrad(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws) 
             if ((nkt + per - 1) / per != sk) continue;
             double cost = makespan(blocks * sk, wfull * (double)per / (double)nkt, t.res, ncu) + 2500.0;
             if (sk > 1) cost += 2.0 * sk * (double)out_elems * 4.0 / 1500.0 + plan_const("SSC_PLAN_REDUCE", 6000.0);
+            if (force_sk > 0) cost = (double)(sk > force_sk ? sk - force_sk : force_sk - sk);     // nearest legal split
             if (cost < best.cost) best = {c, (int)sk, cost};
         }
     }
