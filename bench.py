@@ -198,6 +198,9 @@ def main():
     tr = GanTrainer(img=args.img, seed=0, process_group=pg, use_graphs=not args.no_graphs, block_type=args.block_type)
     bd = synthetic_batch(args.batch, 1234 + rank, args.img)
     bg = synthetic_batch(args.batch, 5678 + rank, args.img)
+    if not args.no_graphs:
+        # resident inputs live in the buffers the replayed graphs read (what an input pipeline would fill): no per-step copies
+        bd, bg = tr.input_buffers('d', bd), tr.input_buffers('g', bg)
 
     def barrier():
         if world > 1:

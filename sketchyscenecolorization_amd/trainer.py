@@ -203,6 +203,27 @@ class GanTrainer(object):
             hip.call('ssc_optimizer_step', 3, scope.flat, scope.grad, scope.adam_v, scope.adam_m, scope.numel, lr_dev,
                      0.95, 0.0, 1e-8, gs)
 
+    def _static_inputs(self, kind, batch):
+        N, _, H, W = batch['sketches'].shape
+        skey = (kind, N, H, W)
+        st = self._static.get(skey)
+        if st is None:
+            st = {k: torch.empty_like(v) for k, v in batch.items() if isinstance(v, torch.Tensor)}
+            self._static[skey] = st
+        return st
+
+    def input_buffers(self, kind, like):
+        """The device tensors a replayed 'd' / 'g' step reads its inputs from (graphs replay fixed addresses), allocated
+        after ``like`` and filled with it.  An input pipeline that writes the next batch straight into them -- and passes them as the step's
+        batch, with the host-side ``text`` -- saves the per-step device copies; any other batch is copied in."""
+        st = self._static_inputs(kind, like)
+        for k, v in st.items():
+            if like[k].data_ptr() != v.data_ptr():
+                v.copy_(like[k])
+        out = dict(like)
+        out.update(st)
+        return out
+
     def _run_step(self, kind, batch, counter):
         """Eager, capture or replay of one D-/G-step."""
         scope, idx, lr = ((self.store.discriminator, 1, self.lr_d) if kind == 'd' else
@@ -214,12 +235,10 @@ class GanTrainer(object):
         # static inputs: graphs replay fixed device addresses
         N, _, H, W = batch['sketches'].shape
         skey = (kind, N, H, W)
-        st = self._static.get(skey)
-        if st is None:
-            st = {k: torch.empty_like(v) for k, v in batch.items() if isinstance(v, torch.Tensor)}
-            self._static[skey] = st
+        st = self._static_inputs(kind, batch)
         for k, v in st.items():
-            v.copy_(batch[k])
+            if batch[k].data_ptr() != v.data_ptr():     # an input pipeline may fill the static buffers itself
+                v.copy_(batch[k])
         sbatch = dict(st)
         sbatch['text'] = self.G.text.prepare(batch['text'], 'g') if self.G.lstm_hybrid else batch['text']
         S = sbatch['text']['S'] if isinstance(sbatch['text'], dict) else -1
