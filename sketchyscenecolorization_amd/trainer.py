@@ -222,6 +222,9 @@ class GanTrainer(object):
                 v.copy_(like[k])
         out = dict(like)
         out.update(st)
+        if self.G.lstm_hybrid and not isinstance(like['text'], dict):
+            # the caption tokens too: time-major ids and skip mask on the device (own buffers per step kind)
+            out['text'] = self.G.text.prepare(like['text'], 'g' + kind)
         return out
 
     def _run_step(self, kind, batch, counter):
@@ -240,7 +243,10 @@ class GanTrainer(object):
             if batch[k].data_ptr() != v.data_ptr():     # an input pipeline may fill the static buffers itself
                 v.copy_(batch[k])
         sbatch = dict(st)
-        sbatch['text'] = self.G.text.prepare(batch['text'], 'g') if self.G.lstm_hybrid else batch['text']
+        if self.G.lstm_hybrid and not isinstance(batch['text'], dict):      # a dict: already prepared (input_buffers)
+            sbatch['text'] = self.G.text.prepare(batch['text'], 'g' + kind)
+        else:
+            sbatch['text'] = batch['text']
         S = sbatch['text']['S'] if isinstance(sbatch['text'], dict) else -1
         key = skey + (S,)
         self._adam_prepare(scope, idx, lr * self.decay(counter))
