@@ -153,6 +153,47 @@ def run_forward_workload(args):
     print(json.dumps(out))
 
 
+def generator_fwd_bwd(tr, batch, args, iters=30):
+    """The quantity BASELINE.json's target is stated on: generator forward + backward alone (no discriminator, no
+    optimizer), batch and image size of the train step, one hipGraph of G.forward + G.backward replayed ``iters`` times.
+    FLOPs as written in the reference: 3 x F_G per image (forward + data and filter gradients)."""
+    import torch
+    from sketchyscenecolorization_amd import hip
+    N, _, H, W = batch['sketches'].shape
+    text = batch['text'] if isinstance(batch['text'], dict) else tr.G.text.prepare(batch['text'], 'gfb')
+    out = torch.zeros(N, H, W, 8, device='cuda')
+    dpre = torch.randn(N, H, W, 4, device='cuda') * 1e-3
+    dpre[..., 3] = 0.0
+
+    def body():
+        ctx = tr.G.forward(batch['sketches'], text, batch['noise_vec'], 'gfb', out=out, out_coff=3)
+        tr.G.backward(ctx, dpre, side_stream=tr._aux_stream)
+
+    body()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        body()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 3 * F_G * N / (ms * 1e-3) / 1e12
+    # executed: the caption branch's algebraic split (SURVEY 8a row A5) does 1.2 instead of 4.53 GFLOP per image
+    f_exec = F_G - 4.53e9 + 1.2e9
+    tfx = 3 * f_exec * N / (ms * 1e-3) / 1e12
+    return {'what': 'generator forward + backward only (hipGraph replay), batch %d, %dx%d' % (N, H, W), 'ms': ms,
+            'images_per_sec': N / (ms * 1e-3), 'tflops_as_written': tf, 'frac_of_fp32_mfma_peak': tf / PEAK_FP32_MFMA_TFLOPS,
+            'flops_per_image_as_written': 3 * F_G, 'tflops_executed': tfx,
+            'frac_of_fp32_mfma_peak_executed': tfx / PEAK_FP32_MFMA_TFLOPS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--workload', default='train', choices=['train', 'fg_infer', 'fg_resid', 'fg_mru', 'bg768', 'bg768_train'],
@@ -242,6 +283,9 @@ def main():
         prof_steps = args.prof_steps
     hip.PROFILE = None
     loss_g, loss_d = [float(v) for v in tr.loss.tolist()]
+    gen_fb = None
+    if args.block_type == 'Pix2Pix' and not args.no_graphs and world == 1:
+        gen_fb = generator_fwd_bwd(tr, bg, args)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -299,6 +343,8 @@ def main():
                                'per_kernel': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / prof_steps * 1e3,
                                                   'launches_per_step': v[2] / prof_steps}
                                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+        if gen_fb is not None:
+            out['generator_fwd_bwd'] = gen_fb
         if not args.no_cpu_baseline and world == 1 and args.block_type == 'Pix2Pix':
             out['cpu_baseline'] = cpu_baseline(args.img)
         print(json.dumps(out))
