@@ -125,10 +125,10 @@ __device__ __forceinline__ FwdPhase fwd_phase(const ssc_conv_desc& d, int phase)
     return p;
 }
 
-// UT ("uniform tap"): every K-tile lies inside one filter tap and one source tensor (C, C0 multiples of 32,
-// no channel padding, float4 filter loads).  Then the tap decode, source selection and filter base are
-// wave-uniform (scalar unit) and a staged row costs ~8 vector instructions instead of ~25.
-template <int WM, int WN, int SM, int SN, int BMODE, bool VECB, bool UT>
+// General form: any channel counts (K-tiles may straddle taps and sources: per-thread tap decode), scalar or float4
+// filter loads.  Phases per wave: issue the next K-tile's loads | MFMAs of the current one | transform + LDS write |
+// barrier.  The layers whose K-tiles lie inside one tap and one source take conv_ut_kernel below instead.
+template <int WM, int WN, int SM, int SN, int BMODE, bool VECB>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, const Magics mg,
                                                         float* __restrict__ slab_base, long slab_stride,
                                                         int splitk) {
@@ -168,7 +168,6 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
     const int a_col4 = tid & 7;            // float4 column inside the K tile
     int a_iyb[A_ROWS], a_ixb[A_ROWS];
     long a_nb[A_ROWS];
-    int a_off0[A_ROWS], a_off1[A_ROWS];    // UT: element offsets of (n, iyb, ixb) in source 0 / 1
     bool a_mv[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
@@ -182,30 +181,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
         a_iyb[i] = py * d.in_stride + ph.ioff_y;
         a_ixb[i] = px * d.in_stride + ph.ioff_x;
         a_nb[i] = (long)n * d.x.H * d.x.W;
-        const int pix0 = (n * d.x.H + a_iyb[i]) * d.x.W + a_ixb[i];
-        a_off0[i] = pix0 * d.x.C0 + a_col4 * 4;
-        a_off1[i] = pix0 * d.x.C1 + a_col4 * 4;
         if (a_col4 == 0)
             rowpix[row] = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
     }
-    // ---- per-thread filter offsets (UT): constant over the K loop ----
-    int b_off[B_SLOTS];
-    float b_m[B_SLOTS];
-#pragma unroll
-    for (int s = 0; s < B_SLOTS; ++s) {
-        if (BMODE == 0) {
-            const int n = n0 + (tid % (BN / 4)) * 4;
-            const bool v = n < d.Nn;
-            b_off[s] = v ? (tid / (BN / 4) + B_RP * s) * d.wC1 + d.n_off + n : 0;
-            b_m[s] = v ? 1.f : 0.f;
-        } else {
-            const int n = n0 + (tid >> 3) + 32 * s;
-            const bool v = n < d.Nn;
-            b_off[s] = v ? (d.n_off + n) * d.wC1 + (tid & 7) * 4 : 0;
-            b_m[s] = v ? 1.f : 0.f;
-        }
-    }
-    const bool b_allvalid = (n0 + BN <= d.Nn);
 
     const int nkt = (Ktot + BK - 1) / BK;
     const int per = (nkt + splitk - 1) / splitk;
@@ -224,51 +202,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
     float4 ra[A_ROWS];
     float rav[A_ROWS];    // 1.0 / 0.0 validity of each staged A row
     float4 raa, rab;
-    bool ra_plain = false;   // UT: this K-tile's source has no affine and no activation
     float ra_slope = 1.f;    // activation slope of the source this K-tile reads
     float4 rb[B_SLOTS];
-    float4 rbm[B_SLOTS];  // generic path: per-element 1.0 / 0.0 validity of the staged filter values
+    float4 rbm[B_SLOTS];  // per-element 1.0 / 0.0 validity of the staged filter values
     const float x_slope0 = act_slope(d.x.act), x_slope1 = act_slope(d.x.act1 >= 0 ? d.x.act1 : d.x.act);
 
     auto load_tile = [&](int kt) {
-        if (UT) {
-            // ---- scalar (wave-uniform) part ----
-            const int kb = kt * BK;
-            const int tap = div32(kb, mg.mC, mg.oneC);
-            const int cch = kb - tap * C;
-            const int ty = div32(tap, mg.mTW, mg.oneTW), tx = tap - ty * d.TW;
-            const bool first = cch < d.x.C0;
-            const int cs = first ? d.x.C0 : d.x.C1;
-            const int cc = first ? cch : cch - d.x.C0;
-            const float* sbase = (first ? d.x.s0 : d.x.s1) + cc;
-            const float* abp = first ? d.x.ab0 : d.x.ab1;
-            const int tapshift = (ty * d.x.W + tx) * cs;
-            const int src_act = (!first && d.x.act1 >= 0) ? d.x.act1 : d.x.act;
-            ra_slope = act_slope(src_act);
-            ra_plain = (abp == nullptr) && (src_act == SSC_ACT_NONE);
-            if (abp != nullptr) {
-                raa = *reinterpret_cast<const float4*>(abp + cc + a_col4 * 4);
-                rab = *reinterpret_cast<const float4*>(abp + cs + cc + a_col4 * 4);
-            } else {
-                raa = make_float4(1.f, 1.f, 1.f, 1.f);
-                rab = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int i = 0; i < A_ROWS; ++i) {
-                const int iy = a_iyb[i] + ty, ix = a_ixb[i] + tx;
-                const bool v = a_mv[i] && (unsigned)iy < (unsigned)d.x.H && (unsigned)ix < (unsigned)d.x.W;
-                const int off = v ? (first ? a_off0[i] : a_off1[i]) + tapshift : a_col4 * 4;
-                rav[i] = v ? 1.f : 0.f;
-                ra[i] = *reinterpret_cast<const float4*>(sbase + off);
-            }
-            const int ky = ph.ky0 + ty * d.kstep, kx = ph.kx0 + tx * d.kstep;
-            const float* wtap = (BMODE == 0) ? d.w + ((long)(ky * d.KW + kx) * d.wC0 + cch) * d.wC1
-                                             : d.w + (long)(ky * d.KW + kx) * d.wC0 * d.wC1 + cch;
-#pragma unroll
-            for (int s = 0; s < B_SLOTS; ++s) rb[s] = *reinterpret_cast<const float4*>(wtap + b_off[s]);
-            return;
-        }
-        // ---- generic path: A (gather view), every load unconditional from a clamped address ----
+        // A (gather view): every load unconditional from a clamped address
         {
             const int kcol = kt * BK + a_col4 * 4;
             const bool kv = kcol < Ktot;
@@ -353,29 +293,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
     auto store_tile = [&](int buf) {
         float* Ab = As + buf * A_SZ;
         float* Bb = Bs + buf * B_SZ;
-        if (UT && ra_plain) {       // wave-uniform: no norm, no activation -> only the padding mask
 #pragma unroll
-            for (int i = 0; i < A_ROWS; ++i) {
-                const float4 v = mask4(ra[i], rav[i]);
-                float* p = Ab + ((tid >> 3) + 32 * i) * A_LD + a_col4 * 4;
-                p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < A_ROWS; ++i) {
-                const float4 v = xform4(ra[i], raa, rab, ra_slope, rav[i]);
-                float* p = Ab + ((tid >> 3) + 32 * i) * A_LD + a_col4 * 4;
-                p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
-            }
+        for (int i = 0; i < A_ROWS; ++i) {
+            const float4 v = xform4(ra[i], raa, rab, ra_slope, rav[i]);
+            float* p = Ab + ((tid >> 3) + 32 * i) * A_LD + a_col4 * 4;
+            p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
         }
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
             float4 v = rb[s];
-            if (UT) {
-                if (!b_allvalid) v = mask4(v, b_m[s]);      // wave-uniform branch
-            } else {
-                v.x *= rbm[s].x; v.y *= rbm[s].y; v.z *= rbm[s].z; v.w *= rbm[s].w;
-            }
+            v.x *= rbm[s].x; v.y *= rbm[s].y; v.z *= rbm[s].z; v.w *= rbm[s].w;
             if (BMODE == 0) {
                 *reinterpret_cast<float4*>(Bb + (tid / (BN / 4) + B_RP * s) * B_LD + (tid % (BN / 4)) * 4) = v;
             } else {
@@ -1214,7 +1141,7 @@ static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long
     return best;
 }
 
-template <int WM, int WN, int SM, int SN, int BMODE, bool VECB, bool UT>
+template <int WM, int WN, int SM, int SN, int BMODE, bool VECB>
 static int launch_fwd_v(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
     constexpr int A_SZ = BM * (BK + 1);
@@ -1229,12 +1156,12 @@ static int launch_fwd_v(const ssc_conv_desc& d, int splitk, float* ws, hipStream
     const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB, UT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
-    hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB, UT>), grid, dim3(256), lds, st, d, mg, ws,
+    hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB>), grid, dim3(256), lds, st, d, mg, ws,
                        out_count, splitk);
     if (splitk > 1) {
         const int thr = 256;
@@ -1256,11 +1183,14 @@ static int tail_split_mode() {
     return mode;
 }
 
-// uniform-tap fast path: every 32-wide K-tile inside one tap and one source, no channel padding; float4 filter loads
-// need 16-byte aligned, fully in-range groups of 4
+// float4 filter loads need 16-byte aligned, fully in-range groups of 4
+static bool fwd_is_vec(const ssc_conv_desc& d) {
+    return (d.bmode == 0) ? (((d.wC1 | d.n_off) & 3) == 0 && (d.Nn & 3) == 0) : ((d.wC1 & 3) == 0 && (d.k_real & 3) == 0);
+}
+
+// uniform-tap fast path: every 32-wide K-tile inside one tap and one source, no channel padding
 static bool fwd_is_ut(const ssc_conv_desc& d) {
-    const bool vec = (d.bmode == 0) ? (((d.wC1 | d.n_off) & 3) == 0 && (d.Nn & 3) == 0)
-                                    : ((d.wC1 & 3) == 0 && (d.k_real & 3) == 0);
+    const bool vec = fwd_is_vec(d);
     const int C = d.x.C0 + d.x.C1;
     return vec && (C % BK) == 0 && (d.x.C0 % BK) == 0 && d.k_real == C &&
            (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x7fffffffL &&
@@ -1270,8 +1200,7 @@ static bool fwd_is_ut(const ssc_conv_desc& d) {
 // chunked uniform-tap form (conv_ut_kernel<KMASK>): vector filter loads possible and at most 20 % of the K-tiles' width
 // wasted on the partly empty last chunk of each source
 static bool fwd_is_utg(const ssc_conv_desc& d) {
-    const bool vec = (d.bmode == 0) ? (((d.wC1 | d.n_off) & 3) == 0 && (d.Nn & 3) == 0)
-                                    : ((d.wC1 & 3) == 0 && (d.k_real & 3) == 0);
+    const bool vec = fwd_is_vec(d);
     const int C = d.x.C0 + d.x.C1;
     const int padded = ((d.x.C0 + BK - 1) / BK + (d.x.C1 + BK - 1) / BK) * BK;
     static int off = -1;
@@ -1282,15 +1211,6 @@ static bool fwd_is_utg(const ssc_conv_desc& d) {
     return !off && vec && d.k_real >= 1 && d.k_real <= C && padded * 5 <= C * 6 &&
            (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x7fffffffL &&
            (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
-}
-
-static int ut2_mode() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = getenv("SSC_UT2");
-        mode = (e != nullptr) ? atoi(e) : 1;
-    }
-    return mode;
 }
 
 template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN, bool KMASK>
@@ -1345,11 +1265,9 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
 
 template <int WM, int WN, int SM, int SN, int BMODE>
 static int launch_fwd(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st) {
-    // float4 filter loads need 16-byte aligned, fully in-range groups of 4
-    const bool vec = (BMODE == 0) ? (((d.wC1 | d.n_off) & 3) == 0 && (d.Nn & 3) == 0)
-                                  : ((d.wC1 & 3) == 0 && (d.k_real & 3) == 0);
+    const bool vec = fwd_is_vec(d);
     const bool ut = fwd_is_ut(d);
-    if ((ut || fwd_is_utg(d)) && ut2_mode() != 0) {
+    if (ut || fwd_is_utg(d)) {
         const bool plain0 = d.x.ab0 == nullptr && d.x.act == SSC_ACT_NONE;
         const bool plain1 = d.x.C1 == 0 || (d.x.ab1 == nullptr && (d.x.act1 >= 0 ? d.x.act1 : d.x.act) == SSC_ACT_NONE);
         const bool plain = plain0 && plain1;
@@ -1358,16 +1276,15 @@ static int launch_fwd(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t
         return plain ? launch_fwd_ut<WM, WN, SM, SN, BMODE, true, true>(d, splitk, ws, st)
                      : launch_fwd_ut<WM, WN, SM, SN, BMODE, false, true>(d, splitk, ws, st);
     }
-    if (ut) return launch_fwd_v<WM, WN, SM, SN, BMODE, true, true>(d, splitk, ws, st);
-    return vec ? launch_fwd_v<WM, WN, SM, SN, BMODE, true, false>(d, splitk, ws, st)
-               : launch_fwd_v<WM, WN, SM, SN, BMODE, false, false>(d, splitk, ws, st);
+    return vec ? launch_fwd_v<WM, WN, SM, SN, BMODE, true>(d, splitk, ws, st)
+               : launch_fwd_v<WM, WN, SM, SN, BMODE, false>(d, splitk, ws, st);
 }
 
 static Plan plan_fwd(const ssc_conv_desc& d, int64_t ws_bytes, bool have_ws) {
     const long M = (long)d.NB * d.PH * d.PW;
     const int C = d.x.C0 + d.x.C1;
     long nkt = ((long)d.TH * d.TW * C + BK - 1) / BK;
-    if (ut2_mode() != 0 && (fwd_is_ut(d) || fwd_is_utg(d)))       // conv_ut_kernel walks whole chunks per tap and source
+    if (fwd_is_ut(d) || fwd_is_utg(d))       // conv_ut_kernel walks whole chunks per tap and source
         nkt = (long)d.TH * d.TW * ((d.x.C0 + BK - 1) / BK + (d.x.C1 + BK - 1) / BK);
     // column tile no wider than needed: <=32 -> 128x32, <=64 -> 128x64, else 128x128 / 64x128 / 128x64
     const bool allowed[5] = {d.Nstore > 64, d.Nstore > 64, d.Nstore > 32, d.Nstore <= 32, d.Nstore > 32};
