@@ -254,6 +254,7 @@ class MRUGenerator(_MRUBlocks):
     def __init__(self, store, bufs, lstm_hybrid=True):
         self._init(store, bufs)
         self.lstm_hybrid = bool(lstm_hybrid)
+        self.text_stream = None     # set by the trainer: side stream for the image-independent half of the caption branch
         self.text = TextFusion(store, bufs)
         for d in (64, 128, 256, 512):
             t = bufs.get('const/quarter/%d' % d, (2 * d,), zero_on_alloc=True)
@@ -357,6 +358,9 @@ class MRUGenerator(_MRUBlocks):
         N, _, H, W = sketches.shape
         assert H % 32 == 0 and W % 32 == 0
         labels = labels.to(device=sketches.device, dtype=torch.int32).contiguous()
+        if self.lstm_hybrid and self.text_stream is not None and hip.PROFILE is None:
+            # the caption's word LSTM does not see the image: start it next to the encoder
+            text = self.text.start_words(text, None, tag, self.text_stream)
         tape = []
         xs = B.get(tag + '/xs', (N, H, W, 4), zero_on_alloc=True)
         hip.nchw_to_nhwc(sketches, xs, 0)

@@ -246,6 +246,7 @@ class ResidualGenerator(_Bottlenecks):
         self.fg = kind == 'fg'
         self.size, self.seg = size, seg_classes
         self.lstm_hybrid = bool(lstm_hybrid) or not self.fg
+        self.text_stream = None     # set by the trainer: side stream for the image-independent half of the caption branch
         self.text = TextFusion(store, bufs, 'generator/TextLSTM' if self.fg else 'generator/mLSTM_G')
         self.top = size * 8 if self.fg else size * 16
         self._tape, self._gdone = [], {}
@@ -265,6 +266,9 @@ class ResidualGenerator(_Bottlenecks):
         s, B = self.s, self.b
         size, top = self.size, self.top
         self._tape = []
+        if self.lstm_hybrid and self.text_stream is not None and hip.PROFILE is None:
+            # the caption's word LSTM does not see the image: start it next to the encoder
+            text = self.text.start_words(text, None, tag, self.text_stream)
         top_bn = (lambda pre: pre) if self.fg else (lambda pre: pre + '/batchnorm')
         if self.fg:
             N, _, H, W = inputs.shape

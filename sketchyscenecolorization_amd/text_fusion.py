@@ -89,7 +89,10 @@ class TextFusion(object):
 
     def start_words(self, text, C, tag, stream):
         """Run the image-independent part on ``stream`` now, so that its chain of small recurrent GEMMs overlaps the
-        encoder convolutions; ``forward`` joins it.  Returns the ``prepare`` result to pass as ``text``."""
+        encoder convolutions; ``forward`` joins it.  Returns the ``prepare`` result to pass as ``text``.
+        C: channels of the bottleneck feature (None: read off the cell's kernel, [2C, 4C])."""
+        if C is None:
+            C = self.s[self.pfx_w + 'kernel'].shape[1] // 4
         prep = text if isinstance(text, dict) else self.prepare(text, tag)
         if prep['S'] > 0 and stream is not None and 'words' not in prep:
             stream.wait_stream(torch.cuda.current_stream())

@@ -92,8 +92,8 @@ class GanTrainer(object):
         self._wgrad_stream = torch.cuda.Stream() if (overlap_wgrad and block_type == 'Pix2Pix') else None
         self._aux_stream = torch.cuda.Stream() if overlap_real else None
         self._text_stream = torch.cuda.Stream() if (overlap_real and os.environ.get('SSC_TEXT_STREAM', '1') == '1') else None
+        self.G.text_stream = self._text_stream          # forward half: every generator
         if block_type == 'Pix2Pix':
-            self.G.text_stream = self._text_stream
             self.G.text_stream_bwd = None if self.segment_graphs else self._text_stream
         self._seg = None
         self.lr_dev = torch.zeros(2, dtype=torch.float32, device=device)     # Adam step sizes [G, D]
