@@ -970,6 +970,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
                         for (int j = 0; j < SN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][q][i], bv[g & 1][q][j], acc[i][j], 0, 0, 0);
             };
+            fill_ptab(kt + 3);              // overwrites ptab[(kt+1)&1], last read before the previous barrier; its
+                                            // lane-divergent branch stays in front of the MFMA block, not inside it
             fetch(0, 0);
             fetch(1, 1);
             mfmas(0);
@@ -977,7 +979,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
             fetch(2, 0);
             mfmas(1);
             load_tile(kt + 2);              // reads ptab[(kt+2)&1], published by the previous barrier
-            fill_ptab(kt + 3);              // overwrites ptab[(kt+1)&1], last read before that barrier
             fetch(3, 1);
             mfmas(2);
             mfmas(3);
