@@ -92,6 +92,11 @@ class GanTrainer(object):
         self._wgrad_stream = torch.cuda.Stream() if (overlap_wgrad and block_type == 'Pix2Pix') else None
         self._aux_stream = torch.cuda.Stream() if overlap_real else None
         self._text_stream = torch.cuda.Stream() if (overlap_real and os.environ.get('SSC_TEXT_STREAM', '1') == '1') else None
+        # generator forward of the next G-step inside the D-step (train_iteration): single GPU, Pix2Pix pair
+        self.run_ahead = (block_type == 'Pix2Pix' and overlap_real and not self.segment_graphs and
+                          os.environ.get('SSC_RUN_AHEAD', '1') == '1')
+        self._ahead_stream = torch.cuda.Stream() if self.run_ahead else None
+        self._ahead = None
         self.G.text_stream = self._text_stream          # forward half: every generator
         if block_type == 'Pix2Pix':
             self.G.text_stream_bwd = None if self.segment_graphs else self._text_stream
@@ -227,17 +232,8 @@ class GanTrainer(object):
             out['text'] = self.G.text.prepare(like['text'], 'g' + kind)
         return out
 
-    def _run_step(self, kind, batch, counter):
-        """Eager, capture or replay of one D-/G-step."""
-        scope, idx, lr = ((self.store.discriminator, 1, self.lr_d) if kind == 'd' else
-                          (self.store.generator, 0, self.lr_g))
-        impl = self._d_impl if kind == 'd' else self._g_impl
-        if not self.use_graphs or hip.PROFILE is not None:
-            self._adam_prepare(scope, idx, lr * self.decay(counter))
-            return impl(batch)
-        # static inputs: graphs replay fixed device addresses
-        N, _, H, W = batch['sketches'].shape
-        skey = (kind, N, H, W)
+    def _static_batch(self, kind, batch):
+        """The step's inputs in the tensors a replayed graph reads (copied in unless they already are those tensors)."""
         st = self._static_inputs(kind, batch)
         for k, v in st.items():
             if batch[k].data_ptr() != v.data_ptr():     # an input pipeline may fill the static buffers itself
@@ -247,8 +243,32 @@ class GanTrainer(object):
             sbatch['text'] = self.G.text.prepare(batch['text'], 'g' + kind)
         else:
             sbatch['text'] = batch['text']
+        return sbatch
+
+    def _run_step(self, kind, batch, counter, ahead=None, use_ahead=False):
+        """Eager, capture or replay of one D-/G-step.  ``ahead``: the NEXT generator step's batch, whose generator
+        forward this discriminator step also runs (on a side stream); ``use_ahead``: this generator step starts from it."""
+        scope, idx, lr = ((self.store.discriminator, 1, self.lr_d) if kind == 'd' else
+                          (self.store.generator, 0, self.lr_g))
+        if kind == 'd':
+            impl = (lambda b: self._d_impl(b, ahead)) if ahead is not None else self._d_impl
+        else:
+            impl = (lambda b: self._g_impl(b, True)) if use_ahead else self._g_impl
+        if not self.use_graphs or hip.PROFILE is not None:
+            self._adam_prepare(scope, idx, lr * self.decay(counter))
+            return impl(batch)
+        # static inputs: graphs replay fixed device addresses
+        N, _, H, W = batch['sketches'].shape
+        skey = (kind, N, H, W)
+        sbatch = self._static_batch(kind, batch)
         S = sbatch['text']['S'] if isinstance(sbatch['text'], dict) else -1
         key = skey + (S,)
+        if ahead is not None:           # the generator step's inputs must be in place before this graph reads them
+            ahead = self._static_batch('g', ahead)
+            key = key + ('ahead', ahead['text']['S'] if isinstance(ahead['text'], dict) else -1)
+            impl = lambda b, a=ahead: self._d_impl(b, a)
+        elif use_ahead:
+            key = key + ('use_ahead',)
         self._adam_prepare(scope, idx, lr * self.decay(counter))
         g = self._graphs.get(key)
         if g is None:
@@ -281,17 +301,17 @@ class GanTrainer(object):
             g.replay()
         return self.loss[1:2] if kind == 'd' else self.loss[0:1]
 
-    def _g_forward(self, batch, **kw):
+    def _g_forward(self, batch, tag='g', **kw):
         if self.block_type == 'MRU':        # class-conditional norms (models_collection.py:80-82, 270-272)
-            return self.G.forward(batch['sketches'], batch['text'], batch['class_id'], batch['noise_vec'], 'g', **kw)
-        return self.G.forward(batch['sketches'], batch['text'], batch['noise_vec'], 'g', **kw)
+            return self.G.forward(batch['sketches'], batch['text'], batch['class_id'], batch['noise_vec'], tag, **kw)
+        return self.G.forward(batch['sketches'], batch['text'], batch['noise_vec'], tag, **kw)
 
-    def _pack_fake(self, batch):
+    def _pack_fake(self, batch, tag='g'):
         B = self.bufs
         N, _, H, W = batch['sketches'].shape
-        xd_f = B.get('xd_fake', (N, H, W, 8), zero_on_alloc=True)
+        xd_f = B.get('xd_fake' if tag == 'g' else 'xd_fake_' + tag, (N, H, W, 8), zero_on_alloc=True)
         hip.nchw_to_nhwc(batch['sketches'], xd_f, 0)
-        gctx = self._g_forward(batch, out=xd_f, out_coff=3)
+        gctx = self._g_forward(batch, tag, out=xd_f, out_coff=3)
         return xd_f, gctx
 
     # ------------------------------------------------------------------ steps
@@ -299,9 +319,23 @@ class GanTrainer(object):
         """One discriminator update; returns the device scalar loss_d (a view of self.loss)."""
         return self._run_step('d', batch, counter)
 
-    def _d_impl(self, batch):
+    def _d_impl(self, batch, ahead=None):
+        if ahead is not None:
+            # The generator does not change during a discriminator step, so the generator forward of the generator step
+            # that follows can run now, on its own stream, in whatever the discriminator step leaves idle (launch tails,
+            # partly filled rounds).  No nested fork: the word half of its caption branch stays in line.
+            main = torch.cuda.current_stream()
+            self._ahead_stream.wait_stream(main)
+            with torch.cuda.stream(self._ahead_stream):
+                ts, self.G.text_stream = self.G.text_stream, None
+                try:
+                    self._ahead = self._pack_fake(ahead, 'ga')
+                finally:
+                    self.G.text_stream = ts
         loss_d = self.d_gradients(batch)
         self._apply_d_launch()
+        if ahead is not None:
+            torch.cuda.current_stream().wait_stream(self._ahead_stream)
         return loss_d
 
     def apply_d(self, counter=0):
@@ -373,8 +407,8 @@ class GanTrainer(object):
         """One generator update (+ spectral-norm u assignment); returns the device scalar loss_g."""
         return self._run_step('g', batch, counter)
 
-    def _g_impl(self, batch):
-        loss_g = self.g_gradients(batch)
+    def _g_impl(self, batch, use_ahead=False):
+        loss_g = self.g_gradients(batch, use_ahead)
         self._apply_g_launch()
         return loss_g
 
@@ -393,19 +427,24 @@ class GanTrainer(object):
                 self.store['discriminator/fully_connected/u'].copy_(self._sn_pending['u_new'])
             self._sn_pending = None
 
-    def g_gradients(self, batch):
+    def g_gradients(self, batch, use_ahead=False):
         """loss_g and d loss_g / d generator variables; section all-reduces start as they finish."""
         hip.WGRAD_STREAM = self._wgrad_stream
         try:
-            return self._g_gradients(batch)
+            return self._g_gradients(batch, use_ahead)
         finally:
             hip.join_wgrad()
             hip.WGRAD_STREAM = None
 
-    def _g_gradients(self, batch):
+    def _g_gradients(self, batch, use_ahead=False):
         B, s = self.bufs, self.store
         N, _, H, W = batch['sketches'].shape
-        if self._aux_stream is not None and hip.PROFILE is None:
+        if use_ahead:       # the forward pass of this batch was run during the discriminator step (_d_impl)
+            xd_f, gctx = self._ahead
+            sn = self.D.prepare_sn()
+            img4 = B.get('img4', (N, H, W, 4), zero_on_alloc=True)
+            hip.nchw_to_nhwc(batch['images'], img4, 0)
+        elif self._aux_stream is not None and hip.PROFILE is None:
             # the spectral-norm power iterations and the target image's layout change do not depend on the generator
             self._aux_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._aux_stream):
@@ -452,7 +491,13 @@ class GanTrainer(object):
         self._allreduce_async(sc.grad, lo, hi)
 
     def train_iteration(self, batch_d, batch_g, counter=0):
-        """D-step then G-step on independent batches (main_procedure.py:178-232)."""
+        """D-step then G-step on independent batches (main_procedure.py:178-232).  Knowing both batches up front, the
+        generator forward of the G-step is run inside the D-step (``run_ahead``; results identical: the generator's
+        variables do not change in between)."""
+        if self.run_ahead and hip.PROFILE is None:
+            ld = self._run_step('d', batch_d, counter, ahead=batch_g)
+            lg = self._run_step('g', batch_g, counter, use_ahead=True)
+            return lg, ld
         ld = self.d_step(batch_d, counter)
         lg = self.g_step(batch_g, counter)
         return lg, ld

@@ -134,6 +134,28 @@ def test_hipgraph_replay_matches_eager():
     assert worst < 4e-3, worst
 
 
+def test_train_iteration_run_ahead_matches_separate_steps():
+    """train_iteration runs the G-step's generator forward inside the D-step (on its own stream, trainer.run_ahead) and
+    starts the G-step from it.  The generator's variables do not change during a D-step, so losses and weights must
+    equal d_step + g_step -- eagerly, while capturing, and in replay, with new data through the captured graphs."""
+    from sketchyscenecolorization_amd.synthetic import synthetic_batch
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    a = GanTrainer(img=64, seed=7, max_iter_step=50)
+    b = GanTrainer(img=64, seed=7, max_iter_step=50, use_graphs=True)
+    assert b.run_ahead
+    bd, bg = synthetic_batch(2, 21, 64), synthetic_batch(2, 22, 64)
+    bd2, bg2 = synthetic_batch(2, 23, 64), synthetic_batch(2, 24, 64)
+    for it in range(6):
+        d_in, g_in = (bd, bg) if it not in (3, 4) else (bd2, bg2)
+        la = (float(a.d_step(d_in, it)), float(a.g_step(g_in, it)))
+        lg, ld = b.train_iteration(d_in, g_in, it)
+        lb = (float(ld), float(lg))
+        assert abs(la[0] - lb[0]) < 1e-4 * max(1.0, abs(la[0])) and abs(la[1] - lb[1]) < 1e-4 * max(1.0, abs(la[1])), (it, la, lb)
+    assert any('ahead' in k for k in b._graphs) and any('use_ahead' in k for k in b._graphs)
+    worst = max(float((a.store[n] - b.store[n]).abs().max()) for n in a.store.names())
+    assert worst < 4e-3, worst      # see test_hipgraph_replay_matches_eager
+
+
 def test_segmented_graphs_with_rccl_world1_match_eager():
     """The multi-GPU step protocol on one GPU: a 1-rank RCCL process group, steps captured as graph SEGMENTS with the
     all-reduces issued eagerly on the side stream between them (what world > 1 uses).  Must equal the eager trainer.
