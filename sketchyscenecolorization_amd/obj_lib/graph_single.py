@@ -112,13 +112,21 @@ class TowerGraph(object):
         images, sketches, images_d, cls, cls_d, text = vals
         return _batch(images, sketches, images_d, cls, cls_d, text)
 
-    def run(self, fetches):
+    def run(self, fetches, g_follows=False):
+        """g_follows (with opt_d): the next run is opt_g -- its batch is dequeued now (same order as the reference's
+        queue: D batch, then G batch) so that the trainer can run its generator forward inside the D-step."""
         kinds = [f.kind for f in fetches]
         c = self.counter.value if isinstance(self.counter, Counter) else int(_value(self.counter))
         if 'opt_d' in kinds:
-            self.last['loss_d'] = self.tr.d_step(self._dequeue(), c)
+            d_batch = self._dequeue()
+            self._g_next = self._dequeue() if (g_follows and getattr(self.tr, 'run_ahead', False)) else None
+            self.last['loss_d'] = self.tr.d_step(d_batch, c, ahead=self._g_next)
         if 'opt_g' in kinds:
-            self.last['loss_g'] = self.tr.g_step(self._dequeue(), c)
+            g_next, self._g_next = getattr(self, '_g_next', None), None
+            if g_next is not None:
+                self.last['loss_g'] = self.tr.g_step(g_next, c, use_ahead=True)
+            else:
+                self.last['loss_g'] = self.tr.g_step(self._dequeue(), c)
         out = []
         for k in kinds:
             if k in ('loss_g', 'loss_d'):
@@ -142,7 +150,7 @@ class Session(object):
     def run(self, fetches, **kw):
         single = not isinstance(fetches, (list, tuple))
         fl = [fetches] if single else list(fetches)
-        res = fl[0].graph.run(fl)
+        res = fl[0].graph.run(fl, **kw)
         return res[0] if single else res
 
 

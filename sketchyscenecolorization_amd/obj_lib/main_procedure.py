@@ -215,7 +215,8 @@ def train(**kwargs):
                 print("Left time:%dd %dh %dm" % (d_, h_, m_))
             prev_time = curr_time
         for j in range(Diters):
-            _, loss_d_out = sess.run([opt_d, loss_d])
+            # g_follows: the trainer may run the G-step's generator forward inside the last D-step (trainer.run_ahead)
+            _, loss_d_out = sess.run([opt_d, loss_d], g_follows=(j == Diters - 1))
             if np.isnan(np.sum(loss_d_out)):
                 print("NaN occurred during training D")
                 return -1

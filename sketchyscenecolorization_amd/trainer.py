@@ -97,6 +97,7 @@ class GanTrainer(object):
                           os.environ.get('SSC_RUN_AHEAD', '1') == '1')
         self._ahead_stream = torch.cuda.Stream() if self.run_ahead else None
         self._ahead = None
+        self._ahead_pending = False
         self.G.text_stream = self._text_stream          # forward half: every generator
         if block_type == 'Pix2Pix':
             self.G.text_stream_bwd = None if self.segment_graphs else self._text_stream
@@ -315,8 +316,14 @@ class GanTrainer(object):
         return xd_f, gctx
 
     # ------------------------------------------------------------------ steps
-    def d_step(self, batch, counter=0):
-        """One discriminator update; returns the device scalar loss_d (a view of self.loss)."""
+    def d_step(self, batch, counter=0, ahead=None):
+        """One discriminator update; returns the device scalar loss_d (a view of self.loss).
+        ahead: the batch of the generator step that follows -- its generator forward then runs inside this step
+        (``run_ahead``; call ``g_step(that batch, use_ahead=True)`` next)."""
+        if ahead is not None and self.run_ahead and hip.PROFILE is None:
+            self._ahead_pending = True
+            return self._run_step('d', batch, counter, ahead=ahead)
+        self._ahead_pending = False
         return self._run_step('d', batch, counter)
 
     def _d_impl(self, batch, ahead=None):
@@ -403,8 +410,13 @@ class GanTrainer(object):
         self.last = {'gctx': gctx, 'cr': cr, 'cf': cf}
         return loss_d
 
-    def g_step(self, batch, counter=0):
-        """One generator update (+ spectral-norm u assignment); returns the device scalar loss_g."""
+    def g_step(self, batch, counter=0, use_ahead=False):
+        """One generator update (+ spectral-norm u assignment); returns the device scalar loss_g.
+        use_ahead: start from the forward pass the preceding ``d_step(..., ahead=batch)`` ran for this batch."""
+        if use_ahead and self._ahead_pending and hip.PROFILE is None:
+            self._ahead_pending = False
+            return self._run_step('g', batch, counter, use_ahead=True)
+        self._ahead_pending = False
         return self._run_step('g', batch, counter)
 
     def _g_impl(self, batch, use_ahead=False):
@@ -494,12 +506,8 @@ class GanTrainer(object):
         """D-step then G-step on independent batches (main_procedure.py:178-232).  Knowing both batches up front, the
         generator forward of the G-step is run inside the D-step (``run_ahead``; results identical: the generator's
         variables do not change in between)."""
-        if self.run_ahead and hip.PROFILE is None:
-            ld = self._run_step('d', batch_d, counter, ahead=batch_g)
-            lg = self._run_step('g', batch_g, counter, use_ahead=True)
-            return lg, ld
-        ld = self.d_step(batch_d, counter)
-        lg = self.g_step(batch_g, counter)
+        ld = self.d_step(batch_d, counter, ahead=batch_g)
+        lg = self.g_step(batch_g, counter, use_ahead=True)
         return lg, ld
 
     def generate(self, sketches, text, noise_vec, labels=None):
