@@ -92,9 +92,8 @@ class GanTrainer(object):
         self._wgrad_stream = torch.cuda.Stream() if (overlap_wgrad and block_type == 'Pix2Pix') else None
         self._aux_stream = torch.cuda.Stream() if overlap_real else None
         self._text_stream = torch.cuda.Stream() if (overlap_real and os.environ.get('SSC_TEXT_STREAM', '1') == '1') else None
-        # generator forward of the next G-step inside the D-step (train_iteration): single GPU, Pix2Pix pair
-        self.run_ahead = (block_type == 'Pix2Pix' and overlap_real and not self.segment_graphs and
-                          os.environ.get('SSC_RUN_AHEAD', '1') == '1')
+        # generator forward of the next G-step inside the D-step (train_iteration): Pix2Pix pair
+        self.run_ahead = (block_type == 'Pix2Pix' and overlap_real and os.environ.get('SSC_RUN_AHEAD', '1') == '1')
         self._ahead_stream = torch.cuda.Stream() if self.run_ahead else None
         self._ahead = None
         self._ahead_pending = False
@@ -340,9 +339,9 @@ class GanTrainer(object):
                 finally:
                     self.G.text_stream = ts
         loss_d = self.d_gradients(batch)
-        self._apply_d_launch()
-        if ahead is not None:
+        if ahead is not None:       # joined before the gradient all-reduce: a fork may not cross the end of a graph segment
             torch.cuda.current_stream().wait_stream(self._ahead_stream)
+        self._apply_d_launch()
         return loss_d
 
     def apply_d(self, counter=0):
