@@ -92,8 +92,8 @@ class GanTrainer(object):
         self._wgrad_stream = torch.cuda.Stream() if (overlap_wgrad and block_type == 'Pix2Pix') else None
         self._aux_stream = torch.cuda.Stream() if overlap_real else None
         self._text_stream = torch.cuda.Stream() if (overlap_real and os.environ.get('SSC_TEXT_STREAM', '1') == '1') else None
-        # generator forward of the next G-step inside the D-step (train_iteration): Pix2Pix pair
-        self.run_ahead = (block_type == 'Pix2Pix' and overlap_real and os.environ.get('SSC_RUN_AHEAD', '1') == '1')
+        # generator forward of the next G-step inside the D-step (train_iteration)
+        self.run_ahead = (overlap_real and os.environ.get('SSC_RUN_AHEAD', '1') == '1')
         self._ahead_stream = torch.cuda.Stream() if self.run_ahead else None
         self._ahead = None
         self._ahead_pending = False

@@ -134,14 +134,15 @@ def test_hipgraph_replay_matches_eager():
     assert worst < 4e-3, worst
 
 
-def test_train_iteration_run_ahead_matches_separate_steps():
+@pytest.mark.parametrize('block_type', ['Pix2Pix', 'Residual', 'MRU'])
+def test_train_iteration_run_ahead_matches_separate_steps(block_type):
     """train_iteration runs the G-step's generator forward inside the D-step (on its own stream, trainer.run_ahead) and
     starts the G-step from it.  The generator's variables do not change during a D-step, so losses and weights must
     equal d_step + g_step -- eagerly, while capturing, and in replay, with new data through the captured graphs."""
     from sketchyscenecolorization_amd.synthetic import synthetic_batch
     from sketchyscenecolorization_amd.trainer import GanTrainer
-    a = GanTrainer(img=64, seed=7, max_iter_step=50)
-    b = GanTrainer(img=64, seed=7, max_iter_step=50, use_graphs=True)
+    a = GanTrainer(img=64, seed=7, max_iter_step=50, block_type=block_type)
+    b = GanTrainer(img=64, seed=7, max_iter_step=50, use_graphs=True, block_type=block_type)
     assert b.run_ahead
     bd, bg = synthetic_batch(2, 21, 64), synthetic_batch(2, 22, 64)
     bd2, bg2 = synthetic_batch(2, 23, 64), synthetic_batch(2, 24, 64)
