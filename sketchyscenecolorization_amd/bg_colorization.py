@@ -63,7 +63,7 @@ class BGTrainer(object):
     taken at the weights the forward pass used."""
 
     def __init__(self, image_size=768, vocab_size=18, ngf=64, ndf=64, seg_classes=3, lr=2e-4, max_steps=100000,
-                 gan_weight=1.0, l1_weight=100.0, seg_weight=100.0, beta1=0.5, seed=0, device='cuda'):
+                 gan_weight=1.0, l1_weight=100.0, seg_weight=100.0, beta1=0.5, seed=0, device='cuda', use_graphs=True):
         if not torch.cuda.is_available():
             raise RuntimeError('BGTrainer needs an MI355X (HIP) device: there is no CPU fallback')
         if ngf != 64 or ndf != 64:
@@ -83,6 +83,11 @@ class BGTrainer(object):
         for sc in (self.store.generator, self.store.discriminator):
             sc.adam_m = torch.zeros_like(sc.adam_v)
         self.global_step = 0
+        # hipGraph replay of whole steps (as GanTrainer): ~1500 launches per step are otherwise issued one by one.  The
+        # step sizes live in device memory so that one captured graph serves every step.
+        self.use_graphs = bool(use_graphs)
+        self.lr_dev = torch.zeros(2, dtype=torch.float32, device=device)
+        self._static, self._graphs, self._seen = {}, {}, set()
 
     def learning_rate(self, step):
         decay_steps = int(round(self.max_steps * 0.75))
@@ -142,17 +147,64 @@ class BGTrainer(object):
         seg = segw / self.w_seg if self.w_seg else 0.0
         return d, gan * self.w_gan + l1w + segw, gan, l1, seg
 
-    def apply_gradients(self):
+    def _adam_prepare(self):
+        """Host part of both Adam applies: advance t, put lr_t = lr*sqrt(1-b2^t)/(1-b1^t) in device memory."""
         lr = self.learning_rate(self.global_step)
-        for sc in (self.store.discriminator, self.store.generator):
+        for i, sc in enumerate((self.store.discriminator, self.store.generator)):
             sc.adam_t += 1
             t = sc.adam_t
-            lr_t = lr * (1.0 - self.beta2 ** t) ** 0.5 / (1.0 - self.beta1 ** t)
-            hip.call('ssc_adam_tf', sc.flat, sc.grad, sc.adam_m, sc.adam_v, sc.numel, float(lr_t), None, self.beta1,
-                     self.beta2, self.eps, 1.0)
+            self.lr_dev[i:i + 1].fill_(float(lr * (1.0 - self.beta2 ** t) ** 0.5 / (1.0 - self.beta1 ** t)))
         self.global_step += 1
 
+    def _adam_launch(self):
+        for i, sc in enumerate((self.store.discriminator, self.store.generator)):
+            hip.call('ssc_adam_tf', sc.flat, sc.grad, sc.adam_m, sc.adam_v, sc.numel, 0.0, self.lr_dev[i:i + 1],
+                     self.beta1, self.beta2, self.eps, 1.0)
+
+    def apply_gradients(self):
+        self._adam_prepare()
+        self._adam_launch()
+
     def train_step(self, inputs, targets, text, labels_gt):
-        gctx = self.gradients(inputs, targets, text, labels_gt)
-        self.apply_gradients()
-        return gctx
+        """One ``sess.run(model.train)``.  The first call of a shape runs eagerly (it allocates), the second is captured
+        into a hipGraph, later ones replay it on the inputs copied into the graph's static tensors."""
+        if not self.use_graphs or hip.PROFILE is not None:
+            gctx = self.gradients(inputs, targets, text, labels_gt)
+            self.apply_gradients()
+            return gctx
+        skey = tuple(inputs.shape)
+        st = self._static.get(skey)
+        if st is None:
+            st = {'inputs': torch.empty_like(inputs.contiguous()), 'targets': torch.empty_like(targets.contiguous()),
+                  'labels': torch.empty(tuple(labels_gt.shape), dtype=torch.int32, device=inputs.device)}
+            self._static[skey] = st
+        st['inputs'].copy_(inputs)
+        st['targets'].copy_(targets)
+        st['labels'].copy_(labels_gt)
+        prep = text if isinstance(text, dict) else self.G.text.prepare(text, 'bg')
+        key = skey + (prep['S'],)
+        self._adam_prepare()
+
+        def impl():
+            self._gctx = self.gradients(st['inputs'], st['targets'], prep, st['labels'])
+            self._adam_launch()
+
+        g = self._graphs.get(key)
+        if g is None:
+            if key not in self._seen:
+                self._seen.add(key)
+                impl()
+                return self._gctx
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    impl()
+            except Exception as e:      # never lose a training run to graph capture
+                print('hipGraph capture failed (%r): continuing with eager launches' % (e,))
+                self.use_graphs = False
+                torch.cuda.synchronize()
+                impl()
+                return self._gctx
+            self._graphs[key] = g
+        g.replay()
+        return self._gctx
