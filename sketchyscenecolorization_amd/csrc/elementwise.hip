@@ -88,11 +88,31 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     const int rlane = threadIdx.x / tcg;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
     if (cgi * 4 < C) {
-        for (long r = (long)blockIdx.x * rl + rlane; r < M; r += (long)gridDim.x * rl) {
+        // 4 rows in flight per thread: the walk is a chain of strided loads, one accumulator pair would serialise them
+        const long step = (long)gridDim.x * rl;
+        long r = (long)blockIdx.x * rl + rlane;
+        float4 s1 = s, q1 = s, s2 = s, q2 = s, s3 = s, q3 = s;
+        for (; r + 3 * step < M; r += 4 * step) {
+            const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + cgi * 4);
+            const float4 v1 = *reinterpret_cast<const float4*>(x + (r + step) * ldx + cgi * 4);
+            const float4 v2 = *reinterpret_cast<const float4*>(x + (r + 2 * step) * ldx + cgi * 4);
+            const float4 v3 = *reinterpret_cast<const float4*>(x + (r + 3 * step) * ldx + cgi * 4);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            q.x += v0.x * v0.x; q.y += v0.y * v0.y; q.z += v0.z * v0.z; q.w += v0.w * v0.w;
+            s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+            q1.x += v1.x * v1.x; q1.y += v1.y * v1.y; q1.z += v1.z * v1.z; q1.w += v1.w * v1.w;
+            s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+            q2.x += v2.x * v2.x; q2.y += v2.y * v2.y; q2.z += v2.z * v2.z; q2.w += v2.w * v2.w;
+            s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+            q3.x += v3.x * v3.x; q3.y += v3.y * v3.y; q3.z += v3.z * v3.z; q3.w += v3.w * v3.w;
+        }
+        for (; r < M; r += step) {
             const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + cgi * 4);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
         }
+        s.x += (s1.x + s2.x) + s3.x; s.y += (s1.y + s2.y) + s3.y; s.z += (s1.z + s2.z) + s3.z; s.w += (s1.w + s2.w) + s3.w;
+        q.x += (q1.x + q2.x) + q3.x; q.y += (q1.y + q2.y) + q3.y; q.z += (q1.z + q2.z) + q3.z; q.w += (q1.w + q2.w) + q3.w;
     }
     sh[0][threadIdx.x] = s;
     sh[1][threadIdx.x] = q;
@@ -222,13 +242,30 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(BnBwdArgs a, int tc
         const float4 bb = *reinterpret_cast<const float4*>(a.ab + a.C + c);
         const float4 mu = *reinterpret_cast<const float4*>(a.stats + c);
         const float4 rs = *reinterpret_cast<const float4*>(a.stats + a.C + c);
-        for (long r = (long)blockIdx.x * rl + rlane; r < a.M; r += (long)gridDim.x * rl) {
+        // 2 rows in flight per thread (each row reads 2-3 tensors)
+        const long step = (long)gridDim.x * rl;
+        long r = (long)blockIdx.x * rl + rlane;
+        float4 s1 = s, q1 = s;
+        for (; r + step < a.M; r += 2 * step) {
+            float4 xv, dz, xw, dw;
+            bn_bwd_dz(a, r, c, aa, bb, xv, dz);
+            bn_bwd_dz(a, r + step, c, aa, bb, xw, dw);
+            s.x += dz.x; s.y += dz.y; s.z += dz.z; s.w += dz.w;
+            q.x += dz.x * (xv.x - mu.x) * rs.x; q.y += dz.y * (xv.y - mu.y) * rs.y;
+            q.z += dz.z * (xv.z - mu.z) * rs.z; q.w += dz.w * (xv.w - mu.w) * rs.w;
+            s1.x += dw.x; s1.y += dw.y; s1.z += dw.z; s1.w += dw.w;
+            q1.x += dw.x * (xw.x - mu.x) * rs.x; q1.y += dw.y * (xw.y - mu.y) * rs.y;
+            q1.z += dw.z * (xw.z - mu.z) * rs.z; q1.w += dw.w * (xw.w - mu.w) * rs.w;
+        }
+        for (; r < a.M; r += step) {
             float4 xv, dz;
             bn_bwd_dz(a, r, c, aa, bb, xv, dz);
             s.x += dz.x; s.y += dz.y; s.z += dz.z; s.w += dz.w;
             q.x += dz.x * (xv.x - mu.x) * rs.x; q.y += dz.y * (xv.y - mu.y) * rs.y;
             q.z += dz.z * (xv.z - mu.z) * rs.z; q.w += dz.w * (xv.w - mu.w) * rs.w;
         }
+        s.x += s1.x; s.y += s1.y; s.z += s1.z; s.w += s1.w;
+        q.x += q1.x; q.y += q1.y; q.z += q1.z; q.w += q1.w;
     }
     sh[0][threadIdx.x] = s;
     sh[1][threadIdx.x] = q;
