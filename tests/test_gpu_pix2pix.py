@@ -157,6 +157,25 @@ def test_train_iteration_run_ahead_matches_separate_steps(block_type):
     assert worst < 4e-3, worst      # see test_hipgraph_replay_matches_eager
 
 
+def test_full_size_overlapped_trainer_equals_inline_trainer_bitwise():
+    """BASELINE configs[2] size (batch 32, 192x192).  Trainer A launches every kernel in line on one stream; trainer B is
+    the default: hipGraph replay, discriminator-real / caption-word / run-ahead branches on their own streams.  Every
+    kernel has a fixed summation order, so a missing stream dependency is the only thing that could make them differ:
+    weights must be bitwise equal, losses equal to double rounding."""
+    from sketchyscenecolorization_amd.synthetic import synthetic_batch
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    a = GanTrainer(img=192, seed=3, max_iter_step=1000, use_graphs=False, overlap_real=False)
+    b = GanTrainer(img=192, seed=3, max_iter_step=1000, use_graphs=True)
+    assert b.run_ahead and b._text_stream is not None and a._aux_stream is None
+    for it in range(6):
+        bd, bg = synthetic_batch(32, 100 + it % 3, 192), synthetic_batch(32, 200 + it % 3, 192)
+        la = (float(a.d_step(bd, it)), float(a.g_step(bg, it)))
+        lg, ld = b.train_iteration(bd, bg, it)
+        assert abs(la[0] - float(ld)) < 1e-9 * max(1.0, abs(la[0])) and abs(la[1] - float(lg)) < 1e-9 * max(1.0, abs(la[1]))
+    for n in a.store.names():
+        assert torch.equal(a.store[n], b.store[n]), n
+
+
 def test_segmented_graphs_with_rccl_world1_match_eager():
     """The multi-GPU step protocol on one GPU: a 1-rank RCCL process group, steps captured as graph SEGMENTS with the
     all-reduces issued eagerly on the side stream between them (what world > 1 uses).  Must equal the eager trainer.
