@@ -119,6 +119,12 @@ int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* d, char* buf, int len);
 int ssc_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int ldc, int coff, void* stream);
 /* dst[n,c,hw] = src[n,hw,coff+c] */
 int ssc_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, int ldc, int coff, void* stream);
+/* Device-side image pre / post-processing of the inference, test and validation procedures
+ * (main_procedure.py:361-621).  src uint8 [N,H,W,3] -> dst float [N,H,W,4] = src/255*2-1 (channel 3 = 0), optionally
+ * after thicken_drawings (input_pipeline.py:242-257: 2x2 grey dilation of the dark strokes of channel 0). */
+int ssc_sketch_preprocess_u8(const uint8_t* src, int N, int H, int W, int thicken, float* dst, void* stream);
+/* src float NHWC rows of ldc floats, image in channels [coff, coff+3) -> dst uint8 [M,3] = ((x+1)/2*255) truncated */
+int ssc_image_postprocess_u8(const float* src, int ldc, int coff, int64_t M, uint8_t* dst, void* stream);
 /* host-side CRC-32C (Castagnoli) of n bytes: TFRecord record framing (tf.TFRecordReader, input_pipeline.py:57-59) */
 uint32_t ssc_crc32c(const uint8_t* data, int64_t n);
 int ssc_fill(float* dst, float value, int64_t n, void* stream);

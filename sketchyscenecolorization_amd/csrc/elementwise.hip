@@ -46,6 +46,63 @@ extern "C" int ssc_nhwc_to_nchw(const float* src, float* dst, int N, int C, int 
     return CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------ image pre / post-processing on the device
+// uint8 HWC sketch -> network input.  dst[n,y,x,0:3] = src/255*2-1 (main_procedure.py:536-538), dst[..,3] = 0.
+// thicken != 0 first applies thicken_drawings (input_pipeline.py:242-257): 2x2 grey dilation of the dark strokes of
+// channel 0 = the minimum over rows {y,y+1} x cols {x,x+1} (edge-clamped), replicated to the three channels.
+__global__ void sketch_preprocess_u8_kernel(const unsigned char* __restrict__ src, int N, int H, int W, int thicken,
+                                            float* __restrict__ dst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * H * W) return;
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const unsigned char* p = src + i * 3;
+    float r, g, b;
+    if (thicken) {
+        const long dx = (x + 1 < W) ? 3 : 0, dy = (y + 1 < H) ? (long)W * 3 : 0;
+        unsigned char m = p[0];
+        m = min(m, p[dx]);
+        m = min(m, p[dy]);
+        m = min(m, p[dy + dx]);
+        r = g = b = (float)m;
+    } else {
+        r = (float)p[0]; g = (float)p[1]; b = (float)p[2];
+    }
+    // the reference computes in float32: x / 255. * 2. - 1
+    const float4 v = make_float4(r / 255.f * 2.f - 1.f, g / 255.f * 2.f - 1.f, b / 255.f * 2.f - 1.f, 0.f);
+    *reinterpret_cast<float4*>(dst + i * 4) = v;
+}
+
+// network output (NHWC, tanh image in channels [coff, coff+3) of rows of ldc floats) -> uint8 HWC with the reference's
+// float32 arithmetic and truncating cast: ((x + 1) / 2 * 255).astype(uint8)  (main_procedure.py:601-610)
+__global__ void image_postprocess_u8_kernel(const float* __restrict__ src, int ldc, int coff, long M,
+                                            unsigned char* __restrict__ dst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float* p = src + i * ldc + coff;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = (p[c] + 1.f) / 2.f * 255.f;
+        v = fminf(fmaxf(v, 0.f), 255.f);        // tanh keeps it inside; guards the cast against NaN / overshoot
+        dst[i * 3 + c] = (unsigned char)(int)v;
+    }
+}
+
+extern "C" int ssc_sketch_preprocess_u8(const uint8_t* src, int N, int H, int W, int thicken, float* dst, void* stream) {
+    const long tot = (long)N * H * W;
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(sketch_preprocess_u8_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, N, H, W, thicken, dst);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int ssc_image_postprocess_u8(const float* src, int ldc, int coff, int64_t M, uint8_t* dst, void* stream) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(image_postprocess_u8_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       ldc, coff, (long)M, dst);
+    return CHECK_LAUNCH();
+}
+
 extern "C" int ssc_fill(float* dst, float value, int64_t n, void* stream) {
     if (n <= 0) return 0;
     long blocks = (n + 255) / 256;

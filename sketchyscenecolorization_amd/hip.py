@@ -72,6 +72,8 @@ SIGNATURES = {
     'ssc_conv_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, _I],
     'ssc_nchw_to_nhwc': [_P, _P, _I, _I, _I, _I, _I, _P],
     'ssc_nhwc_to_nchw': [_P, _P, _I, _I, _I, _I, _I, _P],
+    'ssc_sketch_preprocess_u8': [_P, _I, _I, _I, _I, _P, _P],
+    'ssc_image_postprocess_u8': [_P, _I, _I, _L, _P, _P],
     'ssc_fill': [_P, _F, _L, _P],
     'ssc_affine_act': [_P, _I, _P, _I, _I, _P, _I, _L, _I, _P],
     'ssc_residual_merge': [_P, _P, _P, _P, _I, _P, _L, _I, _P],
@@ -160,7 +162,7 @@ def stream_ptr():
 def ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.float64), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.float64, torch.uint8), (t.device, t.dtype)
     return C.c_void_p(t.data_ptr())
 
 
@@ -455,6 +457,28 @@ def nhwc_to_nchw(src, dst, coff=0):
     n, c, h, w = dst.shape
     assert src.shape[:3] == (n, h, w) and src.is_contiguous() and dst.is_contiguous()
     check(lib().ssc_nhwc_to_nchw(ptr(src), ptr(dst), n, c, h * w, src.shape[3], coff, stream_ptr()), 'nhwc_to_nchw')
+
+
+def sketch_preprocess_u8(src_u8, thicken=False, out=None):
+    """uint8 [N,H,W,3] (device) -> float [N,H,W,4] network input in [-1,1] (channel 3 zero), optionally thickened."""
+    n, h, w, c = src_u8.shape
+    assert c == 3 and src_u8.dtype == torch.uint8 and src_u8.is_contiguous()
+    if out is None:
+        out = torch.empty((n, h, w, 4), dtype=torch.float32, device=src_u8.device)
+    check(lib().ssc_sketch_preprocess_u8(ptr(src_u8), n, h, w, int(bool(thicken)), ptr(out), stream_ptr()),
+          'sketch_preprocess_u8')
+    return out
+
+
+def image_postprocess_u8(src_nhwc, coff=0, out=None):
+    """float NHWC [N,H,W,ldc] with the tanh image in channels [coff, coff+3) -> uint8 [N,H,W,3] (truncating cast)."""
+    n, h, w, ldc = src_nhwc.shape
+    assert src_nhwc.is_contiguous() and coff + 3 <= ldc
+    if out is None:
+        out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=src_nhwc.device)
+    check(lib().ssc_image_postprocess_u8(ptr(src_nhwc), ldc, coff, n * h * w, ptr(out), stream_ptr()),
+          'image_postprocess_u8')
+    return out
 
 
 def fill(t, value):

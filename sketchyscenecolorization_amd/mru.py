@@ -355,15 +355,20 @@ class MRUGenerator(_MRUBlocks):
         """sketches NCHW [N,3,H,W] (device), text int [N,T] (host), labels int32 [N] (device) = class ids,
         noise_vec [N,256] (device).  The tanh image goes to ``out[..., out_coff:out_coff+3]`` (NHWC)."""
         s, B = self.s, self.b
-        N, _, H, W = sketches.shape
+        nhwc_in = sketches.dim() == 4 and sketches.shape[3] == 4 and sketches.shape[1] != 3     # hip.sketch_preprocess_u8
+        N, H, W = (sketches.shape[0], sketches.shape[1], sketches.shape[2]) if nhwc_in else \
+            (sketches.shape[0], sketches.shape[2], sketches.shape[3])
         assert H % 32 == 0 and W % 32 == 0
         labels = labels.to(device=sketches.device, dtype=torch.int32).contiguous()
         if self.lstm_hybrid and self.text_stream is not None and hip.PROFILE is None:
             # the caption's word LSTM does not see the image: start it next to the encoder
             text = self.text.start_words(text, None, tag, self.text_stream)
         tape = []
-        xs = B.get(tag + '/xs', (N, H, W, 4), zero_on_alloc=True)
-        hip.nchw_to_nhwc(sketches, xs, 0)
+        if nhwc_in:
+            xs = sketches
+        else:
+            xs = B.get(tag + '/xs', (N, H, W, 4), zero_on_alloc=True)
+            hip.nchw_to_nhwc(sketches, xs, 0)
         pyr = [xs]          # mean-pool pyramid == AREA resize for the integer factors (models_collection.py:76-80, 264-267)
         for k in range(1, 5):
             p = B.get(tag + '/pyr%d' % k, (N, H >> k, W >> k, 4))

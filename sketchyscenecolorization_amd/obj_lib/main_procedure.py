@@ -292,19 +292,21 @@ def inference(img_name, instruction):
     restore_checkpoint(store, path)
 
     sketch = _load_sketch(os.path.join(wild_data_base_dir, img_name), img_dim, wild_cate)
-    sketch_image = _normalise(sketch)
     class_id = np.array([categories.index(wild_cate)])
     vocab_indices = np.expand_dims(np.array(preprocess_sentence(instruction, vocab_dict, T), dtype=np.int32), axis=0)
     try:
-        generated_img, _, input_sketch = build_single_graph(
-            sketch_image, sketch_image, None, class_id, None, vocab_indices, batch_size=1, training=False,
-            LSTM_hybrid=LSTM_hybrid, vocab_size=Config.vocab_size, data_format=Config.data_format,
-            distance_map=Config.distance_map != 0, block_type=Config.block_type)
+        # uint8 in, uint8 out: normalisation, layout and the truncating cast run on the device (the arithmetic of
+        # _normalise / _postprocess, bit for bit: tests/test_gpu_edge_cases.py), the network reads / writes NHWC
+        from .. import hip
+        tower = models.get_trainer(Config.block_type, Config.vocab_size, img_dim[0])
+        tower.G.lstm_hybrid = bool(LSTM_hybrid)
+        sk_u8 = torch.from_numpy(np.ascontiguousarray(sketch.astype(np.uint8)[None])).cuda()
+        gen_u8 = tower.generate_u8(sk_u8, vocab_indices, torch.randn(1, 256, device='cuda'),
+                                   labels=torch.as_tensor(class_id, dtype=torch.int32, device='cuda')).cpu().numpy()
+        in_u8 = hip.image_postprocess_u8(hip.sketch_preprocess_u8(sk_u8)).cpu().numpy()
     except Exception as e:      # the reference swallows sess.run errors and prints them (:590-599)
         print(e.args)
         raise
-    gen_u8 = _postprocess(generated_img)
-    in_u8 = _postprocess(input_sketch)
     img_out_filename = img_name[:-4] + '_output.png'
     _write_png(os.path.join(output_folder, img_out_filename), gen_u8[0])
     _write_png(os.path.join(output_folder, img_name[:-4] + '_input.png'), in_u8[0])

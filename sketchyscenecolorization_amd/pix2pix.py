@@ -35,14 +35,19 @@ class Pix2PixGenerator(object):
         """sketches NCHW [N,3,H,W] (device), text int [N,T] (host), noise_vec [N,256] (device).
         Writes tanh output into ``out[..., out_coff:out_coff+3]`` (NHWC) and returns the context."""
         s, B = self.s, self.b
-        N, _, H, W = sketches.shape
+        nhwc_in = sketches.dim() == 4 and sketches.shape[3] == 4 and sketches.shape[1] != 3     # hip.sketch_preprocess_u8
+        N, H, W = (sketches.shape[0], sketches.shape[1], sketches.shape[2]) if nhwc_in else \
+            (sketches.shape[0], sketches.shape[2], sketches.shape[3])
         chans = [None, 64, 128, 256, 512, 512]
         tstream = self.text_stream if hip.PROFILE is None else None     # per-kernel timing runs everything in line
         if self.lstm_hybrid and tstream is not None:
             # the caption's word LSTM does not see the image: start it next to the encoder convolutions
             text = self.text.start_words(text, chans[5], tag, tstream)
-        xs = B.get(tag + '/xs', (N, H, W, 4), zero_on_alloc=True)
-        hip.nchw_to_nhwc(sketches, xs, 0)
+        if nhwc_in:
+            xs = sketches
+        else:
+            xs = B.get(tag + '/xs', (N, H, W, 4), zero_on_alloc=True)
+            hip.nchw_to_nhwc(sketches, xs, 0)
         e, ab, st = [None] * 6, [None] * 6, [None] * 6
         h = H
         for k in range(1, 6):

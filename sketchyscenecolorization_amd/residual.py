@@ -270,7 +270,10 @@ class ResidualGenerator(_Bottlenecks):
             # the caption's word LSTM does not see the image: start it next to the encoder
             text = self.text.start_words(text, None, tag, self.text_stream)
         top_bn = (lambda pre: pre) if self.fg else (lambda pre: pre + '/batchnorm')
-        if self.fg:
+        if self.fg and inputs.shape[3] == 4 and inputs.shape[1] != 3:     # NHWC4 from hip.sketch_preprocess_u8
+            N, H, W, _ = inputs.shape
+            xs = inputs
+        elif self.fg:
             N, _, H, W = inputs.shape
             xs = B.get(tag + '/xs', (N, H, W, 4), zero_on_alloc=True)
             hip.nchw_to_nhwc(inputs, xs, 0)

@@ -509,6 +509,19 @@ class GanTrainer(object):
         lg = self.g_step(batch_g, counter, use_ahead=True)
         return lg, ld
 
+    def generate_u8(self, sketch_u8, text, noise_vec, labels=None, thicken=False):
+        """Serving path without host arithmetic: uint8 sketches [N,H,W,3] on the device -> uint8 images [N,H,W,3].
+        Pre-processing (x/255*2-1, optional thicken_drawings) and post-processing ((x+1)/2*255, truncating cast) of
+        main_procedure.py:361-621 run as kernels; the network reads / writes NHWC directly."""
+        xs = hip.sketch_preprocess_u8(sketch_u8.contiguous(), thicken)
+        if self.block_type == 'MRU':
+            if labels is None:
+                raise ValueError('the MRU generator is class-conditional: pass the class ids (image_data_class_id)')
+            ctx = self.G.forward(xs, text, labels, noise_vec, 'g')
+        else:
+            ctx = self.G.forward(xs, text, noise_vec, 'g')
+        return hip.image_postprocess_u8(ctx['out'], ctx['out_coff'])
+
     def generate(self, sketches, text, noise_vec, labels=None):
         """Inference path of build_single_graph (training=False): NCHW in, NCHW out."""
         if self.block_type == 'MRU':

@@ -78,3 +78,50 @@ def test_all_pad_captions_and_batch_one(bt):
     assert abs(ld - float(r['loss_d'])) < 1e-3 * max(1.0, abs(float(r['loss_d'])))
     assert abs(lg - float(r['loss_g'])) < 1e-3 * max(1.0, abs(float(r['loss_g'])))
     assert all(bool(torch.isfinite(g).all()) for g in tr.store.generator.g.values())
+
+
+@pytest.mark.gpu
+def test_device_pre_and_post_processing_match_the_host_functions():
+    """hip.sketch_preprocess_u8 / image_postprocess_u8 against the host restatements of main_procedure.py's
+    normalisation, thicken_drawings and truncating uint8 cast -- bit exact (uint8 / float32 arithmetic)."""
+    import numpy as np
+    from sketchyscenecolorization_amd import hip
+    from sketchyscenecolorization_amd.obj_lib import main_procedure as mp
+    from sketchyscenecolorization_amd.obj_lib.input_pipeline import thicken_drawings
+    rng = np.random.RandomState(0)
+    u8 = rng.randint(0, 256, (3, 40, 56, 3)).astype(np.uint8)
+    u8[1] = np.repeat(((rng.rand(40, 56) > 0.9) * 255).astype(np.uint8)[:, :, None], 3, axis=2)     # a sparse drawing
+    dev = torch.from_numpy(u8).cuda()
+    got = hip.sketch_preprocess_u8(dev).cpu().numpy()
+    for n in range(3):
+        ref = mp._normalise(u8[n].astype(np.float32))[0].transpose(1, 2, 0)
+        assert np.array_equal(got[n, :, :, :3], ref) and (got[n, :, :, 3] == 0).all()
+    got_t = hip.sketch_preprocess_u8(dev, thicken=True).cpu().numpy()
+    for n in range(3):
+        ref = mp._normalise(thicken_drawings(u8[n]).astype(np.float32))[0].transpose(1, 2, 0)
+        assert np.array_equal(got_t[n, :, :, :3], ref)
+    x = (rng.rand(2, 24, 32, 8).astype(np.float32) * 2 - 1)
+    x[0, 0, 0, 3:6] = (1.0, -1.0, 0.0)
+    out = hip.image_postprocess_u8(torch.from_numpy(x).cuda(), coff=3).cpu().numpy()
+    ref = mp._postprocess(np.transpose(x[..., 3:6], (0, 3, 1, 2)))
+    assert out.dtype == np.uint8 and np.array_equal(out, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('block_type', ['Pix2Pix', 'Residual', 'MRU'])
+def test_generate_u8_equals_host_pipeline(block_type):
+    """GanTrainer.generate_u8 (uint8 in, uint8 out, everything on the device, NHWC straight into the network) equals
+    host normalise -> generate (NCHW) -> host post-process."""
+    import numpy as np
+    from sketchyscenecolorization_amd.obj_lib import main_procedure as mp
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    tr = GanTrainer(img=64, seed=2, block_type=block_type)
+    rng = np.random.RandomState(1)
+    u8 = np.repeat(((rng.rand(2, 64, 64) > 0.85) * 255).astype(np.uint8)[..., None], 3, axis=3)
+    text = rng.randint(1, 58, (2, 15)).astype(np.int32)
+    noise = torch.randn(2, 256, device='cuda')
+    labels = torch.tensor([3, 7], dtype=torch.int32, device='cuda')
+    got = tr.generate_u8(torch.from_numpy(u8).cuda(), text, noise, labels=labels).cpu().numpy()
+    z = torch.from_numpy(np.ascontiguousarray(np.concatenate([mp._normalise(u8[n].astype(np.float32)) for n in range(2)]))).cuda()
+    ref = mp._postprocess(tr.generate(z, text, noise, labels=labels))
+    assert got.shape == (2, 64, 64, 3) and np.array_equal(got, ref)
