@@ -125,6 +125,12 @@ int ssc_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, int ldc
 int ssc_sketch_preprocess_u8(const uint8_t* src, int N, int H, int W, int thicken, float* dst, void* stream);
 /* src float NHWC rows of ldc floats, image in channels [coff, coff+3) -> dst uint8 [M,3] = ((x+1)/2*255) truncated */
 int ssc_image_postprocess_u8(const float* src, int ldc, int coff, int64_t M, uint8_t* dst, void* stream);
+/* Training-queue decode (get_paired_input, input_pipeline.py:77-131) of N raw records: img / sk uint8 [N,R,R,3] ->
+ * img_out / sk_out float NCHW [N,3,size,size], R = f * size.  Image: pixel (f*y, f*x) (TF1 bilinear at an integer
+ * factor), (v - min)/(max - min + 1) over the resized image, + noise [N,size,size,3] (uniform [0,1/256), may be NULL),
+ * * 2 - 1.  Sketch: mean of the f x f block (TF1 area), / 255 * 2 - 1.  mnmx: [N,2] scratch (per-image min, max). */
+int ssc_decode_paired_u8(const uint8_t* img, const uint8_t* sk, int N, int R, int size, const float* noise,
+                         float* img_out, float* sk_out, float* mnmx, void* stream);
 /* host-side CRC-32C (Castagnoli) of n bytes: TFRecord record framing (tf.TFRecordReader, input_pipeline.py:57-59) */
 uint32_t ssc_crc32c(const uint8_t* data, int64_t n);
 int ssc_fill(float* dst, float value, int64_t n, void* stream);

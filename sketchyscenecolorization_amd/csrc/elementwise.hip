@@ -88,6 +88,79 @@ __global__ void image_postprocess_u8_kernel(const float* __restrict__ src, int l
     }
 }
 
+// ------------------------------------------------------------------ training-queue decode (input_pipeline.py:77-131)
+// Raw records hold R x R x 3 uint8 images.  For the integer factor f = R / size (tf.image.resize_images, TF1 defaults):
+//   image : BILINEAR = the source pixel at (f*y, f*x); then (v - min) / (max - min + 1) over the whole resized image,
+//           + dequantisation noise (caller-provided uniform [0, 1/256), HWC order like the reference's), * 2 - 1
+//   sketch: AREA = mean of the f x f block; / 255 * 2 - 1
+// Outputs are NCHW float (the trainer's input layout).
+__global__ __launch_bounds__(1024) void decode_minmax_kernel(const unsigned char* __restrict__ img, int R, int f, int size,
+                                                             float* __restrict__ mnmx) {
+    __shared__ float smn[1024], smx[1024];
+    const int n = blockIdx.x;
+    const unsigned char* p = img + (long)n * R * R * 3;
+    float mn = 255.f, mx = 0.f;
+    const int tot = size * size * 3;
+    for (int i = threadIdx.x; i < tot; i += 1024) {
+        const int c = i % 3, x = (i / 3) % size, y = i / (3 * size);
+        const float v = (float)p[((long)(y * f) * R + x * f) * 3 + c];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    smn[threadIdx.x] = mn;
+    smx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            smn[threadIdx.x] = fminf(smn[threadIdx.x], smn[threadIdx.x + s]);
+            smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        mnmx[2 * n] = smn[0];
+        mnmx[2 * n + 1] = smx[0];
+    }
+}
+
+__global__ void decode_write_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ sk, int N,
+                                    int R, int f, int size, const float* __restrict__ mnmx,
+                                    const float* __restrict__ noise, float* __restrict__ img_out,
+                                    float* __restrict__ sk_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over [N, size, size] pixels
+    if (i >= (long)N * size * size) return;
+    const int x = (int)(i % size), y = (int)((i / size) % size), n = (int)(i / ((long)size * size));
+    const long plane = (long)size * size;
+    const unsigned char* pi = img + ((long)n * R * R + (long)(y * f) * R + x * f) * 3;
+    const float mn = mnmx[2 * n], mx = mnmx[2 * n + 1];
+    const float den = mx - mn + 1.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = ((float)pi[c] - mn) / den;
+        if (noise != nullptr) v += noise[i * 3 + c];
+        img_out[((long)n * 3 + c) * plane + (long)y * size + x] = v * 2.f - 1.f;
+        // AREA: the mean of the f x f block, accumulated row-major like numpy's mean over (rows, cols) in float32
+        float s = 0.f;
+        const unsigned char* ps = sk + ((long)n * R * R + (long)(y * f) * R + x * f) * 3 + c;
+        for (int dy = 0; dy < f; ++dy)
+            for (int dx = 0; dx < f; ++dx) s += (float)ps[((long)dy * R + dx) * 3];
+        sk_out[((long)n * 3 + c) * plane + (long)y * size + x] = s / (float)(f * f) / 255.f * 2.f - 1.f;
+    }
+}
+
+extern "C" int ssc_decode_paired_u8(const uint8_t* img, const uint8_t* sk, int N, int R, int size, const float* noise,
+                                    float* img_out, float* sk_out, float* mnmx, void* stream) {
+    if (N <= 0) return 0;
+    if (size <= 0 || R % size != 0) return -1;
+    const int f = R / size;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(decode_minmax_kernel, dim3(N), dim3(1024), 0, st, img, R, f, size, mnmx);
+    const long tot = (long)N * size * size;
+    hipLaunchKernelGGL(decode_write_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, img, sk, N, R, f, size,
+                       mnmx, noise, img_out, sk_out);
+    return CHECK_LAUNCH();
+}
+
 extern "C" int ssc_sketch_preprocess_u8(const uint8_t* src, int N, int H, int W, int thicken, float* dst, void* stream) {
     const long tot = (long)N * H * W;
     if (tot <= 0) return 0;

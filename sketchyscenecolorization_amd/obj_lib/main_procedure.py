@@ -117,7 +117,7 @@ class RecordQueue(object):
 
     def advance(self):
         images, sketches, class_id, text = self.q.dequeue()
-        dev = lambda a: torch.from_numpy(a).cuda()
+        dev = lambda a: a if torch.is_tensor(a) else torch.from_numpy(a).cuda()     # device-decoded batches stay put
         if self.which == 1:
             self.cur = {'images': dev(images), 'sketches': dev(sketches), 'class_id': dev(class_id), 'text': text}
         else:
@@ -382,7 +382,8 @@ def validation(**kwargs):
                 images, sketches, cls, text, cats, names = q.dequeue(with_names=True)
             except StopIteration:
                 break
-            run(torch.from_numpy(images).cuda(), torch.from_numpy(sketches).cuda(), torch.from_numpy(cls).cuda(), text,
+            dev = lambda a: a if torch.is_tensor(a) else torch.from_numpy(a).cuda()
+            run(dev(images), dev(sketches), dev(cls), text,
                 ['%s_%s' % (c, n[:-4] if n.endswith('.png') else n) for c, n in zip(cats, names)])
         return
     b = synthetic_batch(Config.batch_size, 4321, img, Config.vocab_size)

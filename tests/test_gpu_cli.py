@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -143,6 +144,37 @@ def test_cli_trains_from_tfrecords(tmp_path, monkeypatch):
     run = os.path.join('outputs', sorted(os.listdir('outputs'))[0])
     scal = [json.loads(l) for l in open(os.path.join(run, 'log', 'scalars.jsonl'))]
     assert len(scal) == 2 and all(np.isfinite(s['total_loss/g']) for s in scal)
+
+
+def test_paired_queue_device_decode_equals_host_decode(tmp_path):
+    """PairedQueue keeps raw records and decodes a batch on the device (default on a GPU box): same examples in the same
+    order as the host-decoding queue with the same seed, sketches bit-equal, images equal up to the dequantisation noise."""
+    from sketchyscenecolorization_amd import tfrecord as tf
+    from sketchyscenecolorization_amd.obj_lib.input_pipeline import PairedQueue
+    rng = np.random.RandomState(5)
+    d = os.path.join(tmp_path, 'data', 'tfrecord', 'train')
+    os.makedirs(d)
+    recs = []
+    for i in range(7):
+        sk = np.full((384, 384, 3), 255, np.uint8)
+        sk[50 * i:50 * i + 5, 30:350] = 0
+        text = np.zeros(15, np.uint8)
+        text[-2:] = [7, 9]
+        recs.append(tf.make_example({'ImageName': ('n%d.png' % i).encode(), 'cartoon_data': rng.randint(0, 256, (384, 384, 3)).astype(np.uint8).tobytes(),
+                                     'sketch_data': sk.tobytes(), 'Category': b'car', 'Category_id': i,
+                                     'Color_text': b'the car is red', 'Text_vocab_indices': text.tobytes()}))
+    tf.write_records(os.path.join(d, 'a.tfrecord'), recs)
+    base = os.path.join(tmp_path, 'data')
+    qd = PairedQueue('train', 3, min_after_dequeue=2, data_base_dir=base, seed=11)
+    qh = PairedQueue('train', 3, min_after_dequeue=2, data_base_dir=base, seed=11, device_decode=False)
+    assert qd.device_decode and not qh.device_decode
+    for _ in range(3):
+        di, ds, dc, dt = qd.dequeue()
+        hi, hs, hc, ht = qh.dequeue()
+        assert torch.is_tensor(di) and di.is_cuda and di.shape == (3, 3, 192, 192)
+        assert (dc == hc).all() and (dt == ht).all()
+        assert np.array_equal(ds.cpu().numpy(), hs)
+        assert np.abs(di.cpu().numpy() - hi).max() <= 2.0 / 256 + 1e-6
 
 
 @pytest.mark.parametrize('opt', ['RMSprop', 'AdaDelta', 'AdaGrad'])

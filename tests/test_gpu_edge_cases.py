@@ -125,3 +125,36 @@ def test_generate_u8_equals_host_pipeline(block_type):
     z = torch.from_numpy(np.ascontiguousarray(np.concatenate([mp._normalise(u8[n].astype(np.float32)) for n in range(2)]))).cuda()
     ref = mp._postprocess(tr.generate(z, text, noise, labels=labels))
     assert got.shape == (2, 64, 64, 3) and np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('size', [192, 64])
+def test_device_decode_of_training_records_matches_host_decode(size):
+    """hip.decode_paired_u8 against input_pipeline.decode_paired_example (the host restatement of get_paired_input,
+    input_pipeline.py:77-131) on random 384x384 records, with the same dequantisation noise: bit exact."""
+    import numpy as np
+    from sketchyscenecolorization_amd import hip
+    from sketchyscenecolorization_amd.obj_lib.input_pipeline import RECORD_HW, decode_paired_example
+    rng = np.random.RandomState(size)
+    n = 3
+    img = rng.randint(0, 256, (n, RECORD_HW, RECORD_HW, 3)).astype(np.uint8)
+    img[1] = rng.randint(40, 200, (RECORD_HW, RECORD_HW, 3))        # a narrower range: min / max normalisation matters
+    sk = (rng.rand(n, RECORD_HW, RECORD_HW, 3) > 0.1).astype(np.uint8) * 255
+    noise = rng.uniform(0.0, 1.0 / 256, size=(n, size, size, 3)).astype(np.float32)
+
+    class FixedNoise(object):
+        def __init__(self, a):
+            self.a = a
+
+        def uniform(self, lo, hi, size=None):
+            assert tuple(size) == self.a.shape
+            return self.a
+
+    gi, gs = hip.decode_paired_u8(torch.from_numpy(img).cuda(), torch.from_numpy(sk).cuda(), size,
+                                  noise=torch.from_numpy(noise).cuda())
+    gi, gs = gi.cpu().numpy(), gs.cpu().numpy()
+    for k in range(n):
+        feat = {'cartoon_data': [img[k].tobytes()], 'sketch_data': [sk[k].tobytes()], 'Category_id': [1],
+                'Text_vocab_indices': [bytes(15)]}
+        ri, rs = decode_paired_example(feat, (size, size), FixedNoise(noise[k]))[:2]
+        assert np.array_equal(gi[k], ri) and np.array_equal(gs[k], rs), k

@@ -53,7 +53,8 @@ def test_paired_queue_decodes_like_the_reference_graph(tmp_path, small):
     made = [_example(tf, rng, 'car_%d.png' % i, i) for i in range(5)]
     tf.write_records(os.path.join(d, 'part0.tfrecord'), [m[0] for m in made[:3]])
     tf.write_records(os.path.join(d, 'part1.tfrecord'), [m[0] for m in made[3:]])
-    q = PairedQueue('train', 4, small=small, min_after_dequeue=2, data_base_dir=os.path.join(tmp_path, 'data'), seed=3)
+    q = PairedQueue('train', 4, small=small, min_after_dequeue=2, data_base_dir=os.path.join(tmp_path, 'data'), seed=3,
+                    device_decode=False)      # the host decode; the device one is checked against it in test_gpu_cli.py
     images, sketches, cls, text = q.dequeue()
     size = 64 if small else 192
     f = 384 // size
@@ -67,7 +68,8 @@ def test_paired_queue_decodes_like_the_reference_graph(tmp_path, small):
         assert np.abs(images[b].transpose(1, 2, 0) - ref).max() <= 2.0 / 256 + 1e-6        # + dequantisation noise
         area = sk.reshape(size, f, size, f, 3).mean(axis=(1, 3)) / 255.0 * 2 - 1
         assert np.abs(sketches[b].transpose(1, 2, 0) - area).max() < 1e-6
-    vq = PairedQueue('train', 2, small=small, min_after_dequeue=0, data_base_dir=os.path.join(tmp_path, 'data'), seed=1)
+    vq = PairedQueue('train', 2, small=small, min_after_dequeue=0, data_base_dir=os.path.join(tmp_path, 'data'), seed=1,
+                     device_decode=False)
     vq.shuffle = False                                      # the val / test queue: file order, one epoch, names kept
     vq._it = vq._examples()
     got = []
