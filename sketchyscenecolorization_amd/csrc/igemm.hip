@@ -407,7 +407,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
 // enumerated per (tap, source, 32-channel chunk), mg.mC holding the magic of chunks-per-tap, so a tile still lies inside
 // one tap and one source; the last chunk of a source is partly empty: its A float4s beyond the source's channels are
 // not loaded and its filter rows beyond the real channels are zeroed (the A padding channels need not hold zeros).
-template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN, bool KMASK>
+// KM = 2 ("row tap"): few channels, TW * C == 32 (the discriminator's first conv: 4 taps x 8 channels).  A filter ROW is
+// then one K-tile: its TW taps x C channels are 32 contiguous floats both in the NHWC input (consecutive pixels) and in
+// the filter, so the launch runs as TH taps of "32 channels" (the host sets TW = 1); only the x bound differs per thread.
+template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN, int KM>
 __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, const Magics mg,
                                                        float* __restrict__ slab_base, long slab_stride, int splitk,
                                                        int ts_full, int ts_s) {
@@ -417,6 +420,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     // lane half lhi permuted to k = 16*lhi + kk (any bijection works when A and B agree): a lane's 16 A operands of a
     // K-tile are then contiguous, 4 ds_read_b128 instead of 16 ds_read_b32 per row block, and each staged float4 is one
     // ds_write_b128.  Not for the 128-row x <=64-column tiles, whose 3 workgroups per CU would no longer fit the LDS.
+    constexpr bool KMASK = (KM == 1), ROWTAP = (KM == 2);
     constexpr bool AV = UT_AV(BM, BN);
     constexpr int A_LD = AV ? BK + 4 : BK + 1;
     constexpr int A_SZ = BM * A_LD;
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     const float slope0 = act_slope(d.x.act), slope1 = act_slope(d.x.act1 >= 0 ? d.x.act1 : d.x.act);
 
     const int C = xC0 + xC1;
-    const int nch0 = (xC0 + BK - 1) / BK, nch1 = (xC1 + BK - 1) / BK;     // 32-channel chunks per source
+    const int nch0 = ROWTAP ? 1 : (xC0 + BK - 1) / BK, nch1 = ROWTAP ? 0 : (xC1 + BK - 1) / BK;   // 32-channel chunks per source
     const int tpt = nch0 + nch1;                                          // K-tiles per tap
     const int kreal0 = min(xC0, d.k_real), kreal1 = d.k_real - xC0;        // real filter channels of each source
     const long M = (long)d.NB * d.PH * d.PW;
@@ -487,6 +491,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     const FwdPhase ph = fwd_phase(d, phase);
 
     const int a_col4 = tid & 7;
+    const int a_kx = ROWTAP ? (a_col4 * 4) / xC0 : 0;       // row tap: this thread's float4 belongs to pixel ix + a_kx
     int a_iyb[A_ROWS], a_ixb[A_ROWS], a_off0[A_ROWS], a_off1[A_ROWS];
     bool a_mv[A_ROWS];
 #pragma unroll
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             const int iy = a_iyb[i] + ty, ix = a_ixb[i] + tx;
-            const bool v = a_mv[i] & ((unsigned)iy < (unsigned)xH) & ((unsigned)ix < (unsigned)xW) &
+            const bool v = a_mv[i] & ((unsigned)iy < (unsigned)xH) & ((unsigned)(ix + a_kx) < (unsigned)xW) &
                            (!KMASK || cc + a_col4 * 4 < cs);
             const int osel = (a_off0[i] & fmask) | (a_off1[i] & ~fmask);    // bit select: a ?: here became a scratch array
             const int off = v ? osel + tapshift : a_col4 * 4;
@@ -1198,6 +1203,19 @@ static bool fwd_is_ut(const ssc_conv_desc& d) {
            (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
 }
 
+// row-tap form (conv_ut_kernel<KM = 2>): plain single-source view, TW * C == 32, unflipped taps, vector filter loads
+static bool fwd_is_rowtap(const ssc_conv_desc& d) {
+    static int off = -1;
+    if (off < 0) {
+        const char* e = getenv("SSC_ROWTAP");
+        off = (e != nullptr && e[0] == '0') ? 1 : 0;
+    }
+    return !off && d.bmode == 0 && d.nphase == 1 && d.kstep == 1 && d.kx0 == 0 && d.x.C1 == 0 && d.TW * d.x.C0 == BK &&
+           d.TW == d.KW && d.k_real == d.x.C0 && d.wC0 == d.x.C0 && fwd_is_vec(d) && d.x.ab0 == nullptr &&
+           d.x.act == SSC_ACT_NONE && (long)d.NB * d.x.H * d.x.W * d.x.C0 < 0x7fffffffL &&
+           (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
+}
+
 // chunked uniform-tap form (conv_ut_kernel<KMASK>): vector filter loads possible and at most 20 % of the K-tiles' width
 // wasted on the partly empty last chunk of each source
 static bool fwd_is_utg(const ssc_conv_desc& d) {
@@ -1214,7 +1232,7 @@ static bool fwd_is_utg(const ssc_conv_desc& d) {
            (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
 }
 
-template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN, bool KMASK>
+template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN, int KM>
 static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
     constexpr int A_SZ = BM * (UT_AV(BM, BN) ? BK + 4 : BK + 1);
@@ -1222,7 +1240,7 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
     constexpr size_t lds = 2 * (A_SZ + B_SZ) * sizeof(float) + BM * sizeof(long);
     const long M = (long)d.NB * d.PH * d.PW;
     const int C = d.x.C0 + d.x.C1;
-    const int tpt = (d.x.C0 + BK - 1) / BK + (d.x.C1 + BK - 1) / BK;       // K-tiles per tap (mg.mC divides by it)
+    const int tpt = (KM == 2) ? 1 : (d.x.C0 + BK - 1) / BK + (d.x.C1 + BK - 1) / BK;   // K-tiles per tap (mg.mC divides by it)
     const Magics mg = make_magics((unsigned)tpt, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW,
                                   (unsigned long)M);
     const long mt = (M + BM - 1) / BM;
@@ -1230,7 +1248,7 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
     const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KMASK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
@@ -1245,7 +1263,7 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
             if (s > 8) s = 8;
             while (s > 1 && nkt / s < 4) --s;
             if (s > 1 && (int64_t)tail * s * BM * BN * 4 <= g_launch_ws_bytes && full + tail * s < 0x7fffffffL) {
-                hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KMASK>), dim3((unsigned)(full + tail * s)),
+                hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>), dim3((unsigned)(full + tail * s)),
                                    dim3(256), lds, st, d, mg, ws, out_count, 1, (int)full, (int)s);
                 hipLaunchKernelGGL((ts_fixup_kernel<BM, BN>), dim3((unsigned)tail), dim3(256), 0, st, d, mg, ws, (int)full,
                                    (int)s);
@@ -1254,7 +1272,7 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
         }
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
-    hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KMASK>), grid, dim3(256), lds, st, d, mg, ws, out_count,
+    hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>), grid, dim3(256), lds, st, d, mg, ws, out_count,
                        splitk, 0, 0);
     if (splitk > 1) {
         const int thr = 256;
@@ -1272,10 +1290,15 @@ static int launch_fwd(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t
         const bool plain0 = d.x.ab0 == nullptr && d.x.act == SSC_ACT_NONE;
         const bool plain1 = d.x.C1 == 0 || (d.x.ab1 == nullptr && (d.x.act1 >= 0 ? d.x.act1 : d.x.act) == SSC_ACT_NONE);
         const bool plain = plain0 && plain1;
-        if (ut) return plain ? launch_fwd_ut<WM, WN, SM, SN, BMODE, true, false>(d, splitk, ws, st)
-                             : launch_fwd_ut<WM, WN, SM, SN, BMODE, false, false>(d, splitk, ws, st);
-        return plain ? launch_fwd_ut<WM, WN, SM, SN, BMODE, true, true>(d, splitk, ws, st)
-                     : launch_fwd_ut<WM, WN, SM, SN, BMODE, false, true>(d, splitk, ws, st);
+        if (ut) return plain ? launch_fwd_ut<WM, WN, SM, SN, BMODE, true, 0>(d, splitk, ws, st)
+                             : launch_fwd_ut<WM, WN, SM, SN, BMODE, false, 0>(d, splitk, ws, st);
+        return plain ? launch_fwd_ut<WM, WN, SM, SN, BMODE, true, 1>(d, splitk, ws, st)
+                     : launch_fwd_ut<WM, WN, SM, SN, BMODE, false, 1>(d, splitk, ws, st);
+    }
+    if (BMODE == 0 && fwd_is_rowtap(d)) {       // a filter row per K-tile: run as TH taps of 32 "channels"
+        ssc_conv_desc dr = d;
+        dr.TW = 1;
+        return launch_fwd_ut<WM, WN, SM, SN, 0, true, 2>(dr, splitk, ws, st);
     }
     return vec ? launch_fwd_v<WM, WN, SM, SN, BMODE, true>(d, splitk, ws, st)
                : launch_fwd_v<WM, WN, SM, SN, BMODE, false>(d, splitk, ws, st);
@@ -1287,6 +1310,8 @@ static Plan plan_fwd(const ssc_conv_desc& d, int64_t ws_bytes, bool have_ws) {
     long nkt = ((long)d.TH * d.TW * C + BK - 1) / BK;
     if (fwd_is_ut(d) || fwd_is_utg(d))       // conv_ut_kernel walks whole chunks per tap and source
         nkt = (long)d.TH * d.TW * ((d.x.C0 + BK - 1) / BK + (d.x.C1 + BK - 1) / BK);
+    else if (d.bmode == 0 && fwd_is_rowtap(d))
+        nkt = d.TH;
     // column tile no wider than needed: <=32 -> 128x32, <=64 -> 128x64, else 128x128 / 64x128 / 128x64
     const bool allowed[5] = {d.Nstore > 64, d.Nstore > 64, d.Nstore > 32, d.Nstore <= 32, d.Nstore > 32};
     return plan_launch(FWD_CFGS, 5, allowed, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,

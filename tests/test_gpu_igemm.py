@@ -129,6 +129,21 @@ def test_conv_forward_channel_chunks(c0, c1, real1, co, k, same, act):
     close(nchw(out), ref)
 
 
+@pytest.mark.parametrize('stride,h', [(2, 26), (1, 17)])
+def test_conv_forward_row_tap(stride, h):
+    """4x4 conv on a plain 8-channel tensor (the discriminator's first layer, models_collection.py:805-811): TW * C == 32, so
+    conv_ut_kernel<KM = 2> runs one filter row per K-tile; the x bound of the zero padding differs per thread."""
+    hip = _hip()
+    n, ci, co = 3, 8, 64
+    x = rnd(n, ci, h, h, seed=51)
+    w = rnd(4, 4, ci, co, seed=52, std=0.05)
+    ref = T.conv2d_valid_pad(x, w, stride, 1)
+    oh = ref.shape[2]
+    out = torch.full((n, oh, oh, co), float('nan'), device='cuda')
+    hip.conv_forward(hip.View(nhwc(x).cuda()), w.cuda(), stride, 1, out)
+    close(nchw(out), ref)
+
+
 def test_large_launches_tail_split():
     """Launches with more tiles than the chip holds at once (1152-1536 tiles of 64x128 on 768 resident workgroups): the
     partly filled last round is cut into K slices and summed by ts_fixup_kernel (igemm.hip, tail split), for the plain
