@@ -78,6 +78,90 @@ __global__ __launch_bounds__(256) void loop_kernel(float* out, int iters, float 
     out[(long)blockIdx.x * 256 + tid] = s;
 }
 
+// Staging variants: the matrix-wave loop of variant 2 plus, every K-tile, a fresh 32 x 128 B tile brought from global
+// memory into the other LDS buffer:
+//   4: through registers (global_load_dwordx4 -> ds_write_b128), loads issued one step ahead
+//   5: directly (global_load_lds_dwordx4, no registers, no ds_write)
+template <int V>
+__global__ __launch_bounds__(256) void stage_kernel(float* out, const float* __restrict__ gB, int iters, float seed) {
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int A_LD = 33, A_SZ = 128 * A_LD, B_SZ = 32 * 128;
+    for (int i = tid; i < 2 * (A_SZ + B_SZ); i += 256) smem[i] = seed * (float)((i * 7) & 15);
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float* Bs = smem + 2 * A_SZ;
+    // each workgroup streams its own 16 KB slices of gB (L2-resident after the first pass)
+    const float* gsrc = gB + ((long)(blockIdx.x & 63) * 64) * B_SZ;
+    f32x4 rb[4];
+    int cur = 0;
+    if (V == 4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rb[s] = *reinterpret_cast<const f32x4*>(gsrc + (s * 256 + tid) * 4);
+    }
+    for (int it = 0; it < iters; ++it) {
+        const float* Ab = smem + cur * A_SZ + (wm * 64 + l31) * A_LD + lhi;
+        const float* Bb = Bs + cur * B_SZ + lhi * 128 + wn * 64 + l31;
+        const float* gnext = gsrc + (long)((it + 1) & 63) * B_SZ;
+        if (V == 4) {
+            // registers (tile it+1, loaded one step ago) -> LDS buffer cur^1, then issue the loads of tile it+2
+#pragma unroll
+            for (int s = 0; s < 4; ++s) *reinterpret_cast<f32x4*>(Bs + (cur ^ 1) * B_SZ + (s * 256 + tid) * 4) = rb[s];
+            const float* g2 = gsrc + (long)((it + 2) & 63) * B_SZ;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) rb[s] = *reinterpret_cast<const f32x4*>(g2 + (s * 256 + tid) * 4);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                __builtin_amdgcn_global_load_lds(gnext + (s * 256 + tid) * 4,
+                                                 (__attribute__((address_space(3))) void*)(Bs + (cur ^ 1) * B_SZ + (s * 256 + wave * 64) * 4),
+                                                 16, 0, 0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float av[2], bv[2];
+            for (int i = 0; i < 2; ++i) av[i] = Ab[i * 32 * A_LD + kk * 2];
+            for (int j = 0; j < 2; ++j) bv[j] = Bb[kk * 2 * 128 + j * 32];
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (V == 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        cur ^= 1;
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[(long)blockIdx.x * 256 + tid] = s;
+}
+
+template <int V>
+static void run_stage(int wg_per_cu, int iters, float* out, const float* gB) {
+    const size_t lds = (2 * (128 * 33 + 32 * 128)) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_kernel<V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int blocks = 256 * wg_per_cu;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(stage_kernel<V>, dim3(blocks), dim3(256), lds, 0, out, gB, iters, 1e-3f);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(stage_kernel<V>, dim3(blocks), dim3(256), lds, 0, out, gB, iters, 1e-3f);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4 * iters * 64 * (2.0 * 32 * 32 * 2);
+    printf("variant %d  %d workgroup(s)/CU  %8.3f ms  %6.1f TFLOP/s   (%s)\n", V, wg_per_cu, ms, flops / ms / 1e9,
+           V == 4 ? "B tile staged through registers" : "B tile by global_load_lds");
+}
+
 template <int V>
 static void run(int wg_per_cu, int iters, float* out) {
     const size_t lds = (2 * (128 * 33 + 32 * 128) + 128 * 36 * 2) * sizeof(float);
@@ -101,6 +185,13 @@ int main() {
     float* out;
     hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
     const int iters = 2000;
+    float* gB;
+    (void)hipMalloc(&gB, (size_t)64 * 64 * 32 * 128 * sizeof(float) + 65536);
+    (void)hipMemset(gB, 0, (size_t)64 * 64 * 32 * 128 * sizeof(float) + 65536);
+    for (int w = 1; w <= 2; ++w) {
+        run_stage<4>(w, iters, out, gB);
+        run_stage<5>(w, iters, out, gB);
+    }
     for (int w = 1; w <= 2; ++w) {
         run<0>(w, iters, out);
         run<1>(w, iters, out);
