@@ -103,23 +103,16 @@ def run_forward_workload(args):
         z = torch.rand(n, 3, img, img, device='cuda') * 2 - 1
         text = torch.randint(1, 58, (n, 15), dtype=torch.int32).numpy()
         nv = torch.randn(n, 256, device='cuda')
-        if wl == 'fg_mru':
-            from sketchyscenecolorization_amd.mru import MRUGenerator
-            store = ParamStore('MRU', 58, img, 'cuda', 0)
-            gen = MRUGenerator(store, Buffers('cuda'))
-            labels = torch.randint(0, 25, (n,), dtype=torch.int32, device='cuda')
-            flop_img, name = 62.6e9, 'Foreground generate_mru forward'
-        elif wl == 'fg_resid':
-            from sketchyscenecolorization_amd.residual import ResidualGenerator
-            store = ParamStore('Residual', 58, img, 'cuda', 0)
-            gen = ResidualGenerator(store, Buffers('cuda'), 'fg')
-            flop_img, name = 21.1e9, 'Foreground generate_residual forward'
-        else:
-            from sketchyscenecolorization_amd.pix2pix import Pix2PixGenerator
-            store = ParamStore('Pix2Pix', 58, img, 'cuda', 0)
-            gen = Pix2PixGenerator(store, Buffers('cuda'))
-            flop_img, name = 10.84e9, 'Foreground generate_pix2pix forward'
-        step = (lambda: gen.forward(z, text, labels, nv, 'g')) if wl == 'fg_mru' else (lambda: gen.forward(z, text, nv, 'g'))
+        # the inference entry point of build_single_graph (training=False): GanTrainer.generate, NCHW float in / out,
+        # hipGraph replay after the first two calls (--no-graphs: every launch issued eagerly)
+        from sketchyscenecolorization_amd.trainer import GanTrainer
+        bt, flop_img, name = {'fg_mru': ('MRU', 62.6e9, 'Foreground generate_mru forward'),
+                              'fg_resid': ('Residual', 21.1e9, 'Foreground generate_residual forward'),
+                              'fg_infer': ('Pix2Pix', 10.84e9, 'Foreground generate_pix2pix forward')}[wl]
+        tower = GanTrainer(img=img, seed=0, block_type=bt)
+        tower.use_graphs_infer = not args.no_graphs
+        labels = torch.randint(0, 25, (n,), dtype=torch.int32, device='cuda') if wl == 'fg_mru' else None
+        step = lambda: tower.generate(z, text, nv, labels=labels)
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize()
@@ -144,7 +137,8 @@ def run_forward_workload(args):
     out = {'metric': 'generator forward images/sec', 'value': n * args.steps / dt, 'unit': 'images/sec', 'n_gpus': 1,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
-           'config': {'workload': '%s, %dx%d, batch %d' % (name, img, img, n), 'launch': 'eager'},
+           'config': {'workload': '%s, %dx%d, batch %d' % (name, img, img, n),
+                      'launch': 'eager' if (args.no_graphs or wl.startswith('bg768')) and wl != 'bg768_train' else 'hipGraph replay'},
            'step_tflops_as_written': flop_img * n / (ms * 1e-3) / 1e12,
            'step_frac_of_fp32_peak': flop_img * n / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
            'igemm_ms_per_step': tot * 1e3,

@@ -71,15 +71,14 @@ def generate_pix2pix(z, text_vocab_indices, LSTM_hybrid, output_channel, num_cla
     assert data_format == 'NCHW' and output_channel == 3
     z = _as_device(z)
     n, _, h, w = z.shape
-    store, bufs = get_store('Pix2Pix', vocab_size, h)
+    tower = get_trainer('Pix2Pix', vocab_size, h)
     if noise_vec is None:
         noise_vec = torch.randn(n, 256, device='cuda')
     noise_vec = _as_device(noise_vec)
     text = text_vocab_indices.cpu().numpy() if isinstance(text_vocab_indices, torch.Tensor) else np.asarray(text_vocab_indices)
     assert text.shape[0] == n
-    g = Pix2PixGenerator(store, bufs, LSTM_hybrid)
-    ctx = g.forward(z, text, noise_vec, tag=scope_name or 'generator')
-    return g.output_nchw(ctx), noise_vec
+    tower.G.lstm_hybrid = bool(LSTM_hybrid)
+    return tower.generate(z, text, noise_vec), noise_vec
 
 
 def _discriminate(block_type, discrim_inputs, discrim_targets, reuse, data_format, scope_name):

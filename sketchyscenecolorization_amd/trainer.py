@@ -97,6 +97,7 @@ class GanTrainer(object):
         self._ahead_stream = torch.cuda.Stream() if self.run_ahead else None
         self._ahead = None
         self._ahead_pending = False
+        self.use_graphs_infer = os.environ.get('SSC_INFER_GRAPHS', '1') == '1'   # hipGraph replay of generate / generate_u8
         self.G.text_stream = self._text_stream          # forward half: every generator
         if block_type == 'Pix2Pix':
             self.G.text_stream_bwd = None if self.segment_graphs else self._text_stream
@@ -509,28 +510,63 @@ class GanTrainer(object):
         lg = self.g_step(batch_g, counter, use_ahead=True)
         return lg, ld
 
+    def _infer(self, kind, sketches, text, noise_vec, labels, thicken):
+        """The generator forward of ``generate`` ('f32': NCHW float in / out) and ``generate_u8`` ('u8': uint8 NHWC in /
+        out, pre- and post-processing kernels included).  Like the training steps it runs eagerly the first time a
+        shape is seen, is captured into a hipGraph the second time and replayed afterwards (a batch-16 forward is ~150
+        launches of 5-100 us: launch-bound when issued one by one); inputs are copied into the graph's static tensors
+        and the result is returned as a fresh tensor."""
+        if self.block_type == 'MRU' and labels is None:
+            raise ValueError('the MRU generator is class-conditional: pass the class ids (image_data_class_id)')
+        labels = None if self.block_type != 'MRU' else labels.to(device='cuda', dtype=torch.int32).contiguous()
+
+        def body(sk, tx, nv, lb):
+            xs = hip.sketch_preprocess_u8(sk, thicken) if kind == 'u8' else sk
+            ctx = self.G.forward(xs, tx, lb, nv, 'g') if self.block_type == 'MRU' else self.G.forward(xs, tx, nv, 'g')
+            return hip.image_postprocess_u8(ctx['out'], ctx['out_coff']) if kind == 'u8' else self.G.output_nchw(ctx)
+
+        sketches, noise_vec = sketches.contiguous(), noise_vec.contiguous()
+        if not self.use_graphs_infer or hip.PROFILE is not None:
+            return body(sketches, text, noise_vec, labels)
+        prep = text if isinstance(text, dict) or not self.G.lstm_hybrid else self.G.text.prepare(text, 'gi')
+        S = prep['S'] if isinstance(prep, dict) else -1
+        key = ('infer', kind, bool(thicken), bool(self.G.lstm_hybrid), tuple(sketches.shape), S)
+        st = self._static.get(key)
+        if st is None:
+            st = {'sk': torch.empty_like(sketches), 'nv': torch.empty_like(noise_vec),
+                  'lb': None if labels is None else torch.empty_like(labels)}
+            self._static[key] = st
+        st['sk'].copy_(sketches)
+        st['nv'].copy_(noise_vec)
+        if labels is not None:
+            st['lb'].copy_(labels)
+        g = self._graphs.get(key)
+        if g is None:
+            if key not in self._seen:
+                self._seen.add(key)
+                return body(st['sk'], prep, st['nv'], st['lb'])
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    st['out'] = body(st['sk'], prep, st['nv'], st['lb'])
+            except Exception as e:      # never lose a request to graph capture
+                print('hipGraph capture of the inference pass failed (%r): continuing with eager launches' % (e,))
+                self.use_graphs_infer = False
+                torch.cuda.synchronize()
+                return body(sketches, text, noise_vec, labels)
+            self._graphs[key] = g
+        g.replay()
+        return st['out'].clone()
+
     def generate_u8(self, sketch_u8, text, noise_vec, labels=None, thicken=False):
         """Serving path without host arithmetic: uint8 sketches [N,H,W,3] on the device -> uint8 images [N,H,W,3].
         Pre-processing (x/255*2-1, optional thicken_drawings) and post-processing ((x+1)/2*255, truncating cast) of
         main_procedure.py:361-621 run as kernels; the network reads / writes NHWC directly."""
-        xs = hip.sketch_preprocess_u8(sketch_u8.contiguous(), thicken)
-        if self.block_type == 'MRU':
-            if labels is None:
-                raise ValueError('the MRU generator is class-conditional: pass the class ids (image_data_class_id)')
-            ctx = self.G.forward(xs, text, labels, noise_vec, 'g')
-        else:
-            ctx = self.G.forward(xs, text, noise_vec, 'g')
-        return hip.image_postprocess_u8(ctx['out'], ctx['out_coff'])
+        return self._infer('u8', sketch_u8, text, noise_vec, labels, thicken)
 
     def generate(self, sketches, text, noise_vec, labels=None):
         """Inference path of build_single_graph (training=False): NCHW in, NCHW out."""
-        if self.block_type == 'MRU':
-            if labels is None:
-                raise ValueError('the MRU generator is class-conditional: pass the class ids (image_data_class_id)')
-            ctx = self.G.forward(sketches, text, labels, noise_vec, 'g')
-        else:
-            ctx = self.G.forward(sketches, text, noise_vec, 'g')
-        return self.G.output_nchw(ctx)
+        return self._infer('f32', sketches, text, noise_vec, labels, False)
 
 
 Pix2PixTrainer = GanTrainer     # the name the first round used
