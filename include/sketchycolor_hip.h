@@ -128,9 +128,14 @@ int ssc_image_postprocess_u8(const float* src, int ldc, int coff, int64_t M, uin
 /* Training-queue decode (get_paired_input, input_pipeline.py:77-131) of N raw records: img / sk uint8 [N,R,R,3] ->
  * img_out / sk_out float NCHW [N,3,size,size], R = f * size.  Image: pixel (f*y, f*x) (TF1 bilinear at an integer
  * factor), (v - min)/(max - min + 1) over the resized image, + noise [N,size,size,3] (uniform [0,1/256), may be NULL),
- * * 2 - 1.  Sketch: mean of the f x f block (TF1 area), / 255 * 2 - 1.  mnmx: [N,2] scratch (per-image min, max). */
-int ssc_decode_paired_u8(const uint8_t* img, const uint8_t* sk, int N, int R, int size, const float* noise,
-                         float* img_out, float* sk_out, float* mnmx, void* stream);
+ * * 2 - 1.  Sketch: mean of the f x f block (TF1 area), / 255 * 2 - 1; read from sk_f32 [N,R,R,3] instead of sk when
+ * that is not NULL (distance maps).  mnmx: [N,2] scratch (per-image min, max). */
+int ssc_decode_paired_u8(const uint8_t* img, const uint8_t* sk, const float* sk_f32, int N, int R, int size,
+                         const float* noise, float* img_out, float* sk_out, float* mnmx, void* stream);
+/* --distance_map 1 (input_pipeline.py:86-96): sk uint8 [N,R,R,3] -> out float [N,R,R,3] = exact Euclidean distance of
+ * every voxel to the nearest stroke voxel (sk < 250; scipy.ndimage.distance_transform_edt over [R,R,3]) / max * 255.
+ * Pass it to ssc_decode_paired_u8 as sk_f32 (then sk may be NULL).  ws: (2*N*R*R*3 + N) int32 of scratch. */
+int ssc_distance_map_u8(const uint8_t* sk, int N, int R, float* out, int32_t* ws, int64_t ws_bytes, void* stream);
 /* host-side CRC-32C (Castagnoli) of n bytes: TFRecord record framing (tf.TFRecordReader, input_pipeline.py:57-59) */
 uint32_t ssc_crc32c(const uint8_t* data, int64_t n);
 int ssc_fill(float* dst, float value, int64_t n, void* stream);

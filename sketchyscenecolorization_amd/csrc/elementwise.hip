@@ -123,7 +123,8 @@ __global__ __launch_bounds__(1024) void decode_minmax_kernel(const unsigned char
     }
 }
 
-__global__ void decode_write_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ sk, int N,
+__global__ void decode_write_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ sk,
+                                    const float* __restrict__ skf, int N,
                                     int R, int f, int size, const float* __restrict__ mnmx,
                                     const float* __restrict__ noise, float* __restrict__ img_out,
                                     float* __restrict__ sk_out) {
@@ -141,23 +142,125 @@ __global__ void decode_write_kernel(const unsigned char* __restrict__ img, const
         img_out[((long)n * 3 + c) * plane + (long)y * size + x] = v * 2.f - 1.f;
         // AREA: the mean of the f x f block, accumulated row-major like numpy's mean over (rows, cols) in float32
         float s = 0.f;
-        const unsigned char* ps = sk + ((long)n * R * R + (long)(y * f) * R + x * f) * 3 + c;
+        const long so = ((long)n * R * R + (long)(y * f) * R + x * f) * 3 + c;
         for (int dy = 0; dy < f; ++dy)
-            for (int dx = 0; dx < f; ++dx) s += (float)ps[((long)dy * R + dx) * 3];
+            for (int dx = 0; dx < f; ++dx) {
+                const long o = so + ((long)dy * R + dx) * 3;
+                s += (skf != nullptr) ? skf[o] : (float)sk[o];      // skf: the distance map (ssc_distance_map_u8)
+            }
         sk_out[((long)n * 3 + c) * plane + (long)y * size + x] = s / (float)(f * f) / 255.f * 2.f - 1.f;
     }
 }
 
-extern "C" int ssc_decode_paired_u8(const uint8_t* img, const uint8_t* sk, int N, int R, int size, const float* noise,
-                                    float* img_out, float* sk_out, float* mnmx, void* stream) {
+// ------------------------------------------------------------------ --distance_map 1 (input_pipeline.py:86-96)
+// sk -> 0 where sk < 250 else 255; scipy.ndimage.distance_transform_edt of the [R,R,3] array (the channel axis counts as
+// a third spatial axis, as in the reference); / max * 255.  Exact Euclidean distances: squared distances are integers,
+// built axis by axis (x, then y, then channel) by exhaustive search -- 384 candidates per voxel and axis, only this
+// non-default mode pays for it -- then sqrt in double and one rounding to float like scipy's float64 -> float32 cast.
+#define DM_INF (1 << 28)
+__global__ void dm_axis_x_kernel(const unsigned char* __restrict__ sk, int R, long total, int* __restrict__ g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // voxel (n, y, x, c)
+    if (i >= total) return;
+    const int c = (int)(i % 3);
+    const int x = (int)((i / 3) % R);
+    const long row = i / ((long)3 * R);                              // (n, y)
+    const unsigned char* p = sk + row * R * 3 + c;
+    int best = DM_INF;
+    for (int xx = 0; xx < R; ++xx)
+        if (p[xx * 3] < 250) {
+            const int dx = xx - x;
+            best = min(best, dx * dx);
+        }
+    g[i] = best;
+}
+
+__global__ void dm_axis_y_kernel(const int* __restrict__ g, int R, long total, int* __restrict__ h) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % 3);
+    const int x = (int)((i / 3) % R);
+    const int y = (int)((i / ((long)3 * R)) % R);
+    const long n = i / ((long)3 * R * R);
+    const int* p = g + n * R * R * 3 + (long)x * 3 + c;
+    int best = DM_INF;
+    for (int yy = 0; yy < R; ++yy) {
+        const int v = p[(long)yy * R * 3];
+        if (v < DM_INF) {
+            const int dy = yy - y;
+            best = min(best, v + dy * dy);
+        }
+    }
+    h[i] = best;
+}
+
+// channel axis + sqrt; also the per-image maximum (one atomic per block: float bits of non-negative values order as ints)
+__global__ void dm_axis_c_kernel(const int* __restrict__ h, int R, long total, float* __restrict__ out,
+                                 int* __restrict__ maxbits) {
+    __shared__ int smax[256];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float d = 0.f;
+    if (i < total) {
+        const int c = (int)(i % 3);
+        const long base = i - c;
+        int best = DM_INF;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const int v = h[base + cc];
+            if (v < DM_INF) best = min(best, v + (cc - c) * (cc - c));
+        }
+        d = (float)sqrt((double)best);
+        out[i] = d;
+    }
+    // every block lies inside one image when R*R*3 is a multiple of 256 (384: yes); else fall back to per-thread atomics
+    const long img = (long)R * R * 3;
+    if (img % 256 == 0) {
+        smax[threadIdx.x] = __float_as_int(d);
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + s]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && (long)blockIdx.x * 256 < total) atomicMax(maxbits + ((long)blockIdx.x * 256) / img, smax[0]);
+    } else if (i < total) {
+        atomicMax(maxbits + i / img, __float_as_int(d));
+    }
+}
+
+__global__ void dm_normalise_kernel(float* __restrict__ d, int R, long total, const int* __restrict__ maxbits) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float mx = __int_as_float(maxbits[i / ((long)R * R * 3)]);
+    d[i] = d[i] / mx * 255.f;
+}
+
+extern "C" int ssc_distance_map_u8(const uint8_t* sk, int N, int R, float* out, int32_t* ws, int64_t ws_bytes,
+                                   void* stream) {
+    const long total = (long)N * R * R * 3;
+    if (total <= 0) return 0;
+    if ((int64_t)(2 * total + N) * 4 > ws_bytes) return -2;
+    int* g = ws;
+    int* h = ws + total;
+    int* mx = ws + 2 * total;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    (void)hipMemsetAsync(mx, 0, (size_t)N * 4, st);
+    hipLaunchKernelGGL(dm_axis_x_kernel, dim3(blocks), dim3(256), 0, st, sk, R, total, g);
+    hipLaunchKernelGGL(dm_axis_y_kernel, dim3(blocks), dim3(256), 0, st, g, R, total, h);
+    hipLaunchKernelGGL(dm_axis_c_kernel, dim3(blocks), dim3(256), 0, st, h, R, total, out, mx);
+    hipLaunchKernelGGL(dm_normalise_kernel, dim3(blocks), dim3(256), 0, st, out, R, total, mx);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int ssc_decode_paired_u8(const uint8_t* img, const uint8_t* sk, const float* sk_f32, int N, int R, int size,
+                                    const float* noise, float* img_out, float* sk_out, float* mnmx, void* stream) {
     if (N <= 0) return 0;
     if (size <= 0 || R % size != 0) return -1;
     const int f = R / size;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(decode_minmax_kernel, dim3(N), dim3(1024), 0, st, img, R, f, size, mnmx);
     const long tot = (long)N * size * size;
-    hipLaunchKernelGGL(decode_write_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, img, sk, N, R, f, size,
-                       mnmx, noise, img_out, sk_out);
+    hipLaunchKernelGGL(decode_write_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, img, sk, sk_f32, N, R, f,
+                       size, mnmx, noise, img_out, sk_out);
     return CHECK_LAUNCH();
 }
 

@@ -74,7 +74,8 @@ SIGNATURES = {
     'ssc_nhwc_to_nchw': [_P, _P, _I, _I, _I, _I, _I, _P],
     'ssc_sketch_preprocess_u8': [_P, _I, _I, _I, _I, _P, _P],
     'ssc_image_postprocess_u8': [_P, _I, _I, _L, _P, _P],
-    'ssc_decode_paired_u8': [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
+    'ssc_decode_paired_u8': [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
+    'ssc_distance_map_u8': [_P, _I, _I, _P, _P, _L, _P],
     'ssc_fill': [_P, _F, _L, _P],
     'ssc_affine_act': [_P, _I, _P, _I, _I, _P, _I, _L, _I, _P],
     'ssc_residual_merge': [_P, _P, _P, _P, _I, _P, _L, _I, _P],
@@ -482,9 +483,21 @@ def image_postprocess_u8(src_nhwc, coff=0, out=None):
     return out
 
 
-def decode_paired_u8(img_u8, sk_u8, size, noise=None, img_out=None, sk_out=None):
+def distance_map_u8(sk_u8):
+    """--distance_map 1: uint8 sketches [N,R,R,3] (device) -> float [N,R,R,3], exact Euclidean distance to the nearest
+    stroke voxel scaled to [0, 255] (input_pipeline.py:86-96)."""
+    n, r, r2, c = sk_u8.shape
+    assert r == r2 and c == 3 and sk_u8.dtype == torch.uint8 and sk_u8.is_contiguous()
+    out = torch.empty((n, r, r, 3), dtype=torch.float32, device=sk_u8.device)
+    ws = torch.empty(2 * out.numel() + n, dtype=torch.int32, device=sk_u8.device)
+    check(lib().ssc_distance_map_u8(ptr(sk_u8), n, r, ptr(out), ptr(ws), ws.numel() * 4, stream_ptr()), 'distance_map_u8')
+    return out
+
+
+def decode_paired_u8(img_u8, sk_u8, size, noise=None, img_out=None, sk_out=None, distance_map=False):
     """Raw record images uint8 [N,R,R,3] (device) -> (image, sketch) float NCHW [N,3,size,size] in [-1,1], as
-    input_pipeline.decode_paired_example does on the host.  noise: uniform [0,1/256) [N,size,size,3] or None."""
+    input_pipeline.decode_paired_example does on the host.  noise: uniform [0,1/256) [N,size,size,3] or None.
+    distance_map: the sketch is first replaced by its distance map (``distance_map_u8``)."""
     n, r, r2, c = img_u8.shape
     assert r == r2 and c == 3 and sk_u8.shape == img_u8.shape and img_u8.is_contiguous() and sk_u8.is_contiguous()
     assert img_u8.dtype == torch.uint8 and sk_u8.dtype == torch.uint8 and r % size == 0
@@ -493,8 +506,9 @@ def decode_paired_u8(img_u8, sk_u8, size, noise=None, img_out=None, sk_out=None)
     if sk_out is None:
         sk_out = torch.empty((n, 3, size, size), dtype=torch.float32, device=img_u8.device)
     mnmx = torch.empty((n, 2), dtype=torch.float32, device=img_u8.device)
-    check(lib().ssc_decode_paired_u8(ptr(img_u8), ptr(sk_u8), n, r, size, ptr(noise), ptr(img_out), ptr(sk_out),
-                                     ptr(mnmx), stream_ptr()), 'decode_paired_u8')
+    skf = distance_map_u8(sk_u8) if distance_map else None
+    check(lib().ssc_decode_paired_u8(ptr(img_u8), ptr(sk_u8), ptr(skf), n, r, size, ptr(noise), ptr(img_out),
+                                     ptr(sk_out), ptr(mnmx), stream_ptr()), 'decode_paired_u8')
     return img_out, sk_out
 
 

@@ -103,7 +103,7 @@ class PairedQueue(object):
 
     def __init__(self, mode, batch_size, data_format='NCHW', distance_map=False, small=False, min_after_dequeue=512,
                  data_base_dir='data', seed=None, device_decode=None):
-        """device_decode (default: on when a GPU is there, NCHW, no distance map): the shuffle buffer keeps the raw
+        """device_decode (default: on when a GPU is there and the layout is NCHW): the shuffle buffer keeps the raw
         uint8 records and a batch is resized / normalised by one kernel at dequeue (hip.decode_paired_u8, the arithmetic
         of decode_paired_example bit for bit); ``dequeue`` then returns device tensors.  The host decode costs ~3 ms per
         example, ten times the GPU's step time at batch 32."""
@@ -122,7 +122,7 @@ class PairedQueue(object):
         self.buf = []
         if device_decode is None:
             import torch
-            device_decode = torch.cuda.is_available() and data_format == 'NCHW' and not distance_map
+            device_decode = torch.cuda.is_available() and data_format == 'NCHW'
         self.device_decode = bool(device_decode)
         self._gen, self._gen_seed = None, self.rng.randrange(2 ** 31)   # drawn in both modes: same example order
         self._it = self._examples()
@@ -163,7 +163,7 @@ class PairedQueue(object):
             self._gen = torch.Generator(device='cuda')
             self._gen.manual_seed(self._gen_seed)
         noise = torch.rand((n, size, size, 3), device='cuda', generator=self._gen) * (1.0 / 256)   # dequantisation (:117)
-        return hip.decode_paired_u8(dev[0], dev[1], size, noise=noise)
+        return hip.decode_paired_u8(dev[0], dev[1], size, noise=noise, distance_map=self.dm)
 
     def _next(self):
         while len(self.buf) <= self.min_after:

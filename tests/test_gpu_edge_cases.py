@@ -158,3 +158,36 @@ def test_device_decode_of_training_records_matches_host_decode(size):
                 'Text_vocab_indices': [bytes(15)]}
         ri, rs = decode_paired_example(feat, (size, size), FixedNoise(noise[k]))[:2]
         assert np.array_equal(gi[k], ri) and np.array_equal(gs[k], rs), k
+
+
+@pytest.mark.gpu
+def test_device_distance_map_matches_scipy_edt():
+    """--distance_map 1: hip.distance_map_u8 / decode_paired_u8(distance_map=True) against the host path
+    (scipy.ndimage.distance_transform_edt over the [384,384,3] array, input_pipeline.py:86-96): bit exact, also when
+    the three channels differ (the channel axis is a spatial axis of the reference's transform)."""
+    import numpy as np
+    from sketchyscenecolorization_amd import hip
+    from sketchyscenecolorization_amd.obj_lib.input_pipeline import RECORD_HW, decode_paired_example
+    rng = np.random.RandomState(7)
+    n, size = 2, 192
+    img = rng.randint(0, 256, (n, RECORD_HW, RECORD_HW, 3)).astype(np.uint8)
+    sk = np.full((n, RECORD_HW, RECORD_HW, 3), 255, np.uint8)
+    sk[0, 100:103, 40:300] = 0
+    sk[0, 200:330, 250:252] = 30
+    pts = rng.randint(0, RECORD_HW, (60, 2))
+    sk[1, pts[:, 0], pts[:, 1], :] = 0
+    sk[1, 20:24, 20:24, 1] = 100            # a stroke in one channel only
+    noise = np.zeros((n, size, size, 3), np.float32)
+
+    class NoNoise(object):
+        def uniform(self, lo, hi, size=None):
+            return np.zeros(size, np.float32)
+
+    gi, gs = hip.decode_paired_u8(torch.from_numpy(img).cuda(), torch.from_numpy(sk).cuda(), size,
+                                  noise=torch.from_numpy(noise).cuda(), distance_map=True)
+    for k in range(n):
+        feat = {'cartoon_data': [img[k].tobytes()], 'sketch_data': [sk[k].tobytes()], 'Category_id': [1],
+                'Text_vocab_indices': [bytes(15)]}
+        ri, rs = decode_paired_example(feat, (size, size), NoNoise(), distance_map=True)[:2]
+        assert np.array_equal(gs[k].cpu().numpy(), rs), (k, float(np.abs(gs[k].cpu().numpy() - rs).max()))
+        assert np.array_equal(gi[k].cpu().numpy(), ri)
