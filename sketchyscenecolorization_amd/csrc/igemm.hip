@@ -1232,7 +1232,12 @@ static bool fwd_is_utg(const ssc_conv_desc& d) {
         const char* e = getenv("SSC_UTG");
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
-    return !off && vec && d.k_real >= 1 && d.k_real <= C && padded * 5 <= C * 6 &&
+    static double waste = -1.0;     // SSC_UTG_WASTE: largest padded / real K width taken (tuning aid)
+    if (waste < 0.0) {
+        const char* e = getenv("SSC_UTG_WASTE");
+        waste = (e != nullptr) ? atof(e) : 1.2;
+    }
+    return !off && vec && d.k_real >= 1 && d.k_real <= C && (double)padded <= waste * (double)C &&
            (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x7fffffffL &&
            (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
 }
