@@ -15,6 +15,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
 import argparse
 import json
 import os
+
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')     # kernel arguments in device memory (measured: 1570 vs 1540 images/s with 0)
 import sys
 import time
 

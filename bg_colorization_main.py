@@ -12,6 +12,8 @@ file is missing the run uses seeded synthetic scenes, so the CLI can be exercise
 import argparse
 import json
 import os
+
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')     # kernel arguments in device memory (measured: 1570 vs 1540 images/s with 0)
 import random
 import time
 

@@ -13,6 +13,8 @@ inference_results}``, ``log/param_<first iteration>.json`` and the restart-after
 import argparse
 import json
 import os
+
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')     # kernel arguments in device memory (measured: 1570 vs 1540 images/s with 0)
 import time
 
 from sketchyscenecolorization_amd.obj_lib import main_procedure
