@@ -587,7 +587,8 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             const bool v = a_mv[i] & ((unsigned)iy < (unsigned)xH) & ((unsigned)(ix + a_kx) < (unsigned)xW) &
                            (!KMASK || cc + a_col4 * 4 < cs);
             const int osel = (a_off0[i] & fmask) | (a_off1[i] & ~fmask);    // bit select: a ?: here became a scratch array
-            const int off = v ? osel + tapshift : a_col4 * 4;
+            // unsigned 32-bit element offset from a wave-uniform base: one shift, no 64-bit vector address arithmetic
+            const unsigned off = v ? (unsigned)(osel + tapshift) : (unsigned)(a_col4 * 4);
             rav[i] = v ? 1.f : 0.f;
             ra[i] = *reinterpret_cast<const float4*>(sbase + off);
         }
@@ -599,9 +600,9 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             if (KMASK) {
                 const bool bv = b_kk[s] < kreal;        // k_real % 4 == 0 for NK: the float4 is all in or all out
                 rbv[s] = bv ? 1.f : 0.f;
-                rb[s] = *reinterpret_cast<const float4*>(wtap + (bv ? b_k[s] : 0) + b_n[s]);
+                rb[s] = *reinterpret_cast<const float4*>(wtap + (unsigned)((bv ? b_k[s] : 0) + b_n[s]));
             } else {
-                rb[s] = *reinterpret_cast<const float4*>(wtap + b_k[s] + b_n[s]);
+                rb[s] = *reinterpret_cast<const float4*>(wtap + (unsigned)(b_k[s] + b_n[s]));
             }
         }
     };
