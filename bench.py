@@ -129,7 +129,7 @@ def run_forward_workload(args):
     torch.cuda.synchronize()
     hip.PROFILE = None
     agg = {}
-    for kname, fl, e0, e1, _shape in prof:
+    for kname, fl, e0, e1, _shape, _nb in prof:
         a = agg.setdefault(kname, [0.0, 0.0, 0])
         a[0] += fl
         a[1] += e0.elapsed_time(e1) * 1e-3
@@ -141,8 +141,10 @@ def run_forward_workload(args):
            'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
            'config': {'workload': '%s, %dx%d, batch %d' % (name, img, img, n),
                       'launch': 'eager' if (args.no_graphs or wl.startswith('bg768')) and wl != 'bg768_train' else 'hipGraph replay'},
+           'step_tflops_executed': sum(v[0] for v in agg.values()) / (ms * 1e-3) / 1e12,
+           'step_frac_of_fp32_peak': sum(v[0] for v in agg.values()) / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
            'step_tflops_as_written': flop_img * n / (ms * 1e-3) / 1e12,
-           'step_frac_of_fp32_peak': flop_img * n / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+           'step_frac_of_fp32_peak_as_written': flop_img * n / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
            'igemm_ms_per_step': tot * 1e3,
            'per_kernel': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] * 1e3, 'launches_per_step': v[2]}
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
@@ -190,13 +192,94 @@ def generator_fwd_bwd(tr, batch, args, iters=30):
             'frac_of_fp32_mfma_peak_executed': tfx / PEAK_FP32_MFMA_TFLOPS}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` outside torchrun: start N ranks (one per GPU) under torch.distributed.run and pass
+    their output through; rank 0 prints the one JSON line.  Under torchrun (WORLD_SIZE set) this is a no-op except for
+    the consistency check --gpus == WORLD_SIZE (the reference's tower loop, graph_single.py:128-173, is one process per
+    GPU here)."""
+    import subprocess
+    if 'WORLD_SIZE' in os.environ:
+        w = int(os.environ['WORLD_SIZE'])
+        if w != args.gpus:
+            raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, w))
+        return
+    if args.gpus == 1 and not args.launcher:
+        return
+    if not args.stub_cpu:
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            raise SystemExit('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, n_dev))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC (RCCL across processes)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def _csrc_hash():
+    """sha256 over the kernel sources + the C-ABI header: PMC figures are only attached to a bench line measured on the
+    same kernels (profiles/*.json carry the hash of the tree they were collected on)."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, 'sketchyscenecolorization_amd', 'csrc')
+    for f in sorted(os.listdir(base)) + [os.path.join(ROOT, 'include', 'sketchycolor_hip.h')]:
+        fp = f if os.path.isabs(f) else os.path.join(base, f)
+        if fp.endswith(('.hip', '.h')):
+            with open(fp, 'rb') as fh:
+                h.update(os.path.basename(fp).encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
+def run_stub_cpu(args, rank, world):
+    """Launcher self-test on CPU (tests/test_bench_launcher.py): the real rank bootstrap, barrier, max-over-ranks
+    timing and one JSON line from rank 0, with the GradReducer all-reduce of a flat buffer as the "step" on gloo.
+    Not a measurement of anything: the metric name says so."""
+    import torch.distributed as dist
+    from sketchyscenecolorization_amd.dist_utils import GradReducer
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    red = GradReducer(dist.group.WORLD)
+    flat = torch.full((1 << 16,), float(rank + 1))
+    ones = torch.ones(1)
+    dist.all_reduce(ones)
+    for _ in range(args.warmup):
+        red.reduce_async(flat, 0, flat.numel()); red.wait(); flat.mul_(red.grad_scale)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        red.reduce_async(flat, 0, flat.numel()); red.wait(); flat.mul_(red.grad_scale)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    if rank == 0:
+        print(json.dumps({'metric': 'launcher self-test (CPU stub, no GPU work)', 'value': args.batch * world * args.steps / dt,
+                          'unit': 'stub steps*batch/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'fp32', 'data': 'stub',
+                          'config': {'workload': 'launcher self-test', 'global_batch': args.batch * world,
+                                     'parallelism': 'dp%d' % world, 'ranks_observed': int(ones.item()),
+                                     'backend': 'gloo', 'mean_value': float(flat.mean())}}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--workload', default='train', choices=['train', 'fg_infer', 'fg_resid', 'fg_mru', 'bg768', 'bg768_train'],
                     help='train = the headline metric (default); the others are secondary forward-only workloads')
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--gpus', type=int, default=1,
+                    help='ranks = GPUs of this node; >1 outside torchrun starts the ranks itself (torch.distributed.run)')
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (reference --batch_size is per GPU)')
     ap.add_argument('--img', type=int, default=192)
     ap.add_argument('--block-type', default='Pix2Pix', choices=['Pix2Pix', 'Residual', 'MRU'],
@@ -209,30 +292,42 @@ def main():
                     help='extra UNTIMED steps after the warmup until this much wall time has passed: the first GPU '
                          'process on a fresh box runs ~7%% slow for about a second (clock ramp / first touch)')
     ap.add_argument('--prof-steps', type=int, default=2, help='eager, HIP-event-instrumented steps for the roofline leg')
+    ap.add_argument('--launcher', action='store_true',
+                    help='go through the self-launch path (torch.distributed.run) even for --gpus 1')
+    ap.add_argument('--stub-cpu', action='store_true', help=argparse.SUPPRESS)     # launcher self-test, no GPU
     args = ap.parse_args()
+    self_launch(args, sys.argv[1:])
 
-    if args.workload != 'train':
-        assert int(os.environ.get('WORLD_SIZE', 1)) == 1, 'forward workloads are single-GPU'
-        torch.cuda.set_device(0)
-        return run_forward_workload(args)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    under_launcher = 'WORLD_SIZE' in os.environ
+    if args.stub_cpu:
+        return run_stub_cpu(args, rank, world)
+    if args.workload != 'train':
+        assert world == 1, 'forward workloads are single-GPU'
+        torch.cuda.set_device(0)
+        return run_forward_workload(args)
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     torch.cuda.set_device(local_rank)
-    pg = None
-    if world > 1:
+    pg, ranks_observed = None, 1
+    if under_launcher:      # one process per GPU; backend "nccl" is RCCL on ROCm.  Also with 1 rank: proves the bootstrap
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-        pg = dist.group.WORLD
+        pg = dist.group.WORLD if world > 1 else None
+        one = torch.ones(1, device='cuda')
+        dist.all_reduce(one)                # RCCL rank count as the collective itself sees it
+        ranks_observed = int(one.item())
+        assert ranks_observed == world == dist.get_world_size(), (ranks_observed, world)
 
     from sketchyscenecolorization_amd import hip
     from sketchyscenecolorization_amd.synthetic import synthetic_batch
     from sketchyscenecolorization_amd.trainer import GanTrainer
 
     tr = GanTrainer(img=args.img, seed=0, process_group=pg, use_graphs=not args.no_graphs, block_type=args.block_type)
+    assert tr.world == world
     bd = synthetic_batch(args.batch, 1234 + rank, args.img)
     bg = synthetic_batch(args.batch, 5678 + rank, args.img)
     if not args.no_graphs:
@@ -265,11 +360,17 @@ def main():
     prof = None if args.no_kernel_events else []
     if args.no_graphs:
         hip.PROFILE = prof
+    # one event per step boundary on the launch stream (no host sync inside the region): per-step durations for the median
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    barrier()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         tr.train_iteration(bd, bg, counter=args.warmup + i)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     prof_steps = args.steps
     if not args.no_graphs and prof is not None:
         hip.PROFILE = prof
@@ -296,39 +397,58 @@ def main():
         out = {'metric': 'train images/sec (192x192, gen+disc fwd+bwd)', 'value': value, 'unit': 'images/sec',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'preheat_steps': preheat_steps,
                'ms_per_step': ms,
+               'ms_per_step_median': step_ms[len(step_ms) // 2] if step_ms else None,
+               'ms_per_step_min_max': [step_ms[0], step_ms[-1]] if step_ms else None,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32',
-               'data': 'synthetic',
+               'data': 'synthetic (the same two resident batches every step: loss_d collapses, throughput is unaffected)',
                'config': {'workload': 'Foreground_Instance_Colorization ' + args.block_type + ' GAN train step '
                                       '(D-step + G-step, TF-Adam), %dx%d, batch %d per GPU' % (args.img, args.img,
                                                                                              args.batch),
                           'global_batch': global_batch, 'parallelism': 'dp%d' % world,
+                          'ranks_observed_by_allreduce': ranks_observed,
+                          'launcher': ('torch.distributed.run, backend nccl (RCCL)' if under_launcher else 'in-process'),
                           'block_type': args.block_type, 'loss_g': loss_g, 'loss_d': loss_d,
                           'launch': 'eager' if args.no_graphs else 'hipGraph replay'},
                'step_tflops_as_written': flops_step / (ms * 1e-3) / 1e12,
-               'step_frac_of_fp32_peak': flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+               'step_frac_of_fp32_peak_as_written': flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         if prof:
             agg = {}
-            for name, fl, e0, e1, _shape in prof:
-                a = agg.setdefault(name, [0.0, 0.0, 0])
+            for name, fl, e0, e1, _shape, nbytes in prof:
+                a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
                 a[0] += fl
                 a[1] += e0.elapsed_time(e1) * 1e-3
                 a[2] += 1
+                a[3] += nbytes
             dom = max(agg.items(), key=lambda kv: kv[1][1])
-            name, (fl, sec, cnt) = dom
+            name, (fl, sec, cnt, nb) = dom
             tot_sec = sum(v[1] for v in agg.values())
             ach = fl / sec / 1e12
-            traffic = mfma_busy = valu_busy = None      # from the committed PMC passes (same command, --no-graphs)
-            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_final.json')
+            # FLOPs the implicit-GEMM launches of one iteration actually execute (the caption branch's algebraic split
+            # does ~1.2 instead of 4.5 GFLOP/img): the figure that bounds time
+            exec_flops_step = sum(v[0] for v in agg.values()) / prof_steps
+            out['step_tflops_executed'] = exec_flops_step / (ms * 1e-3) / 1e12
+            out['step_frac_of_fp32_peak'] = out['step_tflops_executed'] / PEAK_FP32_MFMA_TFLOPS
+            traffic = mfma_busy = valu_busy = traffic_note = None
+            tree = _csrc_hash()
+            tpath = os.path.join(ROOT, 'profiles', 'r02_pmc.json')
             if os.path.exists(tpath) and args.batch == 32 and args.img == 192 and args.block_type == 'Pix2Pix':
                 with open(tpath) as f:
-                    tk = json.load(f)['kernels'].get(name)
-                if tk:
-                    traffic = tk['hbm_bytes_per_launch']
-                    mfma_busy, valu_busy = tk.get('mfma_busy_frac'), tk.get('valu_busy_frac')
+                    pm = json.load(f)
+                if pm.get('csrc_hash') == tree:
+                    tk = pm['kernels'].get(name)
+                    if tk:
+                        traffic = tk.get('hbm_bytes_per_launch')
+                        mfma_busy, valu_busy = tk.get('mfma_busy_frac'), tk.get('valu_busy_frac')
+                else:
+                    traffic_note = ('profiles/r02_pmc.json was collected on kernel tree %s, this run is %s: not attached'
+                                    % (pm.get('csrc_hash'), tree))
             out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
-                               'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, '
-                                               'profiles/r01_pmc_final.json)',
+                               'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc '
+                                               'passes, profiles/r02_pmc.json; attached only when its csrc_hash matches)',
+                               'traffic_note': traffic_note, 'csrc_hash': tree,
+                               'algorithmic_bytes_per_launch': nb / cnt,
+                               'traffic_ratio': (traffic / (nb / cnt)) if traffic else None,
                                'mfma_busy_frac_pmc': mfma_busy, 'valu_busy_frac_pmc': valu_busy,
                                'flop_per_launch': fl / cnt,
                                'launches': cnt, 'avg_launch_ms': sec / cnt * 1e3,
@@ -336,15 +456,18 @@ def main():
                                'events': ('timed region (eager launches)' if args.no_graphs else
                                           '%d eager steps after the hipGraph-replayed timed region' % prof_steps),
                                'all_igemm_tflops': sum(v[0] for v in agg.values()) / tot_sec / 1e12,
+                               'executed_flops_per_step': exec_flops_step,
                                'per_kernel': {k: {'tflops': v[0] / v[1] / 1e12, 'ms_per_step': v[1] / prof_steps * 1e3,
-                                                  'launches_per_step': v[2] / prof_steps}
+                                                  'launches_per_step': v[2] / prof_steps,
+                                                  'flop_per_launch': v[0] / v[2],
+                                                  'algorithmic_bytes_per_launch': v[3] / v[2]}
                                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
         if gen_fb is not None:
             out['generator_fwd_bwd'] = gen_fb
         if not args.no_cpu_baseline and world == 1 and args.block_type == 'Pix2Pix':
             out['cpu_baseline'] = cpu_baseline(args.img)
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if under_launcher:
         torch.distributed.destroy_process_group()
 
 

@@ -21,7 +21,7 @@ ev1.record()
 torch.cuda.synchronize()
 prof, hip.PROFILE = hip.PROFILE, None
 tot = 0.0
-for i, (name, fl, e0, e1, shp) in enumerate(prof):
+for i, (name, fl, e0, e1, shp, _nb) in enumerate(prof):
     ms = e0.elapsed_time(e1)
     tot += ms
     if i == mark:

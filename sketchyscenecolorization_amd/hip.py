@@ -228,7 +228,8 @@ class View(object):
 
 
 # When PROFILE is a list, every implicit-GEMM launch is bracketed by HIP events on the launch
-# stream and (kernel name, algorithmic FLOPs, start, stop) is appended (bench.py roofline leg).
+# stream and (kernel name, algorithmic FLOPs, start, stop, (M, N, K), algorithmic HBM bytes) is appended
+# (bench.py roofline leg).
 PROFILE = None
 
 
@@ -248,8 +249,11 @@ def _run_conv(d):
     e0.record()
     check(lib().ssc_conv_forward(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_forward')
     e1.record()
+    # algorithmic HBM bytes: every input element, filter element and output element once
+    nbytes = 4.0 * (d.NB * d.x.H * d.x.W * (d.x.C0 + d.x.C1) + d.nphase * d.TH * d.TW * d.k_real * d.Nn +
+                    d.NB * d.PH * d.PW * d.nphase * d.Nstore * (2 if d.accumulate else 1))
     PROFILE.append((_kernel_name('ssc_conv_forward_kernel_name', d), flops, e0, e1,
-                    (d.NB * d.PH * d.PW * d.nphase, d.Nn, d.TH * d.TW * d.k_real)))
+                    (d.NB * d.PH * d.PW * d.nphase, d.Nn, d.TH * d.TW * d.k_real), nbytes))
 
 
 def _run_wgrad(d, side=False):
@@ -271,8 +275,10 @@ def _run_wgrad(d, side=False):
     e0.record()
     check(lib().ssc_conv_wgrad(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_wgrad')
     e1.record()
+    nbytes = 4.0 * (d.NB * d.g.H * d.g.W * (d.g.C0 + d.g.C1) + d.NB * d.PH * d.PW * (d.d.C0 + d.d.C1) +
+                    d.TH * d.TW * d.Cg_real * d.Nn * (2 if d.accumulate else 1))
     PROFILE.append((_kernel_name('ssc_conv_wgrad_kernel_name', d), flops, e0, e1,
-                    (d.TH * d.TW * d.Cg_real, d.Nn, d.NB * d.PH * d.PW)))
+                    (d.TH * d.TW * d.Cg_real, d.Nn, d.NB * d.PH * d.PW), nbytes))
 
 
 def _out_geom(out, coff):
