@@ -68,21 +68,37 @@ def start_or_resume_training(params):
     """One call of main_procedure.train: fresh run (new UTC stamp) or continuation of ``resume_from``."""
     stamp = params['resume_from']
     fresh = stamp is None or stamp == ''
+    rank, multi = int(os.environ.get('RANK', 0)), params['num_gpu'] > 1
+    if multi:       # one process per GPU: rank 0 decides the run directory and the first iteration for everyone
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+            dist.init_process_group('nccl')
     if fresh:
         stamp = time.strftime('%Y-%m-%d-%H-%M-%S', time.gmtime())
         first_iter = 0
     elif not is_stamp(stamp):
         print('Invalid resume folder')
         return None, stamp
+    if multi and fresh:     # ranks that straddle a second boundary would otherwise write to different directories
+        box = [stamp]
+        dist.broadcast_object_list(box, src=0)
+        stamp = box[0]
     log_dir, ckpt_dir, _ = run_dirs(stamp)
     if fresh:
         for d in (log_dir, ckpt_dir):
             os.makedirs(d, exist_ok=True)
     else:
-        latest = main_procedure.latest_checkpoint(ckpt_dir)
-        if latest is None:
+        box = [None]
+        if rank == 0:
+            latest = main_procedure.latest_checkpoint(ckpt_dir)
+            box = [None if latest is None else int(os.path.basename(latest).split('-')[1]) + 1]
+        if multi:
+            dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
             raise RuntimeError('no snapshot under %s' % ckpt_dir)
-        first_iter = int(os.path.basename(latest).split('-')[1]) + 1
+        first_iter = box[0]
     params.update(log_dir=log_dir, ckpt_dir=ckpt_dir, iter_from=first_iter)
     if int(os.environ.get('RANK', 0)) == 0:
         with open(os.path.join(log_dir, 'param_%d.json' % first_iter), 'w') as fp:

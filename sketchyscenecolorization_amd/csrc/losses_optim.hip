@@ -66,16 +66,18 @@ __global__ __launch_bounds__(64) void acgan_loss_kernel(const float* __restrict_
     const float e = lane < K ? expf(v - m) : 0.f;
     const float se = wave_sum_f(e);
     const float p = e / se;
-    const int t = labels[n];
+    const int t = min(max(labels[n], 0), K - 1);     // a label outside [0, K) must not select an invalid lane
     const float pt = __shfl(p, t, 64);
     const float vt = __shfl(v, t, 64);
     const float ce = -(vt - m - logf(se));
     float loss, g;
     if (focal) {
         loss = (1.f - pt) * (1.f - pt) * ce;
-        // d/dp_t [(1-p)^2 * (-log p)] = 2(1-p) log p - (1-p)^2/p ; dp_t/dz_j = p_t(delta_tj - p_j)
-        const float fp = -2.f * (1.f - pt) * ce - (1.f - pt) * (1.f - pt) / pt;
-        g = fp * pt * ((lane == t ? 1.f : 0.f) - p);
+        // d/dp_t [(1-p)^2 * (-log p)] = 2(1-p) log p - (1-p)^2/p ; dp_t/dz_j = p_t(delta_tj - p_j).  The product
+        // (dL/dp_t) * p_t is written out without the division: when p_t underflows to 0 (logit gap > ~88) the quotient
+        // form is inf * 0 = NaN where TF's autodiff (through log_softmax) stays finite.
+        const float fpp = -2.f * (1.f - pt) * ce * pt - (1.f - pt) * (1.f - pt);
+        g = fpp * ((lane == t ? 1.f : 0.f) - p);
     } else {
         loss = ce;
         g = p - (lane == t ? 1.f : 0.f);

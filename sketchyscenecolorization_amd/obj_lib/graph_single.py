@@ -100,17 +100,34 @@ class Counter(object):
 
 
 class TowerGraph(object):
-    def __init__(self, trainer, inputs, counter, rank, world, batch_size, batch_portion):
+    def __init__(self, trainer, inputs, counter, rank, world, batch_size, batch_portion, pg=None):
         self.tr, self.inputs, self.counter = trainer, inputs, counter
         self.rank, self.world, self.batch_size, self.batch_portion = rank, world, batch_size, batch_portion
+        self.pg = pg
         self.last = {'loss_g': float('nan'), 'loss_d': float('nan')}
+        # inputs marked ``per_tower`` already hold this tower's slice (a queue per process that dequeues batch_size
+        # examples: no rank reads and decodes the other towers' share); anything else is the global batch and is cut
+        # by split_inputs as in the reference (graph_single.py:128-135)
+        self.per_tower = all(getattr(x, 'per_tower', False) for x in inputs)
 
     def _dequeue(self):
         vals = [_value(x) for x in self.inputs]
-        if self.world > 1:      # split_inputs: this process is tower `rank`
+        if self.world > 1 and not self.per_tower:      # split_inputs: this process is tower `rank`
             vals = [split_inputs(v, self.batch_size, self.batch_portion, self.world)[self.rank] for v in vals]
         images, sketches, images_d, cls, cls_d, text = vals
         return _batch(images, sketches, images_d, cls, cls_d, text)
+
+    def _tower_mean(self, loss):
+        """The loss every rank reports and tests for NaN: the mean over towers (sum all-reduce, so one tower's NaN is
+        every rank's NaN and all ranks take the same restart branch -- ranks deciding on their local loss would leave
+        the others waiting in the next gradient all-reduce).  The reference fetches the last tower's loss
+        (graph_single.py:144-173, the loop variable) and sees another tower's NaN one iteration later."""
+        if self.world == 1:
+            return loss
+        import torch.distributed as dist
+        t = loss.detach().clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        return t / self.world
 
     def run(self, fetches, g_follows=False):
         """g_follows (with opt_d): the next run is opt_g -- its batch is dequeued now (same order as the reference's
@@ -120,13 +137,13 @@ class TowerGraph(object):
         if 'opt_d' in kinds:
             d_batch = self._dequeue()
             self._g_next = self._dequeue() if (g_follows and getattr(self.tr, 'run_ahead', False)) else None
-            self.last['loss_d'] = self.tr.d_step(d_batch, c, ahead=self._g_next)
+            self.last['loss_d'] = self._tower_mean(self.tr.d_step(d_batch, c, ahead=self._g_next))
         if 'opt_g' in kinds:
             g_next, self._g_next = getattr(self, '_g_next', None), None
             if g_next is not None:
-                self.last['loss_g'] = self.tr.g_step(g_next, c, use_ahead=True)
+                self.last['loss_g'] = self._tower_mean(self.tr.g_step(g_next, c, use_ahead=True))
             else:
-                self.last['loss_g'] = self.tr.g_step(self._dequeue(), c)
+                self.last['loss_g'] = self._tower_mean(self.tr.g_step(self._dequeue(), c))
         out = []
         for k in kinds:
             if k in ('loss_g', 'loss_d'):
@@ -170,18 +187,24 @@ def build_multi_tower_graph(images, sketches, images_d, image_paired_class_ids, 
             raise RuntimeError('num_gpu=%d needs one process per GPU: launch with `python -m torch.distributed.run '
                                '--nproc-per-node %d ...` (the reference looped towers in one process)' % (num_gpu, num_gpu))
         pg, rank, world = dist.group.WORLD, dist.get_rank(), num_gpu
-    probe = _value(sketches)
-    img = probe.shape[2]
+    # image size: from the input's ``img_size`` attribute when it has one (a queue output: nothing may be dequeued
+    # here, or the first training batch would pair batch-0 sketches with batch-1 images), else from the value
+    probe = None
+    img = getattr(sketches, 'img_size', None)
+    if img is None:
+        probe = _value(sketches)
+        img = probe.shape[2]
     tr = models.get_trainer(block_type, vocab_size, img, process_group=pg, optimizer=optimizer)
     tr.G.lstm_hybrid = bool(LSTM_hybrid)
     tr.lr_g, tr.lr_d = learning_rates['generator'], learning_rates['discriminator']
     tr.max_iter_step = max_iter_step
-    if callable(sketches):      # do not consume a queue element for the probe
+    if callable(sketches) and probe is not None:      # the probed value is the first dequeue
         first = {'v': probe}
         orig = sketches
 
         def sketches():
             return first.pop('v') if 'v' in first else orig()
+        sketches.per_tower = getattr(orig, 'per_tower', False)
     g = TowerGraph(tr, [images, sketches, images_d, image_paired_class_ids, image_paired_class_ids_d,
-                        text_vocab_indiceses], counter, rank, world, batch_size, list(batch_portion))
+                        text_vocab_indiceses], counter, rank, world, batch_size, list(batch_portion), pg)
     return Fetch(g, 'opt_g'), Fetch(g, 'opt_d'), Fetch(g, 'loss_g'), Fetch(g, 'loss_d'), Fetch(g, 'summaries')

@@ -69,11 +69,25 @@ def restore_checkpoint(store, path):
             slot = tensors.get(n + '/Adam_1')
             if slot is not None and slot.size == k:
                 sc.adam_v[off:off + k].copy_(torch.from_numpy(slot.reshape(-1)))
-    for key, val in tensors.items():        # beta2_power = beta2 ** t of each optimizer (generator built first)
-        if key.split('/')[-1].startswith('beta2_power') and 0.0 < float(val) < 1.0:
-            t = int(round(np.log(float(val)) / np.log(0.9)))
-            sc = store.discriminator if key.split('/')[-1].endswith('_1') else store.generator
-            sc.adam_t = t
+    # Adam step counts.  beta2_power = 0.9 ** t of each optimizer (generator built first) recovers t only while the
+    # float32 power has not underflowed (t < ~1000); for any longer-trained checkpoint the global step in the file name
+    # ('model_<i>.ckpt-<i>': one D and one G apply per iteration) stands in, so that the bias correction
+    # sqrt(1 - 0.9^t) is ~1 as it was when the checkpoint was written instead of restarting at 0.316.
+    step = None
+    tail = os.path.basename(path).rsplit('-', 1)
+    if len(tail) == 2 and tail[1].isdigit():
+        step = int(tail[1]) + 1
+    seen = set()
+    for key, val in tensors.items():
+        leaf = key.split('/')[-1]
+        if leaf.startswith('beta2_power'):
+            sc = store.discriminator if leaf.endswith('_1') else store.generator
+            if 0.0 < float(val) < 1.0:
+                sc.adam_t = int(round(np.log(float(val)) / np.log(0.9)))
+                seen.add(id(sc))
+    for sc in (store.generator, store.discriminator):
+        if id(sc) not in seen and any((n + '/Adam_1') in tensors for n in sc.offsets):
+            sc.adam_t = step if step is not None else 100000
 
 
 def print_parameter_count(store, verbose=False):
@@ -91,6 +105,7 @@ class SyntheticQueue(object):
         self.pool = [synthetic_batch(batch_size, seed + i, img, vocab_size) for i in range(pool)]
         self.i = 0
         self.cur = self.pool[0]
+        self.img = img
 
     def advance(self):
         self.cur = self.pool[self.i % len(self.pool)]
@@ -101,6 +116,7 @@ class SyntheticQueue(object):
             if advance:
                 self.advance()
             return self.cur[name]
+        f.img_size, f.per_tower = self.img, True
         return f
 
 
@@ -108,12 +124,13 @@ class RecordQueue(object):
     """The same interface over the reference's TFRecords: queue 1 feeds (images, sketches, class_id, text), an
     independently shuffled queue 2 the discriminator's real images and labels (main_procedure.py:109-122)."""
 
-    def __init__(self, batch_size, small, which, data_base_dir='data'):
+    def __init__(self, batch_size, small, which, data_base_dir='data', seed=None):
         from .input_pipeline import PairedQueue
         self.q = PairedQueue('train', batch_size, Config.data_format, Config.distance_map != 0, small,
-                             data_base_dir=data_base_dir)
+                             data_base_dir=data_base_dir, seed=seed)
         self.which = which
         self.cur = None
+        self.img = SIZE[bool(small)][0]
 
     def advance(self):
         images, sketches, class_id, text = self.q.dequeue()
@@ -128,6 +145,7 @@ class RecordQueue(object):
             if advance or self.cur is None:
                 self.advance()
             return self.cur[name]
+        f.img_size, f.per_tower = self.img, True
         return f
 
 
@@ -174,13 +192,15 @@ def train(**kwargs):
 
     # two INDEPENDENT queues, as in the reference (main_procedure.py:109-122): the discriminator's
     # "real" images are not paired with the sketches it sees
+    # Every process is one tower and owns its queues: it dequeues batch_size examples per step (its share of the
+    # reference's batch_size * num_gpu dequeue, input_pipeline.py:143-148 + split_inputs), from its own shuffle.
     if os.path.isdir(os.path.join('data', 'tfrecord', 'train')):     # the reference's dataset location (:109-122)
-        q1 = RecordQueue(batch_size * num_gpu, small, 1)
-        q2 = RecordQueue(batch_size * num_gpu, small, 2)
+        q1 = RecordQueue(batch_size, small, 1, seed=(None if num_gpu == 1 else 7919 * rank + 1))
+        q2 = RecordQueue(batch_size, small, 2, seed=(None if num_gpu == 1 else 7919 * rank + 2))
     else:
         print('data/tfrecord/train not found: training on seeded synthetic batches')
-        q1 = SyntheticQueue(batch_size * num_gpu, img, Config.vocab_size, seed=1234 + 1000 * rank)
-        q2 = SyntheticQueue(batch_size * num_gpu, img, Config.vocab_size, seed=998244 + 1000 * rank)
+        q1 = SyntheticQueue(batch_size, img, Config.vocab_size, seed=1234 + 1000 * rank)
+        q2 = SyntheticQueue(batch_size, img, Config.vocab_size, seed=998244 + 1000 * rank)
     opt_g, opt_d, loss_g, loss_d, merged_all = build_multi_tower_graph(
         q1.field('images', advance=True), q1.field('sketches'), q2.field('images_d', advance=True),
         q1.field('class_id'), q2.field('class_id_d'), q1.field('text'),
@@ -229,9 +249,13 @@ def train(**kwargs):
             summ['step'] = i
             log_f.write(json.dumps(summ) + '\n')
             log_f.flush()
-        if i % save_model_freq == save_model_freq - 1 and rank == 0:
-            save_checkpoint(store, ckpt_dir, 'model_{}.ckpt'.format(i), global_step=i)
-            print('Save model_{}.ckpt'.format(i))
+        if i % save_model_freq == save_model_freq - 1:
+            if rank == 0:
+                save_checkpoint(store, ckpt_dir, 'model_{}.ckpt'.format(i), global_step=i)
+                print('Save model_{}.ckpt'.format(i))
+            if num_gpu > 1:     # a restart on any rank must find the snapshot rank 0 has just written
+                import torch.distributed as dist
+                dist.barrier()
     return status
 
 

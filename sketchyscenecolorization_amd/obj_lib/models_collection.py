@@ -151,14 +151,6 @@ def discriminate_mru(discrim_inputs, discrim_targets, num_classes, labels=None, 
     return _discriminate('MRU', discrim_inputs, discrim_targets, reuse, data_format, scope_name)
 
 
-def _not_built(name):
-    def f(*a, **k):
-        raise NotImplementedError('%s is not built yet: Pix2Pix, Residual (train + infer) and the MRU generator (infer) '
-                                  'and Residual (train + infer) are; the MRU discriminator / training follow' % name)
-    return f
-
-
-
 generator_mru = generate_mru
 discriminator_mru = discriminate_mru
 generator_pix2pix = generate_pix2pix

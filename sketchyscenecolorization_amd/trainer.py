@@ -36,6 +36,12 @@ class GanTrainer(object):
         if not torch.cuda.is_available():
             raise RuntimeError('GanTrainer needs an MI355X (HIP) device: there is no CPU fallback')
         hip.lib()
+        if not sn:
+            # Config.sn = False switches the reference to another loss family (WGAN-GP / DRAGAN gradient penalty) and to
+            # clip_by_global_norm + clip_by_norm before apply_gradients (graph_single.py:185-205, 355-386, 476-482).
+            # Only the live branch (sn = True: softplus loss, spectral norm, no clipping) is built; running it with
+            # spectral norm merely switched off would be a silently different algorithm.
+            raise NotImplementedError('Config.sn = False (gradient-penalty losses + gradient clipping) is not built')
         self.block_type = block_type
         self.store = ParamStore(block_type, vocab_size, img, device, seed)
         self.bufs = Buffers(device)

@@ -1,0 +1,191 @@
+"""Full-size configurations of BASELINE.json through the C ABI (VERDICT r1 "configs untested"):
+  config 5  Background_Colorization create_residual_generator, 768x768, batch 4 (bg_colorization_main.py:302-420)
+  config 2  Foreground generate_pix2pix, 192x192, batch 16, hipGraph replay (main_procedure.py:495-621)
+  config 1  obj_colorization_main.py --mode inference at 192x192 (no --small_img)
+plus the NaN -> -1 -> restart loop of the CLI (main_procedure.py:213-232, obj_colorization_main.py:240-246)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3      # north_star: outputs within 1e-3 max-abs of the reference on fp32 RGB
+
+
+def _bg_inputs(n, img, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, img, img, 3, generator=g) * 2 - 1
+    text = torch.zeros(n, 8, dtype=torch.int32)
+    text[:, :3] = torch.randint(1, 18, (n, 3), generator=g, dtype=torch.int32)
+    text[0, 4] = 7
+    return x, text
+
+
+def test_bg_generator_768_batch4_properties_and_graph_replay():
+    """Config 5 at its full size.  Size-independent properties: finite, tanh range, sample order equivariance (the
+    batch-statistics norms see the same set of samples), eager == hipGraph replay bit for bit."""
+    from sketchyscenecolorization_amd.params import Buffers, ParamStore
+    from sketchyscenecolorization_amd.residual import ResidualGenerator
+    n, img = 4, 768
+    store = ParamStore('BG', 18, img, 'cuda', 3)
+    gen = ResidualGenerator(store, Buffers('cuda'), 'bg')
+    x, text = _bg_inputs(n, img, 21)
+    xd = x.cuda()
+
+    def fwd(xin, tx):
+        ctx = gen.forward(xin, tx, None, 'bg')
+        return ctx['image']
+
+    prep = gen.text.prepare(text.numpy(), 'bg')      # caption tokens on the device: the captured pass holds no H2D copy
+    a = fwd(xd, prep)
+    assert a.shape == (n, img, img, 3) and torch.isfinite(a).all() and float(a.abs().max()) <= 1.0
+    assert float(a.std()) > 1e-3
+    b = fwd(xd, prep)
+    assert torch.equal(a, b)                    # fixed summation order: run-to-run bitwise
+    # hipGraph replay of the same launches
+    gph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(gph, capture_error_mode='thread_local'):
+        c = fwd(xd, prep)
+    for _ in range(2):
+        gph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a, c)
+    # permuting the samples permutes the outputs (up to the summation order of the batch statistics)
+    perm = torch.tensor([2, 0, 3, 1])
+    d = fwd(xd[perm].contiguous(), text[perm].numpy())
+    assert float((d - a[perm.cuda()]).abs().max()) < 5e-4
+
+
+def test_bg_generator_768_oracle_parity():
+    """Config 5 against the oracle at 768x768 (batch 1: the oracle's float64 arbiter runs ~1 min per image on the host).
+    53 batch-statistics norms deep the fp32 CPU restatement itself sits up to ~2e-3 from float64, so float64 is the
+    ground truth and the bar is the north-star 1e-3 or no worse than 1.5x the fp32 CPU path's own distance from it."""
+    from oracle import residual as R
+    from sketchyscenecolorization_amd import bg_colorization as bg
+    n, img = 1, 768
+    p = R.init_params('bg', seed=5, img=img)
+    x, text = _bg_inputs(n, img, 9)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref_img, ref_seg = R.create_residual_generator(p, x, text)
+    img64, seg64 = R.create_residual_generator({k: v.double() for k, v in p.items()}, x.double(), text)
+    bg.reset()
+    store, _, _ = bg.get_tower(img)
+    store.load_dict(p)
+    out_img, out_seg = bg.create_residual_generator(x, 3, text)
+    e1 = (out_img.cpu().double() - img64).abs().max().item()
+    e2 = (out_seg.cpu().double() - seg64).abs().max().item()
+    c1 = (ref_img.double() - img64).abs().max().item()
+    c2 = (ref_seg.double() - seg64).abs().max().item()
+    assert e1 <= max(TOL, 1.5 * c1), ('image vs float64 oracle', e1, 'fp32 CPU oracle vs float64', c1)
+    assert e2 <= max(TOL, 1.5 * c2), ('region logits vs float64 oracle', e2, 'fp32 CPU oracle vs float64', c2)
+
+
+def test_fg_generate_batch16_192_graph_replay_and_oracle():
+    """Config 2: generate_pix2pix at batch 16, 192x192: eager == replay bitwise, and <= 1e-3 from the oracle on every
+    sample (the norms use batch statistics, so the oracle runs the same 16 samples)."""
+    from oracle import pix2pix as O
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    n, img = 16, 192
+    p = O.init_params(0, img=img)
+    tr = GanTrainer(img=img, seed=1)
+    tr.store.load_dict(p)
+    b = O.synthetic_batch(n, seed=77, img=img)
+    sk, nv, text = b['sketches'].cuda(), b['noise_vec'].cuda(), b['text'].numpy()
+    tr.use_graphs_infer = False
+    eager = tr.generate(sk, text, nv)
+    tr.use_graphs_infer = True
+    first = tr.generate(sk, text, nv)           # eager (first sight of the shape)
+    second = tr.generate(sk, text, nv)          # captured
+    third = tr.generate(sk, text, nv)           # replayed
+    assert any(k[0] == 'infer' for k in tr._graphs), 'the inference pass was not captured'
+    assert torch.equal(eager, first) and torch.equal(eager, second) and torch.equal(eager, third)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref = O.generate_pix2pix(p, b['sketches'], b['text'], b['noise_vec'])
+    err = (third.cpu() - ref).abs().amax(dim=(1, 2, 3))
+    assert float(err.max()) <= TOL, err.tolist()
+
+
+def test_cli_inference_192_matches_oracle(tmp_path, monkeypatch):
+    """Config 1 through the CLI at the full 192x192 size: PNG written by --mode inference vs the oracle's generator on
+    the same sketch / caption / noise, after the reference's truncating uint8 cast (main_procedure.py:601-610)."""
+    from PIL import Image, ImageDraw
+    import obj_colorization_main as cli
+    from oracle import pix2pix as O
+    from sketchyscenecolorization_amd.data_processing.default_vocab import default_vocab_dict
+    from sketchyscenecolorization_amd.data_processing.text_processing import preprocess_sentence
+    from sketchyscenecolorization_amd.obj_lib import main_procedure as mp
+    from sketchyscenecolorization_amd.params import ParamStore
+    monkeypatch.chdir(tmp_path)
+    ts = '2019-03-04-05-06-07'
+    run = os.path.join('outputs', ts)
+    p = O.init_params(4, img=192)
+    store = ParamStore('Pix2Pix', 58, 192, 'cuda', seed=3)
+    store.load_dict(p)
+    mp.save_checkpoint(store, os.path.join(run, 'snapshot'), 'model_9.ckpt', 9)
+    os.makedirs('examples')
+    im = Image.new('L', (300, 260), 255)
+    d = ImageDraw.Draw(im)
+    d.rectangle([40, 120, 260, 200], outline=0, width=3)
+    d.ellipse([60, 190, 110, 240], outline=0, width=3)
+    im.save('examples/car.png')
+    noise = torch.randn(1, 256, generator=torch.Generator().manual_seed(11))
+    real_randn = torch.randn
+
+    def fake_randn(*shape, **kw):
+        if tuple(shape) == (1, 256):
+            return noise.to(kw.get('device', 'cpu'))
+        return real_randn(*shape, **kw)
+
+    monkeypatch.setattr(torch, 'randn', fake_randn)
+    caption = 'the car is yellow with blue window'
+    cli.main(['--mode', 'inference', '-rf', ts, '-bt', 'Pix2Pix', '--infer_name', 'car.png', '--instruction', caption])
+    monkeypatch.setattr(torch, 'randn', real_randn)
+    out = np.array(Image.open(os.path.join(run, 'inference_results', 'car_output.png')))
+    inp = np.array(Image.open(os.path.join(run, 'inference_results', 'car_input.png')))
+    assert out.shape == (192, 192, 3) and inp.shape == (192, 192, 3)
+    # the oracle on the host-side pre-processing of the same file
+    sk = mp._load_sketch('examples/car.png', (192, 192), 'car')
+    x = torch.from_numpy(mp._normalise(sk))
+    idx = np.array([preprocess_sentence(caption, default_vocab_dict(), 15)], dtype=np.int32)
+    ref = O.generate_pix2pix(p, x, torch.from_numpy(idx), noise)
+    ref_u8 = mp._postprocess(ref)[0]
+    diff = np.abs(out.astype(np.int32) - ref_u8.astype(np.int32))
+    # <= 1e-3 in [-1, 1] is <= 0.13 grey levels: after the truncating cast at most one level, and only where the value
+    # sits within 0.13 of an integer boundary
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.05, (diff.max(), (diff > 0).mean())
+    assert np.array_equal(inp, mp._postprocess(x)[0])
+
+
+def test_cli_nan_loss_returns_minus_one_and_restarts_from_snapshot(tmp_path, monkeypatch, capsys):
+    """A NaN loss ends train() with -1 and the CLI continues from the last snapshot (reference
+    main_procedure.py:213-232 + obj_colorization_main.py:240-246)."""
+    import obj_colorization_main as cli
+    from sketchyscenecolorization_amd.obj_lib import graph_single
+    monkeypatch.chdir(tmp_path)
+    real_run = graph_single.TowerGraph.run
+    state = {'fired': False}
+
+    def run(self, fetches, **kw):
+        res = real_run(self, fetches, **kw)
+        kinds = [f.kind for f in fetches]
+        if 'opt_g' in kinds and self.counter.value >= 3 and not state['fired']:       # iteration 2's G-step, once
+            state['fired'] = True
+            res[kinds.index('loss_g')] = np.float32('nan')
+        return res
+
+    monkeypatch.setattr(graph_single.TowerGraph, 'run', run)
+    cli.main(['--mode', 'train', '-bt', 'Pix2Pix', '-si', '1', '-bs', '2', '-mi', '5', '-smf', '2', '-swf', '1'])
+    text = capsys.readouterr().out
+    assert state['fired'] and 'NaN occurred during training G' in text
+    assert 'Training ended with status -1. Restarting..' in text and 'Launching training from checkpoint' in text
+    runs = sorted(os.listdir('outputs'))
+    assert len(runs) == 1                       # the restart continues in the same run directory
+    run_dir = os.path.join('outputs', runs[0])
+    assert os.path.exists(os.path.join(run_dir, 'log', 'param_0.json'))
+    p2 = json.load(open(os.path.join(run_dir, 'log', 'param_2.json')))     # snapshot model_1 -> first iteration 2
+    assert p2['iter_from'] == 2 and p2['resume_from'] == runs[0]
+    assert os.path.exists(os.path.join(run_dir, 'snapshot', 'model_3.ckpt-3'))
