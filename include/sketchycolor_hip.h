@@ -79,7 +79,11 @@ typedef struct ssc_conv_desc {
     int32_t out_stride, ooff_y, ooff_x; /* oy = py*out_stride + ooff_y */
     int32_t epi;          /* 0 none, 1 tanh (models_collection.py:533), 2 lrelu 0.2 (MRU gates, mru.py:407-413) */
     int32_t accumulate;   /* 1: out += result */
+    uint32_t* sk_flags;   /* stream-K hand-off flags (device): SSC_SK_FLAG_WORDS words, zero before the first launch that
+                             uses them and private to the launch stream (the kernel leaves them zero); NULL = the launch
+                             may not split tiles across workgroups inside the kernel (split-K slabs + reduce kernel instead) */
 } ssc_conv_desc;
+#define SSC_SK_FLAG_WORDS 8192   /* >= resident workgroups of the largest grid; the last word reports a hand-off timeout */
 
 /*
  * Implicit-GEMM filter gradient:
@@ -113,6 +117,9 @@ int ssc_conv_narrow_forward(const ssc_conv_desc* d, void* stream);
 /* name of the tile configuration the launcher picks for a descriptor (host only; for profiling) */
 int ssc_conv_forward_kernel_name(const ssc_conv_desc* d, char* buf, int len);
 int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* d, char* buf, int len);
+/* the launch plan for a descriptor (host only; tuning and tests): out5 = {tile configuration, split-K slabs, whole
+ * tiles, K slices per remaining tile (combined inside the launch), modelled kilo-cycles} */
+int ssc_conv_forward_plan(const ssc_conv_desc* d, int64_t ws_bytes, int* out5);
 
 /* --- layout (elementwise.hip) --- */
 /* dst[n,hw,coff+c] = src[n,c,hw]; tf.transpose NCHW->NHWC (models_collection.py:381) */

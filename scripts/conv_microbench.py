@@ -1,5 +1,5 @@
 """Single-layer microbenchmark of the implicit-GEMM kernel (for rocprofv3 --pmc passes).
-usage: conv_microbench.py <layer> [iters];  layers: enc2 enc3 enc4 d4 dec3 wg3"""
+usage: conv_microbench.py <layer> [iters] [batch];  layers: enc2 enc3 enc4 d4 dec3 wg3"""
 import sys
 import torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,7 @@ from sketchyscenecolorization_amd import hip
 from sketchyscenecolorization_amd.hip import View
 layer = sys.argv[1] if len(sys.argv) > 1 else 'enc2'
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-N = 32
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 g = torch.Generator(device='cuda').manual_seed(0)
 r = lambda *s: torch.randn(*s, device='cuda', generator=g)
 if layer in ('enc2', 'enc3', 'enc4', 'd4'):

@@ -16,6 +16,7 @@
 // are never written to HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include "sketchycolor_hip.h"
 
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
 template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN, int KM>
 __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, const Magics mg,
                                                        float* __restrict__ slab_base, long slab_stride, int splitk,
-                                                       int ts_full, int ts_s) {
+                                                       int ts_full, int ts_s, unsigned* __restrict__ flags) {
     constexpr int BM = WM * SM * 32;
     constexpr int BN = WN * SN * 32;
     // AV: A rows padded to 36 floats (16-byte aligned, b128 accesses conflict-free) and the K index of MFMA step kk on
@@ -466,8 +467,13 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     // workgroup -> (tile, K range).  Legacy grid: x = row tile, y = column tile, z = phase * splitk + K slice.
     // Tail split (ts_s > 0, 1-D grid, launches without split-K): tiles [0, ts_full) fill whole rounds of the chip and are
     // finished in place; each of the remaining tiles -- the partly filled last round -- is cut into ts_s K slices that
-    // together fill that round, written as raw partial tiles [BM][BN] and summed by ts_fixup_kernel.
-    int phase, ks, sk, n0;
+    // together fill that round.  The slices of a tile are combined INSIDE the launch: slices 0 .. ts_s-2 write raw partial
+    // tiles (accumulator order, write-through stores) and raise a flag each; the last slice -- the highest workgroup id of
+    // the tile, so everything it waits for was dispatched before it -- adds them to its accumulators in slice order (a
+    // fixed summation order) and runs the epilogue.  Agent-scope release / acquire as the CDNA4 guide prescribes: sc1
+    // stores, every storing wave drains, one lane stores the flag relaxed; the owner polls relaxed, one acquire fence,
+    // then plain loads.  The owner leaves the flags zero; its waits are bounded (flag word SSC_SK_FLAG_WORDS-1 = timeout).
+    int phase, ks, sk, n0, slot = 0;
     long m0;
     float* part = nullptr;
     if (ts_s > 0) {
@@ -480,6 +486,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             const int q = r / ts_s;
             tile = ts_full + q; ks = r - q * ts_s; sk = ts_s;
             part = slab_base + (long)r * (BM * BN);
+            slot = r;
         }
         const int mt = (int)((M + BM - 1) / BM), nt = (d.Nstore + BN - 1) / BN;
         const int rest = tile / mt;
@@ -505,9 +512,17 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         const long m = m0 + row;
         a_mv[i] = m < M;
         const long mm = a_mv[i] ? m : 0;
-        const int n = (int)div64(mm, mg.mPHPW, mg.onePHPW);
-        const int rem = (int)(mm - (long)n * PHW);
-        const int py = (int)div64(rem, mg.mPW, mg.onePW), px = rem - py * d.PW;
+        int n, rem, py;
+        if (mg.use32) {     // wave-uniform: every numerator x divisor fits 32 bits
+            n = (int)__umulhi((unsigned)mm, mg.mPHPW32) + (int)((unsigned)mm & (unsigned)mg.onePHPW);
+            rem = (int)mm - n * PHW;
+            py = (int)__umulhi((unsigned)rem, mg.mPW32) + (int)((unsigned)rem & (unsigned)mg.onePW);
+        } else {
+            n = (int)div64(mm, mg.mPHPW, mg.onePHPW);
+            rem = (int)(mm - (long)n * PHW);
+            py = (int)div64(rem, mg.mPW, mg.onePW);
+        }
+        const int px = rem - py * d.PW;
         a_iyb[i] = py * d.in_stride + ph.ioff_y;
         a_ixb[i] = px * d.in_stride + ph.ioff_x;
         const int pix0 = (n * xH + a_iyb[i]) * xW + a_ixb[i];
@@ -704,19 +719,114 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     }
 
     // ---- epilogue ----
-    if (part != nullptr) {      // tail split: raw partial tile
+    if (part != nullptr) {      // tail split
+        if (ks != sk - 1) {
+            // producer: raw partial tile as [pair of accumulator entries][thread], 8-byte write-through (sc1) stores
 #pragma unroll
-        for (int i = 0; i < SM; ++i)
+            for (int i = 0; i < SM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * SM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                for (int j = 0; j < SN; ++j)
 #pragma unroll
-                for (int j = 0; j < SN; ++j) part[row * BN + wn * SN * 32 + j * 32 + l31] = acc[i][j][r];
+                    for (int r = 0; r < 16; r += 2) {
+                        const int e2 = ((i * SN + j) * 16 + r) >> 1;
+                        union { float f[2]; unsigned long long u; } cv;
+                        cv.f[0] = acc[i][j][r]; cv.f[1] = acc[i][j][r + 1];
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + ((long)e2 * 256 + tid) * 2), cv.u,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        // owner: the other slices of this tile are workgroups slot-(sk-1) .. slot-1
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            for (int q = sk - 1; q >= 1; --q) {
+                while (__hip_atomic_load(flags + slot - q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t0 > 200000000ull) {       // 2 s of the 100 MHz counter: report, do not hang
+                        __hip_atomic_store(flags + (SSC_SK_FLAG_WORDS - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __hip_atomic_store(flags + slot - q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // leave them zero
             }
-        return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // one L1 invalidate after the last flag
+        }
+        __syncthreads();
+#pragma nounroll
+        for (int q = sk - 1; q >= 1; --q) {
+            const float* pp = part - (long)q * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < SM; ++i)
+#pragma unroll
+                for (int j = 0; j < SN; ++j) {
+                    float2 pv[8];       // one accumulator's worth of loads in flight
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; ++r2)
+                        pv[r2] = *reinterpret_cast<const float2*>(pp + ((long)((i * SN + j) * 8 + r2) * 256 + tid) * 2);
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; ++r2) {
+                        acc[i][j][2 * r2] += pv[r2].x;
+                        acc[i][j][2 * r2 + 1] += pv[r2].y;
+                    }
+                }
+        }
     }
     float* outp = (ts_s == 0 && splitk > 1) ? (slab_base + (long)ks * slab_stride) : d.out;
     const bool final_pass = (ts_s > 0) || (splitk == 1);
+    // Vector epilogue: the accumulators go through LDS (the tile buffers are free after the loop's last barrier) and leave
+    // as one 16-byte store per thread and 4 columns -- 8 stores per thread instead of 32 with a 64-bit address, a row test
+    // and a column test each.  Every workgroup of a round reaches its epilogue at about the same time, so the epilogue's
+    // length is matrix-pipe idle time.  Needs 16-byte aligned rows (the scalar form below covers the rest).
+    constexpr int C_LD = BN + 4;
+    static_assert(BM * C_LD <= 2 * (A_SZ + B_SZ), "the C tile fits the operand buffers");
+    if ((((d.Nstore | d.ldc) & 3) == 0) & ((reinterpret_cast<unsigned long>(outp) & 15) == 0)) {
+        float* Cs = smem;
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+            for (int j = 0; j < SN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * SM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    Cs[row * C_LD + wn * SN * 32 + j * 32 + l31] = acc[i][j][r];
+                }
+        __syncthreads();
+        const float* const bias = final_pass ? d.bias : nullptr;
+        const int epi = final_pass ? d.epi : 0;
+        const bool accum = final_pass && d.accumulate != 0;
+        const int Nn = d.Nn, Nst = d.Nstore, ldc = d.ldc;
+#pragma unroll
+        for (int p = 0; p < BM * BN / 1024; ++p) {
+            const int e = p * 256 + tid;
+            const int row = e / (BN / 4), col = n0 + (e % (BN / 4)) * 4;
+            if ((m0 + row < M) & (col < Nst)) {
+                float4 v = *reinterpret_cast<const float4*>(Cs + row * C_LD + (col - n0));
+                // the filter loads of columns >= Nn were not masked
+                v.x = col + 0 < Nn ? v.x : 0.f; v.y = col + 1 < Nn ? v.y : 0.f;
+                v.z = col + 2 < Nn ? v.z : 0.f; v.w = col + 3 < Nn ? v.w : 0.f;
+                if (bias != nullptr) {
+                    v.x += col + 0 < Nn ? bias[col + 0] : 0.f; v.y += col + 1 < Nn ? bias[col + 1] : 0.f;
+                    v.z += col + 2 < Nn ? bias[col + 2] : 0.f; v.w += col + 3 < Nn ? bias[col + 3] : 0.f;
+                }
+                if (epi == 1) {
+                    v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+                } else if (epi == 2) {
+                    v.x = fmaxf(v.x, 0.2f * v.x); v.y = fmaxf(v.y, 0.2f * v.y);
+                    v.z = fmaxf(v.z, 0.2f * v.z); v.w = fmaxf(v.w, 0.2f * v.w);
+                }
+                float4* o = reinterpret_cast<float4*>(outp + rowpix[row] * ldc + col);
+                if (accum) {
+                    const float4 t = *o;
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                *o = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
 #pragma unroll
@@ -738,49 +848,6 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                 }
                 *o = v;
             }
-        }
-    }
-}
-
-// tail-split fix-up: one workgroup per tail tile sums its ts_s partial tiles (in slice order) and applies the epilogue
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void ts_fixup_kernel(const ssc_conv_desc d, const Magics mg,
-                                                       const float* __restrict__ parts, int ts_full, int ts_s) {
-    const long M = (long)d.NB * d.PH * d.PW;
-    const int PHW = d.PH * d.PW;
-    const int tile = ts_full + blockIdx.x;
-    const int mt = (int)((M + BM - 1) / BM), nt = (d.Nstore + BN - 1) / BN;
-    const int rest = tile / mt;
-    const long m0 = (long)(tile - rest * mt) * BM;
-    const int phase = rest / nt;
-    const int n0 = (rest - phase * nt) * BN;
-    const FwdPhase ph = fwd_phase(d, phase);
-    const float* base = parts + (long)blockIdx.x * ts_s * (BM * BN);
-    constexpr int C4 = BN / 4;
-    for (int e = threadIdx.x; e < BM * C4; e += 256) {
-        const int row = e / C4, c4 = (e - row * C4) * 4;
-        const long m = m0 + row;
-        if (m >= M) continue;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q = 0; q < ts_s; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (long)q * (BM * BN) + row * BN + c4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        const int n = (int)div64(m, mg.mPHPW, mg.onePHPW);
-        const int rem = (int)(m - (long)n * PHW);
-        const int py = (int)div64(rem, mg.mPW, mg.onePW), px = rem - py * d.PW;
-        float* o = d.out + (((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x) * d.ldc;
-        const float sv[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int col = n0 + c4 + q;
-            if (col >= d.Nstore) continue;
-            float v = col < d.Nn ? sv[q] : 0.f;
-            if (d.bias != nullptr && col < d.Nn) v += d.bias[col];
-            if (d.epi == 1) v = tanhf(v);
-            else if (d.epi == 2) v = fmaxf(v, 0.2f * v);
-            if (d.accumulate) v += o[col];
-            o[col] = v;
         }
     }
 }
@@ -1099,14 +1166,14 @@ static const TileCfg WG_CFGS[5] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.00}
 // and multiplies the block count, at the price of writing + re-reading s partial copies of the output.
 // planner constants, overridable from the environment while tuning (read once)
 static double plan_const(const char* name, double dflt) {
-    static const char* names[8];
-    static double vals[8];
+    static const char* names[16];
+    static double vals[16];
     static int n = 0;
     for (int i = 0; i < n; ++i)
         if (names[i] == name) return vals[i];
     const char* e = getenv(name);
     const double v = (e != nullptr) ? atof(e) : dflt;
-    if (n < 8) { names[n] = name; vals[n] = v; ++n; }
+    if (n < 16) { names[n] = name; vals[n] = v; ++n; }
     return v;
 }
 
@@ -1123,12 +1190,12 @@ static double makespan(long blocks, double w, int res, int ncu) {
     return t;
 }
 
-struct Plan { int cfg; int splitk; double cost; };
+struct Plan { int cfg; int splitk; double cost; long ts_full; int ts_s; };
 
 static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long M, long N, long nphase, long nkt,
-                        long out_elems, int64_t ws_bytes, bool have_ws) {
+                        long out_elems, int64_t ws_bytes, bool have_ws, bool can_ts = false) {
     const int ncu = num_cu();
-    Plan best = {-1, 1, 1e300};
+    Plan best = {-1, 1, 1e300, 0, 1};
     static int force = -2;      // SSC_FWD_CFG=n: tuning aid, restricts the search to tile configuration n where allowed
     if (force == -2) {
         const char* e = getenv("SSC_FWD_CFG");
@@ -1147,7 +1214,42 @@ static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long
             if ((nkt + per - 1) / per != sk) continue;      // would leave empty trailing splits
             double cost = makespan(blocks * sk, wfull * (double)per / (double)nkt, t.res, ncu) + 2500.0;
             if (sk > 1) cost += 2.0 * sk * (double)out_elems * 4.0 / 1500.0 + plan_const("SSC_PLAN_REDUCE", 6000.0);   // slab traffic + reduce launch
-            if (cost < best.cost) best = {c, sk, cost};
+            const long bf = blocks;
+            const int bs = 1;
+            if (cost < best.cost) best = {c, sk, cost, bf, bs};
+        }
+    }
+    // Whole tiles + K slices combined inside the launch (launch_fwd_ut).  Measured on the batch-32 layers with 64x128 tiles
+    // (scripts/ts_sweep.sh): the best layout is as many whole tiles as fill whole rounds of one workgroup per CU, the rest
+    // cut into about (CUs / remaining tiles) slices, i.e. one more workgroup per CU -- encoder_3 (576 tiles) 97 -> 115
+    // TFLOP/s as 512 + 64 x 4, encoder_2 (1152) 105 -> 115 as 1024 + 128 x 2.  Slicing more tiles than that loses to the
+    // fixed cost of a workgroup (first loads, epilogue, hand-off), split-K slabs + reduce kernel lose to both.
+    if (can_ts && have_ws && best.cfg >= 0) {
+        const TileCfg& t = cfgs[best.cfg];
+        const long blocks = ((M + t.BM - 1) / t.BM) * ((N + t.BN - 1) / t.BN) * nphase;
+        long full = (blocks / ncu) * ncu, tail = blocks - full;
+        long sl = 1;
+        static int ff = -2, fs = -2;        // tuning aid: SSC_TS_FORCE="whole tiles per CU,slices" pins the layout
+        if (ff == -2) {
+            const char* e = getenv("SSC_TS_FORCE");
+            ff = fs = -1;
+            if (e != nullptr) sscanf(e, "%d,%d", &ff, &fs);
+        }
+        if (ff >= 0 && fs >= 1) {
+            full = (long)ff * ncu;
+            if (full > blocks) full = (blocks / ncu) * ncu;
+            tail = blocks - full;
+            sl = tail > 0 ? fs : 1;
+        } else if (full > 0 && tail > 0 && tail * 4 <= (long)ncu * 3) {
+            sl = (ncu + tail / 2) / tail;
+            const long smax = (long)plan_const("SSC_TS_MAXS", 8.0);
+            if (sl > smax) sl = smax;
+            while (sl > 1 && nkt / sl < 4) --sl;
+        }
+        if (sl > 1 && tail * sl < SSC_SK_FLAG_WORDS - 1 && (int64_t)tail * sl * t.BM * t.BN * 4 <= ws_bytes) {
+            best.splitk = 1;
+            best.ts_full = full;
+            best.ts_s = (int)sl;
         }
     }
     return best;
@@ -1186,6 +1288,8 @@ static int launch_fwd_v(const ssc_conv_desc& d, int splitk, float* ws, hipStream
 // set by ssc_conv_forward for the launch it is about to make: resident workgroups per CU of the chosen tile, workspace size
 static thread_local int g_launch_res = 2;
 static thread_local int64_t g_launch_ws_bytes = 0;
+static thread_local long g_launch_ts_full = 0;      // the planner's tail split: whole tiles, slices per remaining tile
+static thread_local int g_launch_ts_s = 1;
 static int tail_split_mode() {
     static int mode = -1;
     if (mode < 0) {
@@ -1263,28 +1367,20 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    // tail split: a launch without split-K whose last round would be partly filled
-    if (splitk == 1 && ws != nullptr && tail_split_mode() != 0) {
+    // whole tiles + K slices combined inside the launch, as the planner laid them out (plan_launch / cu_timeline)
+    if (splitk == 1 && ws != nullptr && d.sk_flags != nullptr && g_launch_ts_s > 1) {
         const long tiles = mt * nt * d.nphase;
-        const long slots = (long)num_cu() * g_launch_res;
-        const long nkt = (long)d.TH * d.TW * tpt;
-        const long full = (tiles / slots) * slots, tail = tiles - full;
-        if (full > 0 && tail > 0 && tail * 4 <= slots * 3) {
-            long s = slots / tail;
-            if (s > 8) s = 8;
-            while (s > 1 && nkt / s < 4) --s;
-            if (s > 1 && (int64_t)tail * s * BM * BN * 4 <= g_launch_ws_bytes && full + tail * s < 0x7fffffffL) {
-                hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>), dim3((unsigned)(full + tail * s)),
-                                   dim3(256), lds, st, d, mg, ws, out_count, 1, (int)full, (int)s);
-                hipLaunchKernelGGL((ts_fixup_kernel<BM, BN>), dim3((unsigned)tail), dim3(256), 0, st, d, mg, ws, (int)full,
-                                   (int)s);
-                return (int)hipGetLastError();
-            }
+        const long full = g_launch_ts_full, tail = tiles - full, s = g_launch_ts_s;
+        if (full >= 0 && tail > 0 && (int64_t)tail * s * BM * BN * 4 <= g_launch_ws_bytes && tail * s < SSC_SK_FLAG_WORDS - 1 &&
+            full + tail * s < 0x7fffffffL) {
+            hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>), dim3((unsigned)(full + tail * s)),
+                               dim3(256), lds, st, d, mg, ws, out_count, 1, (int)full, (int)s, d.sk_flags);
+            return (int)hipGetLastError();
         }
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
     hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>), grid, dim3(256), lds, st, d, mg, ws, out_count,
-                       splitk, 0, 0);
+                       splitk, 0, 0, (unsigned*)nullptr);
     if (splitk > 1) {
         const int thr = 256;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
@@ -1325,8 +1421,10 @@ static Plan plan_fwd(const ssc_conv_desc& d, int64_t ws_bytes, bool have_ws) {
         nkt = d.TH;
     // column tile no wider than needed: <=32 -> 128x32, <=64 -> 128x64, else 128x128 / 64x128 / 128x64
     const bool allowed[5] = {d.Nstore > 64, d.Nstore > 64, d.Nstore > 32, d.Nstore <= 32, d.Nstore > 32};
+    const bool can_ts = d.sk_flags != nullptr && tail_split_mode() != 0 &&
+                        (fwd_is_ut(d) || fwd_is_utg(d) || (d.bmode == 0 && fwd_is_rowtap(d)));
     return plan_launch(FWD_CFGS, 5, allowed, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,
-                       have_ws);
+                       have_ws, can_ts);
 }
 
 static void copy_name(const char* src, char* dst, int len) {
@@ -1345,6 +1443,14 @@ extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, 
         {"conv_fwd<128x128,NK>", "conv_fwd<64x128,NK>", "conv_fwd<128x64,NK>", "conv_fwd<128x32,NK>", "conv_fwd<64x64,NK>"}};
     const Plan p = plan_fwd(*dp, (int64_t)1 << 40, true);
     copy_name(names[dp->bmode ? 1 : 0][p.cfg < 0 ? 0 : p.cfg], buf, len);
+    return 0;
+}
+
+extern "C" int ssc_conv_forward_plan(const ssc_conv_desc* dp, int64_t ws_bytes, int* out5) {
+    // host only: {tile configuration, split-K slabs, whole tiles, K slices per remaining tile, modelled cycles / 1000}
+    if (ssc_conv_narrow_supported(dp)) { out5[0] = -1; out5[1] = 1; out5[2] = 0; out5[3] = 1; out5[4] = 0; return 0; }
+    const Plan p = plan_fwd(*dp, ws_bytes, true);
+    out5[0] = p.cfg; out5[1] = p.splitk; out5[2] = (int)p.ts_full; out5[3] = p.ts_s; out5[4] = (int)(p.cost / 1000.0);
     return 0;
 }
 
@@ -1369,6 +1475,8 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
     if (p.cfg < 0) return -4;
     g_launch_res = FWD_CFGS[p.cfg].res;
     g_launch_ws_bytes = ws_bytes;
+    g_launch_ts_full = p.ts_full;
+    g_launch_ts_s = p.ts_s;
     if (d.bmode == 0) {
         switch (p.cfg) {
             case 0: return launch_fwd<2, 2, 2, 2, 0>(d, p.splitk, ws, st);
@@ -1440,7 +1548,7 @@ static Plan plan_wgrad(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws) 
     allowed[3] = d.Nn > 32 && d.Nn <= 64 && Mtot <= 64;
     allowed[4] = d.Nn <= 32;
     const int ncu = num_cu();
-    Plan best = {-1, 1, 1e300};
+    Plan best = {-1, 1, 1e300, 0, 1};
     static int force_cfg = -2, force_sk = -2;       // SSC_WG_CFG / SSC_WG_SPLITK: tuning aids
     if (force_cfg == -2) {
         const char* e = getenv("SSC_WG_CFG");
@@ -1462,7 +1570,7 @@ static Plan plan_wgrad(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws) 
             double cost = makespan(blocks * sk, wfull * (double)per / (double)nkt, t.res, ncu) + 2500.0;
             if (sk > 1) cost += 2.0 * sk * (double)out_elems * 4.0 / 1500.0 + plan_const("SSC_PLAN_REDUCE", 6000.0);
             if (force_sk > 0) cost = (double)(sk > force_sk ? sk - force_sk : force_sk - sk);     // nearest legal split
-            if (cost < best.cost) best = {c, (int)sk, cost};
+            if (cost < best.cost) best = {c, (int)sk, cost, 0, 1};
         }
     }
     return best;

@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
                 ('bmode', C.c_int32), ('k_real', C.c_int32), ('n_off', C.c_int32), ('Nn', C.c_int32),
                 ('Nstore', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32), ('ldc', C.c_int32),
                 ('out_stride', C.c_int32), ('ooff_y', C.c_int32), ('ooff_x', C.c_int32),
-                ('epi', C.c_int32), ('accumulate', C.c_int32)]
+                ('epi', C.c_int32), ('accumulate', C.c_int32), ('sk_flags', C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -70,6 +70,7 @@ SIGNATURES = {
     'ssc_conv_narrow_forward': [C.POINTER(ConvDesc), _P],
     'ssc_conv_forward_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, _I],
     'ssc_conv_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, _I],
+    'ssc_conv_forward_plan': [C.POINTER(ConvDesc), _L, C.POINTER(C.c_int)],
     'ssc_nchw_to_nhwc': [_P, _P, _I, _I, _I, _I, _I, _P],
     'ssc_nhwc_to_nchw': [_P, _P, _I, _I, _I, _I, _I, _P],
     'ssc_sketch_preprocess_u8': [_P, _I, _I, _I, _I, _P, _P],
@@ -147,6 +148,7 @@ def _declare(l):
         fn.restype = C.c_int
 
 
+SK_ENABLED = os.environ.get('SSC_STREAMK', '1') != '0'      # in-kernel stream-K decomposition of the conv launches
 LAUNCHES = 0        # bumped by every C-ABI call (lets the trainer tell an empty graph segment from a real one)
 
 
@@ -239,8 +241,29 @@ def _kernel_name(fn, d):
     return buf.value.decode()
 
 
+SK_FLAG_WORDS = 8192
+_sk_flags = {}
+
+
+def sk_flags():
+    """Stream-K hand-off flags of the CURRENT stream (ssc_conv_desc.sk_flags): zero when created, left zero by every
+    kernel that uses them; one array per device and stream because launches on different streams run concurrently."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    f = _sk_flags.get(key)
+    if f is None:
+        f = torch.zeros(SK_FLAG_WORDS, dtype=torch.int32, device='cuda')
+        _sk_flags[key] = f
+    return f
+
+
+def sk_timeouts():
+    """Number of flag arrays whose last word reports a hand-off that timed out (must be 0; tests check it)."""
+    return sum(int(f[-1].item() != 0) for f in _sk_flags.values())
+
+
 def _run_conv(d):
     ws = workspace()
+    d.sk_flags = sk_flags().data_ptr() if SK_ENABLED else None
     if PROFILE is None:
         check(lib().ssc_conv_forward(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_forward')
         return

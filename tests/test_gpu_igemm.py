@@ -393,3 +393,45 @@ def test_other_optimizers_match_tf_formulas(kind):
             hip.call('ssc_optimizer_step', 3, wd, gr.cuda(), d1, d2, n, lr, 0.95, 0.0, 1e-8, 1.0)
     assert float((wd.cpu() - w).abs().max()) < 1e-6
     assert float((d1.cpu() - s1).abs().max()) < 1e-5 * max(1.0, float(s1.abs().max()))
+
+
+@pytest.mark.parametrize('case', [
+    # N, H, C0, C1, CO, k, stride, pad, norm          (uniform-tap layers of the training step + odd ones)
+    (32, 48, 128, 0, 256, 4, 2, 1, True),       # encoder_3 at batch 32: 576 tiles, fewer than the chip holds
+    (32, 96, 64, 0, 128, 4, 2, 1, True),        # encoder_2: 1152 tiles, 1.5 rounds
+    (32, 12, 512, 0, 512, 4, 2, 1, True),       # encoder_5: 72 tiles x 256 K-tiles, every tile cut in parts
+    (3, 24, 256, 256, 512, 4, 1, 1, False),     # two sources, stride 1, ragged M
+    (2, 24, 64, 0, 579, 3, 1, 1, False),        # N not a multiple of the tile width
+    (5, 20, 320, 260, 64, 3, 1, 1, True),       # channel-chunk K loop (C1 % 32 != 0), 128x64 tile
+])
+def test_in_launch_tail_split_equals_slab_launch(case):
+    """Tail split with the K slices of a tile combined inside the launch (partial tiles handed to the tile's last slice
+    through agent-scope flags) computes what the launch without it (split-K slabs + reduce kernel, or whole tiles only)
+    computes: same products, another summation order.  Also: flags are left zero, no hand-off timed out, run-to-run
+    bitwise."""
+    from sketchyscenecolorization_amd import hip
+    from sketchyscenecolorization_amd.hip import ACT_LRELU, ACT_NONE, View
+    N, H, C0, C1, CO, k, stride, pad, norm = case
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x0 = torch.randn(N, H, H, C0, device='cuda', generator=g)
+    x1 = torch.randn(N, H, H, C1, device='cuda', generator=g) if C1 else None
+    C1p = 0 if x1 is None else C1
+    w = torch.randn(k, k, C0 + C1p, CO, device='cuda', generator=g) * 0.05
+    ab0 = torch.randn(2 * C0, device='cuda', generator=g) if norm else None
+    v = View(x0, x1, ab0, ACT_LRELU if norm else ACT_NONE)
+    OH = (H + 2 * pad - k) // stride + 1
+    ldc = (CO + 3) // 4 * 4
+    outs = []
+    for sk in (False, True, True):
+        hip.SK_ENABLED = sk
+        out = torch.zeros(N, OH, OH, ldc, device='cuda')
+        hip.conv_forward(v, w, stride, pad, out, nstore=ldc if ldc != CO else None)
+        torch.cuda.synchronize()
+        outs.append(out)
+    hip.SK_ENABLED = True
+    ref, a, b = outs
+    assert torch.equal(a, b)
+    scale = float(ref.abs().max())
+    assert float((a - ref).abs().max()) <= 2e-5 * scale, (float((a - ref).abs().max()), scale)
+    assert hip.sk_timeouts() == 0
+    assert int(hip.sk_flags().abs().sum()) == 0
