@@ -8,6 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libsketchycolor_hip.so')
+EXTRA_FLAGS = {}     # per-source compiler flags
 SOURCES = ['igemm.hip', 'narrow.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip', 'mru_ops.hip']
 
 
@@ -39,7 +40,8 @@ def build_library(force=False, verbose=True):
             continue
         obj = os.path.join(LIB_DIR, s.replace('.hip', '.o'))
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'),
-               '-Wno-unused-value', '-c', src, '-o', obj]
+               '-Wno-unused-value', '-Wno-unused-function'] + os.environ.get('SSC_EXTRA_HIPCC_FLAGS', '').split() + \
+              EXTRA_FLAGS.get(s, []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), cmd))

@@ -430,8 +430,11 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     constexpr bool AV = UT_AV(BM, BN);
     constexpr int A_LD = AV ? BK + 4 : BK + 1;
     constexpr int A_SZ = BM * A_LD;
-    constexpr int B_LD = (BMODE == 0) ? BN : (BK + 1);
-    constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * (BK + 1);
+    // NK filters (k contiguous in memory): the B tile is [n][32] with the 16-byte chunk c of row n stored at chunk
+    // c ^ ((n >> 1) & 7) -- b128 writes and b128 operand reads, both conflict-free, no padding (the scalar [n][33] image it
+    // replaces cost 34 address adds per K-tile and wave)
+    constexpr int B_LD = (BMODE == 0) ? BN : BK;
+    constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * BK;
     constexpr int A_ROWS = BM / 32;
     constexpr int B_SLOTS = BN / 32;
     constexpr int B_RP = 1024 / BN;
@@ -526,8 +529,8 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         a_iyb[i] = py * d.in_stride + ph.ioff_y;
         a_ixb[i] = px * d.in_stride + ph.ioff_x;
         const int pix0 = (n * xH + a_iyb[i]) * xW + a_ixb[i];
-        a_off0[i] = pix0 * xC0 + a_col4 * 4;
-        a_off1[i] = pix0 * xC1 + a_col4 * 4;
+        a_off0[i] = (pix0 * xC0 + a_col4 * 4) * 4;      // BYTE offsets from a wave-uniform base: the loads then take the
+        a_off1[i] = (pix0 * xC1 + a_col4 * 4) * 4;      // scalar-base + 32-bit vector-offset form, no 64-bit address arithmetic
         if (a_col4 == 0)
             rowpix[row] = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
     }
@@ -540,14 +543,14 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             const int n = n0 + (tid % (BN / 4)) * 4;
             const bool nv = n < d.Nn;
             b_kk[s] = tid / (BN / 4) + B_RP * s;
-            b_k[s] = nv ? b_kk[s] * wC1 : 0;
-            b_n[s] = nv ? d.n_off + n : 0;
+            b_k[s] = nv ? b_kk[s] * wC1 * 4 : 0;            // bytes
+            b_n[s] = nv ? (d.n_off + n) * 4 : 0;
         } else {
             const int n = n0 + (tid >> 3) + 32 * s;
             const bool nv = n < d.Nn;
             b_kk[s] = (tid & 7) * 4;
-            b_k[s] = nv ? b_kk[s] : 0;
-            b_n[s] = nv ? (d.n_off + n) * wC1 : 0;
+            b_k[s] = nv ? b_kk[s] * 4 : 0;
+            b_n[s] = nv ? (d.n_off + n) * wC1 * 4 : 0;
         }
     }
 
@@ -581,8 +584,8 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         const int cch = first ? cc : xC0 + cc;                  // channel offset inside the filter's K rows
         const int kreal = (first ? kreal0 : kreal1) - cc;       // real channels left in this source from cc on
         const int cchf = (!KMASK || kreal > 0) ? cch : 0;       // a chunk without real channels reads (and drops) row 0
-        const float* sbase = (first ? xs0 : xs1) + cc;
-        const int tapshift = (ty * xW + tx) * cs;
+        const char* sbase = reinterpret_cast<const char*>((first ? xs0 : xs1) + cc);
+        const int tapshift = (ty * xW + tx) * cs * 4;
         const int fmask = first ? -1 : 0;
         if (!PLAIN) {
             const float* abp = first ? xab0 : xab1;
@@ -603,13 +606,13 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                            (!KMASK || cc + a_col4 * 4 < cs);
             const int osel = (a_off0[i] & fmask) | (a_off1[i] & ~fmask);    // bit select: a ?: here became a scratch array
             // unsigned 32-bit element offset from a wave-uniform base: one shift, no 64-bit vector address arithmetic
-            const unsigned off = v ? (unsigned)(osel + tapshift) : (unsigned)(a_col4 * 4);
+            const unsigned off = v ? (unsigned)(osel + tapshift) : (unsigned)(a_col4 * 16);
             rav[i] = v ? 1.f : 0.f;
             ra[i] = *reinterpret_cast<const float4*>(sbase + off);
         }
         const int ky = ph.ky0 + ty * kstep, kx = ph.kx0 + tx * kstep;
-        const float* wtap = (BMODE == 0) ? wbase + ((long)(ky * KWv + kx) * wC0 + cchf) * wC1
-                                         : wbase + (long)(ky * KWv + kx) * wC0 * wC1 + cchf;
+        const char* wtap = reinterpret_cast<const char*>((BMODE == 0) ? wbase + ((long)(ky * KWv + kx) * wC0 + cchf) * wC1
+                                                                      : wbase + (long)(ky * KWv + kx) * wC0 * wC1 + cchf);
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
             if (KMASK) {
@@ -641,8 +644,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             if (BMODE == 0) {
                 *reinterpret_cast<float4*>(Bb + (tid / (BN / 4) + B_RP * s) * B_LD + (tid % (BN / 4)) * 4) = v;
             } else {
-                float* p = Bb + ((tid >> 3) + 32 * s) * B_LD + (tid & 7) * 4;
-                p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+                *reinterpret_cast<float4*>(Bb + ((tid >> 3) + 32 * s) * B_LD + (((tid & 7) ^ ((tid >> 4) & 7)) * 4)) = v;
             }
         }
     };
@@ -655,12 +657,14 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         __syncthreads();
         int cur = 0;
         for (int kt = kt_begin; kt < kt_end; ++kt) {
-            // K index of MFMA step kk on this lane half: 2*kk + lhi, or 16*lhi + kk (AV)
-            constexpr int KS = AV ? 1 : 2;              // k stride between consecutive steps
-            const int kl = AV ? lhi * (BK / 2) : lhi;   // k of step 0
+            // K index of MFMA step kk on lane half lhi: 16*lhi + kk (any bijection works when A and B agree; this one makes
+            // a lane's 16 operands of a K-tile contiguous in the [row][k] images)
+            constexpr int KS = 1;                       // k stride between consecutive steps
+            const int kl = lhi * (BK / 2);              // k of step 0
             const float* Ab = As + cur * A_SZ + (wm * SM * 32 + l31) * A_LD + kl;
             const float* Bb = (BMODE == 0) ? (Bs + cur * B_SZ + kl * B_LD + wn * SN * 32 + l31)
-                                           : (Bs + cur * B_SZ + (wn * SN * 32 + l31) * B_LD + kl);
+                                           : (Bs + cur * B_SZ + (wn * SN * 32 + l31) * B_LD);
+            const int bsw = (l31 >> 1) & 7;         // NK: chunk swizzle of this lane's rows (the same for every j)
             constexpr int FG = 4, NFG = BK / 2 / FG;
             float av[2][FG][SM], bv[2][FG][SN];
             auto fetch = [&](int g, int buf) {
@@ -671,6 +675,13 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                         av[buf][0][i] = v.x; av[buf][1][i] = v.y; av[buf][2][i] = v.z; av[buf][3][i] = v.w;
                     }
                 }
+                if (BMODE == 1) {       // K index of MFMA step kk on lane half lhi is 16*lhi + kk (as for A when AV): chunk 4*lhi + g
+#pragma unroll
+                    for (int j = 0; j < SN; ++j) {
+                        const float4 v = *reinterpret_cast<const float4*>(Bb + j * 32 * B_LD + (((lhi * 4 + g) ^ bsw) * 4));
+                        bv[buf][0][j] = v.x; bv[buf][1][j] = v.y; bv[buf][2][j] = v.z; bv[buf][3][j] = v.w;
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < FG; ++q) {
                     const int kk = g * FG + q;
@@ -678,9 +689,10 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
 #pragma unroll
                         for (int i = 0; i < SM; ++i) av[buf][q][i] = Ab[i * 32 * A_LD + kk * KS];
                     }
+                    if (BMODE == 0) {
 #pragma unroll
-                    for (int j = 0; j < SN; ++j)
-                        bv[buf][q][j] = (BMODE == 0) ? Bb[kk * KS * B_LD + j * 32] : Bb[j * 32 * B_LD + kk * KS];
+                        for (int j = 0; j < SN; ++j) bv[buf][q][j] = Bb[kk * KS * B_LD + j * 32];
+                    }
                 }
             };
             auto mfmas = [&](int g) {
@@ -934,10 +946,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     gview_src(d.d, b_c, b_base, b_cs);
     const int b_act = (b_c >= d.d.C0 && d.d.act1 >= 0) ? d.d.act1 : d.d.act;
 
-    const long nkt = (P + BK - 1) / BK;
-    const long per = (nkt + splitk - 1) / splitk;
-    const long kt_begin = ks * per;
-    const long kt_end = min(nkt, kt_begin + per);
+    // 32-bit K-tile arithmetic (the host checks P < 2^31 and every tensor < 2^29 elements: byte offsets fit 32 bits)
+    const int nkt = (int)((P + BK - 1) / BK);
+    const int per = (nkt + splitk - 1) / splitk;
+    const int kt_begin = ks * per;
+    const int kt_end = min(nkt, kt_begin + per);
 
     f32x16 acc[SM][SN];
 #pragma unroll
@@ -948,15 +961,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[A_SLOTS], rb[B_SLOTS];
-    float rav[A_SLOTS], rbv[B_SLOTS];
+    float rav[A_SLOTS];
     const float g_slope = act_slope(a_act), d_slope = act_slope(b_act);
 
-    // one thread per pixel of K-tile `kt` fills ptab[kt & 1] (threads 0..BK-1)
-    auto fill_ptab = [&](long kt) {
-        if (tid < BK) {
-            const long p = kt * BK + tid;
-            const bool pv = p < P;
-            const long pp = pv ? p : 0;
+    // one thread per pixel of K-tile `kt` fills ptab[kt & 1] (threads 0..BK-1): {byte offset of (n, iy0, ix0) in source 0,
+    // iy0, ix0, byte offset in source 1} with iy0 = py*stride + ioff_y (tap offsets are per-thread constants)
+    const int gC0b = d.g.C0 * 4, gC1b = d.g.C1 * 4;
+    const unsigned Pu = (unsigned)P;
+    auto fill_ptab = [&](int kt) {
+        // the waves take turns (K-tile kt is decoded by wave kt & 3): the decode is ~35 vector instructions that only
+        // 32 lanes need, and a wave that did it every step would be the one the barrier waits for
+        if ((wave == (kt & 3)) & (lane < BK)) {
+            const unsigned p = (unsigned)kt * BK + lane;
+            const bool pv = p < Pu;
+            const long pp = pv ? (long)p : 0;
             int n, py, px;
             if (mg.use32) {     // wave-uniform: numerators fit the 32-bit multiply-high
                 n = (int)__umulhi((unsigned)pp, mg.mPHPW32) + (int)((unsigned)pp & (unsigned)mg.onePHPW);
@@ -970,28 +988,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
                 px = rem - py * d.PW;
             }
             const int iy0 = py * d.in_stride + d.ioff_y, ix0 = px * d.in_stride + d.ioff_x;
+            const int pix = (n * d.g.H + iy0) * d.g.W + ix0;
             // an invalid pixel gets coordinates no tap can bring inside the image
-            ptab[(kt & 1) * BK + tid] = make_int4((n * d.g.H + iy0) * d.g.W + ix0, pv ? iy0 : -(1 << 20), ix0, 0);
+            ptab[(kt & 1) * BK + lane] = make_int4(pix * gC0b, pv ? iy0 : -(1 << 20), ix0, pix * gC1b);
         }
     };
-    const int a_tapoff = a_ty * d.g.W + a_tx;
+    // per-thread constants of the gathered side: which ptab word holds this thread's source offset, the tap's byte shift
+    const bool a_first = a_c < d.g.C0;
+    const int a_tapb = (a_ty * d.g.W + a_tx) * a_cs * 4;
+    const char* const a_bytes = reinterpret_cast<const char*>(a_base);
     const int gH = d.g.H, gW = d.g.W;
-    auto load_tile = [&](long kt) {
+    // dense side: rows beyond the last pixel are CLAMPED to it, not masked -- the gathered side of those rows is staged as
+    // zeros (ptab marks them invalid), so what they hold never reaches a sum; every load is unconditional and unmasked
+    const char* const b_bytes = reinterpret_cast<const char*>(b_base);
+    const unsigned b_rowb = (unsigned)b_cs * 4u;
+    const unsigned b_last = (unsigned)(P - 1) * b_rowb;
+    unsigned b_off[B_SLOTS];
+#pragma unroll
+    for (int s = 0; s < B_SLOTS; ++s) b_off[s] = (unsigned)(tid / (BN / 4) + B_RP * s) * b_rowb;
+    const unsigned b_step = (unsigned)BK * b_rowb;
+    auto load_tile = [&](int kt) {
 #pragma unroll
         for (int s = 0; s < A_SLOTS; ++s) {
             const int4 e = ptab[(kt & 1) * BK + tid / (BM / 4) + A_RP * s];
             const int iy = e.y + a_ty, ix = e.z + a_tx;
             const bool v = a_cv & ((unsigned)iy < (unsigned)gH) & ((unsigned)ix < (unsigned)gW);
-            const long pix = v ? (long)(e.x + a_tapoff) : 0;
+            const unsigned off = v ? (unsigned)((a_first ? e.x : e.w) + a_tapb) : 0u;
             rav[s] = v ? 1.f : 0.f;
-            ra[s] = *reinterpret_cast<const float4*>(a_base + pix * a_cs);
+            ra[s] = *reinterpret_cast<const float4*>(a_bytes + off);
         }
+        const unsigned kb = (unsigned)kt * b_step;
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
-            const long p = kt * BK + tid / (BN / 4) + B_RP * s;
-            const bool v = b_cv & (p < P);  // D lattice == its own pixel grid (d.d.H==PH, d.d.W==PW)
-            rbv[s] = v ? 1.f : 0.f;
-            rb[s] = *reinterpret_cast<const float4*>(b_base + (v ? p : 0) * b_cs);
+            const unsigned off = min(kb + b_off[s], b_last);
+            rb[s] = *reinterpret_cast<const float4*>(b_bytes + (b_cv ? off : 0u));
         }
     };
     auto store_tile = [&](int buf) {
@@ -1007,7 +1037,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
         for (int s = 0; s < B_SLOTS; ++s) {
             const int row = tid / (BN / 4) + B_RP * s;
             *reinterpret_cast<float4*>(Bb + row * B_LD + (tid % (BN / 4)) * 4) =
-                DPLAIN ? mask4(rb[s], rbv[s]) : xform4(rb[s], ba, bb, d_slope, rbv[s]);
+                DPLAIN ? rb[s] : xform4(rb[s], ba, bb, d_slope, 1.f);
         }
     };
 
@@ -1024,7 +1054,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
         fill_ptab(kt_begin + 2);
         __syncthreads();
         int cur = 0;
-        for (long kt = kt_begin; kt < kt_end; ++kt) {
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
             const float* Ab = As + cur * A_SZ + lhi * A_LD + wm * SM * 32 + l31;
             const float* Bb = Bs + cur * B_SZ + lhi * B_LD + wn * SN * 32 + l31;
             constexpr int FG = 4, NFG = BK / 2 / FG;
@@ -1137,6 +1167,12 @@ static void launch_wgrad_reduce(const float* ws, long count, int splitk, float* 
     }
 }
 
+#ifdef SSC_ISA_ONLY
+// scripts/isa_one.sh: compile a single instantiation to look at its ISA (the whole file takes over a minute)
+template __global__ void conv_ut_kernel<2, 2, 1, 2, 0, false, 0>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*);
+template __global__ void conv_ut_kernel<2, 2, 1, 2, 1, true, 0>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*);
+template __global__ void conv_wgrad_kernel<1, 4, 2, 1, false, true>(const ssc_wgrad_desc, const Magics, float*, long, int);
+#else
 // ---------------------------------------------------------------------------------------------
 // host launchers (C ABI)
 // ---------------------------------------------------------------------------------------------
@@ -1309,8 +1345,8 @@ static bool fwd_is_ut(const ssc_conv_desc& d) {
     const bool vec = fwd_is_vec(d);
     const int C = d.x.C0 + d.x.C1;
     return vec && (C % BK) == 0 && (d.x.C0 % BK) == 0 && d.k_real == C &&
-           (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x7fffffffL &&
-           (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
+           (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x1fffffffL &&
+           (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x1fffffffL;
 }
 
 // row-tap form (conv_ut_kernel<KM = 2>): plain single-source view, TW * C == 32, unflipped taps, vector filter loads
@@ -1322,8 +1358,8 @@ static bool fwd_is_rowtap(const ssc_conv_desc& d) {
     }
     return !off && d.bmode == 0 && d.nphase == 1 && d.kstep == 1 && d.kx0 == 0 && d.x.C1 == 0 && d.TW * d.x.C0 == BK &&
            d.TW == d.KW && d.k_real == d.x.C0 && d.wC0 == d.x.C0 && fwd_is_vec(d) && d.x.ab0 == nullptr &&
-           d.x.act == SSC_ACT_NONE && (long)d.NB * d.x.H * d.x.W * d.x.C0 < 0x7fffffffL &&
-           (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
+           d.x.act == SSC_ACT_NONE && (long)d.NB * d.x.H * d.x.W * d.x.C0 < 0x1fffffffL &&
+           (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x1fffffffL;
 }
 
 // chunked uniform-tap form (conv_ut_kernel<KMASK>): vector filter loads possible and at most 20 % of the K-tiles' width
@@ -1343,15 +1379,15 @@ static bool fwd_is_utg(const ssc_conv_desc& d) {
         waste = (e != nullptr) ? atof(e) : 1.2;
     }
     return !off && vec && d.k_real >= 1 && d.k_real <= C && (double)padded <= waste * (double)C &&
-           (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x7fffffffL &&
-           (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x7fffffffL;
+           (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x1fffffffL &&
+           (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x1fffffffL;
 }
 
 template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN, int KM>
 static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
     constexpr int A_SZ = BM * (UT_AV(BM, BN) ? BK + 4 : BK + 1);
-    constexpr int B_SZ = (BMODE == 0) ? BK * BN : BN * (BK + 1);
+    constexpr int B_SZ = BK * BN;
     constexpr size_t lds = 2 * (A_SZ + B_SZ) * sizeof(float) + BM * sizeof(long);
     const long M = (long)d.NB * d.PH * d.PW;
     const int C = d.x.C0 + d.x.C1;
@@ -1602,3 +1638,4 @@ extern "C" int ssc_conv_wgrad(const ssc_wgrad_desc* dp, float* ws, int64_t ws_by
         default: return -4;
     }
 }
+#endif  // SSC_ISA_ONLY
