@@ -79,6 +79,8 @@ typedef struct ssc_conv_desc {
     int32_t out_stride, ooff_y, ooff_x; /* oy = py*out_stride + ooff_y */
     int32_t epi;          /* 0 none, 1 tanh (models_collection.py:533), 2 lrelu 0.2 (MRU gates, mru.py:407-413) */
     int32_t accumulate;   /* 1: out += result */
+    float* stat_partial;  /* set by ssc_conv_forward_bn (callers leave it NULL): per row tile [2][Nstore] sums / sums of squares
+                             of the output columns, written by the epilogue */
     uint32_t* sk_flags;   /* stream-K hand-off flags (device): SSC_SK_FLAG_WORDS words, zero before the first launch that
                              uses them and private to the launch stream (the kernel leaves them zero); NULL = the launch
                              may not split tiles across workgroups inside the kernel (split-K slabs + reduce kernel instead) */
@@ -111,6 +113,11 @@ int ssc_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
 /* implicit GEMM (igemm.hip).  ws: split-K slab workspace (may be NULL). */
 int ssc_conv_forward(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, void* stream);
 int ssc_conv_wgrad(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void* stream);
+/* conv + the batch-statistics norm of its output [M*nphase rows, Nstore == ldc columns] folded to ab = [a; b] (y = a*x + b)
+ * and stats = [mean; rstd] (models_collection.py:36-46 after :389 / :402): the column sums come out of the conv epilogue
+ * when the launch allows it, else ssc_bn_stats reads the output back */
+int ssc_conv_forward_bn(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, const float* scale, const float* offset,
+                        float eps, float* ab, float* stats, void* stream);
 /* direct (vector-ALU, LDS patch) form for <= 4 output channels; ssc_conv_forward dispatches to it (narrow.hip) */
 int ssc_conv_narrow_supported(const ssc_conv_desc* d);
 int ssc_conv_narrow_forward(const ssc_conv_desc* d, void* stream);
@@ -227,6 +234,9 @@ int ssc_residual_merge(const float* x1, const float* ab1, const float* x2, const
  * scale/offset into ab=[a;b] (y = a*x+b); stats = [mean; rstd].  ws >= nblk*2*C floats. */
 int ssc_bn_stats(const float* x, int64_t M, int C, int ldx, const float* scale, const float* offset,
                  float eps, float* ab, float* stats, float* ws, int64_t ws_bytes, void* stream);
+/* the second half of ssc_bn_stats: partial [nblk][2][C] column sums / sums of squares over M rows -> ab, stats */
+int ssc_bn_finalize(const float* partial, int nblk, int C, int64_t M, const float* scale, const float* offset, float eps,
+                    float* ab, float* stats, void* stream);
 /*
  * Backward of y = act(a*x+b) for up to two consumers (g1 through act1, g2
  * through act2):  dz = g1*act1'(z) + g2*act2'(z).

@@ -408,6 +408,13 @@ extern "C" int ssc_bn_stats(const float* x, int64_t M, int C, int ldx, const flo
     return CHECK_LAUNCH();
 }
 
+extern "C" int ssc_bn_finalize(const float* partial, int nblk, int C, int64_t M, const float* scale, const float* offset,
+                               float eps, float* ab, float* stats, void* stream) {
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
+                       (long)M, scale, offset, eps, ab, stats);
+    return CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ column sums (bias gradients, mru.py:128-132)
 // the float4 row-strided partial kernel above, folded per channel in double by one wavefront
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partial, int nblk, int Cv, int C,

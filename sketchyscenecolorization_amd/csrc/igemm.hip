@@ -810,6 +810,11 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         const int epi = final_pass ? d.epi : 0;
         const bool accum = final_pass && d.accumulate != 0;
         const int Nn = d.Nn, Nst = d.Nstore, ldc = d.ldc;
+        // batch-statistics norm of this layer's output (models_collection.py:36-46): per-column sum and sum of squares of the
+        // tile, taken here from the values on their way out instead of by a second pass over the tensor; one row of
+        // partials per row tile, folded per channel by bn_stats_finalize (ssc_conv_forward_bn)
+        float* const stat = final_pass ? d.stat_partial : nullptr;
+        float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
 #pragma unroll
         for (int p = 0; p < BM * BN / 1024; ++p) {
             const int e = p * 256 + tid;
@@ -823,6 +828,8 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                     v.x += col + 0 < Nn ? bias[col + 0] : 0.f; v.y += col + 1 < Nn ? bias[col + 1] : 0.f;
                     v.z += col + 2 < Nn ? bias[col + 2] : 0.f; v.w += col + 3 < Nn ? bias[col + 3] : 0.f;
                 }
+                ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
+                ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
                 if (epi == 1) {
                     v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
                 } else if (epi == 2) {
@@ -835,6 +842,32 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                     v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
                 }
                 *o = v;
+            }
+        }
+        if (stat != nullptr) {
+            // thread t holds columns 4*(t % (BN/4)).. of the rows t / (BN/4) + k*1024/BN: fold the 1024/BN row groups in a
+            // fixed order through LDS (behind the C tile), one writer per column group
+            constexpr int CG = BN / 4, RG = 256 / CG;
+            static_assert(BM * C_LD + 2 * 256 * 4 <= 2 * (A_SZ + B_SZ) || BM * BN >= 128 * 128, "reduction scratch behind the C tile");
+            float4* red = reinterpret_cast<float4*>(smem + BM * C_LD);
+            red[tid] = ssum;
+            red[256 + tid] = ssq;
+            __syncthreads();
+            if (tid < CG) {
+                float4 s = red[tid], q = red[256 + tid];
+#pragma unroll
+                for (int g = 1; g < RG; ++g) {
+                    const float4 a = red[g * CG + tid], c = red[256 + g * CG + tid];
+                    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+                    q.x += c.x; q.y += c.y; q.z += c.z; q.w += c.w;
+                }
+                const int col = n0 + tid * 4;
+                if (col < Nst) {
+                    const long blk = (long)phase * ((M + BM - 1) / BM) + m0 / BM;
+                    float* sp = stat + blk * 2 * Nst;
+                    *reinterpret_cast<float4*>(sp + col) = s;
+                    *reinterpret_cast<float4*>(sp + Nst + col) = q;
+                }
             }
         }
         return;
@@ -1480,6 +1513,55 @@ extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, 
     const Plan p = plan_fwd(*dp, (int64_t)1 << 40, true);
     copy_name(names[dp->bmode ? 1 : 0][p.cfg < 0 ? 0 : p.cfg], buf, len);
     return 0;
+}
+
+// elementwise.hip
+extern "C" int ssc_bn_stats(const float* x, int64_t M, int C, int ldx, const float* scale, const float* offset, float eps,
+                            float* ab, float* stats, float* ws, int64_t ws_bytes, void* stream);
+extern "C" int ssc_bn_finalize(const float* partial, int nblk, int C, int64_t M, const float* scale, const float* offset,
+                               float eps, float* ab, float* stats, void* stream);
+
+// conv + batch-statistics norm fold of its output.  When the launch finishes every output tile in one workgroup with the
+// vector epilogue (uniform-tap kernel, no split-K slabs, 16-byte aligned rows, not the 128x128 tile whose C image leaves no
+// LDS for the reduction) the per-column sums come out of the conv epilogue; otherwise the output is read back once.
+extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, const float* scale,
+                                   const float* offset, float eps, float* ab, float* stats, void* stream) {
+    ssc_conv_desc d = *dp;
+    d.stat_partial = nullptr;
+    const long M = (long)d.NB * d.PH * d.PW;
+    const long Mall = M * d.nphase;
+    static int off = -1;        // SSC_FUSE_STATS=0: always the separate pass (A/B)
+    if (off < 0) {
+        const char* e = getenv("SSC_FUSE_STATS");
+        off = (e != nullptr && e[0] == '0') ? 1 : 0;
+    }
+    bool fused = false;
+    int64_t ws_conv = ws_bytes;
+    if (!off && ws != nullptr && !ssc_conv_narrow_supported(dp) && d.epi == 0 && !d.accumulate && d.Nstore == d.ldc &&
+        ((d.Nstore & 3) == 0) && ((reinterpret_cast<unsigned long>(d.out) & 15) == 0) &&
+        (fwd_is_ut(d) || fwd_is_utg(d) || (d.bmode == 0 && fwd_is_rowtap(d)))) {
+        const Plan p = plan_fwd(d, ws_bytes, true);
+        if (p.cfg > 0 && p.splitk == 1) {
+            const long mt = (M + FWD_CFGS[p.cfg].BM - 1) / FWD_CFGS[p.cfg].BM;
+            const int64_t need = (int64_t)mt * d.nphase * 2 * d.Nstore * 4;
+            if (need * 4 <= ws_bytes) {     // the partial rows sit at the end of the workspace, the conv keeps the rest
+                ws_conv = (ws_bytes - need) & ~(int64_t)255;
+                const Plan p2 = plan_fwd(d, ws_conv, true);
+                if (p2.cfg == p.cfg && p2.splitk == 1) {
+                    d.stat_partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_conv);
+                    fused = true;
+                    const int rc = ssc_conv_forward(&d, ws, ws_conv, stream);
+                    if (rc != 0) return rc;
+                    return ssc_bn_finalize(d.stat_partial, (int)(mt * d.nphase), d.Nstore, Mall, scale, offset, eps, ab, stats,
+                                           stream);
+                }
+            }
+        }
+    }
+    (void)fused;
+    const int rc = ssc_conv_forward(&d, ws, ws_bytes, stream);
+    if (rc != 0) return rc;
+    return ssc_bn_stats(d.out, Mall, d.Nstore, d.ldc, scale, offset, eps, ab, stats, ws, ws_bytes, stream);
 }
 
 extern "C" int ssc_conv_forward_plan(const ssc_conv_desc* dp, int64_t ws_bytes, int* out5) {

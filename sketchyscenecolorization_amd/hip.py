@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
                 ('bmode', C.c_int32), ('k_real', C.c_int32), ('n_off', C.c_int32), ('Nn', C.c_int32),
                 ('Nstore', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32), ('ldc', C.c_int32),
                 ('out_stride', C.c_int32), ('ooff_y', C.c_int32), ('ooff_x', C.c_int32),
-                ('epi', C.c_int32), ('accumulate', C.c_int32), ('sk_flags', C.c_void_p)]
+                ('epi', C.c_int32), ('accumulate', C.c_int32), ('stat_partial', C.c_void_p), ('sk_flags', C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -66,6 +66,8 @@ SIGNATURES = {
     'ssc_device_info': [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, _I],
     'ssc_conv_forward': [C.POINTER(ConvDesc), _P, _L, _P],
     'ssc_conv_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
+    'ssc_conv_forward_bn': [C.POINTER(ConvDesc), _P, _L, _P, _P, _F, _P, _P, _P],
+    'ssc_bn_finalize': [_P, _I, _I, _L, _P, _P, _F, _P, _P, _P],
     'ssc_conv_narrow_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_narrow_forward': [C.POINTER(ConvDesc), _P],
     'ssc_conv_forward_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, _I],
@@ -261,16 +263,27 @@ def sk_timeouts():
     return sum(int(f[-1].item() != 0) for f in _sk_flags.values())
 
 
-def _run_conv(d):
+def _run_conv(d, bn=None):
+    """bn = (scale, offset, ab, stats[, eps]): also fold the batch-statistics norm of the conv's output (the whole
+    [rows, ldc] output must be the normed tensor)."""
     ws = workspace()
     d.sk_flags = sk_flags().data_ptr() if SK_ENABLED else None
+
+    def launch():
+        if bn is None:
+            check(lib().ssc_conv_forward(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_forward')
+        else:
+            eps = bn[4] if len(bn) > 4 else 1e-5
+            check(lib().ssc_conv_forward_bn(C.byref(d), ptr(ws), ws.numel() * 4, ptr(bn[0]), ptr(bn[1]), eps, ptr(bn[2]),
+                                            ptr(bn[3]), stream_ptr()), 'ssc_conv_forward_bn')
+
     if PROFILE is None:
-        check(lib().ssc_conv_forward(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_forward')
+        launch()
         return
     flops = 2.0 * d.NB * d.PH * d.PW * d.nphase * d.TH * d.TW * d.k_real * d.Nn
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib().ssc_conv_forward(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_forward')
+    launch()
     e1.record()
     # algorithmic HBM bytes (DESIGN 3): every input element, filter element and output element once
     nbytes = 4.0 * (d.NB * d.x.H * d.x.W * (d.x.C0 + d.x.C1) + d.nphase * d.TH * d.TW * d.k_real * d.Nn +
@@ -315,7 +328,7 @@ def same_pad_before(size, k, stride):
     return max((out - 1) * stride + k - size, 0) // 2
 
 
-def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, accumulate=False, same=False):
+def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, accumulate=False, same=False, bn=None):
     """tf.pad + tf.nn.conv2d(VALID): x View, w [KH,KW,Cin_real,Cout] -> out[..., coff:coff+Cout].
     same=True: tf.nn.conv2d(padding='SAME') -- output ceil(in/stride), asymmetric pad (mru.py:125, conv_ex)."""
     KH, KW, ci, co = w.shape
@@ -337,10 +350,20 @@ def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, 
     d.n_off, d.Nn, d.Nstore = 0, co, (nstore if nstore is not None else co)
     d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 1, 0, 0
     d.epi, d.accumulate = epi, int(accumulate)
-    _run_conv(d)
+    _run_conv(d, _bn_arg(bn, d, coff, out))
 
 
-def deconv_forward(x, f, out, coff=0, nstore=None, epi=0):
+def _bn_arg(bn, d, coff, out):
+    """The fused conv + norm entry covers the plain case (the conv fills whole rows of ``out``); anything else keeps the two
+    calls apart."""
+    if bn is None:
+        return None
+    assert coff == 0 and d.Nstore == out.shape[3] == bn[0].numel() and bn[2].numel() == 2 * d.Nstore, \
+        (coff, d.Nstore, out.shape, bn[0].shape)
+    return bn
+
+
+def deconv_forward(x, f, out, coff=0, nstore=None, epi=0, bn=None):
     """tf.nn.conv2d_transpose(k=4, s=2, SAME): x View [N,H,W,Cin], f [4,4,Cout,Cin] -> out [N,2H,2W,*]."""
     KH, KW, co, ci = f.shape
     assert KH == 4 and KW == 4 and ci <= x.C        # ci < x.C: 3-channel tensors padded to 4 (BG region branch)
@@ -356,7 +379,7 @@ def deconv_forward(x, f, out, coff=0, nstore=None, epi=0):
     d.n_off, d.Nn, d.Nstore = 0, co, (nstore if nstore is not None else co)
     d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 2, 0, 0
     d.epi, d.accumulate = epi, 0
-    _run_conv(d)
+    _run_conv(d, _bn_arg(bn, d, coff, out))
 
 
 def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=None, accumulate=False):

@@ -56,12 +56,12 @@ class Pix2PixGenerator(object):
             if k == 1:
                 hip.conv_forward(View(xs), s['generator/encoder_1/conv/filter'], 2, 1, e[1])
             else:
-                hip.conv_forward(View(e[k - 1], None, ab[k - 1], ACT_LRELU), s['generator/encoder_%d/conv/filter' % k],
-                                 2, 1, e[k])
                 ab[k] = B.get(tag + '/ab_e%d' % k, (2 * chans[k],))
                 st[k] = B.get(tag + '/st_e%d' % k, (2 * chans[k],))
-                hip.bn_stats(_rows(e[k]), s['generator/encoder_%d/scale' % k], s['generator/encoder_%d/offset' % k],
-                             ab[k], st[k])
+                # conv + batch statistics of its output in one launch (the sums come out of the conv epilogue)
+                hip.conv_forward(View(e[k - 1], None, ab[k - 1], ACT_LRELU), s['generator/encoder_%d/conv/filter' % k],
+                                 2, 1, e[k], bn=(s['generator/encoder_%d/scale' % k], s['generator/encoder_%d/offset' % k],
+                                                 ab[k], st[k]))
         ctx = {'tag': tag, 'N': N, 'H': H, 'W': W, 'xs': xs, 'e': e, 'ab': ab, 'st': st, 'noise_vec': noise_vec}
         hh, ww = e[5].shape[1], e[5].shape[2]
         P = hh * ww
@@ -91,11 +91,10 @@ class Pix2PixGenerator(object):
                 v = View(d[k + 1], e[k], abd[k + 1], ACT_RELU, ab[k])
             views[k] = v
             d[k] = B.get(tag + '/d%d' % k, (N, 2 * v.H, 2 * v.W, dch[k]))
-            hip.deconv_forward(v, s['generator/decoder_%d/deconv/filter' % k], d[k])
             abd[k] = B.get(tag + '/ab_d%d' % k, (2 * dch[k],))
             std[k] = B.get(tag + '/st_d%d' % k, (2 * dch[k],))
-            hip.bn_stats(_rows(d[k]), s['generator/decoder_%d/scale' % k], s['generator/decoder_%d/offset' % k],
-                         abd[k], std[k])
+            hip.deconv_forward(v, s['generator/decoder_%d/deconv/filter' % k], d[k],
+                               bn=(s['generator/decoder_%d/scale' % k], s['generator/decoder_%d/offset' % k], abd[k], std[k]))
         v1 = View(d[2], e[1], abd[2], ACT_RELU, None)
         views[1] = v1
         if out is None:
@@ -264,13 +263,13 @@ class Pix2PixDiscriminator(object):
                 v = View(l[1], None, None, ACT_LRELU)
             else:
                 v = View(l[k - 1], None, ab[k - 1], ACT_LRELU)
-            hip.conv_forward(v, s['discriminator/layer_%d/conv/filter' % k], self.strides[k], 1, l[k],
-                             nstore=(4 if k == 5 else None))
+            bn = None
             if 2 <= k <= 4:
                 ab[k] = B.get(tag + '/ab%d' % k, (2 * co,))
                 st[k] = B.get(tag + '/st%d' % k, (2 * co,))
-                hip.bn_stats(_rows(l[k]), s['discriminator/layer_%d/scale' % k], s['discriminator/layer_%d/offset' % k],
-                             ab[k], st[k])
+                bn = (s['discriminator/layer_%d/scale' % k], s['discriminator/layer_%d/offset' % k], ab[k], st[k])
+            hip.conv_forward(v, s['discriminator/layer_%d/conv/filter' % k], self.strides[k], 1, l[k],
+                             nstore=(4 if k == 5 else None), bn=bn)
         P4 = l[4].shape[1] * l[4].shape[2]
         img = B.get(tag + '/img', (N, 512))
         hip.call('ssc_act_mean_hw', l[4], ab[4], ACT_LRELU, N, P4, 512, img)

@@ -51,11 +51,11 @@ class _Bottlenecks(object):
         self.s, self.b = store, bufs
 
     # ------------------------------------------------------------------ forward pieces
-    def _bn(self, tag, pre, raw, c_real=None):
-        """Batch statistics of ``raw`` folded with scale/offset -> (ab [2*C], stats [2*C]).  c_real < C: the
-        tensor is channel padded and the affine of the pad channels is (0, 0)."""
+    def _bn_prep(self, tag, pre, C, c_real=None):
+        """(scale, offset, ab [2*C], stats [2*C]) of the norm ``pre`` over a C-channel tensor: the ``bn=`` argument of the
+        conv that produces the tensor (hip.conv_forward / deconv_forward fold the batch statistics in their epilogue).
+        c_real < C: the tensor is channel padded and the affine of the pad channels is (0, 0)."""
         s, B = self.s, self.b
-        C = raw.shape[-1]
         scale, offset = s[pre + '/scale'], s[pre + '/offset']
         if c_real is not None and c_real != C:
             sp = B.get(tag + '/' + pre + '/scale_p', (C,), zero_on_alloc=True)
@@ -65,20 +65,21 @@ class _Bottlenecks(object):
             scale, offset = sp, op
         ab = B.get(tag + '/' + pre + '/ab', (2 * C,))
         st = B.get(tag + '/' + pre + '/st', (2 * C,))
-        hip.bn_stats(_rows(raw), scale, offset, ab, st)
-        return ab, st
+        return scale, offset, ab, st
 
-    def _tail(self, tag, pre, r1, c4, cout, act, rec):
-        """block_2 (3x3 SAME) and block_3 (1x1) of every bottleneck; r1 = raw block_1 output."""
+    def _tail(self, tag, pre, r1, bn1, c4, cout, act, rec):
+        """block_2 (3x3 SAME) and block_3 (1x1) of every bottleneck; r1 = raw block_1 output, bn1 its folded norm."""
         s, B = self.s, self.b
         N, h, w, _ = r1.shape
-        ab1, st1 = self._bn(tag, pre + '/block_1/batchnorm', r1)
+        ab1, st1 = bn1[2], bn1[3]
         r2 = B.get(tag + '/' + pre + '/r2', (N, h, w, c4))
-        hip.conv_forward(View(r1, None, ab1, act), s[pre + '/block_2/conv_ex/filter'], 1, 0, r2, same=True)
-        ab2, st2 = self._bn(tag, pre + '/block_2/batchnorm', r2)
+        bn2 = self._bn_prep(tag, pre + '/block_2/batchnorm', c4)
+        hip.conv_forward(View(r1, None, ab1, act), s[pre + '/block_2/conv_ex/filter'], 1, 0, r2, same=True, bn=bn2)
+        ab2, st2 = bn2[2], bn2[3]
         r3 = B.get(tag + '/' + pre + '/r3', (N, h, w, cout))
-        hip.conv_forward(View(r2, None, ab2, act), s[pre + '/block_3/conv_ex/filter'], 1, 0, r3, same=True)
-        ab3, st3 = self._bn(tag, pre + '/block_3/batchnorm', r3)
+        bn3 = self._bn_prep(tag, pre + '/block_3/batchnorm', cout)
+        hip.conv_forward(View(r2, None, ab2, act), s[pre + '/block_3/conv_ex/filter'], 1, 0, r3, same=True, bn=bn3)
+        ab3, st3 = bn3[2], bn3[3]
         rec.update(r1=r1, ab1=ab1, st1=st1, r2=r2, ab2=ab2, st2=st2, r3=r3, ab3=ab3, st3=st3)
         return r3, ab3
 
@@ -98,11 +99,13 @@ class _Bottlenecks(object):
         N, h, w = xv.N, xv.H // 2, xv.W // 2
         rec = {'kind': 'en', 'srcs': srcs, 'xv': xv}
         r1 = B.get(tag + '/' + pre + '/r1', (N, h, w, c4))
-        hip.conv_forward(xv, s[pre + '/block_1/conv/filter'], 2, 1, r1)
-        r3, ab3 = self._tail(tag, pre, r1, c4, cout, ACT_LRELU, rec)
+        bn1 = self._bn_prep(tag, pre + '/block_1/batchnorm', c4)
+        hip.conv_forward(xv, s[pre + '/block_1/conv/filter'], 2, 1, r1, bn=bn1)
+        r3, ab3 = self._tail(tag, pre, r1, bn1, c4, cout, ACT_LRELU, rec)
         sc = B.get(tag + '/' + pre + '/sc', (N, h, w, cout))
-        hip.conv_forward(xv, s[pre + '/block_add/conv/filter'], 2, 1, sc)
-        absc, stsc = self._bn(tag, pre + '/block_add/batchnorm', sc)
+        bnsc = self._bn_prep(tag, pre + '/block_add/batchnorm', cout)
+        hip.conv_forward(xv, s[pre + '/block_add/conv/filter'], 2, 1, sc, bn=bnsc)
+        absc, stsc = bnsc[2], bnsc[3]
         rec.update(sc=sc, absc=absc, stsc=stsc)
         return self._merge(tag, pre, r3, ab3, sc, absc, ACT_LRELU, rec)
 
@@ -114,11 +117,13 @@ class _Bottlenecks(object):
         N, h, w = xv.N, xv.H * 2, xv.W * 2
         rec = {'kind': 'de', 'srcs': srcs, 'xv': xv}
         r1 = B.get(tag + '/' + pre + '/r1', (N, h, w, c4))
-        hip.deconv_forward(xv, s[pre + '/block_1/deconv/filter'], r1)
-        r3, ab3 = self._tail(tag, pre, r1, c4, cout, ACT_RELU, rec)
+        bn1 = self._bn_prep(tag, pre + '/block_1/batchnorm', c4)
+        hip.deconv_forward(xv, s[pre + '/block_1/deconv/filter'], r1, bn=bn1)
+        r3, ab3 = self._tail(tag, pre, r1, bn1, c4, cout, ACT_RELU, rec)
         sc = B.get(tag + '/' + pre + '/sc', (N, h, w, cout))
-        hip.deconv_forward(xv, s[pre + '/block_add/deconv/filter'], sc)
-        absc, stsc = self._bn(tag, pre + '/block_add/batchnorm', sc)
+        bnsc = self._bn_prep(tag, pre + '/block_add/batchnorm', cout)
+        hip.deconv_forward(xv, s[pre + '/block_add/deconv/filter'], sc, bn=bnsc)
+        absc, stsc = bnsc[2], bnsc[3]
         rec.update(sc=sc, absc=absc, stsc=stsc)
         return self._merge(tag, pre, r3, ab3, sc, absc, ACT_RELU, rec)
 
@@ -129,8 +134,9 @@ class _Bottlenecks(object):
         c4 = c // 4
         rec = {'kind': 'pu', 'srcs': (x,), 'xv': _view(x)}
         r1 = B.get(tag + '/' + pre + '/r1', (N, h, w, c4))
-        hip.conv_forward(rec['xv'], s[pre + '/block_1/conv_ex/filter'], 1, 0, r1, same=True)
-        r3, ab3 = self._tail(tag, pre, r1, c4, c, act, rec)
+        bn1 = self._bn_prep(tag, pre + '/block_1/batchnorm', c4)
+        hip.conv_forward(rec['xv'], s[pre + '/block_1/conv_ex/filter'], 1, 0, r1, same=True, bn=bn1)
+        r3, ab3 = self._tail(tag, pre, r1, bn1, c4, c, act, rec)
         return self._merge(tag, pre, r3, ab3, x.t, None, act, rec)
 
     # ------------------------------------------------------------------ backward pieces
@@ -283,8 +289,9 @@ class ResidualGenerator(_Bottlenecks):
         assert H % 32 == 0 and W % 32 == 0
         # encoder_1: conv 7x7 s2 SAME + norm + lrelu (applied by the consumers)
         e1 = B.get(tag + '/e1', (N, H // 2, W // 2, size))
-        hip.conv_forward(View(xs), s['generator/encoder_1/conv_ex/filter'], 2, 0, e1, same=True)
-        ab_e1, st_e1 = self._bn(tag, top_bn('generator/encoder_1'), e1)
+        bne1 = self._bn_prep(tag, top_bn('generator/encoder_1'), size)
+        hip.conv_forward(View(xs), s['generator/encoder_1/conv_ex/filter'], 2, 0, e1, same=True, bn=bne1)
+        ab_e1, st_e1 = bne1[2], bne1[3]
         layers = [_Val(e1, ab_e1, ACT_LRELU, st_e1, top_bn('generator/encoder_1'))]
         enc_c = [size, size * 2, size * 4, size * 8, top]
         for k in range(2, 6):
@@ -315,9 +322,10 @@ class ResidualGenerator(_Bottlenecks):
             first = (featv,)
             # region_br_projection: 1x1 conv 1024 -> seg + norm + relu
             rp = B.get(tag + '/reg_p', (N, hh, ww, 4), zero_on_alloc=True)
+            bnp = self._bn_prep(tag, 'generator/region_br_projection/batchnorm', 4, self.seg)
             hip.conv_forward(_view(layers[-1]), s['generator/region_br_projection/conv_ex/filter'], 1, 0, rp, nstore=4,
-                             same=True)
-            abp, stp = self._bn(tag, 'generator/region_br_projection/batchnorm', rp, self.seg)
+                             same=True, bn=bnp)
+            abp, stp = bnp[2], bnp[3]
             reg = _Val(rp, abp, ACT_RELU, stp, 'generator/region_br_projection/batchnorm')
             ctx['region'] = [reg]
         dec_out = {5: size * 8, 4: size * 4, 3: size * 2, 2: size}
@@ -335,8 +343,9 @@ class ResidualGenerator(_Bottlenecks):
         # decoder_1: deconv(concat[decoder_2, encoder_1]) + norm + tanh
         d1 = B.get(tag + '/d1', (N, H, W, 4))
         v1 = _view(layers[-1], layers[0])
-        hip.deconv_forward(v1, s['generator/decoder_1/deconv/filter'], d1, nstore=4)
-        ab1, st1 = self._bn(tag, top_bn('generator/decoder_1'), d1, 3)
+        bnd1 = self._bn_prep(tag, top_bn('generator/decoder_1'), 4, 3)
+        hip.deconv_forward(v1, s['generator/decoder_1/deconv/filter'], d1, nstore=4, bn=bnd1)
+        ab1, st1 = bnd1[2], bnd1[3]
         ctx.update(layers=layers, feat=feat, d1=d1, ab_d1=ab1, st_d1=st1, v1=v1, tape=self._tape,
                    bn_d1=top_bn('generator/decoder_1'))
         if self.fg:
@@ -360,8 +369,9 @@ class ResidualGenerator(_Bottlenecks):
         """region_br_k: deconv seg->seg + norm + relu (bg_colorization_main.py:392-397, 411-416)."""
         N, h, w, _ = reg.t.shape
         r = self.b.get(tag + '/reg_%d' % k, (N, 2 * h, 2 * w, 4), zero_on_alloc=True)
-        hip.deconv_forward(_view(reg), self.s['generator/region_br_%d/deconv/filter' % k], r, nstore=4)
-        ab, st = self._bn(tag, 'generator/region_br_%d/batchnorm' % k, r, self.seg)
+        bnr = self._bn_prep(tag, 'generator/region_br_%d/batchnorm' % k, 4, self.seg)
+        hip.deconv_forward(_view(reg), self.s['generator/region_br_%d/deconv/filter' % k], r, nstore=4, bn=bnr)
+        ab, st = bnr[2], bnr[3]
         return _Val(r, ab, ACT_RELU, st, 'generator/region_br_%d' % k)
 
     def output_nchw(self, ctx):
