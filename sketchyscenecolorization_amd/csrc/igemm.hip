@@ -26,6 +26,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 int ssc_conv_narrow_forward_ws(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, void* stream, int* csplit_out);
 
 #define BK 32
+#ifndef SSC_BDMA
+#define SSC_BDMA 1       // filter tiles of conv_ut_kernel by LDS-DMA (global_load_lds) instead of through registers
+#endif
 #ifndef SSC_UT_SGB
 #define SSC_UT_SGB 1     // sched_group_barrier interleave hints in conv_ut_kernel (+1-2 % over the compiler's own order)
 #endif
@@ -397,6 +400,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ssc_conv_desc d, co
     }
 }
 
+// One LDS-DMA instruction: 16 bytes per lane from sbase (wave-uniform) + voff straight into LDS at lds_addr + 16 * lane.
+// Inline asm, not __builtin_amdgcn_global_load_lds: behind the builtin hipcc waits vmcnt(0) before the next ds_read (it
+// assumes the DMA's LDS write may alias it), which would expose the DMA's whole latency in every K step.  M0 (the LDS
+// destination) is saved and restored inside the statement; the completion is counted by hand (s_waitcnt vmcnt(N) before the
+// barrier that publishes the tile).
+__device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
 // uniform-tap form with the staging of later K-tiles interleaved into the MFMA stream of the same wave
 // ---------------------------------------------------------------------------------------------
@@ -427,6 +443,12 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     // K-tile are then contiguous, 4 ds_read_b128 instead of 16 ds_read_b32 per row block, and each staged float4 is one
     // ds_write_b128.  Not for the 128-row x <=64-column tiles, whose 3 workgroups per CU would no longer fit the LDS.
     constexpr bool KMASK = (KM == 1), ROWTAP = (KM == 2);
+    // BDMA: the filter tile goes global memory -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave instruction, lane L
+    // lands at +16 L), no staging registers, no ds_write, no vector ALU work per K-tile.  A wave instruction covers
+    // 256 / BN consecutive k rows of the [k][n] image (KN) or 8 rows of the swizzled [n][32] image (NK: each lane fetches the
+    // 16-byte chunk whose swizzled position is its own slot).  Not with KMASK, whose partial chunks need zeroed rows.
+    constexpr bool BDMA = SSC_BDMA && !KMASK;
+    constexpr int B_IPW = BK * BN / 1024;          // DMA instructions per wave and K-tile
     constexpr bool AV = UT_AV(BM, BN);
     constexpr int A_LD = AV ? BK + 4 : BK + 1;
     constexpr int A_SZ = BM * A_LD;
@@ -554,6 +576,23 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         }
     }
 
+    unsigned bd_off[B_IPW];     // BDMA: this lane's byte offset inside the filter for each of its wave's instructions
+    if (BDMA) {
+#pragma unroll
+        for (int q = 0; q < B_IPW; ++q) {
+            const int ins = wave * B_IPW + q;
+            if (BMODE == 0) {
+                constexpr int RPI = 256 / BN;           // k rows per instruction
+                const int r = ins * RPI + lane / (BN / 4), n = n0 + (lane % (BN / 4)) * 4;
+                bd_off[q] = n < d.Nn ? (unsigned)((r * wC1 + d.n_off + n) * 4) : (unsigned)(r * wC1 * 4);
+            } else {
+                const int r = ins * 8 + (lane >> 3), n = n0 + r;
+                const int c = (lane & 7) ^ ((r >> 1) & 7);      // the chunk whose swizzled slot is lane & 7
+                bd_off[q] = n < d.Nn ? (unsigned)(((d.n_off + n) * wC1 + c * 4) * 4) : (unsigned)(c * 16);
+            }
+        }
+    }
+
     const int nkt = d.TH * d.TW * tpt;
     const int per = (nkt + sk - 1) / sk;
     const int kt_begin = ks * per;
@@ -610,6 +649,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             rav[i] = v ? 1.f : 0.f;
             ra[i] = *reinterpret_cast<const float4*>(sbase + off);
         }
+        if (BDMA) return;
         const int ky = ph.ky0 + ty * kstep, kx = ph.kx0 + tx * kstep;
         const char* wtap = reinterpret_cast<const char*>((BMODE == 0) ? wbase + ((long)(ky * KWv + kx) * wC0 + cchf) * wC1
                                                                       : wbase + (long)(ky * KWv + kx) * wC0 * wC1 + cchf);
@@ -625,6 +665,21 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         }
     };
 
+    // BDMA: filter K-tile kt straight into LDS buffer `buf`
+    auto dma_b = [&](int kt, int buf) {
+        const int tap = div32(kt, mg.mC, mg.oneC);
+        const int chunk = kt - tap * tpt;
+        const int ty = div32(tap, mg.mTW, mg.oneTW), tx = tap - ty * TWv;
+        const int cch = ROWTAP ? 0 : (chunk < nch0 ? chunk * BK : xC0 + (chunk - nch0) * BK);
+        const int ky = ph.ky0 + ty * kstep, kx = ph.kx0 + tx * kstep;
+        const char* wtap = reinterpret_cast<const char*>((BMODE == 0) ? wbase + ((long)(ky * KWv + kx) * wC0 + cch) * wC1
+                                                                      : wbase + (long)(ky * KWv + kx) * wC0 * wC1 + cch);
+        // LDS byte address of this wave's first slot (the dynamic LDS segment starts at 0: the kernel has no static LDS)
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(((Bs - smem) + buf * B_SZ + wave * B_IPW * 256) * 4));
+#pragma unroll
+        for (int q = 0; q < B_IPW; ++q) glds16(wtap, bd_off[q], dst + q * 1024);
+    };
+
     auto stage = [&](int buf) {
         float* Ab = As + buf * A_SZ;
         float* Bb = Bs + buf * B_SZ;
@@ -638,6 +693,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                 p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
             }
         }
+        if (BDMA) return;
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
             const float4 v = KMASK ? mask4(rb[s], rbv[s]) : rb[s];
@@ -651,9 +707,11 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
 
     if (kt_begin < kt_end) {
         const int last = kt_end - 1;
+        if (BDMA) dma_b(kt_begin, 0);
         issue_loads(kt_begin);
         stage(0);
         issue_loads(min(kt_begin + 1, last));
+        if (BDMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_ROWS) : "memory");   // the first filter tile has landed
         __syncthreads();
         int cur = 0;
         for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -708,6 +766,10 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             fetch(1, 1);
             mfmas(0);
             stage(cur ^ 1);                         // K-tile kt+1: registers -> the LDS buffer nobody reads now
+            // the filter tile of K-tile kt+1 into the same free buffer; issued after the staging (whose wait on the register
+            // loads would otherwise also wait for the DMA) and before the loads of K-tile kt+2 (so that the counted wait
+            // at the end of the step can leave exactly those outstanding)
+            if (BDMA) dma_b(min(kt + 1, last), cur ^ 1);
             fetch(2, 0);
             mfmas(1);
             issue_loads(min(kt + 2, last));         // K-tile kt+2 into the registers just drained
@@ -725,7 +787,16 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                 __builtin_amdgcn_sched_group_barrier(0x220, 1, 0);
             }
 #endif
-            __syncthreads();
+            if (BDMA) {
+                // counted wait instead of __syncthreads(): its fence would wait vmcnt(0) and drain the register prefetch of
+                // K-tile kt+2 with the DMA.  vmcnt retires in order and the A_ROWS gather loads are the last vector-memory
+                // operations issued after the DMA on every path (the norm-table loads, when a source has a table, come before
+                // them): at most A_ROWS outstanding means the DMA has landed.  lgkmcnt(0): this wave's ds_writes of the A tile.
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(A_ROWS) : "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                __syncthreads();
+            }
             cur ^= 1;
         }
     }
