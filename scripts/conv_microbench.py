@@ -1,5 +1,5 @@
 """Single-layer microbenchmark of the implicit-GEMM kernel (for rocprofv3 --pmc passes).
-usage: conv_microbench.py <layer> [iters] [batch];  layers: enc2 enc3 enc4 d4 dec3 wg3"""
+usage: conv_microbench.py <layer> [iters] [batch];  layers: enc2 enc3 enc4 d4 dec3 dg3 wg3"""
 import sys
 import torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,6 +24,11 @@ elif layer == 'dec3':
     out = torch.empty(N, 48, 48, 128, device='cuda')
     fn = lambda: hip.deconv_forward(View(x0, x1, None, 1, None), f, out)
     flops = 2.0 * N * 48 * 48 * 128 * 4 * 512
+elif layer == 'dg3':      # data gradient of encoder_3 (4 sub-pixel phases of 2x2 taps, NK filter, no norm / activation on load)
+    dy, w = r(N, 24, 24, 256), r(4, 4, 128, 256) * 0.02
+    dx = torch.empty(N, 48, 48, 128, device='cuda')
+    fn = lambda: hip.conv_dgrad(View(dy), w, 2, 1, dx)
+    flops = 2.0 * N * 48 * 48 * 128 * 4 * 256
 elif layer == 'wg3':
     x, dy, dw = r(N, 48, 48, 128), r(N, 24, 24, 256), torch.empty(4, 4, 128, 256, device='cuda')
     fn = lambda: hip.conv_wgrad(View(x, None, None, 2), View(dy), dw, 2, 1)

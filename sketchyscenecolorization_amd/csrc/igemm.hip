@@ -29,6 +29,9 @@ int ssc_conv_narrow_forward_ws(const ssc_conv_desc* dp, float* ws, int64_t ws_by
 #ifndef SSC_BDMA
 #define SSC_BDMA 1       // filter tiles of conv_ut_kernel by LDS-DMA (global_load_lds) instead of through registers
 #endif
+#ifndef SSC_ADMA
+#define SSC_ADMA 1       // gathered tiles of the launches without norm / activation by LDS-DMA too (buffer_load ... lds)
+#endif
 #ifndef SSC_UT_SGB
 #define SSC_UT_SGB 1     // sched_group_barrier interleave hints in conv_ut_kernel (+1-2 % over the compiler's own order)
 #endif
@@ -413,6 +416,16 @@ __device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigne
                  : "memory");
 }
 
+// The same through a buffer descriptor: sbase/range from rsrc, voff per lane (an offset >= the descriptor's size makes the
+// lane's 16 bytes in LDS zeros -- measured, scripts/glds_oob_test.hip), soff wave-uniform.
+__device__ __forceinline__ void glds16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+                 : "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
 // uniform-tap form with the staging of later K-tiles interleaved into the MFMA stream of the same wave
 // ---------------------------------------------------------------------------------------------
@@ -449,9 +462,14 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     // 16-byte chunk whose swizzled position is its own slot).  Not with KMASK, whose partial chunks need zeroed rows.
     constexpr bool BDMA = SSC_BDMA && !KMASK;
     constexpr int B_IPW = BK * BN / 1024;          // DMA instructions per wave and K-tile
-    constexpr bool AV = UT_AV(BM, BN);
-    constexpr int A_LD = AV ? BK + 4 : BK + 1;
-    constexpr int A_SZ = BM * A_LD;
+    // ADMA (launches without norm / activation on any source, i.e. every data gradient): the gathered tile too goes straight
+    // into LDS -- buffer_load_dwordx4 ... lds through a buffer descriptor per source, whose range check writes ZEROS for the
+    // lanes sent out of range (padding taps, rows beyond M): no mask, no staging registers, no ds_write.  The tile is the
+    // swizzled [row][32] image of the NK filter tile (8 rows per wave instruction).
+    constexpr bool ADMA = SSC_ADMA && BDMA && PLAIN && KM == 0;
+    constexpr bool AV = ADMA || UT_AV(BM, BN);
+    constexpr int A_LD = ADMA ? BK : (AV ? BK + 4 : BK + 1);
+    constexpr int A_SZ = BM * (UT_AV(BM, BN) ? BK + 4 : BK + 1);       // buffer size as the host allocates it (the ADMA image is smaller)
     // NK filters (k contiguous in memory): the B tile is [n][32] with the 16-byte chunk c of row n stored at chunk
     // c ^ ((n >> 1) & 7) -- b128 writes and b128 operand reads, both conflict-free, no padding (the scalar [n][33] image it
     // replaces cost 34 address adds per K-tile and wave)
@@ -527,13 +545,16 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     }
     const FwdPhase ph = fwd_phase(d, phase);
 
-    const int a_col4 = tid & 7;
-    const int a_kx = ROWTAP ? (a_col4 * 4) / xC0 : 0;       // row tap: this thread's float4 belongs to pixel ix + a_kx
+    const int a_kx = ROWTAP ? ((tid & 7) * 4) / xC0 : 0;    // row tap: this thread's float4 belongs to pixel ix + a_kx
     int a_iyb[A_ROWS], a_ixb[A_ROWS], a_off0[A_ROWS], a_off1[A_ROWS];
     bool a_mv[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-        const int row = (tid >> 3) + 32 * i;
+        // tile row and 16-byte chunk of this thread's i-th piece.  Register path: 32 rows per pass, chunk tid & 7.  ADMA: wave
+        // instruction w * A_ROWS + i covers 8 rows, lane L lands at slot L & 7 of row L >> 3 and so fetches the chunk whose
+        // swizzled position that is.
+        const int row = ADMA ? (wave * A_ROWS + i) * 8 + (lane >> 3) : (tid >> 3) + 32 * i;
+        const int a_col4 = ADMA ? ((lane & 7) ^ ((row >> 1) & 7)) : (tid & 7);
         const long m = m0 + row;
         a_mv[i] = m < M;
         const long mm = a_mv[i] ? m : 0;
@@ -553,9 +574,10 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         const int pix0 = (n * xH + a_iyb[i]) * xW + a_ixb[i];
         a_off0[i] = (pix0 * xC0 + a_col4 * 4) * 4;      // BYTE offsets from a wave-uniform base: the loads then take the
         a_off1[i] = (pix0 * xC1 + a_col4 * 4) * 4;      // scalar-base + 32-bit vector-offset form, no 64-bit address arithmetic
-        if (a_col4 == 0)
+        if ((tid & 7) == 0)
             rowpix[row] = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
     }
+    const int a_col4 = tid & 7;     // register path: chunk of this thread's float4s
     // filter offsets of this thread's float4 slots, split into the part along K (b_k: filter rows of the tile for KN,
     // element offset along the row for NK) and the rest (b_n), so that KMASK can drop the K part of an empty slot
     int b_k[B_SLOTS], b_n[B_SLOTS], b_kk[B_SLOTS];     // b_kk: k index inside the tile
@@ -614,6 +636,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     float rbv[B_SLOTS];      // KMASK: 1.0 / 0.0 validity of each staged filter float4
 
     auto issue_loads = [&](int kt) {
+        if (ADMA) return;
         const int tap = div32(kt, mg.mC, mg.oneC);      // mC: magic of tpt
         const int chunk = kt - tap * tpt;
         const int ty = div32(tap, mg.mTW, mg.oneTW), tx = tap - ty * TWv;
@@ -665,6 +688,30 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         }
     };
 
+    // ADMA: gathered K-tile kt straight into LDS buffer `buf`
+    const int a_px = d.NB * xH * xW;        // pixels of a source (host: pixels x channels < 2^29)
+    auto dma_a = [&](int kt, int buf) {
+        const int tap = div32(kt, mg.mC, mg.oneC);
+        const int chunk = kt - tap * tpt;
+        const int ty = div32(tap, mg.mTW, mg.oneTW), tx = tap - ty * TWv;
+        const bool first = chunk < nch0;
+        const int cs = first ? xC0 : xC1;
+        const int cc = (first ? chunk : chunk - nch0) * BK;
+        const int tapshift = (ty * xW + tx) * cs * 4;
+        const int fmask = first ? -1 : 0;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)((buf * A_SZ + wave * A_ROWS * 256) * 4));
+        // the descriptor of the source this K-tile reads (scalar ALU only): base, size in bytes = the range the check enforces
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? xs0 : xs1), 0, a_px * cs * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const int iy = a_iyb[i] + ty, ix = a_ixb[i] + tx;
+            const bool v = a_mv[i] & ((unsigned)iy < (unsigned)xH) & ((unsigned)ix < (unsigned)xW);
+            const int osel = (a_off0[i] & fmask) | (a_off1[i] & ~fmask);
+            const unsigned off = v ? (unsigned)(osel + tapshift) : 0x80000000u;     // out of range: the DMA writes zeros
+            glds16_buf(rs, off, (unsigned)(cc * 4), dst + i * 1024);
+        }
+    };
+
     // BDMA: filter K-tile kt straight into LDS buffer `buf`
     auto dma_b = [&](int kt, int buf) {
         const int tap = div32(kt, mg.mC, mg.oneC);
@@ -681,6 +728,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     };
 
     auto stage = [&](int buf) {
+        if (ADMA) return;
         float* Ab = As + buf * A_SZ;
         float* Bb = Bs + buf * B_SZ;
 #pragma unroll
@@ -707,11 +755,12 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
 
     if (kt_begin < kt_end) {
         const int last = kt_end - 1;
+        if (ADMA) dma_a(kt_begin, 0);
         if (BDMA) dma_b(kt_begin, 0);
         issue_loads(kt_begin);
         stage(0);
         issue_loads(min(kt_begin + 1, last));
-        if (BDMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_ROWS) : "memory");   // the first filter tile has landed
+        if (BDMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ADMA ? 0 : A_ROWS) : "memory");   // the first DMA tile(s) have landed
         __syncthreads();
         int cur = 0;
         for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -719,7 +768,13 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             // a lane's 16 operands of a K-tile contiguous in the [row][k] images)
             constexpr int KS = 1;                       // k stride between consecutive steps
             const int kl = lhi * (BK / 2);              // k of step 0
-            const float* Ab = As + cur * A_SZ + (wm * SM * 32 + l31) * A_LD + kl;
+            const float* Ab = As + cur * A_SZ + (wm * SM * 32 + l31) * A_LD + (ADMA ? 0 : kl);
+            // ADMA: every wave is past the barrier that ended K-tile kt-1, so buffer cur^1 is free: both tiles of K-tile kt+1
+            // are issued now and have this whole K step to land
+            if (ADMA) {
+                dma_a(min(kt + 1, last), cur ^ 1);
+                dma_b(min(kt + 1, last), cur ^ 1);
+            }
             const float* Bb = (BMODE == 0) ? (Bs + cur * B_SZ + kl * B_LD + wn * SN * 32 + l31)
                                            : (Bs + cur * B_SZ + (wn * SN * 32 + l31) * B_LD);
             const int bsw = (l31 >> 1) & 7;         // NK: chunk swizzle of this lane's rows (the same for every j)
@@ -729,7 +784,8 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                 if (AV) {
 #pragma unroll
                     for (int i = 0; i < SM; ++i) {
-                        const float4 v = *reinterpret_cast<const float4*>(Ab + i * 32 * A_LD + g * FG);
+                        const float4 v = *reinterpret_cast<const float4*>(Ab + i * 32 * A_LD +
+                                                                          (ADMA ? ((lhi * 4 + g) ^ bsw) * 4 : g * FG));
                         av[buf][0][i] = v.x; av[buf][1][i] = v.y; av[buf][2][i] = v.z; av[buf][3][i] = v.w;
                     }
                 }
@@ -769,7 +825,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             // the filter tile of K-tile kt+1 into the same free buffer; issued after the staging (whose wait on the register
             // loads would otherwise also wait for the DMA) and before the loads of K-tile kt+2 (so that the counted wait
             // at the end of the step can leave exactly those outstanding)
-            if (BDMA) dma_b(min(kt + 1, last), cur ^ 1);
+            if (BDMA && !ADMA) dma_b(min(kt + 1, last), cur ^ 1);
             fetch(2, 0);
             mfmas(1);
             issue_loads(min(kt + 2, last));         // K-tile kt+2 into the registers just drained
@@ -792,7 +848,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                 // K-tile kt+2 with the DMA.  vmcnt retires in order and the A_ROWS gather loads are the last vector-memory
                 // operations issued after the DMA on every path (the norm-table loads, when a source has a table, come before
                 // them): at most A_ROWS outstanding means the DMA has landed.  lgkmcnt(0): this wave's ds_writes of the A tile.
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(A_ROWS) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(ADMA ? 0 : A_ROWS) : "memory");
                 __builtin_amdgcn_s_barrier();
             } else {
                 __syncthreads();
