@@ -1047,7 +1047,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_st
 // One K-tile step is a single branch-free block, as in conv_ut_kernel: K-tile kt+1 goes from registers to the free LDS
 // buffer and K-tile kt+2 is loaded into the drained registers between the MFMAs of K-tile kt.  GPLAIN / DPLAIN: the
 // gathered / dense view has no folded norm and no activation on any source (decided per launch).
-template <int WM, int WN, int SM, int SN, bool GPLAIN, bool DPLAIN>
+template <int WM, int WN, int SM, int SN, bool GPLAIN, bool DPLAIN, bool DDMA>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d, const Magics mg,
                                                           float* __restrict__ slab_base, long slab_stride,
                                                           int splitk) {
@@ -1061,6 +1061,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     constexpr int B_SLOTS = BN / 32;
     constexpr int A_RP = 1024 / BM;   // pixel rows per pass
     constexpr int B_RP = 1024 / BN;
+    // DDMA (dense side = one tensor without norm / activation, e.g. every dy): its [pixel][channel] tile goes to LDS by
+    // LDS-DMA as the filter tiles of conv_ut_kernel do -- a wave instruction covers 256 / BN pixel rows
+    constexpr int B_IPW = BK * BN / 1024;
+    static_assert(!DDMA || DPLAIN, "DMA tiles cannot be transformed");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
@@ -1167,6 +1171,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
 #pragma unroll
     for (int s = 0; s < B_SLOTS; ++s) b_off[s] = (unsigned)(tid / (BN / 4) + B_RP * s) * b_rowb;
     const unsigned b_step = (unsigned)BK * b_rowb;
+    unsigned d_row[B_IPW];      // DDMA: byte offset of this lane's pixel row inside a K-tile, per instruction of its wave
+    const unsigned d_col = (n0 + (lane % (BN / 4)) * 4) < Cd ? (unsigned)((n0 + (lane % (BN / 4)) * 4) * 4) : 0u;
+#pragma unroll
+    for (int q = 0; q < B_IPW; ++q) d_row[q] = (unsigned)((wave * B_IPW + q) * (256 / BN) + lane / (BN / 4)) * b_rowb;
+    auto dma_d = [&](int kt, int buf) {
+        const unsigned kb = (unsigned)kt * b_step;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)((2 * A_SZ + buf * B_SZ + wave * B_IPW * 256) * 4));
+#pragma unroll
+        for (int q = 0; q < B_IPW; ++q)
+            glds16(reinterpret_cast<const char*>(d.d.s0), min(kb + d_row[q], b_last) + d_col, dst + q * 1024);
+    };
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int s = 0; s < A_SLOTS; ++s) {
@@ -1177,6 +1192,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
             rav[s] = v ? 1.f : 0.f;
             ra[s] = *reinterpret_cast<const float4*>(a_bytes + off);
         }
+        if (DDMA) return;
         const unsigned kb = (unsigned)kt * b_step;
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
@@ -1193,6 +1209,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
             *reinterpret_cast<float4*>(Ab + row * A_LD + (tid % (BM / 4)) * 4) =
                 GPLAIN ? mask4(ra[s], rav[s]) : xform4(ra[s], aa, ab, g_slope, rav[s]);
         }
+        if (DDMA) return;
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
             const int row = tid / (BN / 4) + B_RP * s;
@@ -1204,12 +1221,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     const int l31 = lane & 31, lhi = lane >> 5;
     if (kt_begin < kt_end) {
         // K-tiles past kt_end (another split's, or past the last pixel: every row masked) are staged but never multiplied
+        if (DDMA) dma_d(kt_begin, 0);
         fill_ptab(kt_begin);
         fill_ptab(kt_begin + 1);
         __syncthreads();
         load_tile(kt_begin);
         store_tile(0);
         load_tile(kt_begin + 1);
+        if (DDMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_SLOTS) : "memory");      // the first dense tile has landed
         __syncthreads();                    // every thread has read ptab slots kt_begin, kt_begin + 1
         fill_ptab(kt_begin + 2);
         __syncthreads();
@@ -1244,6 +1263,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
             fetch(1, 1);
             mfmas(0);
             store_tile(cur ^ 1);            // K-tile kt+1: registers -> the LDS buffer nobody reads now
+            if (DDMA) dma_d(kt + 1, cur ^ 1);       // its dense tile: DMA into the same free buffer (see conv_ut_kernel)
             fetch(2, 0);
             mfmas(1);
             load_tile(kt + 2);              // reads ptab[(kt+2)&1], published by the previous barrier
@@ -1260,7 +1280,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
                 __builtin_amdgcn_sched_group_barrier(0x220, 1, 0);
             }
 #endif
-            __syncthreads();
+            if (DDMA) {     // counted wait + bare barrier: the gathered loads of K-tile kt+2 stay in flight (conv_ut_kernel)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(A_SLOTS) : "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                __syncthreads();
+            }
             cur ^= 1;
         }
     }
@@ -1331,7 +1356,7 @@ static void launch_wgrad_reduce(const float* ws, long count, int splitk, float* 
 // scripts/isa_one.sh: compile a single instantiation to look at its ISA (the whole file takes over a minute)
 template __global__ void conv_ut_kernel<2, 2, 1, 2, 0, false, 0>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*);
 template __global__ void conv_ut_kernel<2, 2, 1, 2, 1, true, 0>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*);
-template __global__ void conv_wgrad_kernel<1, 4, 2, 1, false, true>(const ssc_wgrad_desc, const Magics, float*, long, int);
+template __global__ void conv_wgrad_kernel<1, 4, 2, 1, false, true, true>(const ssc_wgrad_desc, const Magics, float*, long, int);
 #else
 // ---------------------------------------------------------------------------------------------
 // host launchers (C ABI)
@@ -1746,7 +1771,7 @@ static bool gview_plain(const ssc_gview& g) {
            (g.C1 == 0 || (g.ab1 == nullptr && (g.act1 >= 0 ? g.act1 : g.act) == SSC_ACT_NONE));
 }
 
-template <int WM, int WN, int SM, int SN, bool GPLAIN, bool DPLAIN>
+template <int WM, int WN, int SM, int SN, bool GPLAIN, bool DPLAIN, bool DDMA>
 static int launch_wgrad_v(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
     constexpr size_t lds = 2 * (BK * BM + BK * BN) * sizeof(float) + 2 * BK * sizeof(int4);
@@ -1760,12 +1785,12 @@ static int launch_wgrad_v(const ssc_wgrad_desc& d, int splitk, float* ws, hipStr
     const long out_count = (long)d.TH * d.TW * d.Cg_real * d.ldc;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<WM, WN, SM, SN, GPLAIN, DPLAIN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<WM, WN, SM, SN, GPLAIN, DPLAIN, DDMA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)splitk);
-    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, SM, SN, GPLAIN, DPLAIN>), grid, dim3(256), lds, st, d, mg, ws, out_count,
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, SM, SN, GPLAIN, DPLAIN, DDMA>), grid, dim3(256), lds, st, d, mg, ws, out_count,
                        splitk);
     if (splitk > 1) launch_wgrad_reduce(ws, out_count, splitk, d.out, d.accumulate, st);
     return (int)hipGetLastError();
@@ -1774,9 +1799,18 @@ static int launch_wgrad_v(const ssc_wgrad_desc& d, int splitk, float* ws, hipStr
 template <int WM, int WN, int SM, int SN>
 static int launch_wgrad(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
     const bool gp = gview_plain(d.g), dp = gview_plain(d.d);
-    if (dp) return gp ? launch_wgrad_v<WM, WN, SM, SN, true, true>(d, splitk, ws, st)
-                      : launch_wgrad_v<WM, WN, SM, SN, false, true>(d, splitk, ws, st);
-    return launch_wgrad_v<WM, WN, SM, SN, false, false>(d, splitk, ws, st);   // the full transform covers a plain side
+    static int ddma_on = -1;       // SSC_WGRAD_DMA=0: dense tiles through registers (A/B)
+    if (ddma_on < 0) {
+        const char* e = getenv("SSC_WGRAD_DMA");
+        ddma_on = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    // LDS-DMA of the dense tile: one plain tensor whose byte offsets fit 32 bits
+    const bool ddma = SSC_BDMA && ddma_on && dp && d.d.C1 == 0 && (long)d.NB * d.PH * d.PW * d.d.C0 < 0x1fffffffL;
+    if (dp && ddma) return gp ? launch_wgrad_v<WM, WN, SM, SN, true, true, true>(d, splitk, ws, st)
+                              : launch_wgrad_v<WM, WN, SM, SN, false, true, true>(d, splitk, ws, st);
+    if (dp) return gp ? launch_wgrad_v<WM, WN, SM, SN, true, true, false>(d, splitk, ws, st)
+                      : launch_wgrad_v<WM, WN, SM, SN, false, true, false>(d, splitk, ws, st);
+    return launch_wgrad_v<WM, WN, SM, SN, false, false, false>(d, splitk, ws, st);   // the full transform covers a plain side
 }
 
 // split over the pixel (K) dimension: many more choices than the forward form, so search a wider range
