@@ -261,6 +261,11 @@ int ssc_row_l2norm_bwd(const float* y, const float* ss, const float* dy, int64_t
 int ssc_lstm_pointwise_fwd(const float* g0, const float* g1, const float* g2, int div2, const int* mask, int mdiv,
                            const float* c_in, const float* h_in, int64_t rows, int C, float* c_out, float* h_out,
                            float* acts, void* stream);
+/* One recurrent step in one launch: gates = h_in @ Kh (Kh: [C rows][4C], row stride ldk; skipped when with_gemm == 0,
+ * i.e. h_in = 0) + g1[row] + g2[row/div2], then the cell above (tf.matmul + BasicLSTMCell of models_collection.py:230-236). */
+int ssc_lstm_step_fwd(const float* h_in, const float* Kh, int ldk, const float* g1, const float* g2, int div2,
+                      const int* mask, int mdiv, const float* c_in, int64_t rows, int C, int with_gemm, float* c_out,
+                      float* h_out, float* acts, void* stream);
 int ssc_lstm_pointwise_bwd(const float* dh, const float* dc, const float* acts, const float* c_in, const float* c_out,
                            const int* mask, int mdiv, int64_t rows, int C, float* dg, float* dc_in, float* dh_pass,
                            float* gacc, void* stream);

@@ -201,6 +201,126 @@ __global__ void lstm_bwd_kernel(const float* __restrict__ dh, const float* __res
     if (gacc != nullptr) { gacc[gb] += di; gacc[gb + C] += dj; gacc[gb + 2 * C] += df; gacc[gb + 3 * C] += dO; }
 }
 
+// ------------------------------------------------------------------ one recurrent step in one launch
+// gates = h_in @ Kh + g1[row] + g2[row / div2], then the pointwise cell above: the [rows, C] x [C, 4C] product of a step
+// (models_collection.py:230-236, the only sequential GEMM of the caption branch) and its gate math, which were a GEMM
+// launch + split-K reduce + pointwise launch per step.  A workgroup owns 64 rows x 16 hidden units: the four 16-column
+// gate slices i, j, f, o of those units form its 64-column B tile, so the gate math finds its four inputs in the
+// workgroup's own accumulators (through LDS).  fp32 MFMA (v_mfma_f32_32x32x2_f32), 4 waves, one 32x32 accumulator each;
+// K-tile 32, register prefetch of the next K-tile, one barrier per K-tile.
+typedef float lstm_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const float* __restrict__ h_in, const float* __restrict__ Kh,
+                                                            int ldk, const float* __restrict__ g1,
+                                                            const float* __restrict__ g2, int div2,
+                                                            const int* __restrict__ mask, int mdiv,
+                                                            const float* __restrict__ c_in, int rows, int C, int with_gemm,
+                                                            float* __restrict__ c_out, float* __restrict__ h_out,
+                                                            float* __restrict__ acts) {
+    constexpr int BM = 64, BK = 32, A_LD = 36, B_LD = 64, C_LD = 68;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * A_LD + 2 * BK * B_LD];     // 34.8 KB; the C tile reuses it
+    float* As = smem;
+    float* Bs = smem + 2 * BM * A_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+    const int m0 = blockIdx.x * BM, u0 = blockIdx.y * 16;
+
+    lstm_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    if (with_gemm) {
+        // A: thread t stages rows t >> 3 and 32 + (t >> 3), 16-byte chunk t & 7 of the K-tile
+        // B: k row t >> 4 (and + 16), 16-byte piece t & 15 = gate (t & 15) >> 2, units 4 * (t & 3) ..
+        const int a_r = tid >> 3, a_c = (tid & 7) * 4;
+        const int b_k = tid >> 4, b_g = (tid & 15) >> 2, b_u = (tid & 3) * 4;
+        const float* ap0 = h_in + (long)min(m0 + a_r, rows - 1) * C + a_c;
+        const float* ap1 = h_in + (long)min(m0 + a_r + 32, rows - 1) * C + a_c;
+        const float* bp = Kh + (long)b_k * ldk + b_g * C + u0 + b_u;
+        float4 ra0, ra1, rb0, rb1;
+        auto load = [&](int kt) {
+            ra0 = *reinterpret_cast<const float4*>(ap0 + kt * BK);
+            ra1 = *reinterpret_cast<const float4*>(ap1 + kt * BK);
+            rb0 = *reinterpret_cast<const float4*>(bp + (long)kt * BK * ldk);
+            rb1 = *reinterpret_cast<const float4*>(bp + (long)(kt * BK + 16) * ldk);
+        };
+        auto store = [&](int buf) {
+            float* A = As + buf * BM * A_LD;
+            float* B = Bs + buf * BK * B_LD;
+            *reinterpret_cast<float4*>(A + a_r * A_LD + a_c) = ra0;
+            *reinterpret_cast<float4*>(A + (a_r + 32) * A_LD + a_c) = ra1;
+            *reinterpret_cast<float4*>(B + b_k * B_LD + (tid & 15) * 4) = rb0;
+            *reinterpret_cast<float4*>(B + (b_k + 16) * B_LD + (tid & 15) * 4) = rb1;
+        };
+        const int nkt = C / BK;
+        load(0);
+        store(0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt) load(kt + 1);
+            // K index of MFMA step kk on lane half lhi: 16 * lhi + kk (A and B agree)
+            const float* A = As + cur * BM * A_LD + (wm * 32 + l31) * A_LD + lhi * 16;
+            const float* B = Bs + cur * BK * B_LD + lhi * 16 * B_LD + wn * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 av = *reinterpret_cast<const float4*>(A + g * 4);
+                const float b0 = B[(g * 4 + 0) * B_LD], b1 = B[(g * 4 + 1) * B_LD], b2 = B[(g * 4 + 2) * B_LD],
+                            b3 = B[(g * 4 + 3) * B_LD];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
+            }
+            if (kt + 1 < nkt) store(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // accumulators -> LDS [row][gate * 16 + unit]
+    float* Cs = smem;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * C_LD + wn * 32 + l31] = acc[r];
+    __syncthreads();
+    // gate math: 64 rows x 16 units, 4 per thread (a row's 16 units by 16 consecutive threads)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int e = p * 256 + tid;
+        const int rl = e >> 4, u = e & 15;
+        const long r = m0 + rl;
+        if (r >= rows) continue;
+        const long i = r * C + u0 + u;
+        const float c0 = c_in[i], h0 = h_in[i];
+        if (mask[r / mdiv] == 0) {
+            c_out[i] = c0;
+            h_out[i] = h0;
+            continue;       // acts are never read for skipped steps
+        }
+        const long gb = r * 4 * C + u0 + u;
+        float gi = Cs[rl * C_LD + u], gj = Cs[rl * C_LD + 16 + u], gf = Cs[rl * C_LD + 32 + u], go = Cs[rl * C_LD + 48 + u];
+        if (g1 != nullptr) { gi += g1[gb]; gj += g1[gb + C]; gf += g1[gb + 2 * C]; go += g1[gb + 3 * C]; }
+        if (g2 != nullptr) {
+            const long q = (r / div2) * 4 * C + u0 + u;
+            gi += g2[q]; gj += g2[q + C]; gf += g2[q + 2 * C]; go += g2[q + 3 * C];
+        }
+        const float ai = sigmoidf_(gi), aj = tanhf(gj), af = sigmoidf_(gf + 1.0f), ao = sigmoidf_(go);
+        const float c1 = c0 * af + ai * aj;
+        c_out[i] = c1;
+        h_out[i] = tanhf(c1) * ao;
+        acts[gb] = ai; acts[gb + C] = aj; acts[gb + 2 * C] = af; acts[gb + 3 * C] = ao;
+    }
+}
+
+extern "C" int ssc_lstm_step_fwd(const float* h_in, const float* Kh, int ldk, const float* g1, const float* g2, int div2,
+                                 const int* mask, int mdiv, const float* c_in, int64_t rows, int C, int with_gemm,
+                                 float* c_out, float* h_out, float* acts, void* stream) {
+    if ((C & 31) || (ldk & 3) || rows <= 0 || rows > 0x7fffffffL / (4L * C)) return -1;
+    hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(C / 16)), dim3(256), 0,
+                       (hipStream_t)stream, h_in, Kh, ldk, g1, g2, div2 > 0 ? div2 : 1, mask, mdiv > 0 ? mdiv : 1, c_in,
+                       (int)rows, C, with_gemm, c_out, h_out, acts);
+    return CHECK_LAUNCH();
+}
+
 extern "C" int ssc_lstm_pointwise_fwd(const float* g0, const float* g1, const float* g2, int div2, const int* mask,
                                       int mdiv, const float* c_in, const float* h_in, int64_t rows, int C,
                                       float* c_out, float* h_out, float* acts, void* stream) {

@@ -89,6 +89,7 @@ SIGNATURES = {
     'ssc_row_l2norm_fwd': [_P, _I, _P, _L, _I, _P, _P, _P],
     'ssc_row_l2norm_bwd': [_P, _P, _P, _L, _I, _P, _I, _P],
     'ssc_lstm_pointwise_fwd': [_P, _P, _P, _I, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P],
+    'ssc_lstm_step_fwd': [_P, _P, _I, _P, _P, _I, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P],
     'ssc_lstm_pointwise_bwd': [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P],
     'ssc_squash_fwd': [_P, _L, _P, _P],
     'ssc_squash_bwd': [_P, _P, _P, _L, _P, _P],
@@ -599,6 +600,20 @@ def call(name, *args):
         else:
             conv.append(a)
     check(getattr(lib(), name)(*conv, stream_ptr()), name)
+
+
+def lstm_step_fwd(h_in, Kh, ldk, g1, g2, div2, mask, mdiv, c_in, rows, C, with_gemm, c_out, h_out, acts):
+    """One recurrent step (GEMM + gate math) in one launch; counted with the implicit-GEMM launches when profiling."""
+    args = (h_in, Kh, ldk, g1, g2, div2, mask, mdiv, c_in, rows, C, int(with_gemm), c_out, h_out, acts)
+    if PROFILE is None or not with_gemm:
+        call('ssc_lstm_step_fwd', *args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call('ssc_lstm_step_fwd', *args)
+    e1.record()
+    PROFILE.append(('lstm_step_fwd<64x64>', 2.0 * rows * C * 4 * C, e0, e1, (rows, 4 * C, C),
+                    4.0 * (rows * C + C * 4 * C + 3 * rows * 4 * C)))
 
 
 def concat_parts(out, parts):

@@ -21,7 +21,10 @@ import torch
 
 from . import hip
 
+import os
+
 CELL = '/RNN/%s/multi_rnn_cell/cell_0/basic_lstm_cell/'
+FUSED_STEP = os.environ.get('SSC_LSTM_FUSED', '1') != '0'     # recurrent GEMM + gate math in one launch per step
 
 
 class TextFusion(object):
@@ -76,6 +79,10 @@ class TextFusion(object):
         hip.fill(cw[0], 0.0)
         hip.fill(hw[0], 0.0)
         for i in range(S):
+            if FUSED_STEP:      # the step's GEMM and its gate math in one launch
+                hip.lstm_step_fwd(hw[i], Kw[C:2 * C], G4, EW[i * N:(i + 1) * N], None, 1, mask[i], 1, cw[i], N, C, i > 0,
+                                  cw[i + 1], hw[i + 1], acts_w[i])
+                continue
             hip.matmul(hw[i], Kw[C:2 * C], tmp_w)
             hip.call('ssc_lstm_pointwise_fwd', tmp_w, EW[i * N:(i + 1) * N], None, 1, mask[i], 1, cw[i], hw[i], N, C,
                      cw[i + 1], hw[i + 1], acts_w[i])
@@ -141,6 +148,10 @@ class TextFusion(object):
         hip.fill(ca[0], 0.0)
         hip.fill(ha[0], 0.0)
         for i in range(S):
+            if FUSED_STEP:
+                hip.lstm_step_fwd(ha[i], Ka[3 * C:4 * C], G4, Gv, Rall[i * N:(i + 1) * N], P, mask[i], P, ca[i], R, C, i > 0,
+                                  ca[i + 1], ha[i + 1], acts_a[i])
+                continue
             if i == 0:
                 hip.fill(tmp_a, 0.0)        # h_a = 0: skip the GEMM
             else:
