@@ -97,6 +97,10 @@ class GanTrainer(object):
             overlap_wgrad = os.environ.get('SSC_OVERLAP_WGRAD', '0') == '1'
         self._wgrad_stream = torch.cuda.Stream() if (overlap_wgrad and block_type == 'Pix2Pix') else None
         self._aux_stream = torch.cuda.Stream() if overlap_real else None
+        # discriminator backward of the real and of the fake pair side by side (Pix2Pix / Residual discriminators: their
+        # backward touches a gradient only through store.grad(); the MRU one keeps per-call spectral-norm state)
+        self._dbwd_concurrent = (overlap_real and block_type in ('Pix2Pix', 'Residual') and
+                                 os.environ.get('SSC_DBWD_CONCURRENT', '1') == '1')
         self._text_stream = torch.cuda.Stream() if (overlap_real and os.environ.get('SSC_TEXT_STREAM', '1') == '1') else None
         # generator forward of the next G-step inside the D-step (train_iteration)
         self.run_ahead = (overlap_real and os.environ.get('SSC_RUN_AHEAD', '1') == '1')
@@ -406,8 +410,30 @@ class GanTrainer(object):
         K = cr['logits'].shape[1]
         dlog_r = B.get('dlog_r', (N, K))
         hip.call('ssc_acgan_loss', cr['logits'], batch['class_id_d'], N, K, 1, 1.0, loss_d, dlog_r)
-        self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False)
-        self.D.backward(cf, dl5_f, None, sn, True, False, accumulate=True)
+        if self._dbwd_concurrent and self._aux_stream is not None and hip.PROFILE is None:
+            # The two backward passes of the discriminator step (real pair, fake pair) share nothing but the filters they
+            # read: run them side by side -- real on the second stream into a second gradient buffer, fake in line -- so
+            # that each chain's launch tails and partly filled rounds are filled by the other, then add the buffers.  The
+            # fake pair's pass goes to the second buffer: it touches a subset of the variables (no class head), the rest of
+            # that buffer stays zero from its allocation.
+            sc = s.discriminator
+            if getattr(sc, 'grad2', None) is None:
+                sc.grad2 = torch.zeros_like(sc.grad)
+                sc.g2 = type(sc.g)((n, sc.grad2[o:o + k].view(shp)) for n, (o, k, shp) in sc.offsets.items())
+            main = torch.cuda.current_stream()
+            self._aux_stream.wait_stream(main)
+            with torch.cuda.stream(self._aux_stream):
+                sc.g, sc.g2 = sc.g2, sc.g
+                try:
+                    self.D.backward(cf, dl5_f, None, sn, True, False, accumulate=False)
+                finally:
+                    sc.g, sc.g2 = sc.g2, sc.g
+            self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False)
+            main.wait_stream(self._aux_stream)
+            hip.call('ssc_axpy', sc.grad, sc.grad2, 1.0, sc.numel)
+        else:
+            self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False)
+            self.D.backward(cf, dl5_f, None, sn, True, False, accumulate=True)
         hip.join_wgrad()
         self.D.finish_sn_backward(sn)
         hip.call('ssc_l2_reg', s['discriminator/fully_connected/weights'],
