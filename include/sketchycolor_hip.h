@@ -139,6 +139,16 @@ int ssc_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, int ldc
 int ssc_sketch_preprocess_u8(const uint8_t* src, int N, int H, int W, int thicken, float* dst, void* stream);
 /* src float NHWC rows of ldc floats, image in channels [coff, coff+3) -> dst uint8 [M,3] = ((x+1)/2*255) truncated */
 int ssc_image_postprocess_u8(const float* src, int ldc, int coff, int64_t M, uint8_t* dst, void* stream);
+/* PIL.Image.resize of an 8-bit image on the device (resize_and_padding_mask_image, input_pipeline.py:199-239: ANTIALIAS =
+ * LANCZOS; reverse_resize_image, Pipeline_utils/fg_color_utils.py:137-160: scipy.misc.imresize = PIL bilinear): Pillow's
+ * two-pass 8-bit resampler, horizontal then vertical, bit for bit.  src uint8 [H,W,C]; chan >= 0: only that channel,
+ * replicated over the OC channels of dst; chan < 0: all C channels (OC == C).  bnd_* [new][2] = {first tap, taps}, k_* [new][ks]
+ * 22-bit fixed-point coefficients (host: obj_lib/input_pipeline.py::resample_coeffs); NULL tables = that axis keeps its size.
+ * The result fills [top, top+new_h) x [left, left+new_w) of dst uint8 [OH,OW,OC], the rest of dst is `fill`.
+ * tmp: H * new_w * (chan >= 0 ? 1 : C) bytes. */
+int ssc_resample_u8(const uint8_t* src, int H, int W, int C, int chan, const int32_t* bnd_h, const int32_t* k_h, int ks_h,
+                    int new_w, const int32_t* bnd_v, const int32_t* k_v, int ks_v, int new_h, uint8_t* tmp, uint8_t* dst,
+                    int OH, int OW, int OC, int top, int left, int fill, void* stream);
 /* Training-queue decode (get_paired_input, input_pipeline.py:77-131) of N raw records: img / sk uint8 [N,R,R,3] ->
  * img_out / sk_out float NCHW [N,3,size,size], R = f * size.  Image: pixel (f*y, f*x) (TF1 bilinear at an integer
  * factor), (v - min)/(max - min + 1) over the resized image, + noise [N,size,size,3] (uniform [0,1/256), may be NULL),

@@ -415,6 +415,75 @@ extern "C" int ssc_bn_finalize(const float* partial, int nblk, int C, int64_t M,
     return CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------ 8-bit image resampling (PIL.Image.resize)
+// Two passes of Pillow's 8-bit resampler (libImaging/Resample.c): out = clip8((2^21 + sum_k pixel[x0 + k] * coeff[k]) >> 22),
+// horizontal first, an 8-bit image in between.  Bounds {first tap, tap count} and 22-bit fixed-point coefficients per output
+// coordinate come from the host (obj_lib/input_pipeline.py::resample_coeffs): a NULL table = that axis keeps its size.
+__global__ void resample_h_u8_kernel(const uint8_t* __restrict__ src, int H, int W, int C, int c0, int Cn,
+                                     const int* __restrict__ bnd, const int* __restrict__ kk, int ks, int new_w,
+                                     uint8_t* __restrict__ tmp) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)H * new_w * Cn) return;
+    const int c = (int)(i % Cn);
+    const int xx = (int)((i / Cn) % new_w);
+    const int y = (int)(i / ((long)Cn * new_w));
+    const uint8_t* row = src + ((long)y * W) * C + c0 + c;
+    if (kk == nullptr) {
+        tmp[i] = row[(long)xx * C];
+        return;
+    }
+    const int x0 = bnd[2 * xx], n = bnd[2 * xx + 1];
+    int ss = 1 << 21;
+    for (int k = 0; k < n; ++k) ss += (int)row[(long)(x0 + k) * C] * kk[(long)xx * ks + k];
+    ss >>= 22;
+    tmp[i] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+}
+
+// vertical pass into the region [top, top+new_h) x [left, left+new_w) of dst [OH][OW][OC]; the rest of dst is `fill`;
+// a single source channel (Cn == 1) is replicated over the OC output channels
+__global__ void resample_v_u8_kernel(const uint8_t* __restrict__ tmp, int H, int new_w, int Cn,
+                                     const int* __restrict__ bnd, const int* __restrict__ kk, int ks, int new_h,
+                                     uint8_t* __restrict__ dst, int OH, int OW, int OC, int top, int left, int fill) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)OH * OW * OC) return;
+    const int oc = (int)(i % OC);
+    const int ox = (int)((i / OC) % OW);
+    const int oy = (int)(i / ((long)OC * OW));
+    const int yy = oy - top, xx = ox - left;
+    if (yy < 0 || yy >= new_h || xx < 0 || xx >= new_w) {
+        dst[i] = (uint8_t)fill;
+        return;
+    }
+    const int c = Cn == 1 ? 0 : oc;
+    const uint8_t* col = tmp + (long)xx * Cn + c;
+    if (kk == nullptr) {
+        dst[i] = col[(long)yy * new_w * Cn];
+        return;
+    }
+    const int y0 = bnd[2 * yy], n = bnd[2 * yy + 1];
+    int ss = 1 << 21;
+    for (int k = 0; k < n; ++k) ss += (int)col[(long)(y0 + k) * new_w * Cn] * kk[(long)yy * ks + k];
+    ss >>= 22;
+    dst[i] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+}
+
+extern "C" int ssc_resample_u8(const uint8_t* src, int H, int W, int C, int chan, const int32_t* bnd_h,
+                               const int32_t* k_h, int ks_h, int new_w, const int32_t* bnd_v, const int32_t* k_v, int ks_v,
+                               int new_h, uint8_t* tmp, uint8_t* dst, int OH, int OW, int OC, int top, int left, int fill,
+                               void* stream) {
+    const int Cn = chan >= 0 ? 1 : C;
+    if (chan >= C || (chan < 0 && OC != C) || new_h > OH || new_w > OW || top < 0 || left < 0 || top + new_h > OH ||
+        left + new_w > OW || (k_h == nullptr && new_w != W) || (k_v == nullptr && new_h != H))
+        return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const long n1 = (long)H * new_w * Cn, n2 = (long)OH * OW * OC;
+    hipLaunchKernelGGL(resample_h_u8_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, src, H, W, C,
+                       chan >= 0 ? chan : 0, Cn, bnd_h, k_h, ks_h, new_w, tmp);
+    hipLaunchKernelGGL(resample_v_u8_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, tmp, H, new_w, Cn, bnd_v,
+                       k_v, ks_v, new_h, dst, OH, OW, OC, top, left, fill);
+    return CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ column sums (bias gradients, mru.py:128-132)
 // the float4 row-strided partial kernel above, folded per channel in double by one wavefront
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partial, int nblk, int Cv, int C,

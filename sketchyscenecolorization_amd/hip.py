@@ -77,6 +77,7 @@ SIGNATURES = {
     'ssc_nhwc_to_nchw': [_P, _P, _I, _I, _I, _I, _I, _P],
     'ssc_sketch_preprocess_u8': [_P, _I, _I, _I, _I, _P, _P],
     'ssc_image_postprocess_u8': [_P, _I, _I, _L, _P, _P],
+    'ssc_resample_u8': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'ssc_decode_paired_u8': [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     'ssc_distance_map_u8': [_P, _I, _I, _P, _P, _L, _P],
     'ssc_fill': [_P, _F, _L, _P],
@@ -534,6 +535,25 @@ def image_postprocess_u8(src_nhwc, coff=0, out=None):
     check(lib().ssc_image_postprocess_u8(ptr(src_nhwc), ldc, coff, n * h * w, ptr(out), stream_ptr()),
           'image_postprocess_u8')
     return out
+
+
+def resample_u8(src_u8, new_h, new_w, coeffs_h, coeffs_v, chan=-1, out_hw=None, top=0, left=0, fill=255, out_channels=None):
+    """PIL.Image.resize of a uint8 [H,W,C] device tensor (Pillow's 8-bit two-pass resampler, bit for bit).  coeffs_* =
+    (bounds int32 [new,2], coefficients int32 [new,ks]) device tensors from input_pipeline.resample_coeffs, or None when that
+    axis keeps its size.  chan >= 0: that channel only, replicated over ``out_channels``.  The result lands at (top, left) of a
+    [out_hw[0], out_hw[1], channels] canvas filled with ``fill``."""
+    H, W, Cc = src_u8.shape
+    assert src_u8.dtype == torch.uint8 and src_u8.is_contiguous() and src_u8.is_cuda
+    OC = out_channels if out_channels is not None else (Cc if chan < 0 else 1)
+    OH, OW = out_hw if out_hw is not None else (new_h, new_w)
+    tmp = torch.empty((H, new_w, 1 if chan >= 0 else Cc), dtype=torch.uint8, device=src_u8.device)
+    dst = torch.empty((OH, OW, OC), dtype=torch.uint8, device=src_u8.device)
+    bh, kh = coeffs_h if coeffs_h is not None else (None, None)
+    bv, kv = coeffs_v if coeffs_v is not None else (None, None)
+    check(lib().ssc_resample_u8(ptr(src_u8), H, W, Cc, chan, ptr(bh), ptr(kh), kh.shape[1] if kh is not None else 0, new_w,
+                                ptr(bv), ptr(kv), kv.shape[1] if kv is not None else 0, new_h, ptr(tmp), ptr(dst), OH, OW, OC,
+                                top, left, fill, stream_ptr()), 'ssc_resample_u8')
+    return dst
 
 
 def distance_map_u8(sk_u8):

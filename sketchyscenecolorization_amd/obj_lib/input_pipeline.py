@@ -46,6 +46,82 @@ def resize_and_padding_mask_image(image, new_size, resample_method=None, margin_
     return np.repeat(canvas[:, :, None], 3, axis=2)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# the same on the device: Pillow's 8-bit resampler as HIP kernels (ssc_resample_u8), coefficient tables from the host
+# ---------------------------------------------------------------------------------------------------------------
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def resample_coeffs(in_size, out_size, filt='lanczos'):
+    """Bounds and 22-bit fixed-point coefficients of one axis of PIL.Image.resize for 8-bit images (Pillow
+    libImaging/Resample.c: precompute_coeffs + normalize_coeffs_8bpc), box = the whole axis.
+    -> (bounds int32 [out,2] = {first tap, taps}, coefficients int32 [out,ksize])."""
+    support = {'lanczos': 3.0, 'bilinear': 1.0}[filt]
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support *= filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)           # C int(): the values are >= -support
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    x = np.arange(ksize, dtype=np.float64)[None, :]
+    arg = (x + xmin[:, None] - center[:, None] + 0.5) / filterscale
+    if filt == 'lanczos':
+        with np.errstate(divide='ignore', invalid='ignore'):
+            a = np.pi * arg
+            w = np.where(arg == 0.0, 1.0, (np.sin(a) / a) * (np.sin(a / 3.0) / (a / 3.0)))
+        w = np.where((arg >= -3.0) & (arg < 3.0), w, 0.0)
+    else:
+        w = np.where(np.abs(arg) < 1.0, 1.0 - np.abs(arg), 0.0)
+    w = np.where(x < xmax[:, None], w, 0.0)
+    ww = w.sum(axis=1, keepdims=True)
+    w = np.where(ww != 0.0, w / np.where(ww != 0.0, ww, 1.0), w)
+    kk = np.trunc(w * (1 << _PRECISION_BITS) + np.where(w >= 0, 0.5, -0.5)).astype(np.int32)
+    return np.stack([xmin, xmax], axis=1).astype(np.int32), kk
+
+
+def _dev_coeffs(in_size, out_size, filt):
+    import torch
+    if in_size == out_size:
+        return None
+    b, k = resample_coeffs(in_size, out_size, filt)
+    return torch.from_numpy(b).cuda(), torch.from_numpy(np.ascontiguousarray(k)).cuda()
+
+
+def resize_and_padding_mask_image_device(img_u8, new_size, margin_size=10):
+    """resize_and_padding_mask_image on the device: img_u8 uint8 [H,W,3] (device tensor) -> uint8 [new_size,new_size,3]
+    (device), the PIL LANCZOS resize of channel 0, centred on a white canvas, replicated over 3 channels -- bit for bit what
+    the host function above returns."""
+    from .. import hip
+    h, w = int(img_u8.shape[0]), int(img_u8.shape[1])
+    scale = new_size / max(h + 2 * margin_size, w + 2 * margin_size)
+    new_h, new_w = int(round(h * scale)), int(round(w * scale))
+    assert new_h <= new_size and new_w <= new_size
+    if scale == 1:
+        new_h, new_w = h, w
+    top, left = (new_size - new_h) // 2, (new_size - new_w) // 2
+    return hip.resample_u8(img_u8, new_h, new_w, _dev_coeffs(w, new_w, 'lanczos'), _dev_coeffs(h, new_h, 'lanczos'), chan=0,
+                           out_hw=(new_size, new_size), top=top, left=left, fill=255, out_channels=3)
+
+
+def reverse_resize_image_device(inst_u8, box_h, box_w, h_w_ratio=1, margin_size=10):
+    """Pipeline_utils/fg_color_utils.py:137-160 on the device: cut the padding of the generated [S,S,3] instance, bilinear
+    resize (scipy.misc.imresize = PIL) to the box plus margins, cut the margins -> uint8 [box_h, box_w, 3] (device)."""
+    from .. import hip
+    s = int(inst_u8.shape[0])
+    bh, bw = box_h + 2 * margin_size, box_w + 2 * margin_size
+    if bh * h_w_ratio > bw:
+        pad = int(round(s * (bh * h_w_ratio - bw) / (bh * h_w_ratio) / 2.))
+        cut = inst_u8[:, pad:s - pad]
+    else:
+        pad = int(round(s * (bw - bh * h_w_ratio) / bw / 2.))
+        cut = inst_u8[pad:s - pad, :]
+    cut = cut.contiguous()
+    ch, cw = int(cut.shape[0]), int(cut.shape[1])
+    rev = hip.resample_u8(cut, bh, bw, _dev_coeffs(cw, bw, 'bilinear'), _dev_coeffs(ch, bh, 'bilinear'))
+    return rev[margin_size:margin_size + box_h, margin_size:margin_size + box_w].contiguous()
+
+
 def thicken_drawings(image):
     """2x2 grey dilation of the (dark) strokes (input_pipeline.py:242-257 calls
     skimage.morphology.dilation(img, square(2))).  skimage pads an even footprint with a zero row/column at

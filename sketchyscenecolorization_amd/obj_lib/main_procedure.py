@@ -315,7 +315,6 @@ def inference(img_name, instruction):
     print('Restore trained model:', path)
     restore_checkpoint(store, path)
 
-    sketch = _load_sketch(os.path.join(wild_data_base_dir, img_name), img_dim, wild_cate)
     class_id = np.array([categories.index(wild_cate)])
     vocab_indices = np.expand_dims(np.array(preprocess_sentence(instruction, vocab_dict, T), dtype=np.int32), axis=0)
     try:
@@ -324,7 +323,15 @@ def inference(img_name, instruction):
         from .. import hip
         tower = models.get_trainer(Config.block_type, Config.vocab_size, img_dim[0])
         tower.G.lstm_hybrid = bool(LSTM_hybrid)
-        sk_u8 = torch.from_numpy(np.ascontiguousarray(sketch.astype(np.uint8)[None])).cuda()
+        # the file's pixels go to the device as they are; resize (PIL LANCZOS arithmetic), padding and channel
+        # replication of resize_and_padding_mask_image run there (ssc_resample_u8, bit-equal: tests/test_gpu_edge_cases.py)
+        from PIL import Image
+        from .input_pipeline import resize_and_padding_mask_image_device
+        raw = np.array(Image.open(os.path.join(wild_data_base_dir, img_name)).convert('RGB'), dtype=np.uint8)
+        sk_dev = torch.from_numpy(np.ascontiguousarray(raw)).cuda()
+        if raw.shape[1] != img_dim[0] or raw.shape[0] != img_dim[1]:
+            sk_dev = resize_and_padding_mask_image_device(sk_dev, img_dim[0], margin_size=0 if wild_cate in ['road'] else 10)
+        sk_u8 = sk_dev[None].contiguous()
         gen_u8 = tower.generate_u8(sk_u8, vocab_indices, torch.randn(1, 256, device='cuda'),
                                    labels=torch.as_tensor(class_id, dtype=torch.int32, device='cuda')).cpu().numpy()
         in_u8 = hip.image_postprocess_u8(hip.sketch_preprocess_u8(sk_u8)).cpu().numpy()

@@ -81,30 +81,24 @@ def test_all_pad_captions_and_batch_one(bt):
 
 
 @pytest.mark.gpu
-def test_device_pre_and_post_processing_match_the_host_functions():
-    """hip.sketch_preprocess_u8 / image_postprocess_u8 against the host restatements of main_procedure.py's
-    normalisation, thicken_drawings and truncating uint8 cast -- bit exact (uint8 / float32 arithmetic)."""
+def test_device_pre_and_post_processing_match_the_oracle():
+    """hip.sketch_preprocess_u8 / image_postprocess_u8 against oracle/image_ops.py (NumPy restatement of main_procedure.py's
+    normalisation, thicken_drawings and truncating uint8 cast) -- bit exact (uint8 / float32 arithmetic)."""
     import numpy as np
+    from oracle import image_ops as I
     from sketchyscenecolorization_amd import hip
-    from sketchyscenecolorization_amd.obj_lib import main_procedure as mp
-    from sketchyscenecolorization_amd.obj_lib.input_pipeline import thicken_drawings
     rng = np.random.RandomState(0)
     u8 = rng.randint(0, 256, (3, 40, 56, 3)).astype(np.uint8)
     u8[1] = np.repeat(((rng.rand(40, 56) > 0.9) * 255).astype(np.uint8)[:, :, None], 3, axis=2)     # a sparse drawing
     dev = torch.from_numpy(u8).cuda()
     got = hip.sketch_preprocess_u8(dev).cpu().numpy()
-    for n in range(3):
-        ref = mp._normalise(u8[n].astype(np.float32))[0].transpose(1, 2, 0)
-        assert np.array_equal(got[n, :, :, :3], ref) and (got[n, :, :, 3] == 0).all()
+    assert np.array_equal(got[..., :3], I.sketch_preprocess(u8)) and (got[..., 3] == 0).all()
     got_t = hip.sketch_preprocess_u8(dev, thicken=True).cpu().numpy()
-    for n in range(3):
-        ref = mp._normalise(thicken_drawings(u8[n]).astype(np.float32))[0].transpose(1, 2, 0)
-        assert np.array_equal(got_t[n, :, :, :3], ref)
+    assert np.array_equal(got_t[..., :3], I.sketch_preprocess(u8, thicken=True))
     x = (rng.rand(2, 24, 32, 8).astype(np.float32) * 2 - 1)
     x[0, 0, 0, 3:6] = (1.0, -1.0, 0.0)
     out = hip.image_postprocess_u8(torch.from_numpy(x).cuda(), coff=3).cpu().numpy()
-    ref = mp._postprocess(np.transpose(x[..., 3:6], (0, 3, 1, 2)))
-    assert out.dtype == np.uint8 and np.array_equal(out, ref)
+    assert out.dtype == np.uint8 and np.array_equal(out, I.image_postprocess(x[..., 3:6]))
 
 
 @pytest.mark.gpu
@@ -113,7 +107,7 @@ def test_generate_u8_equals_host_pipeline(block_type):
     """GanTrainer.generate_u8 (uint8 in, uint8 out, everything on the device, NHWC straight into the network) equals
     host normalise -> generate (NCHW) -> host post-process."""
     import numpy as np
-    from sketchyscenecolorization_amd.obj_lib import main_procedure as mp
+    from oracle import image_ops as I
     from sketchyscenecolorization_amd.trainer import GanTrainer
     tr = GanTrainer(img=64, seed=2, block_type=block_type)
     rng = np.random.RandomState(1)
@@ -122,17 +116,19 @@ def test_generate_u8_equals_host_pipeline(block_type):
     noise = torch.randn(2, 256, device='cuda')
     labels = torch.tensor([3, 7], dtype=torch.int32, device='cuda')
     got = tr.generate_u8(torch.from_numpy(u8).cuda(), text, noise, labels=labels).cpu().numpy()
-    z = torch.from_numpy(np.ascontiguousarray(np.concatenate([mp._normalise(u8[n].astype(np.float32)) for n in range(2)]))).cuda()
-    ref = mp._postprocess(tr.generate(z, text, noise, labels=labels))
+    z = torch.from_numpy(np.ascontiguousarray(I.sketch_preprocess(u8).transpose(0, 3, 1, 2))).cuda()
+    ref = I.image_postprocess(tr.generate(z, text, noise, labels=labels).cpu().numpy().transpose(0, 2, 3, 1))
     assert got.shape == (2, 64, 64, 3) and np.array_equal(got, ref)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('size', [192, 64])
-def test_device_decode_of_training_records_matches_host_decode(size):
-    """hip.decode_paired_u8 against input_pipeline.decode_paired_example (the host restatement of get_paired_input,
-    input_pipeline.py:77-131) on random 384x384 records, with the same dequantisation noise: bit exact."""
+def test_device_decode_of_training_records_matches_the_oracle(size):
+    """hip.decode_paired_u8 against oracle/image_ops.decode_paired_example (NumPy restatement of get_paired_input,
+    input_pipeline.py:77-131) on random 384x384 records, with the same dequantisation noise: bit exact.  The product's own
+    host decode (input_pipeline.decode_paired_example) is held to the same oracle."""
     import numpy as np
+    from oracle import image_ops as I
     from sketchyscenecolorization_amd import hip
     from sketchyscenecolorization_amd.obj_lib.input_pipeline import RECORD_HW, decode_paired_example
     rng = np.random.RandomState(size)
@@ -154,10 +150,12 @@ def test_device_decode_of_training_records_matches_host_decode(size):
                                   noise=torch.from_numpy(noise).cuda())
     gi, gs = gi.cpu().numpy(), gs.cpu().numpy()
     for k in range(n):
+        ri, rs = I.decode_paired_example(img[k], sk[k], size, noise[k])
+        assert np.array_equal(gi[k], ri) and np.array_equal(gs[k], rs), k
         feat = {'cartoon_data': [img[k].tobytes()], 'sketch_data': [sk[k].tobytes()], 'Category_id': [1],
                 'Text_vocab_indices': [bytes(15)]}
-        ri, rs = decode_paired_example(feat, (size, size), FixedNoise(noise[k]))[:2]
-        assert np.array_equal(gi[k], ri) and np.array_equal(gs[k], rs), k
+        hi, hs = decode_paired_example(feat, (size, size), FixedNoise(noise[k]))[:2]
+        assert np.array_equal(hi, ri) and np.array_equal(hs, rs), k
 
 
 @pytest.mark.gpu
@@ -166,8 +164,9 @@ def test_device_distance_map_matches_scipy_edt():
     (scipy.ndimage.distance_transform_edt over the [384,384,3] array, input_pipeline.py:86-96): bit exact, also when
     the three channels differ (the channel axis is a spatial axis of the reference's transform)."""
     import numpy as np
+    from oracle import image_ops as I
     from sketchyscenecolorization_amd import hip
-    from sketchyscenecolorization_amd.obj_lib.input_pipeline import RECORD_HW, decode_paired_example
+    from sketchyscenecolorization_amd.obj_lib.input_pipeline import RECORD_HW
     rng = np.random.RandomState(7)
     n, size = 2, 192
     img = rng.randint(0, 256, (n, RECORD_HW, RECORD_HW, 3)).astype(np.uint8)
@@ -179,15 +178,38 @@ def test_device_distance_map_matches_scipy_edt():
     sk[1, 20:24, 20:24, 1] = 100            # a stroke in one channel only
     noise = np.zeros((n, size, size, 3), np.float32)
 
-    class NoNoise(object):
-        def uniform(self, lo, hi, size=None):
-            return np.zeros(size, np.float32)
-
     gi, gs = hip.decode_paired_u8(torch.from_numpy(img).cuda(), torch.from_numpy(sk).cuda(), size,
                                   noise=torch.from_numpy(noise).cuda(), distance_map=True)
     for k in range(n):
-        feat = {'cartoon_data': [img[k].tobytes()], 'sketch_data': [sk[k].tobytes()], 'Category_id': [1],
-                'Text_vocab_indices': [bytes(15)]}
-        ri, rs = decode_paired_example(feat, (size, size), NoNoise(), distance_map=True)[:2]
+        ri, rs = I.decode_paired_example(img[k], sk[k], size, noise[k], distance_map=True)
         assert np.array_equal(gs[k].cpu().numpy(), rs), (k, float(np.abs(gs[k].cpu().numpy() - rs).max()))
         assert np.array_equal(gi[k].cpu().numpy(), ri)
+
+
+@pytest.mark.gpu
+def test_device_resize_matches_pillow_fixtures():
+    """ssc_resample_u8 (Pillow's 8-bit two-pass resampler as kernels) against the outputs of the Pillow installed in the
+    build container, stored as fixtures (tests/golden/resize_goldens.npz, made by make_resize_goldens.py): LANCZOS =
+    resize_and_padding_mask_image (input_pipeline.py:199-239), bilinear = reverse_resize_image
+    (Pipeline_utils/fg_color_utils.py:137-160).  Bit exact."""
+    import os
+    import numpy as np
+    from sketchyscenecolorization_amd import hip
+    from sketchyscenecolorization_amd.obj_lib import input_pipeline as ip
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'resize_goldens.npz'))
+    n = int(g['n_cases'])
+    for i in range(n):
+        src, filt, ref = g['src_%d' % i], str(g['filt_%d' % i]), g['out_%d' % i]
+        nh, nw = ref.shape[:2]
+        out = hip.resample_u8(torch.from_numpy(src).cuda(), nh, nw, ip._dev_coeffs(src.shape[1], nw, filt),
+                              ip._dev_coeffs(src.shape[0], nh, filt)).cpu().numpy()
+        assert np.array_equal(out, ref), (i, filt, src.shape, ref.shape)
+    for i in range(int(g['n_pad'])):
+        src, size, margin, ref = g['pad_src_%d' % i], int(g['pad_size_%d' % i]), int(g['pad_margin_%d' % i]), g['pad_out_%d' % i]
+        out = ip.resize_and_padding_mask_image_device(torch.from_numpy(src).cuda(), size, margin).cpu().numpy()
+        assert np.array_equal(out, ref), (i, src.shape, size, margin)
+    for i in range(int(g['n_rev'])):
+        src, bh, bw, margin, ref = (g['rev_src_%d' % i], int(g['rev_bh_%d' % i]), int(g['rev_bw_%d' % i]),
+                                    int(g['rev_margin_%d' % i]), g['rev_out_%d' % i])
+        out = ip.reverse_resize_image_device(torch.from_numpy(src).cuda(), bh, bw, margin_size=margin).cpu().numpy()
+        assert np.array_equal(out, ref), (i, bh, bw, margin)

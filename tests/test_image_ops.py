@@ -1,0 +1,47 @@
+"""oracle/image_ops.py (NumPy restatement of Pillow's 8-bit resampler and of the pre / post-processing either side of the
+generator) against the Pillow-generated fixtures, and the product's host functions against the oracle."""
+import os
+
+import numpy as np
+
+from oracle import image_ops as I
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'resize_goldens.npz'))
+
+
+def test_oracle_resampler_matches_pillow_fixtures():
+    for i in range(int(G['n_cases'])):
+        src, filt, ref = G['src_%d' % i], str(G['filt_%d' % i]), G['out_%d' % i]
+        assert np.array_equal(I.resample_u8(src, ref.shape[0], ref.shape[1], filt), ref), i
+    for i in range(int(G['n_pad'])):
+        out = I.resize_and_padding_mask_image(G['pad_src_%d' % i], int(G['pad_size_%d' % i]), int(G['pad_margin_%d' % i]))
+        assert np.array_equal(out, G['pad_out_%d' % i]), i
+    for i in range(int(G['n_rev'])):
+        out = I.reverse_resize_image(G['rev_src_%d' % i], int(G['rev_bh_%d' % i]), int(G['rev_bw_%d' % i]),
+                                     margin_size=int(G['rev_margin_%d' % i]))
+        assert np.array_equal(out, G['rev_out_%d' % i]), i
+
+
+def test_product_coefficient_tables_match_the_oracle():
+    from sketchyscenecolorization_amd.obj_lib.input_pipeline import resample_coeffs
+    for a, b in [(300, 173), (260, 150), (64, 192), (500, 97), (37, 192), (91, 100), (192, 212), (10, 10), (7, 1)]:
+        for f in ('lanczos', 'bilinear'):
+            bo, ko, _ = I.precompute_coeffs(a, b, f)
+            bp, kp = resample_coeffs(a, b, f)
+            assert np.array_equal(bo, bp) and np.array_equal(ko, kp), (a, b, f)
+
+
+def test_product_host_functions_match_the_oracle():
+    from PIL import Image
+    from sketchyscenecolorization_amd.obj_lib import input_pipeline as ip
+    from sketchyscenecolorization_amd.obj_lib import main_procedure as mp
+    for i in range(int(G['n_pad'])):
+        src = G['pad_src_%d' % i]
+        out = ip.resize_and_padding_mask_image(Image.fromarray(src), int(G['pad_size_%d' % i]), margin_size=int(G['pad_margin_%d' % i]))
+        assert np.array_equal(out, G['pad_out_%d' % i])
+    rng = np.random.RandomState(3)
+    u8 = np.repeat(((rng.rand(40, 56) > 0.9) * 255).astype(np.uint8)[:, :, None], 3, axis=2)
+    assert np.array_equal(ip.thicken_drawings(u8), I.thicken_drawings(u8))
+    assert np.array_equal(mp._normalise(u8.astype(np.float32))[0].transpose(1, 2, 0), I.sketch_preprocess(u8[None])[0])
+    x = rng.rand(1, 3, 8, 8).astype(np.float32) * 2 - 1
+    assert np.array_equal(mp._postprocess(x), I.image_postprocess(x.transpose(0, 2, 3, 1)))
