@@ -201,7 +201,7 @@ def _grad_errors(get, ref_grads):
     return l2s
 
 
-@pytest.mark.parametrize('n,img,noise', [(2, 64, True), (2, 64, False), (2, 192, False)])
+@pytest.mark.parametrize('n,img,noise', [(2, 64, True), (2, 192, True), (2, 64, False), (2, 192, False)])
 def test_mru_train_step_gradients_parity(n, img, noise):
     """loss_d / loss_g and every gradient of one MRU tower vs float64 autograd on the oracle.
 
@@ -209,9 +209,11 @@ def test_mru_train_step_gradients_parity(n, img, noise):
     channel) plane.  On sketches (large flat regions) several positions are within fp32 rounding of the extremum, so
     WHICH one is selected differs between any two fp32 evaluations -- observed on both sides: HIP 5e-3 vs torch-CPU
     fp32 5e-5 on one input, HIP 3.5e-5 vs torch-CPU 4e-4 on another -- and one flipped selection shifts every
-    upstream variable by the same relative amount.  The end-to-end bar is therefore loose (median relative L2 < 2e-2
-    on sketches, < 5e-3 on noise images that have no near-ties; a wrong formula gives O(1)); the exact formulas are
-    pinned at 2e-4 by test_mru_blocks_backward."""
+    upstream variable by the same relative amount.  On TIE-FREE inputs (uniform noise instead of sketches: every plane
+    has a unique extremum) the whole tower is therefore held to the tight bar -- median relative L2 < 2e-3 per scope
+    (measured 1e-5 .. 6e-4, the torch-CPU fp32 oracle itself 1e-5 .. 4e-4), worst variable < 1e-2 (measured <= 6.7e-3 on a
+    scalar prelu leak) -- at 64x64 and at the full 192x192; on sketches the bar stays loose (median < 2e-2; a wrong formula
+    gives O(1)) and the exact formulas are pinned at 2e-4 by test_mru_blocks_backward."""
     from oracle import mru as M
     p, tr, b, dev = _make_trainer(n, img)
     if noise:
@@ -225,11 +227,11 @@ def test_mru_train_step_gradients_parity(n, img, noise):
     lg = tr.g_step(dev, counter=0)
     assert abs(float(lg) - float(r['loss_g'])) < 1e-4 * max(1.0, abs(float(r['loss_g'])))
     eg = _grad_errors(lambda k: tr.store.generator.g[k], r['grad_g'])
-    med_tol = 5e-3 if noise else 2e-2
+    med_tol, worst_tol = (2e-3, 1e-2) if noise else (2e-2, 2e-1)
     for e in (ed, eg):
         assert float(np.median(list(e.values()))) < med_tol, float(np.median(list(e.values())))
         worst = max(e.items(), key=lambda kv: kv[1])
-        assert worst[1] < 10 * med_tol, worst
+        assert worst[1] < worst_tol, worst
     for k, u in r['u_new'].items():          # the G-step commits every spectral-norm u (graph_single.py:178-210)
         assert _rel(tr.store[k], u) < 1e-3, k
 
