@@ -1,6 +1,8 @@
 """Per-kernel summary of the rocprofv3 --pmc passes (rocpd sqlite, view counters_collection):
-HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM) and MFMA / VALU busy fractions.
-usage: pmc_summary.py <dir with pmc_final_*/p_results.db> <out.json>"""
+HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), the algorithmic bytes per launch the
+bench line of the same tree reports (-> traffic_ratio) and MFMA / VALU busy fractions; stamped with the hash of the kernel
+sources so that bench.py only attaches it to runs of the same kernels.
+usage: pmc_summary.py <dir with pmc_final_*/p_results.db> <out.json> [<bench json line with roofline.per_kernel>]"""
 import json
 import os
 import re
@@ -10,6 +12,8 @@ from collections import defaultdict
 
 def demangled_short(name):
     # rocpd stores demangled names: "void conv_fwd_kernel<2, 2, 1, 2, 0, true, true>(...)"
+    if name.startswith('lstm_step_fwd_kernel') or 'lstm_step_fwd_kernel(' in name:
+        return 'lstm_step_fwd<64x64>'
     m = re.match(r'void (conv_fwd_kernel|conv_ut_kernel|conv_wgrad_kernel|narrow_fwd_kernel)<([^>]*)>', name)
     if not m:
         return None
@@ -33,9 +37,20 @@ def collect(db):
     return out
 
 
-def main(base, dst):
+def main(base, dst, bench_json=None):
+    import os as _os
+    import sys as _sys
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    import bench as _bench
+    alg = {}
+    if bench_json and _os.path.exists(bench_json):
+        lines = [l for l in open(bench_json).read().splitlines() if l.startswith('{')]
+        if lines:
+            pk = json.loads(lines[-1]).get('roofline', {}).get('per_kernel', {})
+            alg = {k: v.get('algorithmic_bytes_per_launch') for k, v in pk.items()}
     res = {'source': 'rocprofv3 --kernel-trace --pmc <one pass each> of `python bench.py --steps 2 --warmup 1 --no-graphs '
-                     '--no-kernel-events` (scripts/run_profile_v4.sh), 1x MI355X, batch 32, 192x192, final round-1 tree',
+                     '--no-kernel-events` (scripts/run_profile_r02_pmc.sh), 1x MI355X, batch 32, 192x192',
+           'csrc_hash': _bench._csrc_hash(),
            'correction': 'FETCH_SIZE (KB) x2 (gfx950 tallies the 128-B requests of coalesced 16-B/lane reads at 64 B, '
                          'MI355X_MICROARCH.md section HBM); WRITE_SIZE (KB) as reported',
            'kernels': {}}
@@ -49,6 +64,8 @@ def main(base, dst):
             w = sum(write[k]['WRITE_SIZE']) / len(write[k]['WRITE_SIZE']) * 1024
             e.update(launches_profiled=len(fetch[k]['FETCH_SIZE']), fetch_bytes_per_launch_raw=f,
                      fetch_bytes_per_launch_corrected=2 * f, write_bytes_per_launch=w, hbm_bytes_per_launch=2 * f + w)
+            if alg.get(k):
+                e.update(algorithmic_bytes_per_launch=alg[k], traffic_ratio=(2 * f + w) / alg[k])
         if k in sq and sq[k].get('GRBM_GUI_ACTIVE'):
             tot = lambda n: sum(sq[k].get(n, [0.0]))
             gui = tot('GRBM_GUI_ACTIVE') / 8.0      # the counter is summed over the 8 XCDs: /8 = shader-clock cycles
@@ -68,4 +85,4 @@ def main(base, dst):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)

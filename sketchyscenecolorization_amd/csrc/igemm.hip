@@ -526,16 +526,30 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             tile = bid; ks = 0; sk = 1;
         } else {
             const int r = bid - ts_full;
-            const int q = r / ts_s;
-            tile = ts_full + q; ks = r - q * ts_s; sk = ts_s;
+            const int q = r / (ts_s & 0xffff);
+            tile = ts_full + q; ks = r - q * (ts_s & 0xffff); sk = ts_s & 0xffff;
             part = slab_base + (long)r * (BM * BN);
             slot = r;
         }
         const int mt = (int)((M + BM - 1) / BM), nt = (d.Nstore + BN - 1) / BN;
-        const int rest = tile / mt;
-        m0 = (long)(tile - rest * mt) * BM;
-        phase = rest / nt;
-        n0 = (rest - phase * nt) * BN;
+        if (ts_s >= 0x10000) {
+            // XCD-aware order (ts_s high half set by the host): tiles are numbered column tile fastest, then row tile, then
+            // phase, and the whole tiles are dealt so that workgroup ids with the same id % 8 -- the same XCD, the same L2
+            // -- walk a contiguous run of that order: the column tiles of a row tile (same gathered rows) and spatially
+            // neighbouring row tiles (overlapping taps) meet in one L2 instead of eight
+            if (bid < ts_full) tile = (bid & 7) * (ts_full >> 3) + (bid >> 3);
+            const int r2 = tile / nt;
+            n0 = (tile - r2 * nt) * BN;
+            phase = r2 / mt;
+            m0 = (long)(r2 - phase * mt) * BM;
+            ts_s &= 0xffff;
+            sk = bid < ts_full ? 1 : ts_s;
+        } else {
+            const int rest = tile / mt;
+            m0 = (long)(tile - rest * mt) * BM;
+            phase = rest / nt;
+            n0 = (rest - phase * nt) * BN;
+        }
     } else {
         phase = blockIdx.z / splitk;
         ks = blockIdx.z % splitk;
@@ -1568,6 +1582,15 @@ static bool fwd_is_utg(const ssc_conv_desc& d) {
            (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x1fffffffL;
 }
 
+static int xcd_order() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("SSC_XCD_ORDER");
+        on = (e != nullptr) ? atoi(e) : 1;
+    }
+    return on;
+}
+
 template <int WM, int WN, int SM, int SN, int BMODE, bool PLAIN, int KM>
 static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
@@ -1595,7 +1618,17 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
         if (full >= 0 && tail > 0 && (int64_t)tail * s * BM * BN * 4 <= g_launch_ws_bytes && tail * s < SSC_SK_FLAG_WORDS - 1 &&
             full + tail * s < 0x7fffffffL) {
             hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>), dim3((unsigned)(full + tail * s)),
-                               dim3(256), lds, st, d, mg, ws, out_count, 1, (int)full, (int)s, d.sk_flags);
+                               dim3(256), lds, st, d, mg, ws, out_count, 1, (int)full,
+                               (int)s | ((xcd_order() && (full & 7) == 0) ? 0x10000 : 0), d.sk_flags);
+            return (int)hipGetLastError();
+        }
+    }
+    if (splitk == 1 && xcd_order()) {        // whole tiles only, 1-D grid in the XCD-aware order (no flags needed)
+        const long tiles = mt * nt * d.nphase;
+        const long full = tiles & ~7L;
+        if (tiles < 0x7fffffffL && full > 0) {
+            hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>), dim3((unsigned)tiles), dim3(256), lds, st, d,
+                               mg, ws, out_count, 1, (int)full, 1 | 0x10000, (unsigned*)nullptr);
             return (int)hipGetLastError();
         }
     }
