@@ -30,7 +30,8 @@ int ssc_conv_narrow_forward_ws(const ssc_conv_desc* dp, float* ws, int64_t ws_by
 #define SSC_BDMA 1       // filter tiles of conv_ut_kernel by LDS-DMA (global_load_lds) instead of through registers
 #endif
 #ifndef SSC_ADMA
-#define SSC_ADMA 1       // gathered tiles of the launches without norm / activation by LDS-DMA too (buffer_load ... lds)
+#define SSC_ADMA 0       // gathered tiles of the launches without norm / activation by LDS-DMA too (buffer_load ... lds):
+                         // works, measured equal to the register path (1714-1720 images/s either way) -- off by default
 #endif
 #ifndef SSC_UT_SGB
 #define SSC_UT_SGB 1     // sched_group_barrier interleave hints in conv_ut_kernel (+1-2 % over the compiler's own order)
