@@ -5,4 +5,5 @@ rm -rf /tmp/prof_r02
 timeout 600 rocprofv3 --kernel-trace -d /tmp/prof_r02 -o bench -- python $R/bench.py --steps 20 --warmup 5 --preheat-seconds 0.5 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/bench_under_rocprof_$TAG.json 2>/dev/null
 python $R/scripts/rocpd_stats.py $(find /tmp/prof_r02 -name '*.db' | head -1) > $R/gpurun_out/r02_bench_n1_kernel_stats_$TAG.txt 2>&1
 python $R/scripts/timeline_busy.py $(find /tmp/prof_r02 -name '*.db' | head -1) >> $R/gpurun_out/r02_bench_n1_kernel_stats_$TAG.txt 2>&1
+python $R/scripts/stream_busy.py $(find /tmp/prof_r02 -name "*.db" | head -1) >> $R/gpurun_out/r02_bench_n1_kernel_stats_$TAG.txt 2>&1
 cd $R; head -50 gpurun_out/r02_bench_n1_kernel_stats_$TAG.txt

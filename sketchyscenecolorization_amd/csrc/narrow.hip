@@ -25,7 +25,9 @@ __device__ __forceinline__ float nr_act(float v, int act) {
 }
 
 // MODE 0: conv form, nphase == 1, in_stride == 1.   MODE 1: k=4 s=2 transposed form (4 phases).
-template <int MODE, int NOUT>
+// BIGK (conv form): filters up to 7x7 (the MRU generator's last conv, 64 -> 3 at 7x7, models_collection.py:372-374): a
+// (16+6)^2 patch and 49 taps of filter per chunk -- more staging registers and LDS, one workgroup per CU.
+template <int MODE, int NOUT, bool BIGK>
 __global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d, float* __restrict__ slabs,
                                                          long slab_stride, int csplit) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -57,8 +59,8 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d, 
         for (int n = 0; n < NOUT; ++n) acc[p][n] = (f32x2){0.f, 0.f};
 
     // staging registers: all global loads of a chunk are issued before the first one is consumed
-    constexpr int MAXE = 12;            // ceil(19*19*8 / 256) patch float4 per thread
-    constexpr int MAXW = (16 * NOUT * NCH + 255) / 256;      // filter floats per thread (<= 16 taps)
+    constexpr int MAXE = BIGK ? 16 : 12;        // ceil(19*19*8 / 256) (22*22*8 / 256) patch float4 per thread
+    constexpr int MAXW = ((BIGK ? 49 : 16) * NOUT * NCH + 255) / 256;      // filter floats per thread (<= 16 / 49 taps)
     const int c4s = (tid & 7) * 4;      // fixed per thread: 256 % 8 == 0
     float4 rv[MAXE];
     bool ok[MAXE];
@@ -208,7 +210,7 @@ extern "C" int ssc_conv_narrow_supported(const ssc_conv_desc* dp) {
     if (d.Nn > 4 || d.Nstore > 4) return 0;
     if ((C % NCH) != 0 || (d.x.C0 % NCH) != 0 || d.k_real != C) return 0;
     if (d.nphase == 4) return (d.TH == 2 && d.TW == 2 && d.KH == 4 && d.KW == 4) ? 1 : 0;
-    if (d.nphase != 1 || d.in_stride != 1 || d.TH > 4 || d.TW > 4 || d.KH * d.KW > 16) return 0;
+    if (d.nphase != 1 || d.in_stride != 1 || d.TH > 7 || d.TW > 7 || d.KH * d.KW > 49) return 0;
     return 1;
 }
 
@@ -235,13 +237,20 @@ static int launch_narrow(const ssc_conv_desc& d, hipStream_t st, float* ws, int6
     {                                                                                                              \
         static bool attr = false;                                                                                  \
         if (!attr) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_fwd_kernel<MODE, NO>),                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_fwd_kernel<MODE, NO, BIG>),            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                      \
             attr = true;                                                                                           \
         }                                                                                                          \
-        hipLaunchKernelGGL((narrow_fwd_kernel<MODE, NO>), grid, dim3(256), lds, st, d, ws, out_count, csplit);     \
+        hipLaunchKernelGGL((narrow_fwd_kernel<MODE, NO, BIG>), grid, dim3(256), lds, st, d, ws, out_count, csplit); \
     }
-    if (nout == 1) NARROW_LAUNCH(1) else if (nout == 2) NARROW_LAUNCH(2) else if (nout == 3) NARROW_LAUNCH(3) else NARROW_LAUNCH(4)
+    if (lds > 96 * 1024) return -5;
+    if (MODE == 0 && (d.TH > 4 || d.TW > 4 || d.KH * d.KW > 16)) {
+        constexpr bool BIG = true;
+        if (nout == 1) NARROW_LAUNCH(1) else if (nout == 2) NARROW_LAUNCH(2) else if (nout == 3) NARROW_LAUNCH(3) else NARROW_LAUNCH(4)
+    } else {
+        constexpr bool BIG = false;
+        if (nout == 1) NARROW_LAUNCH(1) else if (nout == 2) NARROW_LAUNCH(2) else if (nout == 3) NARROW_LAUNCH(3) else NARROW_LAUNCH(4)
+    }
 #undef NARROW_LAUNCH
     return (int)hipGetLastError();
 }
