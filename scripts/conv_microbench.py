@@ -1,5 +1,5 @@
 """Single-layer microbenchmark of the implicit-GEMM kernel (for rocprofv3 --pmc passes).
-usage: conv_microbench.py <layer> [iters] [batch];  layers: enc2 enc3 enc4 d4 dec3 dg3 wg3"""
+usage: conv_microbench.py <layer> [iters] [batch];  layers: enc2 enc3 enc4 d4 dec3 dg3 wg3 dec1 dl1g logit"""
 import sys
 import torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,6 +33,23 @@ elif layer == 'wg3':
     x, dy, dw = r(N, 48, 48, 128), r(N, 24, 24, 256), torch.empty(4, 4, 128, 256, device='cuda')
     fn = lambda: hip.conv_wgrad(View(x, None, None, 2), View(dy), dw, 2, 1)
     flops = 2.0 * N * 24 * 24 * 256 * 16 * 128
+elif layer == 'dec1':     # generator's last transposed conv 2 x 64 -> 3 (narrow kernel, folded norm + relu on both sources)
+    x0, x1, f = r(N, 96, 96, 64), r(N, 96, 96, 64), r(4, 4, 3, 128) * 0.02
+    ab = torch.cat([torch.ones(64, device='cuda'), torch.zeros(64, device='cuda')])
+    out = torch.empty(N, 192, 192, 4, device='cuda')
+    fn = lambda: hip.deconv_forward(View(x0, x1, ab, 1, ab), f, out, nstore=4, epi=1)
+    flops = 2.0 * N * 192 * 192 * 3 * 4 * 128
+elif layer == 'dl1g':     # data gradient of the discriminator's first conv w.r.t. the 3 generated channels
+    dy, w = r(N, 96, 96, 64), r(4, 4, 8, 64) * 0.02
+    dx = torch.empty(N, 192, 192, 4, device='cuda')
+    fn = lambda: hip.conv_dgrad(View(dy), w, 2, 1, dx, n_off=3, nn=3, nstore=4)
+    flops = 2.0 * N * 192 * 192 * 3 * 4 * 64
+elif layer == 'logit':    # PatchGAN logit conv 512 -> 1, 4x4 stride 1
+    x, w = r(N, 23, 23, 512), r(4, 4, 512, 1) * 0.02
+    ab = torch.cat([torch.ones(512, device='cuda'), torch.zeros(512, device='cuda')])
+    out = torch.empty(N, 22, 22, 4, device='cuda')
+    fn = lambda: hip.conv_forward(View(x, None, ab, 2), w, 1, 1, out, nstore=4)
+    flops = 2.0 * N * 22 * 22 * 16 * 512
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

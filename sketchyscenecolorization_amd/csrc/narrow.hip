@@ -9,6 +9,7 @@
 // form), reading the patch with conflict-free ds_read_b128 and the filter as LDS broadcasts.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "sketchycolor_hip.h"
 
 #define NT 16            // lattice tile edge (16x16 = 256 lanes)
@@ -204,6 +205,194 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Scalar-filter form.  With the filter slice in LDS a lane issues one ds_read_b128 per two packed FMAs and, worse, a chunk is
+// load -> LDS -> barrier -> accumulate -> barrier with nothing in flight during the accumulate.  Here:
+//   * the filter is read with scalar loads into SGPR pairs (v_pk_fma_f32 takes one as an operand): no filter staging, no
+//     filter LDS.  Needs the channels of one (tap, output) contiguous in memory: the [n][k] orientation or one output column;
+//   * 16-channel chunks: 6 staging float4 per thread, so the global loads of chunk c+1 stay in flight across the accumulate
+//     of chunk c, and two LDS images (2 x 26 KB, 3 workgroups per CU) need one barrier per chunk.
+// ---------------------------------------------------------------------------------------------
+#define SCH 16           // channels per chunk
+#define SPAD 20          // floats per patch pixel (80 B: odd multiple of 16 B -> conflict-free b128 reads)
+typedef const __attribute__((address_space(4))) float* cfloatp;
+typedef const __attribute__((address_space(4))) f32x4* cf32x4p;
+
+template <int MODE, int NOUT>
+__global__ __launch_bounds__(256) void narrow_sc_kernel(const ssc_conv_desc d, float* __restrict__ slabs,
+                                                        long slab_stride, int csplit) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int C = d.x.C0 + d.x.C1;
+    const int PYD = (MODE == 1) ? NT + 2 : (NT - 1) + d.TH;
+    const int PXD = (MODE == 1) ? NT + 2 : (NT - 1) + d.TW;
+    const int PSZ = PYD * PXD * SPAD;            // floats per patch image
+
+    const int tid = threadIdx.x;
+    const int ly = tid >> 4, lx = tid & 15;
+    const int nimg = blockIdx.z / csplit;
+    const int cslice = blockIdx.z - nimg * csplit;
+    const int py0 = blockIdx.y * NT, px0 = blockIdx.x * NT;
+    const int iy0 = (MODE == 1) ? py0 - 1 : py0 + d.ioff_y;
+    const int ix0 = (MODE == 1) ? px0 - 1 : px0 + d.ioff_x;
+
+    constexpr int NPH = (MODE == 1) ? 4 : 1;
+    f32x2 acc[NPH][NOUT];
+#pragma unroll
+    for (int p = 0; p < NPH; ++p)
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) acc[p][n] = (f32x2){0.f, 0.f};
+
+    // element (tap, n, channel k) of the filter at wsc + tap * w_ts + n * w_ns + k
+    const long w_ts = (long)d.wC0 * d.wC1;
+    const long w_ns = (d.bmode == 0) ? 0 : (long)d.wC1;
+    const cfloatp wsc = (cfloatp)(d.w + ((d.bmode == 0) ? (long)d.n_off : (long)d.n_off * d.wC1));
+
+    constexpr int MAXE = 6;             // ceil(19 * 19 * 4 / 256) patch float4 per thread
+    const int c4s = (tid & 3) * 4;
+    // per-thread patch positions: fixed for the whole kernel
+    int poff[MAXE];                     // pixel index into the source, or -1: outside the image / the patch
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) {
+        const int pos = (tid >> 2) + 64 * q;
+        const int pr = pos / PXD, pc = pos - pr * PXD;
+        const int iy = iy0 + pr, ix = ix0 + pc;
+        const bool ok = pos < PYD * PXD && (unsigned)iy < (unsigned)d.x.H && (unsigned)ix < (unsigned)d.x.W;
+        poff[q] = ok ? (nimg * d.x.H + iy) * d.x.W + ix : -1;
+    }
+    float4 rv[MAXE];
+    float4 ra, rb;
+    int cur_act = d.x.act;
+    auto load_chunk = [&](int cb) {
+        const bool first = cb < d.x.C0;
+        const float* src = first ? d.x.s0 : d.x.s1;
+        const int cs = first ? d.x.C0 : d.x.C1;
+        const int cc = first ? cb : cb - d.x.C0;
+        const float* abp = first ? d.x.ab0 : d.x.ab1;
+        cur_act = (!first && d.x.act1 >= 0) ? d.x.act1 : d.x.act;
+        ra = make_float4(1.f, 1.f, 1.f, 1.f);
+        rb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (abp != nullptr) {
+            ra = *reinterpret_cast<const float4*>(abp + cc + c4s);
+            rb = *reinterpret_cast<const float4*>(abp + cs + cc + c4s);
+        }
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const long off = poff[q] >= 0 ? (long)poff[q] * cs : 0;
+            rv[q] = *reinterpret_cast<const float4*>(src + off + cc + c4s);
+        }
+    };
+    auto store_chunk = [&](float* patch) {
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int pos = (tid >> 2) + 64 * q;
+            if (pos < PYD * PXD) {
+                float4 v = rv[q];
+                v.x = nr_act(fmaf(ra.x, v.x, rb.x), cur_act); v.y = nr_act(fmaf(ra.y, v.y, rb.y), cur_act);
+                v.z = nr_act(fmaf(ra.z, v.z, rb.z), cur_act); v.w = nr_act(fmaf(ra.w, v.w, rb.w), cur_act);
+                if (poff[q] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(patch + pos * SPAD + c4s) = v;
+            }
+        }
+    };
+
+    const int nchunk = C / SCH;
+    const int cper = (nchunk + csplit - 1) / csplit;
+    const int cb_begin = cslice * cper * SCH, cb_end = min(C, cb_begin + cper * SCH);
+    if (cb_begin < cb_end) load_chunk(cb_begin);
+    int buf = 0;
+    for (int cb = cb_begin; cb < cb_end; cb += SCH) {
+        float* patch = smem + buf * PSZ;
+        store_chunk(patch);
+        // one barrier per chunk: the image written next (the other one) was last read before this barrier
+        __syncthreads();
+        if (cb + SCH < cb_end) load_chunk(cb + SCH);        // in flight across the accumulate below
+        if (MODE == 1) {
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const int ry = ph >> 1, rx = ph & 1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ty = t >> 1, tx = t & 1;
+                    const float* xp = patch + ((ly + ry + ty) * PXD + lx + rx + tx) * SPAD;
+                    const cfloatp ws = wsc + ((3 - ry - 2 * ty) * 4 + (3 - rx - 2 * tx)) * w_ts + cb;
+#pragma unroll
+                    for (int c4 = 0; c4 < SCH; c4 += 4) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(xp + c4);
+#pragma unroll
+                        for (int n = 0; n < NOUT; ++n) {
+                            const f32x4 w = *(cf32x4p)(ws + n * w_ns + c4);
+                            acc[ph][n] = __builtin_elementwise_fma(x.xy, w.xy, acc[ph][n]);
+                            acc[ph][n] = __builtin_elementwise_fma(x.zw, w.zw, acc[ph][n]);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int ty = 0; ty < d.TH; ++ty) {
+                for (int tx = 0; tx < d.TW; ++tx) {
+                    const float* xp = patch + ((ly + ty) * PXD + lx + tx) * SPAD;
+                    const int ky = d.ky0 + ty * d.kstep, kx = d.kx0 + tx * d.kstep;
+                    const cfloatp ws = wsc + (ky * d.KW + kx) * w_ts + cb;
+#pragma unroll
+                    for (int c4 = 0; c4 < SCH; c4 += 4) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(xp + c4);
+#pragma unroll
+                        for (int n = 0; n < NOUT; ++n) {
+                            const f32x4 w = *(cf32x4p)(ws + n * w_ns + c4);
+                            acc[0][n] = __builtin_elementwise_fma(x.xy, w.xy, acc[0][n]);
+                            acc[0][n] = __builtin_elementwise_fma(x.zw, w.zw, acc[0][n]);
+                        }
+                    }
+                }
+            }
+        }
+        buf ^= 1;
+    }
+
+    // ---- epilogue (as narrow_fwd_kernel) ----
+    const int py = py0 + ly, px = px0 + lx;
+    if (py >= d.PH || px >= d.PW) return;
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+        const int oy = (MODE == 1) ? 2 * py + (ph >> 1) : py * d.out_stride + d.ooff_y;
+        const int ox = (MODE == 1) ? 2 * px + (ph & 1) : px * d.out_stride + d.ooff_x;
+        const long opix = (((long)nimg * d.OH + oy) * d.OW + ox) * d.ldc;
+        float* o = (csplit > 1) ? slabs + (long)cslice * slab_stride + opix : d.out + opix;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            if (n >= d.Nstore) break;
+            float v = 0.f;
+            if (n < NOUT && n < d.Nn) {
+                v = acc[ph][n < NOUT ? n : 0].x + acc[ph][n < NOUT ? n : 0].y;
+                if (csplit > 1) {
+                    o[n] = v;
+                    continue;
+                }
+                if (d.bias != nullptr) v += d.bias[n];
+                if (d.epi == 1) v = tanhf(v);
+                else if (d.epi == 2) v = fmaxf(v, 0.2f * v);
+                if (d.accumulate) v += o[n];
+            }
+            o[n] = v;
+        }
+    }
+}
+
+// the scalar-filter form applies: channels of a (tap, output) contiguous and 16-byte aligned, <= 4x4 taps
+static bool narrow_sc_ok(const ssc_conv_desc& d) {
+    static const bool on = getenv("SSC_NARROW_WSC") == nullptr || atoi(getenv("SSC_NARROW_WSC")) != 0;
+    const int nout = d.Nn < 1 ? 1 : d.Nn;
+    const bool kcontig = (d.bmode == 1) ? (d.wC1 % 4 == 0) : (d.wC1 == 1 && nout == 1 && d.n_off == 0);
+    if (!on || !kcontig || (reinterpret_cast<uintptr_t>(d.w) & 15) != 0) return false;
+    // measured (scripts/conv_microbench.py, batch 32): 128 -> 3 transposed 135 -> 127 us, the 64 -> 3 data gradient 79 -> 59 us,
+    // but the 512 -> 1 conv form 41 -> 56 us (one output: a scalar fetch feeds a single packed FMA) -- transposed form only.
+    // What bounds it now is the scalar data path: with constant weights the same launch takes 83 us, without the accumulate 49.
+    if (d.nphase != 4) return false;
+    // pixel offsets are 32-bit in this form
+    return (long)d.NB * d.x.H * d.x.W < 0x7fffffffL;
+}
+
 extern "C" int ssc_conv_narrow_supported(const ssc_conv_desc* dp) {
     const ssc_conv_desc& d = *dp;
     const int C = d.x.C0 + d.x.C1;
@@ -219,7 +408,9 @@ static int launch_narrow(const ssc_conv_desc& d, hipStream_t st, float* ws, int6
     const int PYD = (MODE == 1) ? NT + 2 : (NT - 1) + d.TH;
     const int PXD = (MODE == 1) ? NT + 2 : (NT - 1) + d.TW;
     const int nout = d.Nn < 1 ? 1 : d.Nn;       // accumulators per phase (1..4)
-    const size_t lds = ((size_t)PYD * PXD * NPAD + (size_t)d.KH * d.KW * nout * NCH) * sizeof(float);
+    const bool sc = narrow_sc_ok(d);
+    const size_t lds = sc ? (size_t)2 * PYD * PXD * SPAD * sizeof(float)
+                          : ((size_t)PYD * PXD * NPAD + (size_t)d.KH * d.KW * nout * NCH) * sizeof(float);
     dim3 grid((d.PW + NT - 1) / NT, (d.PH + NT - 1) / NT, d.NB);
     // channel split when the lattice alone gives the chip too few workgroups (conv form only)
     int csplit = 1;
@@ -243,8 +434,11 @@ static int launch_narrow(const ssc_conv_desc& d, hipStream_t st, float* ws, int6
         }                                                                                                          \
         hipLaunchKernelGGL((narrow_fwd_kernel<MODE, NO, BIG>), grid, dim3(256), lds, st, d, ws, out_count, csplit); \
     }
+#define NARROW_SC_LAUNCH(NO) hipLaunchKernelGGL((narrow_sc_kernel<MODE, NO>), grid, dim3(256), lds, st, d, ws, out_count, csplit);
     if (lds > 96 * 1024) return -5;
-    if (MODE == 0 && (d.TH > 4 || d.TW > 4 || d.KH * d.KW > 16)) {
+    if (sc) {
+        if (nout == 1) NARROW_SC_LAUNCH(1) else if (nout == 2) NARROW_SC_LAUNCH(2) else if (nout == 3) NARROW_SC_LAUNCH(3) else NARROW_SC_LAUNCH(4)
+    } else if (MODE == 0 && (d.TH > 4 || d.TW > 4 || d.KH * d.KW > 16)) {
         constexpr bool BIG = true;
         if (nout == 1) NARROW_LAUNCH(1) else if (nout == 2) NARROW_LAUNCH(2) else if (nout == 3) NARROW_LAUNCH(3) else NARROW_LAUNCH(4)
     } else {
@@ -252,6 +446,7 @@ static int launch_narrow(const ssc_conv_desc& d, hipStream_t st, float* ws, int6
         if (nout == 1) NARROW_LAUNCH(1) else if (nout == 2) NARROW_LAUNCH(2) else if (nout == 3) NARROW_LAUNCH(3) else NARROW_LAUNCH(4)
     }
 #undef NARROW_LAUNCH
+#undef NARROW_SC_LAUNCH
     return (int)hipGetLastError();
 }
 

@@ -111,6 +111,23 @@ class Pix2PixGenerator(object):
         hip.nhwc_to_nchw(ctx['out'], o, ctx['out_coff'])
         return o
 
+    bn_stream = None        # helper stream of backward (set by the trainer): see _fork
+
+    def _fork(self, fn):
+        """Issue fn's launches on the helper stream, ordered after everything issued so far on the current stream.
+        Returns whether a fork happened (then _join() before the next dependent or full-size launch)."""
+        st = self.bn_stream if hip.PROFILE is None else None
+        if st is None:
+            fn()
+            return False
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            fn()
+        return True
+
+    def _join(self):
+        torch.cuda.current_stream().wait_stream(self.bn_stream)
+
     def backward(self, ctx, dpre, on_section=None, side_stream=None):
         """dpre [N,H,W,4]: gradient w.r.t. the pre-tanh output.  Writes every generator gradient.
         ``on_section(name)`` is called when a contiguous block of the flat gradient buffer is final
@@ -126,20 +143,27 @@ class Pix2PixGenerator(object):
         gcur = dpre
         g_skip = [None] * 6
         g_feat = g_noise = None
+        hold = side_stream is not None and self.lstm_hybrid
         for k in (1, 2, 3, 4, 5):
             f = s['generator/decoder_%d/deconv/filter' % k]
             v = views[k]
             dyv = View(gcur)
             wg = (lambda v=v, dyv=dyv, k=k:
                   hip.deconv_wgrad(v, dyv, s.grad('generator/decoder_%d/deconv/filter' % k)))
-            if side_stream is None or not self.lstm_hybrid:
-                wg()
-            else:
+            if hold:
                 held.append(wg)
             g0 = B.get(tag + '/gb/d%d_in0' % k, (N, v.H, v.W, v.C0))
             g1 = B.get(tag + '/gb/d%d_in1' % k, (N, v.H, v.W, v.C1))
+            # the chain continues from g0 (through the norm backward); the filter gradient and the skip half g1 are read
+            # much later, so they run on the helper stream NEXT TO the three small launches of the norm backward, and the
+            # chain waits for them before its next full-size launch (one implicit-GEMM launch at a time, as in line)
             hip.deconv_dgrad(dyv, f, g0, n_off=0, nn=v.C0)
-            hip.deconv_dgrad(dyv, f, g1, n_off=v.C0, nn=v.C1)
+
+            def rest(wg=wg, dyv=dyv, f=f, g1=g1, v=v):
+                if not hold:
+                    wg()
+                hip.deconv_dgrad(dyv, f, g1, n_off=v.C0, nn=v.C1)
+            forked = self._fork(rest)
             if k < 5:
                 g_skip[k] = g1          # through relu to encoder_k's output
                 src = d[k + 1]
@@ -150,6 +174,8 @@ class Pix2PixGenerator(object):
                 gcur = dx
             else:
                 g_feat, g_noise = g0, g1
+            if forked:
+                self._join()
         # noise head
         P = ctx['noise'].shape[1] * ctx['noise'].shape[2]
         cd = ctx['noise'].shape[3]
@@ -201,9 +227,10 @@ class Pix2PixGenerator(object):
             w = s['generator/encoder_%d/conv/filter' % k]
             xin = View(e[k - 1], None, ab[k - 1], ACT_LRELU)
             dyv = View(gcur)
-            hip.conv_wgrad(xin, dyv, s.grad('generator/encoder_%d/conv/filter' % k), 2, 1)
             gin = B.get(tag + '/gb/e%d_in' % k, e[k - 1].shape)
             hip.conv_dgrad(dyv, w, 2, 1, gin)
+            forked = self._fork(lambda xin=xin, dyv=dyv, k=k:
+                                hip.conv_wgrad(xin, dyv, s.grad('generator/encoder_%d/conv/filter' % k), 2, 1))
             dx = B.get(tag + '/gb/de%d' % (k - 1), e[k - 1].shape)
             if k - 1 >= 2:
                 hip.bn_act_backward(_rows(e[k - 1]), ab[k - 1], st[k - 1], _rows(gin), ACT_LRELU, _rows(dx),
@@ -213,6 +240,8 @@ class Pix2PixGenerator(object):
             else:
                 hip.bn_act_backward(_rows(e[1]), None, None, _rows(gin), ACT_LRELU, _rows(dx),
                                     g2=_rows(g_skip[1]), act2=ACT_RELU)
+            if forked:
+                self._join()
             gcur = dx
         hip.conv_wgrad(View(ctx['xs']), View(gcur), s.grad('generator/encoder_1/conv/filter'), 2, 1)
         if text_pending:

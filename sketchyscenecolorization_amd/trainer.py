@@ -111,6 +111,11 @@ class GanTrainer(object):
         self.G.text_stream = self._text_stream          # forward half: every generator
         if block_type == 'Pix2Pix':
             self.G.text_stream_bwd = None if self.segment_graphs else self._text_stream
+            # norm backward of a layer next to the filter gradient of the layer above (Pix2PixGenerator._fork).  OFF: measured
+            # 18.28 vs 18.07 ms/step -- a fork + join per layer costs more in cross-queue dependencies of the replayed
+            # graph than the three small launches it hides
+            if overlap_real and os.environ.get('SSC_BN_OVERLAP', '0') == '1':
+                self.G.bn_stream = torch.cuda.Stream()
         self._seg = None
         self.lr_dev = torch.zeros(2, dtype=torch.float32, device=device)     # Adam step sizes [G, D]
 
