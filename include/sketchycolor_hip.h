@@ -84,6 +84,14 @@ typedef struct ssc_conv_desc {
     uint32_t* sk_flags;   /* stream-K hand-off flags (device): SSC_SK_FLAG_WORDS words, zero before the first launch that
                              uses them and private to the launch stream (the kernel leaves them zero); NULL = the launch
                              may not split tiles across workgroups inside the kernel (split-K slabs + reduce kernel instead) */
+    /* set by ssc_conv_forward_bnbwd (callers leave sb_x NULL): the output of this launch is the gradient g w.r.t. act(a*x+b)
+       of a batch-statistics-normed tensor x laid out like the output; the rows of stat_partial then hold
+       [sum dz | sum dz*xhat], dz = g * act'(a*x+b), xhat = (x - mean) * rstd -- the two sums of the norm's backward */
+    const float* sb_x;
+    const float* sb_ab;   /* [2][Nstore]: a, b */
+    const float* sb_stats;/* [2][Nstore]: mean, 1/std */
+    int32_t sb_ldx;       /* row stride of x */
+    int32_t sb_act;       /* SSC_ACT_* of the consumer */
 } ssc_conv_desc;
 #define SSC_SK_FLAG_WORDS 8192   /* >= resident workgroups of the largest grid; the last word reports a hand-off timeout */
 
@@ -257,6 +265,26 @@ int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, const float* 
                         const float* scale, const float* g1, int ldg1, int act1, const float* g2, int ldg2,
                         int act2, int has_bn, float* dx, int lddx, float* dscale, float* doffset, float* ws,
                         int64_t ws_bytes, void* stream);
+/*
+ * The same with the two per-channel sums taken elsewhere: `pre` = nrows rows [2][C] of partial sums
+ * [sum dz | sum dz*xhat] written by the epilogues of the launches that produced g1 (and g2) -- see
+ * ssc_conv_forward_bnbwd; pre = NULL: as ssc_bn_act_backward.  Saves the pass over x, g1, g2 of
+ * the gradient chain generate_pix2pix -> batchnorm -> lrelu/relu (models_collection.py:36-46, 434-439).
+ */
+int ssc_bn_act_backward_pre(const float* x, int64_t M, int C, int ldx, const float* ab, const float* stats,
+                            const float* g1, int ldg1, int act1, const float* g2, int ldg2, int act2, int has_bn,
+                            float* dx, int lddx, float* dscale, float* doffset, const float* pre, int nrows,
+                            float* ws, int64_t ws_bytes, void* stream);
+/*
+ * ssc_conv_forward for a launch whose output g is the gradient w.r.t. act(a*x+b) of a batch-statistics-normed
+ * tensor x ([rows][ldx], addressed like the output): when the launch qualifies (uniform-tap kernel, no split-K
+ * slabs, whole 16-byte aligned rows) its epilogue also writes rows of `partial` ([2][Nstore] each: sum dz,
+ * sum dz*xhat with dz = g*act'(a*x+b)) and *nrows is their count; else *nrows = 0 (take the sums with
+ * ssc_bn_act_backward).  partial_bytes >= nphase * ceil(M / 64) * 2 * Nstore * 4 always suffices.
+ */
+int ssc_conv_forward_bnbwd(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, const float* x, int ldx,
+                           const float* ab, const float* stats, int act, float* partial, int64_t partial_bytes,
+                           int* nrows, void* stream);
 
 /* --- caption branch (text_lstm.hip): encode_feat_with_text, models_collection.py:150-248 --- */
 /* tf.nn.embedding_lookup (:182) and its (dense) gradient; tok rows are time-major [T*N] */

@@ -644,11 +644,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
     }
 }
 
-extern "C" int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, const float* ab, const float* stats,
-                                   const float* scale, const float* g1, int ldg1, int act1, const float* g2,
-                                   int ldg2, int act2, int has_bn, float* dx, int lddx, float* dscale,
-                                   float* doffset, float* ws, int64_t ws_bytes, void* stream) {
-    (void)scale;
+// pre / nrows: the rows [nrows][2][C] of partial sums already taken by the epilogues of the launches that produced g1 (and g2)
+// (ssc_conv_forward_bnbwd); NULL / 0: take them here with a pass over x, g1, g2.
+extern "C" int ssc_bn_act_backward_pre(const float* x, int64_t M, int C, int ldx, const float* ab, const float* stats,
+                                       const float* g1, int ldg1, int act1, const float* g2, int ldg2, int act2, int has_bn,
+                                       float* dx, int lddx, float* dscale, float* doffset, const float* pre, int nrows,
+                                       float* ws, int64_t ws_bytes, void* stream) {
     if ((C & 3) || (ldx & 3) || (ldg1 & 3) || (lddx & 3) || (g2 != nullptr && (ldg2 & 3))) return -1;
     hipStream_t st = (hipStream_t)stream;
     BnBwdArgs a;
@@ -660,8 +661,14 @@ extern "C" int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, co
         col_grid(M, C, tcg, rl, nbr, nbc);
         if (((int64_t)nbr * 2 * C + 2 * C) * (int64_t)sizeof(float) > ws_bytes) return -2;
         coef = ws + (int64_t)nbr * 2 * C;
-        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, a, tcg, ws);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, ws, nbr, C, (long)M, coef,
+        const float* partial = ws;
+        if (pre != nullptr && nrows > 0) {
+            partial = pre;
+            nbr = nrows;
+        } else {
+            hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, a, tcg, ws);
+        }
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, nbr, C, (long)M, coef,
                            dscale, doffset);
     }
     long tot = (long)M * (C / 4);
@@ -670,6 +677,15 @@ extern "C" int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, co
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, coef, dx, lddx);
     return CHECK_LAUNCH();
+}
+
+extern "C" int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, const float* ab, const float* stats,
+                                   const float* scale, const float* g1, int ldg1, int act1, const float* g2,
+                                   int ldg2, int act2, int has_bn, float* dx, int lddx, float* dscale,
+                                   float* doffset, float* ws, int64_t ws_bytes, void* stream) {
+    (void)scale;
+    return ssc_bn_act_backward_pre(x, M, C, ldx, ab, stats, g1, ldg1, act1, g2, ldg2, act2, has_bn, dx, lddx, dscale, doffset,
+                                   nullptr, 0, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------ materialising helpers

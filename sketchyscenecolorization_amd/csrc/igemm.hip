@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             slot = r;
         }
         const int mt = (int)((M + BM - 1) / BM), nt = (d.Nstore + BN - 1) / BN;
-        if (ts_s >= 0x10000) {
+        if (ts_s & 0x10000) {
             // XCD-aware order (ts_s high half set by the host): tiles are numbered column tile fastest, then row tile, then
             // phase, and the whole tiles are dealt so that workgroup ids with the same id % 8 -- the same XCD, the same L2
             // -- walk a contiguous run of that order: the column tiles of a row tile (same gathered rows) and spatially
@@ -541,8 +541,13 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             if (bid < ts_full) tile = (bid & 7) * (ts_full >> 3) + (bid >> 3);
             const int r2 = tile / nt;
             n0 = (tile - r2 * nt) * BN;
-            phase = r2 / mt;
-            m0 = (long)(r2 - phase * mt) * BM;
+            if (ts_s & 0x20000) {       // 4 sub-pixel phases of a row tile next to each other: they gather the same 3x3 input
+                phase = r2 & 3;         // neighbourhoods (16 (phase, tap) pairs, 9 distinct pixels), so they share them in one L2
+                m0 = (long)(r2 >> 2) * BM;
+            } else {
+                phase = r2 / mt;
+                m0 = (long)(r2 - phase * mt) * BM;
+            }
             ts_s &= 0xffff;
             sk = bid < ts_full ? 1 : ts_s;
         } else {
@@ -957,6 +962,22 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         // partials per row tile, folded per channel by bn_stats_finalize (ssc_conv_forward_bn)
         float* const stat = final_pass ? d.stat_partial : nullptr;
         float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
+        // ... or, when the output is the gradient w.r.t. the activated norm of a tensor x (sb_x: same layout as the output),
+        // the two sums of that norm's backward: sum dz and sum dz * xhat with dz = out * act'(a x + b) (ssc_conv_forward_bnbwd);
+        // the column group of a thread is the same in every pass of the loop below (256 % (BN / 4) == 0)
+        const float* const sbx = (stat != nullptr) ? d.sb_x : nullptr;
+        float4 sb_a = make_float4(1.f, 1.f, 1.f, 1.f), sb_b = make_float4(0.f, 0.f, 0.f, 0.f), sb_mu = sb_b, sb_rs = sb_a;
+        float sb_neg = 1.f;         // act'(z) for z <= 0
+        if (sbx != nullptr) {
+            const int c = n0 + (tid % (BN / 4)) * 4;
+            if (c < Nst) {
+                sb_a = *reinterpret_cast<const float4*>(d.sb_ab + c);
+                sb_b = *reinterpret_cast<const float4*>(d.sb_ab + Nst + c);
+                sb_mu = *reinterpret_cast<const float4*>(d.sb_stats + c);
+                sb_rs = *reinterpret_cast<const float4*>(d.sb_stats + Nst + c);
+            }
+            sb_neg = d.sb_act == SSC_ACT_RELU ? 0.f : (d.sb_act == SSC_ACT_LRELU ? 0.2f : 1.f);
+        }
 #pragma unroll
         for (int p = 0; p < BM * BN / 1024; ++p) {
             const int e = p * 256 + tid;
@@ -970,8 +991,20 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                     v.x += col + 0 < Nn ? bias[col + 0] : 0.f; v.y += col + 1 < Nn ? bias[col + 1] : 0.f;
                     v.z += col + 2 < Nn ? bias[col + 2] : 0.f; v.w += col + 3 < Nn ? bias[col + 3] : 0.f;
                 }
-                ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
-                ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
+                if (sbx == nullptr) {
+                    ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
+                    ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
+                } else {
+                    const float4 xv = *reinterpret_cast<const float4*>(sbx + rowpix[row] * d.sb_ldx + col);
+                    float4 dz;
+                    dz.x = v.x * (fmaf(sb_a.x, xv.x, sb_b.x) > 0.f ? 1.f : sb_neg);
+                    dz.y = v.y * (fmaf(sb_a.y, xv.y, sb_b.y) > 0.f ? 1.f : sb_neg);
+                    dz.z = v.z * (fmaf(sb_a.z, xv.z, sb_b.z) > 0.f ? 1.f : sb_neg);
+                    dz.w = v.w * (fmaf(sb_a.w, xv.w, sb_b.w) > 0.f ? 1.f : sb_neg);
+                    ssum.x += dz.x; ssum.y += dz.y; ssum.z += dz.z; ssum.w += dz.w;
+                    ssq.x += dz.x * (xv.x - sb_mu.x) * sb_rs.x; ssq.y += dz.y * (xv.y - sb_mu.y) * sb_rs.y;
+                    ssq.z += dz.z * (xv.z - sb_mu.z) * sb_rs.z; ssq.w += dz.w * (xv.w - sb_mu.w) * sb_rs.w;
+                }
                 if (epi == 1) {
                     v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
                 } else if (epi == 2) {
@@ -1587,7 +1620,7 @@ static int xcd_order() {
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("SSC_XCD_ORDER");
-        on = (e != nullptr) ? atoi(e) : 1;
+        on = (e != nullptr) ? atoi(e) : 2;     // 0: off, 1: XCD-aware order, 2: + the 4 phases of a row tile adjacent
     }
     return on;
 }
@@ -1620,7 +1653,8 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
             full + tail * s < 0x7fffffffL) {
             hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>), dim3((unsigned)(full + tail * s)),
                                dim3(256), lds, st, d, mg, ws, out_count, 1, (int)full,
-                               (int)s | ((xcd_order() && (full & 7) == 0) ? 0x10000 : 0), d.sk_flags);
+                               (int)s | ((xcd_order() && (full & 7) == 0) ? (0x10000 | ((xcd_order() >= 2 && d.nphase == 4) ? 0x20000 : 0)) : 0),
+                               d.sk_flags);
             return (int)hipGetLastError();
         }
     }
@@ -1629,7 +1663,8 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
         const long full = tiles & ~7L;
         if (tiles < 0x7fffffffL && full > 0) {
             hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>), dim3((unsigned)tiles), dim3(256), lds, st, d,
-                               mg, ws, out_count, 1, (int)full, 1 | 0x10000, (unsigned*)nullptr);
+                               mg, ws, out_count, 1, (int)full, 1 | 0x10000 | ((xcd_order() >= 2 && d.nphase == 4) ? 0x20000 : 0),
+                               (unsigned*)nullptr);
             return (int)hipGetLastError();
         }
     }
@@ -1748,6 +1783,41 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
     const int rc = ssc_conv_forward(&d, ws, ws_bytes, stream);
     if (rc != 0) return rc;
     return ssc_bn_stats(d.out, Mall, d.Nstore, d.ldc, scale, offset, eps, ab, stats, ws, ws_bytes, stream);
+}
+
+// conv whose output g is the gradient w.r.t. act(a*x+b) of a batch-statistics-normed tensor x ([rows][ldx], laid out like
+// the output): when the launch qualifies (as ssc_conv_forward_bn) the two per-channel sums of the norm's backward come out of
+// the epilogue as rows of `partial` ([rows][2][Nstore], caller's buffer of at least nphase * ceil(M / 64) rows) and *nrows is
+// their count; otherwise *nrows = 0 and the caller takes the sums with the separate pass (ssc_bn_act_backward).
+extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, const float* x, int ldx,
+                                      const float* ab, const float* stats, int act, float* partial, int64_t partial_bytes,
+                                      int* nrows, void* stream) {
+    ssc_conv_desc d = *dp;
+    d.stat_partial = nullptr;
+    d.sb_x = nullptr;
+    *nrows = 0;
+    const long M = (long)d.NB * d.PH * d.PW;
+    static int off = -1;        // SSC_FUSE_BNBWD=0: always the separate pass (A/B)
+    if (off < 0) {
+        const char* e = getenv("SSC_FUSE_BNBWD");
+        off = (e != nullptr && e[0] == '0') ? 1 : 0;
+    }
+    if (!off && ws != nullptr && partial != nullptr && x != nullptr && ab != nullptr && stats != nullptr &&
+        !ssc_conv_narrow_supported(dp) && d.epi == 0 && !d.accumulate && d.bias == nullptr && d.Nstore == d.ldc &&
+        d.Nn == d.Nstore && ((d.Nstore & 3) == 0) && ((ldx & 3) == 0) && ((reinterpret_cast<unsigned long>(d.out) & 15) == 0) &&
+        ((reinterpret_cast<unsigned long>(x) & 15) == 0) &&
+        (fwd_is_ut(d) || fwd_is_utg(d) || (d.bmode == 0 && fwd_is_rowtap(d)))) {
+        const Plan p = plan_fwd(d, ws_bytes, true);
+        if (p.cfg > 0 && p.splitk == 1) {
+            const long mt = (M + FWD_CFGS[p.cfg].BM - 1) / FWD_CFGS[p.cfg].BM;
+            if ((int64_t)mt * d.nphase * 2 * d.Nstore * 4 <= partial_bytes) {
+                d.stat_partial = partial;
+                d.sb_x = x; d.sb_ldx = ldx; d.sb_ab = ab; d.sb_stats = stats; d.sb_act = act;
+                *nrows = (int)(mt * d.nphase);
+            }
+        }
+    }
+    return ssc_conv_forward(&d, ws, ws_bytes, stream);
 }
 
 extern "C" int ssc_conv_forward_plan(const ssc_conv_desc* dp, int64_t ws_bytes, int* out5) {

@@ -32,7 +32,9 @@ class ConvDesc(C.Structure):
                 ('bmode', C.c_int32), ('k_real', C.c_int32), ('n_off', C.c_int32), ('Nn', C.c_int32),
                 ('Nstore', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32), ('ldc', C.c_int32),
                 ('out_stride', C.c_int32), ('ooff_y', C.c_int32), ('ooff_x', C.c_int32),
-                ('epi', C.c_int32), ('accumulate', C.c_int32), ('stat_partial', C.c_void_p), ('sk_flags', C.c_void_p)]
+                ('epi', C.c_int32), ('accumulate', C.c_int32), ('stat_partial', C.c_void_p), ('sk_flags', C.c_void_p),
+                ('sb_x', C.c_void_p), ('sb_ab', C.c_void_p), ('sb_stats', C.c_void_p), ('sb_ldx', C.c_int32),
+                ('sb_act', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -68,6 +70,8 @@ SIGNATURES = {
     'ssc_conv_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
     'ssc_conv_forward_bn': [C.POINTER(ConvDesc), _P, _L, _P, _P, _F, _P, _P, _P],
     'ssc_bn_finalize': [_P, _I, _I, _L, _P, _P, _F, _P, _P, _P],
+    'ssc_conv_forward_bnbwd': [C.POINTER(ConvDesc), _P, _L, _P, _I, _P, _P, _I, _P, _L, C.POINTER(C.c_int), _P],
+    'ssc_bn_act_backward_pre': [_P, _L, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _L, _P],
     'ssc_conv_narrow_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_narrow_forward': [C.POINTER(ConvDesc), _P],
     'ssc_conv_forward_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, _I],
@@ -265,14 +269,48 @@ def sk_timeouts():
     return sum(int(f[-1].item() != 0) for f in _sk_flags.values())
 
 
-def _run_conv(d, bn=None):
+class BnBwdSums(object):
+    """Partial sums of a norm backward gathered from the epilogues of the launches that produce its incoming gradients
+    (ssc_conv_forward_bnbwd).  x2d [M, C]: the normed tensor (raw), ab / stats its folded norm.  ``take(act)`` gives the
+    argument for conv_dgrad / deconv_dgrad(..., bnbwd=...); bn_act_backward(..., pre=this) uses the rows when every
+    gradient source delivered them and falls back to its own pass otherwise."""
+
+    def __init__(self, x2d, ab, stats, buf):
+        self.x2d, self.ab, self.stats, self.buf = x2d, ab, stats, buf
+        self.rows, self.sources, self.missed = 0, 0, 0
+
+    @staticmethod
+    def rows_needed(M, sources=1):
+        """Rows of ``buf`` that always suffice: one per 64-row tile and sub-pixel phase, per gradient source."""
+        return sources * 4 * ((M // 4 + 63) // 64 + 1)
+
+    def take(self, act):
+        return (self, act)
+
+
+def _run_conv(d, bn=None, bnbwd=None):
     """bn = (scale, offset, ab, stats[, eps]): also fold the batch-statistics norm of the conv's output (the whole
-    [rows, ldc] output must be the normed tensor)."""
+    [rows, ldc] output must be the normed tensor).  bnbwd = BnBwdSums.take(act): the output is a gradient w.r.t. that
+    activated norm; its backward sums come out of the epilogue when the launch qualifies."""
     ws = workspace()
     d.sk_flags = sk_flags().data_ptr() if SK_ENABLED else None
 
     def launch():
-        if bn is None:
+        if bnbwd is not None:
+            sums, act = bnbwd
+            C2 = 2 * sums.x2d.shape[1]
+            part = sums.buf[sums.rows:]
+            n = C.c_int(0)
+            check(lib().ssc_conv_forward_bnbwd(C.byref(d), ptr(ws), ws.numel() * 4, ptr(sums.x2d), sums.x2d.stride(0),
+                                               ptr(sums.ab), ptr(sums.stats), act, ptr(part), part.numel() * 4,
+                                               C.byref(n), stream_ptr()), 'ssc_conv_forward_bnbwd')
+            sums.sources += 1
+            if n.value > 0:
+                assert part.shape[1] == C2
+                sums.rows += n.value
+            else:
+                sums.missed += 1
+        elif bn is None:
             check(lib().ssc_conv_forward(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_forward')
         else:
             eps = bn[4] if len(bn) > 4 else 1e-5
@@ -384,7 +422,7 @@ def deconv_forward(x, f, out, coff=0, nstore=None, epi=0, bn=None):
     _run_conv(d, _bn_arg(bn, d, coff, out))
 
 
-def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=None, accumulate=False):
+def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=None, accumulate=False, bnbwd=None):
     """Gradient of a conv w.r.t. its input channels [n_off, n_off+nn): dy View -> out [N,Hin,Win,*].
     stride 2: the k=4 pad-1 conv (4 sub-pixel phases).  stride 1: any square kernel, ``pad`` = padding before
     (SAME: (k-1)//2, the extra element after), input size taken from ``out``."""
@@ -410,10 +448,10 @@ def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=No
     d.n_off, d.Nn, d.Nstore = n_off, nn, (nstore if nstore is not None else nn)
     d.OH, d.OW, d.ldc, d.ooff_y, d.ooff_x = OH, OW, ldc, 0, 0
     d.epi, d.accumulate = 0, int(accumulate)
-    _run_conv(d)
+    _run_conv(d, bnbwd=bnbwd)
 
 
-def deconv_dgrad(dy, f, out, n_off=0, nn=None, accumulate=False):
+def deconv_dgrad(dy, f, out, n_off=0, nn=None, accumulate=False, bnbwd=None):
     """Gradient of the k=4 s=2 transposed conv w.r.t. its input channels: a stride-2 conv of dy with f as HWIO."""
     KH, KW, co, ci = f.shape
     nn = ci - n_off if nn is None else nn
@@ -429,7 +467,7 @@ def deconv_dgrad(dy, f, out, n_off=0, nn=None, accumulate=False):
     d.n_off, d.Nn, d.Nstore = n_off, nn, nn
     d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 1, 0, 0
     d.epi, d.accumulate = 0, int(accumulate)
-    _run_conv(d)
+    _run_conv(d, bnbwd=bnbwd)
 
 
 def conv_wgrad(x, dy, w_grad, stride, pad, accumulate=False):
@@ -597,15 +635,19 @@ def bn_stats(x2d, scale, offset, ab, stats, eps=1e-5):
                              ptr(ws), ws.numel() * 4, stream_ptr()), 'bn_stats')
 
 
-def bn_act_backward(x2d, ab, stats, g1, act1, dx, g2=None, act2=ACT_NONE, dscale=None, doffset=None):
-    """Backward through act(a*x+b) (has_bn when ab is given) for one or two consumers."""
+def bn_act_backward(x2d, ab, stats, g1, act1, dx, g2=None, act2=ACT_NONE, dscale=None, doffset=None, pre=None):
+    """Backward through act(a*x+b) (has_bn when ab is given) for one or two consumers.  pre: BnBwdSums whose rows replace
+    the pass that takes the two per-channel sums (only when every gradient source delivered its rows)."""
     M, Cc = x2d.shape
     ws = workspace()
     has_bn = ab is not None
-    check(lib().ssc_bn_act_backward(ptr(x2d), M, Cc, x2d.stride(0), ptr(ab), ptr(stats), None,
-                                    ptr(g1), g1.stride(0), act1, ptr(g2), (g2.stride(0) if g2 is not None else 0),
-                                    act2, int(has_bn), ptr(dx), dx.stride(0), ptr(dscale), ptr(doffset),
-                                    ptr(ws), ws.numel() * 4, stream_ptr()), 'bn_act_backward')
+    rows, nrows = None, 0
+    if pre is not None and has_bn and pre.missed == 0 and pre.sources == (1 if g2 is None else 2) and pre.rows > 0:
+        rows, nrows = pre.buf, pre.rows
+    check(lib().ssc_bn_act_backward_pre(ptr(x2d), M, Cc, x2d.stride(0), ptr(ab), ptr(stats),
+                                        ptr(g1), g1.stride(0), act1, ptr(g2), (g2.stride(0) if g2 is not None else 0),
+                                        act2, int(has_bn), ptr(dx), dx.stride(0), ptr(dscale), ptr(doffset),
+                                        ptr(rows), nrows, ptr(ws), ws.numel() * 4, stream_ptr()), 'bn_act_backward')
 
 
 # ---------------------------------------------------------------------------

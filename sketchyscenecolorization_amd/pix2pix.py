@@ -128,6 +128,11 @@ class Pix2PixGenerator(object):
     def _join(self):
         torch.cuda.current_stream().wait_stream(self.bn_stream)
 
+    def _sums(self, tag, name, x, ab, stats, sources=1):
+        x2d = _rows(x)
+        buf = self.b.get(tag + '/gb/bnsums_' + name, (hip.BnBwdSums.rows_needed(x2d.shape[0], sources), 2 * x2d.shape[1]))
+        return hip.BnBwdSums(x2d, ab, stats, buf)
+
     def backward(self, ctx, dpre, on_section=None, side_stream=None):
         """dpre [N,H,W,4]: gradient w.r.t. the pre-tanh output.  Writes every generator gradient.
         ``on_section(name)`` is called when a contiguous block of the flat gradient buffer is final
@@ -142,6 +147,7 @@ class Pix2PixGenerator(object):
         e, ab, st, d, abd, std, views = ctx['e'], ctx['ab'], ctx['st'], ctx['d'], ctx['abd'], ctx['std'], ctx['views']
         gcur = dpre
         g_skip = [None] * 6
+        sums_e = [None] * 6
         g_feat = g_noise = None
         hold = side_stream is not None and self.lstm_hybrid
         for k in (1, 2, 3, 4, 5):
@@ -157,12 +163,17 @@ class Pix2PixGenerator(object):
             # the chain continues from g0 (through the norm backward); the filter gradient and the skip half g1 are read
             # much later, so they run on the helper stream NEXT TO the three small launches of the norm backward, and the
             # chain waits for them before its next full-size launch (one implicit-GEMM launch at a time, as in line)
-            hip.deconv_dgrad(dyv, f, g0, n_off=0, nn=v.C0)
+            # the two per-channel sums of each norm's backward are taken by the epilogues of the data-gradient launches
+            # that produce its incoming gradients (hip.BnBwdSums): decoder_{k+1}'s norm from g0, encoder_k's from g1 + gin
+            sums_d = self._sums(tag, 'd%d' % (k + 1), d[k + 1], abd[k + 1], std[k + 1]) if k < 5 else None
+            if 2 <= k <= 4:
+                sums_e[k] = self._sums(tag, 'e%d' % k, e[k], ab[k], st[k], sources=2)
+            hip.deconv_dgrad(dyv, f, g0, n_off=0, nn=v.C0, bnbwd=(sums_d.take(ACT_RELU) if sums_d else None))
 
-            def rest(wg=wg, dyv=dyv, f=f, g1=g1, v=v):
+            def rest(wg=wg, dyv=dyv, f=f, g1=g1, v=v, k=k):
                 if not hold:
                     wg()
-                hip.deconv_dgrad(dyv, f, g1, n_off=v.C0, nn=v.C1)
+                hip.deconv_dgrad(dyv, f, g1, n_off=v.C0, nn=v.C1, bnbwd=(sums_e[k].take(ACT_RELU) if sums_e[k] else None))
             forked = self._fork(rest)
             if k < 5:
                 g_skip[k] = g1          # through relu to encoder_k's output
@@ -170,7 +181,7 @@ class Pix2PixGenerator(object):
                 dx = B.get(tag + '/gb/dd%d' % (k + 1), src.shape)
                 hip.bn_act_backward(_rows(src), abd[k + 1], std[k + 1], _rows(g0), ACT_RELU, _rows(dx),
                                     dscale=s.grad('generator/decoder_%d/scale' % (k + 1)),
-                                    doffset=s.grad('generator/decoder_%d/offset' % (k + 1)))
+                                    doffset=s.grad('generator/decoder_%d/offset' % (k + 1)), pre=sums_d)
                 gcur = dx
             else:
                 g_feat, g_noise = g0, g1
@@ -228,7 +239,7 @@ class Pix2PixGenerator(object):
             xin = View(e[k - 1], None, ab[k - 1], ACT_LRELU)
             dyv = View(gcur)
             gin = B.get(tag + '/gb/e%d_in' % k, e[k - 1].shape)
-            hip.conv_dgrad(dyv, w, 2, 1, gin)
+            hip.conv_dgrad(dyv, w, 2, 1, gin, bnbwd=(sums_e[k - 1].take(ACT_LRELU) if sums_e[k - 1] else None))
             forked = self._fork(lambda xin=xin, dyv=dyv, k=k:
                                 hip.conv_wgrad(xin, dyv, s.grad('generator/encoder_%d/conv/filter' % k), 2, 1))
             dx = B.get(tag + '/gb/de%d' % (k - 1), e[k - 1].shape)
@@ -236,7 +247,7 @@ class Pix2PixGenerator(object):
                 hip.bn_act_backward(_rows(e[k - 1]), ab[k - 1], st[k - 1], _rows(gin), ACT_LRELU, _rows(dx),
                                     g2=_rows(g_skip[k - 1]), act2=ACT_RELU,
                                     dscale=s.grad('generator/encoder_%d/scale' % (k - 1)),
-                                    doffset=s.grad('generator/encoder_%d/offset' % (k - 1)))
+                                    doffset=s.grad('generator/encoder_%d/offset' % (k - 1)), pre=sums_e[k - 1])
             else:
                 hip.bn_act_backward(_rows(e[1]), None, None, _rows(gin), ACT_LRELU, _rows(dx),
                                     g2=_rows(g_skip[1]), act2=ACT_RELU)
@@ -336,6 +347,7 @@ class Pix2PixDiscriminator(object):
             hip.call('ssc_add_row_bcast', g4, dimg, 1.0 / ctx['P4'], N, ctx['P4'], 512)
         gcur = g4
         dgen = None
+        sums = None         # partial sums of layer k's norm backward, taken by the launch that produced gcur (hip.BnBwdSums)
         for k in (4, 3, 2, 1):
             dx = B.get(tag + '/gb/dl%d' % k, l[k].shape)
             if k >= 2:
@@ -345,7 +357,8 @@ class Pix2PixDiscriminator(object):
                     ds, do = tmp_s[0], tmp_s[1]
                 elif need_params:
                     ds, do = gname(k, 'scale'), gname(k, 'offset')
-                hip.bn_act_backward(_rows(l[k]), ab[k], st[k], _rows(gcur), ACT_LRELU, _rows(dx), dscale=ds, doffset=do)
+                hip.bn_act_backward(_rows(l[k]), ab[k], st[k], _rows(gcur), ACT_LRELU, _rows(dx), dscale=ds, doffset=do,
+                                    pre=sums)
                 if need_params and accumulate:
                     hip.call('ssc_axpy', gname(k, 'scale'), ds, 1.0, self.chans[k])
                     hip.call('ssc_axpy', gname(k, 'offset'), do, 1.0, self.chans[k])
@@ -363,7 +376,13 @@ class Pix2PixDiscriminator(object):
                 hip.conv_wgrad(xin, dyv, gname(k, 'conv/filter'), self.strides[k], 1, accumulate=accumulate)
             if k > 1:
                 gin = B.get(tag + '/gb/g%d' % (k - 1), l[k - 1].shape)
-                hip.conv_dgrad(dyv, w, self.strides[k], 1, gin)
+                sums = None
+                if k - 1 >= 2:
+                    x2d = _rows(l[k - 1])
+                    sums = hip.BnBwdSums(x2d, ab[k - 1], st[k - 1],
+                                         B.get(tag + '/gb/bnsums%d' % (k - 1),
+                                               (hip.BnBwdSums.rows_needed(x2d.shape[0]), 2 * x2d.shape[1])))
+                hip.conv_dgrad(dyv, w, self.strides[k], 1, gin, bnbwd=(sums.take(ACT_LRELU) if sums else None))
                 gcur = gin
             elif need_input:
                 dgen = B.get(tag + '/gb/dgen', (N, l[0].shape[1], l[0].shape[2], 4))

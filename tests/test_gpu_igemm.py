@@ -435,3 +435,49 @@ def test_in_launch_tail_split_equals_slab_launch(case):
     assert float((a - ref).abs().max()) <= 2e-5 * scale, (float((a - ref).abs().max()), scale)
     assert hip.sk_timeouts() == 0
     assert int(hip.sk_flags().abs().sum()) == 0
+
+
+@pytest.mark.parametrize('n,h,c,expect_fused', [(16, 48, 128, True), (2, 16, 64, False)])
+def test_norm_backward_sums_from_dgrad_epilogues(n, h, c, expect_fused):
+    """batchnorm -> (lrelu -> stride-2 conv) + (relu -> transposed conv), models_collection.py:36-46, 434-439, 512-531: the two
+    per-channel sums of the norm's backward taken by the epilogues of the two data-gradient launches
+    (ssc_conv_forward_bnbwd + ssc_bn_act_backward_pre) against the oracle's autograd, and against the separate pass."""
+    hip = _hip()
+    co1, co2 = 2 * c, c // 2
+    x = (rnd(n, c, h, h, seed=71) * 1.5 + 0.3).requires_grad_(True)
+    scale = (1.0 + 0.1 * rnd(c, seed=72)).requires_grad_(True)
+    offset = (0.1 * rnd(c, seed=73)).requires_grad_(True)
+    w1 = rnd(4, 4, c, co1, seed=74, std=0.05)
+    f2 = rnd(4, 4, co2, c, seed=75, std=0.05)
+    y = T.batchnorm(x, scale, offset)
+    o1 = T.conv2d_valid_pad(T.lrelu(y, 0.2), w1, 2, 1)
+    o2 = T.conv2d_transpose_same_s2(torch.relu(y), f2)
+    dy1, dy2 = rnd(*o1.shape, seed=76), rnd(*o2.shape, seed=77)
+    ((o1 * dy1).sum() + (o2 * dy2).sum()).backward()
+
+    xd = nhwc(x.detach()).cuda()
+    x2d = xd.view(-1, c)
+    ab, st = torch.empty(2 * c, device='cuda'), torch.empty(2 * c, device='cuda')
+    hip.bn_stats(x2d, scale.detach().cuda(), offset.detach().cuda(), ab, st)
+    res = {}
+    for fused in (True, False):
+        sums = hip.BnBwdSums(x2d, ab, st, torch.zeros(hip.BnBwdSums.rows_needed(x2d.shape[0], 2), 2 * c, device='cuda')) \
+            if fused else None
+        g1 = torch.full((n, h, h, c), float('nan'), device='cuda')
+        g2 = torch.full((n, h, h, c), float('nan'), device='cuda')
+        hip.conv_dgrad(hip.View(nhwc(dy1).cuda()), w1.cuda(), 2, 1, g1, bnbwd=(sums.take(2) if fused else None))
+        hip.deconv_dgrad(hip.View(nhwc(dy2).cuda()), f2.cuda(), g2, bnbwd=(sums.take(1) if fused else None))
+        dx = torch.full((n * h * h, c), float('nan'), device='cuda')
+        ds, do = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+        hip.bn_act_backward(x2d, ab, st, g1.view(-1, c), 2, dx, g2=g2.view(-1, c), act2=1, dscale=ds, doffset=do, pre=sums)
+        if fused:
+            assert sums.sources == 2
+            if expect_fused:        # both launches finish their tiles in one workgroup each: the rows come from the epilogues
+                assert sums.missed == 0 and sums.rows > 0
+        res[fused] = (dx, ds, do)
+        close(nchw(dx.view(n, h, h, c)), x.grad, tol=5e-4)
+        close(ds, scale.grad, tol=5e-4)
+        close(do, offset.grad, tol=5e-4)
+    for a, b in zip(res[True], res[False]):
+        close(a, b, tol=1e-4)
+    assert hip.sk_timeouts() == 0
