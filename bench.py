@@ -221,7 +221,7 @@ def self_launch(args, argv):
         return
     if args.gpus == 1 and not args.launcher:
         return
-    if not args.stub_cpu:
+    if not args.stub_cpu and os.environ.get('SSC_BENCH_ONE_DEVICE') != '1':
         n_dev = torch.cuda.device_count()
         if n_dev < args.gpus:
             raise SystemExit('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, n_dev))
@@ -318,13 +318,19 @@ def main():
         torch.cuda.set_device(0)
         return run_forward_workload(args)
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
-    torch.cuda.set_device(local_rank)
+    # SSC_BENCH_ONE_DEVICE=1 (test hook, tests/test_bench_launcher.py): every rank on cuda:0 over gloo -- a REHEARSAL of the N-rank
+    # bench on a single-GPU box (RCCL refuses two ranks on one device); the JSON line says so and its value is not a measurement
+    rehearsal = under_launcher and os.environ.get('SSC_BENCH_ONE_DEVICE') == '1'
+    torch.cuda.set_device(0 if rehearsal else local_rank)
     pg, ranks_observed = None, 1
     if under_launcher:      # one process per GPU; backend "nccl" is RCCL on ROCm.  Also with 1 rank: proves the bootstrap
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         pg = dist.group.WORLD if world > 1 else None
         one = torch.ones(1, device='cuda')
         dist.all_reduce(one)                # RCCL rank count as the collective itself sees it
@@ -415,7 +421,9 @@ def main():
                                                                                              args.batch),
                           'global_batch': global_batch, 'parallelism': 'dp%d' % world,
                           'ranks_observed_by_allreduce': ranks_observed,
-                          'launcher': ('torch.distributed.run, backend nccl (RCCL)' if under_launcher else 'in-process'),
+                          'launcher': ('torch.distributed.run, REHEARSAL: all ranks on one GPU over gloo (not a measurement)'
+                                       if rehearsal else
+                                       'torch.distributed.run, backend nccl (RCCL)' if under_launcher else 'in-process'),
                           'block_type': args.block_type, 'loss_g': loss_g, 'loss_d': loss_d,
                           'launch': 'eager' if args.no_graphs else 'hipGraph replay'},
                'step_tflops_as_written': flops_step / (ms * 1e-3) / 1e12,

@@ -1749,6 +1749,7 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
                                    const float* offset, float eps, float* ab, float* stats, void* stream) {
     ssc_conv_desc d = *dp;
     d.stat_partial = nullptr;
+    d.sb_x = nullptr;
     const long M = (long)d.NB * d.PH * d.PW;
     const long Mall = M * d.nphase;
     static int off = -1;        // SSC_FUSE_STATS=0: always the separate pass (A/B)

@@ -58,3 +58,19 @@ def test_launcher_path_one_rank_rccl_matches_in_process():
     assert b['n_gpus'] == 1 and b['config']['ranks_observed_by_allreduce'] == 1
     assert 'torch.distributed.run' in b['config']['launcher'] and a['config']['launcher'] == 'in-process'
     assert abs(a['value'] - b['value']) / a['value'] < 0.05, (a['value'], b['value'])
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_on_one_gpu():
+    """The whole N = 2 bench path on one GPU: `bench.py --gpus 2` starts two ranks, each runs the segmented-graph train step
+    with its own batch, gradients are all-reduced (gloo over device tensors: RCCL refuses two ranks on one device), timing is the
+    max over ranks, rank 0 prints one line.  A rehearsal of what the driver launches on an 8-GPU node, labelled as such."""
+    r, lines = _run(['--gpus', '2', '--steps', '4', '--warmup', '3', '--batch', '2', '--img', '64', '--preheat-seconds', '0.2',
+                     '--no-cpu-baseline', '--prof-steps', '1'], {'SSC_BENCH_ONE_DEVICE': '1'}, timeout=900)
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['config']['parallelism'] == 'dp2' and j['config']['ranks_observed_by_allreduce'] == 2
+    assert j['config']['global_batch'] == 4 and 'REHEARSAL' in j['config']['launcher']
+    assert j['value'] > 0 and j['scaling'] == 'weak'
+    import math
+    assert math.isfinite(j['config']['loss_g']) and math.isfinite(j['config']['loss_d'])
