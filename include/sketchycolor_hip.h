@@ -270,11 +270,13 @@ int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, const float* 
  * [sum dz | sum dz*xhat] written by the epilogues of the launches that produced g1 (and g2) -- see
  * ssc_conv_forward_bnbwd; pre = NULL: as ssc_bn_act_backward.  Saves the pass over x, g1, g2 of
  * the gradient chain generate_pix2pix -> batchnorm -> lrelu/relu (models_collection.py:36-46, 434-439).
+ * rowb != NULL (only with pre == NULL): g1[r][c] += rowb[r / rowb_P][c] * rowb_scale on the fly -- the gradient of the
+ * discriminator's class head through its spatial mean (models_collection.py:836-840), one row per image.
  */
 int ssc_bn_act_backward_pre(const float* x, int64_t M, int C, int ldx, const float* ab, const float* stats,
                             const float* g1, int ldg1, int act1, const float* g2, int ldg2, int act2, int has_bn,
                             float* dx, int lddx, float* dscale, float* doffset, const float* pre, int nrows,
-                            float* ws, int64_t ws_bytes, void* stream);
+                            const float* rowb, float rowb_scale, int rowb_P, float* ws, int64_t ws_bytes, void* stream);
 /*
  * ssc_conv_forward for a launch whose output g is the gradient w.r.t. act(a*x+b) of a batch-statistics-normed
  * tensor x ([rows][ldx], addressed like the output): when the launch qualifies (uniform-tap kernel, no split-K

@@ -1,5 +1,5 @@
 """Single-layer microbenchmark of the implicit-GEMM kernel (for rocprofv3 --pmc passes).
-usage: conv_microbench.py <layer> [iters] [batch];  layers: enc2 enc3 enc4 d4 dec3 dg3 wg3 dec1 dl1g logit"""
+usage: conv_microbench.py <layer> [iters] [batch];  layers: enc2 enc3 enc4 d4 dec3 dg3 wg3 dec1 dl1g logit d1 d1p e1 dec1g"""
 import sys
 import torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -50,6 +50,22 @@ elif layer == 'logit':    # PatchGAN logit conv 512 -> 1, 4x4 stride 1
     out = torch.empty(N, 22, 22, 4, device='cuda')
     fn = lambda: hip.conv_forward(View(x, None, ab, 2), w, 1, 1, out, nstore=4)
     flops = 2.0 * N * 22 * 22 * 16 * 512
+elif layer in ('d1', 'd1p'):    # discriminator's first conv: 8-channel input (6 real); d1p: filter padded to 8 rows per tap (row-tap form)
+    cr = 6 if layer == 'd1' else 8
+    x, w = r(N, 192, 192, 8), r(4, 4, cr, 64) * 0.02
+    out = torch.empty(N, 96, 96, 64, device='cuda')
+    fn = lambda: hip.conv_forward(View(x), w, 2, 1, out)
+    flops = 2.0 * N * 96 * 96 * 64 * 16 * cr
+elif layer == 'e1':             # generator's first conv: 4-channel input (3 real)
+    x, w = r(N, 192, 192, 4), r(4, 4, 3, 64) * 0.02
+    out = torch.empty(N, 96, 96, 64, device='cuda')
+    fn = lambda: hip.conv_forward(View(x), w, 2, 1, out)
+    flops = 2.0 * N * 96 * 96 * 64 * 16 * 3
+elif layer == 'dec1g':          # data gradient of the generator's last transposed conv w.r.t. its first 64 input channels
+    dy, f = r(N, 192, 192, 4), r(4, 4, 3, 128) * 0.02
+    g0 = torch.empty(N, 96, 96, 64, device='cuda')
+    fn = lambda: hip.deconv_dgrad(View(dy), f, g0, n_off=0, nn=64)
+    flops = 2.0 * N * 96 * 96 * 64 * 16 * 3
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

@@ -517,6 +517,7 @@ struct BnBwdArgs {
     const float* g1; int ldg1; int act1;
     const float* g2; int ldg2; int act2;
     int has_bn;
+    const float* rowb; float rowb_scale; int rowb_P;    // g1[r][c] += rowb[r / rowb_P][c] * rowb_scale (NULL: nothing added)
 };
 
 __device__ __forceinline__ void bn_bwd_dz(const BnBwdArgs& a, long r, int c, const float4& aa, const float4& bb,
@@ -529,7 +530,12 @@ __device__ __forceinline__ void bn_bwd_dz(const BnBwdArgs& a, long r, int c, con
     } else {
         z = xv;
     }
-    const float4 g = *reinterpret_cast<const float4*>(a.g1 + r * a.ldg1 + c);
+    float4 g = *reinterpret_cast<const float4*>(a.g1 + r * a.ldg1 + c);
+    if (a.rowb != nullptr) {        // a per-image term broadcast over the pixels (the class head's gradient through its spatial mean)
+        const float4 t = *reinterpret_cast<const float4*>(a.rowb + (r / a.rowb_P) * a.C + c);
+        g.x = fmaf(t.x, a.rowb_scale, g.x); g.y = fmaf(t.y, a.rowb_scale, g.y);
+        g.z = fmaf(t.z, a.rowb_scale, g.z); g.w = fmaf(t.w, a.rowb_scale, g.w);
+    }
     dz.x = g.x * dact(z.x, a.act1); dz.y = g.y * dact(z.y, a.act1);
     dz.z = g.z * dact(z.z, a.act1); dz.w = g.w * dact(z.w, a.act1);
     if (a.g2 != nullptr) {
@@ -649,12 +655,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
 extern "C" int ssc_bn_act_backward_pre(const float* x, int64_t M, int C, int ldx, const float* ab, const float* stats,
                                        const float* g1, int ldg1, int act1, const float* g2, int ldg2, int act2, int has_bn,
                                        float* dx, int lddx, float* dscale, float* doffset, const float* pre, int nrows,
-                                       float* ws, int64_t ws_bytes, void* stream) {
+                                       const float* rowb, float rowb_scale, int rowb_P, float* ws, int64_t ws_bytes,
+                                       void* stream) {
     if ((C & 3) || (ldx & 3) || (ldg1 & 3) || (lddx & 3) || (g2 != nullptr && (ldg2 & 3))) return -1;
+    if (rowb != nullptr && (rowb_P <= 0 || (pre != nullptr && nrows > 0))) return -3;   // sums taken elsewhere cannot include rowb
     hipStream_t st = (hipStream_t)stream;
     BnBwdArgs a;
     a.x = x; a.M = (long)M; a.C = C; a.ldx = ldx; a.ab = ab; a.stats = stats;
     a.g1 = g1; a.ldg1 = ldg1; a.act1 = act1; a.g2 = g2; a.ldg2 = ldg2; a.act2 = act2; a.has_bn = has_bn;
+    a.rowb = rowb; a.rowb_scale = rowb_scale; a.rowb_P = rowb_P;
     float* coef = nullptr;
     if (has_bn) {
         int tcg, rl, nbr, nbc;
@@ -685,7 +694,7 @@ extern "C" int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, co
                                    float* doffset, float* ws, int64_t ws_bytes, void* stream) {
     (void)scale;
     return ssc_bn_act_backward_pre(x, M, C, ldx, ab, stats, g1, ldg1, act1, g2, ldg2, act2, has_bn, dx, lddx, dscale, doffset,
-                                   nullptr, 0, ws, ws_bytes, stream);
+                                   nullptr, 0, nullptr, 0.f, 0, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------ materialising helpers

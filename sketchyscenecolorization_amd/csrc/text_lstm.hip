@@ -445,6 +445,18 @@ __global__ void add_row_bcast_kernel(float* __restrict__ g, const float* __restr
     g[i] += v[(long)n * C + c] * scale;
 }
 
+// the same, 4 channels per thread (C % 4 == 0, 16-byte aligned): one 16-byte read-modify-write instead of four 4-byte ones
+__global__ __launch_bounds__(256) void add_row_bcast4_kernel(float4* __restrict__ g, const float4* __restrict__ v, float scale,
+                                                             unsigned tot4, unsigned C4, unsigned PC4) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < tot4; i += gridDim.x * 256u) {
+        const unsigned n = i / PC4, c4 = i % C4;
+        float4 x = g[i];
+        const float4 t = v[n * C4 + c4];
+        x.x = fmaf(t.x, scale, x.x); x.y = fmaf(t.y, scale, x.y); x.z = fmaf(t.z, scale, x.z); x.w = fmaf(t.w, scale, x.w);
+        g[i] = x;
+    }
+}
+
 extern "C" int ssc_act_mean_hw(const float* x, const float* ab, int act, int N, int P, int C, float* out,
                                void* stream) {
     hipLaunchKernelGGL(act_mean_hw_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)N), dim3(256), 0,
@@ -454,6 +466,14 @@ extern "C" int ssc_act_mean_hw(const float* x, const float* ab, int act, int N, 
 
 extern "C" int ssc_add_row_bcast(float* g, const float* v, float scale, int N, int P, int C, void* stream) {
     const long tot = (long)N * P * C;
+    if ((C & 3) == 0 && tot / 4 < 0x7fffffffL && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        const unsigned tot4 = (unsigned)(tot / 4);
+        unsigned blocks = (tot4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(add_row_bcast4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(g),
+                           reinterpret_cast<const float4*>(v), scale, tot4, (unsigned)(C / 4), (unsigned)((long)P * C / 4));
+        return CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(add_row_bcast_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, v,
                        scale, N, P, C);
     return CHECK_LAUNCH();

@@ -71,7 +71,8 @@ SIGNATURES = {
     'ssc_conv_forward_bn': [C.POINTER(ConvDesc), _P, _L, _P, _P, _F, _P, _P, _P],
     'ssc_bn_finalize': [_P, _I, _I, _L, _P, _P, _F, _P, _P, _P],
     'ssc_conv_forward_bnbwd': [C.POINTER(ConvDesc), _P, _L, _P, _I, _P, _P, _I, _P, _L, C.POINTER(C.c_int), _P],
-    'ssc_bn_act_backward_pre': [_P, _L, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _L, _P],
+    'ssc_bn_act_backward_pre': [_P, _L, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _F, _I, _P,
+                                _L, _P],
     'ssc_conv_narrow_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_narrow_forward': [C.POINTER(ConvDesc), _P],
     'ssc_conv_forward_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, _I],
@@ -635,9 +636,10 @@ def bn_stats(x2d, scale, offset, ab, stats, eps=1e-5):
                              ptr(ws), ws.numel() * 4, stream_ptr()), 'bn_stats')
 
 
-def bn_act_backward(x2d, ab, stats, g1, act1, dx, g2=None, act2=ACT_NONE, dscale=None, doffset=None, pre=None):
+def bn_act_backward(x2d, ab, stats, g1, act1, dx, g2=None, act2=ACT_NONE, dscale=None, doffset=None, pre=None, rowb=None):
     """Backward through act(a*x+b) (has_bn when ab is given) for one or two consumers.  pre: BnBwdSums whose rows replace
-    the pass that takes the two per-channel sums (only when every gradient source delivered its rows)."""
+    the pass that takes the two per-channel sums (only when every gradient source delivered its rows).
+    rowb = (v [N, C], scale, P): g1[r] += v[r // P] * scale while it is read (a per-image gradient broadcast over P pixels)."""
     M, Cc = x2d.shape
     ws = workspace()
     has_bn = ab is not None
@@ -647,7 +649,8 @@ def bn_act_backward(x2d, ab, stats, g1, act1, dx, g2=None, act2=ACT_NONE, dscale
     check(lib().ssc_bn_act_backward_pre(ptr(x2d), M, Cc, x2d.stride(0), ptr(ab), ptr(stats),
                                         ptr(g1), g1.stride(0), act1, ptr(g2), (g2.stride(0) if g2 is not None else 0),
                                         act2, int(has_bn), ptr(dx), dx.stride(0), ptr(dscale), ptr(doffset),
-                                        ptr(rows), nrows, ptr(ws), ws.numel() * 4, stream_ptr()), 'bn_act_backward')
+                                        ptr(rows), nrows, ptr(rowb[0]) if rowb else None, float(rowb[1]) if rowb else 0.0,
+                                        int(rowb[2]) if rowb else 0, ptr(ws), ws.numel() * 4, stream_ptr()), 'bn_act_backward')
 
 
 # ---------------------------------------------------------------------------

@@ -332,6 +332,7 @@ class Pix2PixDiscriminator(object):
             hip.conv_wgrad(x5, dyv, gname(5, 'conv/filter'), 1, 1, accumulate=accumulate)
         g4 = B.get(tag + '/gb/g4', l[4].shape)
         hip.conv_dgrad(dyv, s['discriminator/layer_5/conv/filter'], 1, 1, g4, k_real=1)
+        rowb = None
         if dlogits is not None:
             dimg = B.get(tag + '/gb/dimg', (N, 512))
             K = dlogits.shape[1]
@@ -344,7 +345,9 @@ class Pix2PixDiscriminator(object):
                 else:
                     gw, acc = s.grad('discriminator/fully_connected/weights'), int(accumulate)
             hip.call('ssc_fc_small_bwd', ctx['img'], sn['wbar'], dlogits, N, 512, K, dimg, gw, gb_, acc)
-            hip.call('ssc_add_row_bcast', g4, dimg, 1.0 / ctx['P4'], N, ctx['P4'], 512)
+            # the class head reads the spatial mean of layer 4: its gradient dimg / P4 is added to g4 by the norm backward
+            # below while it reads g4 (no pass of its own over the tensor)
+            rowb = (dimg, 1.0 / ctx['P4'], ctx['P4'])
         gcur = g4
         dgen = None
         sums = None         # partial sums of layer k's norm backward, taken by the launch that produced gcur (hip.BnBwdSums)
@@ -358,7 +361,7 @@ class Pix2PixDiscriminator(object):
                 elif need_params:
                     ds, do = gname(k, 'scale'), gname(k, 'offset')
                 hip.bn_act_backward(_rows(l[k]), ab[k], st[k], _rows(gcur), ACT_LRELU, _rows(dx), dscale=ds, doffset=do,
-                                    pre=sums)
+                                    pre=sums, rowb=(rowb if k == 4 else None))
                 if need_params and accumulate:
                     hip.call('ssc_axpy', gname(k, 'scale'), ds, 1.0, self.chans[k])
                     hip.call('ssc_axpy', gname(k, 'offset'), do, 1.0, self.chans[k])
