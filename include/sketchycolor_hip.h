@@ -129,6 +129,10 @@ int ssc_conv_forward_bn(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, con
 /* direct (vector-ALU, LDS patch) form for <= 4 output channels; ssc_conv_forward dispatches to it (narrow.hip) */
 int ssc_conv_narrow_supported(const ssc_conv_desc* d);
 int ssc_conv_narrow_forward(const ssc_conv_desc* d, void* stream);
+/* 1 when ssc_conv_forward runs the launch on the few-input-channel kernel (fewchan.hip): 4x4 stride-2 pad-1 conv over a
+ * single 4- or 8-channel raw source to 33..64 outputs, output lattice a multiple of 4 x 32 -- generator encoder_1
+ * (models_collection.py:454-458), discriminator layer_1 (:798-801), the data gradient of decoder_1 (:529-534) */
+int ssc_conv_fewchan_supported(const ssc_conv_desc* d);
 /* name of the tile configuration the launcher picks for a descriptor (host only; for profiling) */
 int ssc_conv_forward_kernel_name(const ssc_conv_desc* d, char* buf, int len);
 int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* d, char* buf, int len);

@@ -13,6 +13,10 @@ from sketchyscenecolorization_amd.trainer import Pix2PixTrainer
 
 GROUPS = {
     'none': [],
+    'none2': [],
+    # convs with <= 8 input channels and a full-width output (the three first layers and decoder_1's data gradient)
+    'fewchan': [lambda d: d.x.C0 + d.x.C1 <= 8 and d.Nn >= 32],
+    'narrow': [lambda d: d.Nn <= 4],
     'bn_bwd': ['ssc_bn_act_backward'],
     'bn_fin': ['ssc_bn_finalize', 'ssc_bn_stats'],
     'text': ['ssc_lstm_step_fwd', 'ssc_lstm_pointwise_fwd', 'ssc_lstm_pointwise_bwd', 'ssc_embedding_gather',
@@ -26,14 +30,20 @@ GROUPS = {
 }
 
 
-def measure(names, n=32, steps=30):
+def measure(names, n=32, steps=80):
     L = hip.lib()
+    convpred = None
+    if names and callable(names[0]):
+        convpred, names = names[0], []
     saved = {k: getattr(L, k) for k in names}
     for k in names:
         setattr(L, k, lambda *a: 0)
+    run_conv = hip._run_conv
+    if convpred is not None:        # skip the conv launches the predicate selects
+        hip._run_conv = lambda d, bn=None, bnbwd=None: None if convpred(d) else run_conv(d, bn=bn, bnbwd=bnbwd)
     tr = Pix2PixTrainer(img=192, seed=0)
     bd, bg = synthetic_batch(n, 1, 192), synthetic_batch(n, 2, 192)
-    for i in range(6):
+    for i in range(40):
         tr.train_iteration(bd, bg, i)
     torch.cuda.synchronize()
     t0 = time.time()
@@ -43,6 +53,7 @@ def measure(names, n=32, steps=30):
     ms = (time.time() - t0) / steps * 1e3
     for k, v in saved.items():
         setattr(L, k, v)
+    hip._run_conv = run_conv
     del tr
     return ms
 

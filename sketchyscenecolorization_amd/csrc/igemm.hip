@@ -24,6 +24,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // narrow.hip
 int ssc_conv_narrow_forward_ws(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, void* stream, int* csplit_out);
+// fewchan.hip
+int ssc_conv_fewchan_forward(const ssc_conv_desc* dp, int num_cu, void* stream);
 
 #define BK 32
 #ifndef SSC_BDMA
@@ -1728,6 +1730,10 @@ extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, 
         copy_name(dp->nphase == 4 ? "narrow_fwd<transposed>" : "narrow_fwd<conv>", buf, len);
         return 0;
     }
+    if (ssc_conv_fewchan_supported(dp)) {
+        copy_name(dp->x.C0 == 8 ? "conv_fewchan<8>" : "conv_fewchan<4>", buf, len);
+        return 0;
+    }
     static const char* names[2][5] = {
         {"conv_fwd<128x128,KN>", "conv_fwd<64x128,KN>", "conv_fwd<128x64,KN>", "conv_fwd<128x32,KN>", "conv_fwd<64x64,KN>"},
         {"conv_fwd<128x128,NK>", "conv_fwd<64x128,NK>", "conv_fwd<128x64,NK>", "conv_fwd<128x32,NK>", "conv_fwd<64x64,NK>"}};
@@ -1759,8 +1765,8 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
     }
     bool fused = false;
     int64_t ws_conv = ws_bytes;
-    if (!off && ws != nullptr && !ssc_conv_narrow_supported(dp) && d.epi == 0 && !d.accumulate && d.Nstore == d.ldc &&
-        ((d.Nstore & 3) == 0) && ((reinterpret_cast<unsigned long>(d.out) & 15) == 0) &&
+    if (!off && ws != nullptr && !ssc_conv_narrow_supported(dp) && !ssc_conv_fewchan_supported(dp) && d.epi == 0 &&
+        !d.accumulate && d.Nstore == d.ldc && ((d.Nstore & 3) == 0) && ((reinterpret_cast<unsigned long>(d.out) & 15) == 0) &&
         (fwd_is_ut(d) || fwd_is_utg(d) || (d.bmode == 0 && fwd_is_rowtap(d)))) {
         const Plan p = plan_fwd(d, ws_bytes, true);
         if (p.cfg > 0 && p.splitk == 1) {
@@ -1804,7 +1810,8 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
     if (!off && ws != nullptr && partial != nullptr && x != nullptr && ab != nullptr && stats != nullptr &&
-        !ssc_conv_narrow_supported(dp) && d.epi == 0 && !d.accumulate && d.bias == nullptr && d.Nstore == d.ldc &&
+        !ssc_conv_narrow_supported(dp) && !ssc_conv_fewchan_supported(dp) && d.epi == 0 && !d.accumulate &&
+        d.bias == nullptr && d.Nstore == d.ldc &&
         d.Nn == d.Nstore && ((d.Nstore & 3) == 0) && ((ldx & 3) == 0) && ((reinterpret_cast<unsigned long>(d.out) & 15) == 0) &&
         ((reinterpret_cast<unsigned long>(x) & 15) == 0) &&
         (fwd_is_ut(d) || fwd_is_utg(d) || (d.bmode == 0 && fwd_is_rowtap(d)))) {
@@ -1823,7 +1830,10 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
 
 extern "C" int ssc_conv_forward_plan(const ssc_conv_desc* dp, int64_t ws_bytes, int* out5) {
     // host only: {tile configuration, split-K slabs, whole tiles, K slices per remaining tile, modelled cycles / 1000}
-    if (ssc_conv_narrow_supported(dp)) { out5[0] = -1; out5[1] = 1; out5[2] = 0; out5[3] = 1; out5[4] = 0; return 0; }
+    if (ssc_conv_narrow_supported(dp) || ssc_conv_fewchan_supported(dp)) {
+        out5[0] = -1; out5[1] = 1; out5[2] = 0; out5[3] = 1; out5[4] = 0;
+        return 0;
+    }
     const Plan p = plan_fwd(*dp, ws_bytes, true);
     out5[0] = p.cfg; out5[1] = p.splitk; out5[2] = (int)p.ts_full; out5[3] = p.ts_s; out5[4] = (int)(p.cost / 1000.0);
     return 0;
@@ -1846,6 +1856,8 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
                            csplit, d.out, out_count, d.ldc, d.Nn, d.Nstore, d.bias, d.epi, d.accumulate);
         return (int)hipGetLastError();
     }
+    if (ssc_conv_fewchan_supported(dp))         // 4x4 stride-2 over 4 or 8 input channels
+        return ssc_conv_fewchan_forward(dp, num_cu(), stream);
     const Plan p = plan_fwd(d, ws_bytes, ws != nullptr);
     if (p.cfg < 0) return -4;
     g_launch_res = FWD_CFGS[p.cfg].res;

@@ -481,3 +481,37 @@ def test_norm_backward_sums_from_dgrad_epilogues(n, h, c, expect_fused):
     for a, b in zip(res[True], res[False]):
         close(a, b, tol=1e-4)
     assert hip.sk_timeouts() == 0
+
+
+@pytest.mark.parametrize('n,h,cp,cr', [(3, 64, 8, 6), (2, 128, 4, 3), (1, 192, 8, 8)])
+def test_few_channel_stride2_conv(n, h, cp, cr):
+    """encoder_1 / discriminator layer_1 / decoder_1's data gradient (models_collection.py:454-458, 798-801, 529-534): 4x4
+    stride-2 conv over a 4- or 8-channel tensor of which cr are real -- the persistent few-channel kernel (fewchan.hip)."""
+    hip = _hip()
+    x = rnd(n, cr, h, h, seed=81)
+    xp = torch.zeros(n, h, h, cp)
+    xp[..., :cr] = nhwc(x)
+    xp[..., cr:] = 7.0          # padding channels may hold anything: the filter has no rows for them
+    w = rnd(4, 4, cr, 64, seed=82, std=0.05)
+    ref = T.conv2d_valid_pad(x, w, 2, 1)
+    out = torch.full((n, h // 2, h // 2, 64), float('nan'), device='cuda')
+    hip.PROFILE = []
+    try:
+        hip.conv_forward(hip.View(xp.cuda()), w.cuda(), 2, 1, out)
+        names = [p[0] for p in hip.PROFILE]
+    finally:
+        hip.PROFILE = None
+    assert names == ['conv_fewchan<%d>' % cp], names
+    close(nchw(out), ref)
+    # the conv form of the transposed conv's data gradient: filter [4,4,co,ci] read as HWIO, channel sub-range [64, 128)
+    if cp == 4:
+        f = rnd(4, 4, cr, 128, seed=83, std=0.05)
+        xin = rnd(n, 128, h // 2, h // 2, seed=84).requires_grad_(True)
+        y = T.conv2d_transpose_same_s2(xin, f)
+        dy = rnd(*y.shape, seed=85)
+        y.backward(dy)
+        dyp = torch.zeros(n, h, h, cp)
+        dyp[..., :cr] = nhwc(dy)
+        g1 = torch.full((n, h // 2, h // 2, 64), float('nan'), device='cuda')
+        hip.deconv_dgrad(hip.View(dyp.cuda()), f.cuda(), g1, n_off=64, nn=64)
+        close(nchw(g1), xin.grad[:, 64:])
