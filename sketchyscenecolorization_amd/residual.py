@@ -152,7 +152,14 @@ class _Bottlenecks(object):
     def _gget(self, t):
         return self._gdone.get(t.data_ptr())
 
-    def _bn_bwd(self, tag, pre, raw, ab, st, g, act, need_params, accumulate, c_real=None):
+    def _sums(self, tag, pre, raw, ab, st):
+        """Partial sums of this norm's backward, to be delivered by the epilogue of the launch that produces its incoming
+        gradient (hip.BnBwdSums / ssc_conv_forward_bnbwd)."""
+        x2d = _rows(raw)
+        buf = self.b.get(tag + '/gb/' + pre + '/bnsums', (hip.BnBwdSums.rows_needed(x2d.shape[0]), 2 * x2d.shape[1]))
+        return hip.BnBwdSums(x2d, ab, st, buf)
+
+    def _bn_bwd(self, tag, pre, raw, ab, st, g, act, need_params, accumulate, c_real=None, sums=None):
         """Backward through act(norm(raw)): returns d raw; writes / adds the scale and offset gradients."""
         s, B = self.s, self.b
         C = raw.shape[-1]
@@ -164,7 +171,7 @@ class _Bottlenecks(object):
         elif need_params:
             tmp = B.get(tag + '/gb/' + pre + '/dso', (2, C))
             ds, do = tmp[0], tmp[1]
-        hip.bn_act_backward(_rows(raw), ab, st, _rows(g), act, _rows(dx), dscale=ds, doffset=do)
+        hip.bn_act_backward(_rows(raw), ab, st, _rows(g), act, _rows(dx), dscale=ds, doffset=do, pre=sums)
         if need_params and not direct:
             cr = C if c_real is None else c_real
             if accumulate:
@@ -192,14 +199,18 @@ class _Bottlenecks(object):
         if need_params:
             hip.conv_wgrad(x3, View(dr3), s.grad(pre + '/block_3/conv_ex/filter'), 1, 0, accumulate=acc)
         g2 = B.get(tag + '/gb/' + pre + '/g2', rec['r2'].shape)
-        hip.conv_dgrad(View(dr3), s[pre + '/block_3/conv_ex/filter'], 1, 0, g2)
-        dr2 = self._bn_bwd(tag, pre + '/block_2/batchnorm', rec['r2'], rec['ab2'], rec['st2'], g2, act, need_params, acc)
+        sums2 = self._sums(tag, pre + '/block_2', rec['r2'], rec['ab2'], rec['st2'])
+        hip.conv_dgrad(View(dr3), s[pre + '/block_3/conv_ex/filter'], 1, 0, g2, bnbwd=sums2.take(act))
+        dr2 = self._bn_bwd(tag, pre + '/block_2/batchnorm', rec['r2'], rec['ab2'], rec['st2'], g2, act, need_params, acc,
+                           sums=sums2)
         x2 = View(rec['r1'], None, rec['ab1'], act)
         if need_params:
             hip.conv_wgrad(x2, View(dr2), s.grad(pre + '/block_2/conv_ex/filter'), 1, 1, accumulate=acc)
         g1 = B.get(tag + '/gb/' + pre + '/g1', rec['r1'].shape)
-        hip.conv_dgrad(View(dr2), s[pre + '/block_2/conv_ex/filter'], 1, 1, g1)
-        dr1 = self._bn_bwd(tag, pre + '/block_1/batchnorm', rec['r1'], rec['ab1'], rec['st1'], g1, act, need_params, acc)
+        sums1 = self._sums(tag, pre + '/block_1', rec['r1'], rec['ab1'], rec['st1'])
+        hip.conv_dgrad(View(dr2), s[pre + '/block_2/conv_ex/filter'], 1, 1, g1, bnbwd=sums1.take(act))
+        dr1 = self._bn_bwd(tag, pre + '/block_1/batchnorm', rec['r1'], rec['ab1'], rec['st1'], g1, act, need_params, acc,
+                           sums=sums1)
         xv = rec['xv']
         branches = [(dr1, 'block_1')]
         if kind != 'pu':
