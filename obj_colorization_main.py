@@ -70,11 +70,8 @@ def start_or_resume_training(params):
     fresh = stamp is None or stamp == ''
     rank, multi = int(os.environ.get('RANK', 0)), params['num_gpu'] > 1
     if multi:       # one process per GPU: rank 0 decides the run directory and the first iteration for everyone
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
-            dist.init_process_group('nccl')
+        from sketchyscenecolorization_amd.dist_utils import init_distributed
+        dist = init_distributed()
     if fresh:
         stamp = time.strftime('%Y-%m-%d-%H-%M-%S', time.gmtime())
         first_iter = 0

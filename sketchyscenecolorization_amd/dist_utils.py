@@ -3,7 +3,21 @@
 sum all-reduce of flat gradient sections (RCCL over xGMI on GPUs, gloo in CPU tests) issued on a side
 stream as soon as the backward pass has finished a section; the 1/world factor is applied by the
 consumer (the Adam kernel's gradient scale)."""
+import os
+
 import torch
+
+
+def init_distributed():
+    """Process group of a multi-GPU run (one process per GPU under torch.distributed.run): backend "nccl" = RCCL, the
+    process's GPU = LOCAL_RANK.  SSC_DIST_ONE_DEVICE=1 (tests on a single-GPU box): every rank on cuda:0 over gloo, which
+    reduces device tensors through host memory -- RCCL refuses two ranks on one device."""
+    import torch.distributed as dist
+    one = os.environ.get('SSC_DIST_ONE_DEVICE') == '1'
+    torch.cuda.set_device(0 if one else int(os.environ.get('LOCAL_RANK', 0)))
+    if not dist.is_initialized():
+        dist.init_process_group('gloo' if one else 'nccl')
+    return dist
 
 
 def tower_slice(global_n, batch_size, rank, world, batch_portion=None):

@@ -180,10 +180,8 @@ def train(**kwargs):
     img = SIZE[small][0]
 
     if num_gpu > 1:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            dist.init_process_group('nccl')
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+        from ..dist_utils import init_distributed
+        dist = init_distributed()
     rank = int(os.environ.get('RANK', 0))
 
     models.reset_default_graph()

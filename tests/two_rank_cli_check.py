@@ -1,0 +1,32 @@
+"""Body of test_gpu_two_ranks.py::test_two_rank_cli_nan_restart: `obj_colorization_main.py --mode train -gpu 2` as rank
+RANK of 2 (started by torch.distributed.run with SSC_DIST_ONE_DEVICE=1: both ranks on cuda:0 over gloo).  Rank 1's LOCAL loss
+of the G-step of iteration 2 is made NaN once: the tower-mean all-reduce must carry it to rank 0 as well, both ranks must
+leave train() with -1 and continue together from the snapshot rank 0 wrote (main_procedure.py:213-232 and
+obj_colorization_main.py:240-246 of the reference; graph_single.TowerGraph._tower_mean here)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import obj_colorization_main as cli                                         # noqa: E402
+from sketchyscenecolorization_amd.obj_lib import graph_single              # noqa: E402
+
+rank = int(os.environ['RANK'])
+state = {'calls': 0, 'fired': False}
+orig = graph_single.TowerGraph._tower_mean
+
+
+def tower_mean(self, loss):
+    k = state['calls']          # two per iteration: D-step, G-step
+    state['calls'] += 1
+    if rank == 1 and not state['fired'] and k == 5:
+        state['fired'] = True
+        loss = loss * float('nan')
+    return orig(self, loss)
+
+
+graph_single.TowerGraph._tower_mean = tower_mean
+cli.main(['--mode', 'train', '-bt', 'Pix2Pix', '-si', '1', '-bs', '2', '-mi', '5', '-smf', '2', '-swf', '1', '-clt', '2',
+          '-gpu', '2'])
+print('RANK%d_DONE fired=%s' % (rank, state['fired']), flush=True)
