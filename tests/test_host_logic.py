@@ -159,3 +159,34 @@ def test_synthetic_batch_shapes():
     assert set(np.unique(b['sketches'].numpy())) <= {-1.0, 1.0}
     assert (b['text'][:, :5] == 0).all() and (b['text'][:, -4:] >= 2).all()      # left-padded captions
     assert b['class_id'].dtype == torch.int32 and int(b['class_id'].max()) < 25
+
+
+def test_config_matches_reference_module_goldens():
+    """obj_lib.config.Config against values read from the reference module itself (tests/golden/make_config_goldens.py)."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'config_goldens.json')))
+    import sketchyscenecolorization_amd.obj_lib.config as cfg
+    C = cfg.Config
+
+    def fields():
+        return {k: v for k, v in vars(C).items() if not k.startswith('__') and not isinstance(v, staticmethod)}
+
+    saved = fields()            # other tests copy CLI parameters onto the class: back to a fresh import's state, restored below
+    try:
+        for k in saved:
+            delattr(C, k)
+        C.set_from_dict(dict(cfg._DEFAULTS))
+        assert fields() == g['defaults']
+        C.set_from_dict({'batch_size': 7, 'sn': False})
+        assert fields() == g['after_set_from_dict']
+        try:
+            C.set_from_dict([('a', 1)])
+            bad = 'accepted'
+        except AssertionError:
+            bad = 'AssertionError'
+        assert bad == g['non_dict_argument']
+    finally:
+        for k in fields():
+            delattr(C, k)
+        C.set_from_dict(saved)

@@ -45,3 +45,23 @@ def test_product_host_functions_match_the_oracle():
     assert np.array_equal(mp._normalise(u8.astype(np.float32))[0].transpose(1, 2, 0), I.sketch_preprocess(u8[None])[0])
     x = rng.rand(1, 3, 8, 8).astype(np.float32) * 2 - 1
     assert np.array_equal(mp._postprocess(x), I.image_postprocess(x.transpose(0, 2, 3, 1)))
+
+
+def test_bg_image_loading_matches_reference_goldens():
+    """load_image / load_region_mask of the Background_Colorization module against outputs of the REFERENCE module itself
+    (tests/golden/make_bg_image_goldens.py imports Background_Colorization/data_processing/image_processing.py, which needs
+    only numpy + PIL): shapes, dtypes and every value."""
+    import os
+    import numpy as np
+    from sketchyscenecolorization_amd.data_processing.image_processing import load_image, load_region_mask
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    g = np.load(os.path.join(here, 'bg_image_goldens.npz'))
+    n = 0
+    for key in g.files:
+        kind, name = key.split('/')[0], key.split('/')[1]
+        path = os.path.join(here, 'bg_images', name)
+        got = load_image(path, 24) if kind == 'image' else load_region_mask(path, 24, key.endswith('/test'))
+        assert got.shape == g[key].shape and got.dtype == g[key].dtype, key
+        assert np.array_equal(got, g[key]), key
+        n += 1
+    assert n == 7
