@@ -1100,7 +1100,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_st
 template <int WM, int WN, int SM, int SN, bool GPLAIN, bool DPLAIN, bool DDMA>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d, const Magics mg,
                                                           float* __restrict__ slab_base, long slab_stride,
-                                                          int splitk) {
+                                                          int splitk, int xcd) {
     constexpr int BM = WM * SM * 32;
     constexpr int BN = WN * SN * 32;
     constexpr int A_LD = BM;
@@ -1133,9 +1133,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ssc_wgrad_desc d,
     const int Mtot = d.TH * d.TW * Cg;
     const long P = (long)d.NB * d.PH * d.PW;
     const int PHW = d.PH * d.PW;
-    const int ks = blockIdx.z;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // workgroup -> (row tile, column tile, K slice).  All tiles of a K slice read the same pixels (every (tap, channel) block of
+    // the gathered side and every block of the dense side of that pixel range), so they should meet in ONE L2: with the plain
+    // grid order a slice's tiles are dealt round-robin to the 8 XCDs and each of them fetches the range.  xcd (host flag): ids
+    // with the same id % 8 walk a contiguous run of (row tile, column tile, slice) order -- whole slices per XCD.
+    int ks = blockIdx.z, mtile = blockIdx.x, ntile = blockIdx.y;
+    if (xcd) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned t2 = (lin & 7u) * (total >> 3) + (lin >> 3);
+        const unsigned per_slice = gridDim.x * gridDim.y;
+        ks = (int)(t2 / per_slice);
+        const unsigned r = t2 - (unsigned)ks * per_slice;
+        ntile = (int)(r / gridDim.x);
+        mtile = (int)(r - (unsigned)ntile * gridDim.x);
+    }
+    const int m0 = mtile * BM;
+    const int n0 = ntile * BN;
 
     // fixed per-thread columns: (tap, channel) of the gathered side, channel of the dense side
     const int a_col = m0 + (tid % (BM / 4)) * 4;
@@ -1406,7 +1420,7 @@ static void launch_wgrad_reduce(const float* ws, long count, int splitk, float* 
 // scripts/isa_one.sh: compile a single instantiation to look at its ISA (the whole file takes over a minute)
 template __global__ void conv_ut_kernel<2, 2, 1, 2, 0, false, 0>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*);
 template __global__ void conv_ut_kernel<2, 2, 1, 2, 1, true, 0>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*);
-template __global__ void conv_wgrad_kernel<1, 4, 2, 1, false, true, true>(const ssc_wgrad_desc, const Magics, float*, long, int);
+template __global__ void conv_wgrad_kernel<1, 4, 2, 1, false, true, true>(const ssc_wgrad_desc, const Magics, float*, long, int, int);
 #else
 // ---------------------------------------------------------------------------------------------
 // host launchers (C ABI)
@@ -1907,8 +1921,17 @@ static int launch_wgrad_v(const ssc_wgrad_desc& d, int splitk, float* ws, hipStr
         attr_set = true;
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)splitk);
+    // SSC_WG_XCD=1: whole K slices per XCD.  Measured (scripts/wg_xcd_ab.sh): FETCH_SIZE of the encoder_3 filter gradient 113 ->
+    // 35 MB, the launch itself unchanged (94.5 vs 94.9 TFLOP/s), the train step 0.4 % SLOWER (18.05 vs 17.98 ms) -- the re-reads
+    // of the plain order are served by the Infinity Cache while all XCDs walk the same pixel range -- so it stays off
+    static int wg_xcd = -1;
+    if (wg_xcd < 0) {
+        const char* e = getenv("SSC_WG_XCD");
+        wg_xcd = (e != nullptr && e[0] == '1') ? 1 : 0;
+    }
+    const int xcd = (wg_xcd && splitk > 1 && (((long)mt * nt * splitk) & 7) == 0) ? 1 : 0;
     hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, SM, SN, GPLAIN, DPLAIN, DDMA>), grid, dim3(256), lds, st, d, mg, ws, out_count,
-                       splitk);
+                       splitk, xcd);
     if (splitk > 1) launch_wgrad_reduce(ws, out_count, splitk, d.out, d.accumulate, st);
     return (int)hipGetLastError();
 }
