@@ -9,6 +9,7 @@
 // atanh-like squash (:238-242) and their backward forms.  All HBM-bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "sketchycolor_hip.h"
 
 #define CHECK_LAUNCH() ((int)hipGetLastError())
@@ -311,13 +312,133 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const float* __restr
     }
 }
 
+// The same step for FEW rows (inference batches: N*36 = 576 rows are 9 x 32 = 288 of the workgroups above, 1.1 per CU: two
+// rounds, the second one almost empty).  A workgroup here owns 64 rows x 8 hidden units (32 gate columns) and its two wave
+// pairs split the K steps of every K-tile between them (partial sums added through LDS before the gate math): twice the
+// workgroups, half the MFMA chain each -- all of them resident at once.
+__global__ __launch_bounds__(256) void lstm_step_fwd_k2_kernel(const float* __restrict__ h_in, const float* __restrict__ Kh,
+                                                                int ldk, const float* __restrict__ g1,
+                                                                const float* __restrict__ g2, int div2,
+                                                                const int* __restrict__ mask, int mdiv,
+                                                                const float* __restrict__ c_in, int rows, int C, int with_gemm,
+                                                                float* __restrict__ c_out, float* __restrict__ h_out,
+                                                                float* __restrict__ acts) {
+    constexpr int BM = 64, BK = 32, A_LD = 36, B_LD = 32, C_LD = 36;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * A_LD + 2 * BK * B_LD];     // 26 KB; the two C images reuse it
+    static_assert(2 * BM * C_LD <= 2 * BM * A_LD + 2 * BK * B_LD, "C images fit");
+    float* As = smem;
+    float* Bs = smem + 2 * BM * A_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, kh = wave >> 1, l31 = lane & 31, lhi = lane >> 5;
+    const int m0 = blockIdx.x * BM, u0 = blockIdx.y * 8;
+
+    lstm_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    if (with_gemm) {
+        // A as above; B: k row t >> 3, 16-byte piece t & 7 = gate (t & 7) >> 1, units 4 * (t & 1) ..
+        const int a_r = tid >> 3, a_c = (tid & 7) * 4;
+        const int b_k = tid >> 3, b_g = (tid & 7) >> 1, b_u = (tid & 1) * 4;
+        const float* ap0 = h_in + (long)min(m0 + a_r, rows - 1) * C + a_c;
+        const float* ap1 = h_in + (long)min(m0 + a_r + 32, rows - 1) * C + a_c;
+        const float* bp = Kh + (long)b_k * ldk + b_g * C + u0 + b_u;
+        float4 ra0, ra1, rb0;
+        auto load = [&](int kt) {
+            ra0 = *reinterpret_cast<const float4*>(ap0 + kt * BK);
+            ra1 = *reinterpret_cast<const float4*>(ap1 + kt * BK);
+            rb0 = *reinterpret_cast<const float4*>(bp + (long)kt * BK * ldk);
+        };
+        auto store = [&](int buf) {
+            float* A = As + buf * BM * A_LD;
+            float* B = Bs + buf * BK * B_LD;
+            *reinterpret_cast<float4*>(A + a_r * A_LD + a_c) = ra0;
+            *reinterpret_cast<float4*>(A + (a_r + 32) * A_LD + a_c) = ra1;
+            *reinterpret_cast<float4*>(B + b_k * B_LD + (tid & 7) * 4) = rb0;
+        };
+        const int nkt = C / BK;
+        load(0);
+        store(0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt) load(kt + 1);
+            // K index of MFMA step kk on lane half lhi: 16 * lhi + kk; this wave pair takes kk in [8 * kh, 8 * kh + 8)
+            const float* A = As + cur * BM * A_LD + (wm * 32 + l31) * A_LD + lhi * 16 + kh * 8;
+            const float* B = Bs + cur * BK * B_LD + (lhi * 16 + kh * 8) * B_LD + l31;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4 av = *reinterpret_cast<const float4*>(A + g * 4);
+                const float b0 = B[(g * 4 + 0) * B_LD], b1 = B[(g * 4 + 1) * B_LD], b2 = B[(g * 4 + 2) * B_LD],
+                            b3 = B[(g * 4 + 3) * B_LD];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
+            }
+            if (kt + 1 < nkt) store(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // accumulators -> LDS [K half][row][gate * 8 + unit]
+    float* Cs = smem + kh * BM * C_LD;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * C_LD + l31] = acc[r];
+    __syncthreads();
+    const float* C0 = smem;
+    const float* C1 = smem + BM * C_LD;
+    // gate math: 64 rows x 8 units, 2 per thread
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int e = p * 256 + tid;
+        const int rl = e >> 3, u = e & 7;
+        const long r = m0 + rl;
+        if (r >= rows) continue;
+        const long i = r * C + u0 + u;
+        const float c0 = c_in[i], h0 = h_in[i];
+        if (mask[r / mdiv] == 0) {
+            c_out[i] = c0;
+            h_out[i] = h0;
+            continue;
+        }
+        const long gb = r * 4 * C + u0 + u;
+        const int o = rl * C_LD + u;
+        float gi = C0[o] + C1[o], gj = C0[o + 8] + C1[o + 8], gf = C0[o + 16] + C1[o + 16], go = C0[o + 24] + C1[o + 24];
+        if (g1 != nullptr) { gi += g1[gb]; gj += g1[gb + C]; gf += g1[gb + 2 * C]; go += g1[gb + 3 * C]; }
+        if (g2 != nullptr) {
+            const long q = (r / div2) * 4 * C + u0 + u;
+            gi += g2[q]; gj += g2[q + C]; gf += g2[q + 2 * C]; go += g2[q + 3 * C];
+        }
+        const float ai = sigmoidf_(gi), aj = tanhf(gj), af = sigmoidf_(gf + 1.0f), ao = sigmoidf_(go);
+        const float c1 = c0 * af + ai * aj;
+        c_out[i] = c1;
+        h_out[i] = tanhf(c1) * ao;
+        acts[gb] = ai; acts[gb + C] = aj; acts[gb + 2 * C] = af; acts[gb + 3 * C] = ao;
+    }
+}
+
 extern "C" int ssc_lstm_step_fwd(const float* h_in, const float* Kh, int ldk, const float* g1, const float* g2, int div2,
                                  const int* mask, int mdiv, const float* c_in, int64_t rows, int C, int with_gemm,
                                  float* c_out, float* h_out, float* acts, void* stream) {
     if ((C & 31) || (ldk & 3) || rows <= 0 || rows > 0x7fffffffL / (4L * C)) return -1;
-    hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(C / 16)), dim3(256), 0,
-                       (hipStream_t)stream, h_in, Kh, ldk, g1, g2, div2 > 0 ? div2 : 1, mask, mdiv > 0 ? mdiv : 1, c_in,
-                       (int)rows, C, with_gemm, c_out, h_out, acts);
+    // few rows: the K-split form while the plain grid holds under ~4.5 workgroups per CU (SSC_LSTM_K2=0 / 1 pins it).  Measured:
+    // batch 16 (576 rows) generator forward 9080 -> 9390 images/s; batch 32 (1152 rows) train step 17.96 -> 17.88 ms
+    static int k2 = -2;
+    if (k2 == -2) {
+        const char* e = getenv("SSC_LSTM_K2");
+        k2 = (e == nullptr) ? -1 : atoi(e);
+    }
+    const long wgs = ((rows + 63) / 64) * (C / 16);
+    const bool use_k2 = with_gemm && (k2 == 1 || (k2 == -1 && wgs < 1200));
+    if (use_k2)
+        hipLaunchKernelGGL(lstm_step_fwd_k2_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(C / 8)), dim3(256), 0,
+                           (hipStream_t)stream, h_in, Kh, ldk, g1, g2, div2 > 0 ? div2 : 1, mask, mdiv > 0 ? mdiv : 1, c_in,
+                           (int)rows, C, with_gemm, c_out, h_out, acts);
+    else
+        hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(C / 16)), dim3(256), 0,
+                           (hipStream_t)stream, h_in, Kh, ldk, g1, g2, div2 > 0 ? div2 : 1, mask, mdiv > 0 ? mdiv : 1, c_in,
+                           (int)rows, C, with_gemm, c_out, h_out, acts);
     return CHECK_LAUNCH();
 }
 
