@@ -515,3 +515,34 @@ def test_few_channel_stride2_conv(n, h, cp, cr):
         g1 = torch.full((n, h // 2, h // 2, 64), float('nan'), device='cuda')
         hip.deconv_dgrad(hip.View(dyp.cuda()), f.cuda(), g1, n_off=64, nn=64)
         close(nchw(g1), xin.grad[:, 64:])
+
+
+@pytest.mark.parametrize('rows,div2,form', [(200, 1, 'k2'), (2592, 36, 'plain'), (72, 36, 'k2')])
+def test_recurrent_step_both_kernel_forms(rows, div2, form):
+    """ssc_lstm_step_fwd = h.K_h + the BasicLSTMCell gate math with the tf.cond pad skip (models_collection.py:184-236) in one
+    launch; few rows take the K-split kernel, many rows the plain one (2592 rows x 512 units = 1312 workgroups >= 1200)."""
+    hip = _hip()
+    C = 512
+    assert ((rows + 63) // 64) * (C // 16) >= 1200 if form == 'plain' else ((rows + 63) // 64) * (C // 16) < 1200
+    h = rnd(rows, C, seed=91, std=0.5)
+    c = rnd(rows, C, seed=92, std=0.5)
+    K = rnd(3 * C, 4 * C, seed=93, std=0.04)       # the recurrent rows are a slice of a wider kernel: ldk = 4C, rows [C, 2C)
+    g1 = rnd(rows, 4 * C, seed=94, std=0.5)
+    g2 = rnd(rows // div2, 4 * C, seed=95, std=0.5)
+    mdiv = div2
+    mask = (torch.arange(rows // mdiv) % 3 != 1).to(torch.int32)
+    z = h.double() @ K[C:2 * C].double() + g1.double() + g2.double().repeat_interleave(div2, dim=0)
+    i, j, f, o = z[:, :C], z[:, C:2 * C], z[:, 2 * C:3 * C], z[:, 3 * C:]
+    c1 = c.double() * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+    h1 = torch.tanh(c1) * torch.sigmoid(o)
+    keep = mask.repeat_interleave(mdiv).bool().unsqueeze(1)
+    c_ref, h_ref = torch.where(keep, c1, c.double()), torch.where(keep, h1, h.double())
+    co = torch.full((rows, C), float('nan'), device='cuda')
+    ho = torch.full((rows, C), float('nan'), device='cuda')
+    acts = torch.zeros(rows, 4 * C, device='cuda')
+    Kd = K.cuda()
+    hip.lstm_step_fwd(h.cuda(), Kd[C:2 * C], 4 * C, g1.cuda(), g2.cuda(), div2, mask.cuda(), mdiv, c.cuda(), rows, C, True, co, ho, acts)
+    close(co, c_ref, tol=2e-5)
+    close(ho, h_ref, tol=2e-5)
+    a_ref = torch.cat([torch.sigmoid(i), torch.tanh(j), torch.sigmoid(f + 1.0), torch.sigmoid(o)], dim=1)
+    close(acts[keep.squeeze(1).cuda()], a_ref[keep.squeeze(1)], tol=2e-5)
