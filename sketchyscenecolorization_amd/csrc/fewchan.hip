@@ -158,11 +158,11 @@ int ssc_conv_fewchan_forward(const ssc_conv_desc* dp, int num_cu, void* stream) 
     const int tiles_x = d.PW / FC_TC, tiles_y = d.PH / FC_TR;
     const int tiles = d.NB * tiles_y * tiles_x;
     // persistent workgroups: as many as are resident at once (2 per CU with 8 channels -- 48 KB of LDS and ~64 filter
-    // registers each --, 3 with 4), cut down so that every workgroup walks the same number of tiles where that divides
+    // registers each --, 3 with 4); workgroup b walks tiles b, b + G, ...: with 2304 tiles on 512 workgroups the first half
+    // of the ids walks 5 and the second half 4, and the dispatcher pairs one of each on a CU (9 tiles per CU; equal counts on
+    // fewer workgroups left a fifth of the CUs with one workgroup: 10)
     const int slots = num_cu * (d.x.C0 == 8 ? 2 : 3);
-    int G = tiles < slots ? tiles : slots;
-    const int per = (tiles + G - 1) / G;
-    G = (tiles + per - 1) / per;
+    const int G = tiles < slots ? tiles : slots;
     hipStream_t st = (hipStream_t)stream;
     if (d.x.C0 == 8)
         hipLaunchKernelGGL(fewchan_conv_kernel<8>, dim3(G), dim3(256), 0, st, d, tiles, tiles_x, tiles_y);

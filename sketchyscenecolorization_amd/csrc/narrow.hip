@@ -434,9 +434,9 @@ static int launch_narrow(const ssc_conv_desc& d, hipStream_t st, float* ws, int6
         }                                                                                                          \
         hipLaunchKernelGGL((narrow_fwd_kernel<MODE, NO, BIG>), grid, dim3(256), lds, st, d, ws, out_count, csplit); \
     }
-#define NARROW_SC_LAUNCH(NO) hipLaunchKernelGGL((narrow_sc_kernel<MODE, NO>), grid, dim3(256), lds, st, d, ws, out_count, csplit);
+#define NARROW_SC_LAUNCH(NO) hipLaunchKernelGGL((narrow_sc_kernel<1, NO>), grid, dim3(256), lds, st, d, ws, out_count, csplit);
     if (lds > 96 * 1024) return -5;
-    if (sc) {
+    if (sc) {       // transposed form only (narrow_sc_ok)
         if (nout == 1) NARROW_SC_LAUNCH(1) else if (nout == 2) NARROW_SC_LAUNCH(2) else if (nout == 3) NARROW_SC_LAUNCH(3) else NARROW_SC_LAUNCH(4)
     } else if (MODE == 0 && (d.TH > 4 || d.TW > 4 || d.KH * d.KW > 16)) {
         constexpr bool BIG = true;
