@@ -424,8 +424,8 @@ def deconv_forward(x, f, out, coff=0, nstore=None, epi=0, bn=None):
     _run_conv(d, _bn_arg(bn, d, coff, out))
 
 
-def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=None, accumulate=False, bnbwd=None):
-    """Gradient of a conv w.r.t. its input channels [n_off, n_off+nn): dy View -> out [N,Hin,Win,*].
+def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=None, accumulate=False, bnbwd=None, coff=0):
+    """Gradient of a conv w.r.t. its input channels [n_off, n_off+nn): dy View -> out[..., coff:coff+nstore] [N,Hin,Win,*].
     stride 2: the k=4 pad-1 conv (4 sub-pixel phases).  stride 1: any square kernel, ``pad`` = padding before
     (SAME: (k-1)//2, the extra element after), input size taken from ``out``."""
     KH, KW, ci, co = w.shape
@@ -433,7 +433,7 @@ def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=No
     d = ConvDesc()
     d.x = dy.c()
     d.w, d.bias = w.data_ptr(), None
-    d.out, OH, OW, ldc = _out_geom(out, 0)
+    d.out, OH, OW, ldc = _out_geom(out, coff)
     d.NB = dy.N
     if stride == 2:
         assert KH == 4 and KW == 4 and pad == 1 and (OH, OW) == (2 * dy.H, 2 * dy.W)

@@ -24,6 +24,9 @@ from . import hip
 from .hip import ACT_MIU, ACT_NONE, ACT_PRELU, View
 from .text_fusion import TextFusion
 
+import os as _os
+_SPLIT_DGRAD = _os.environ.get('SSC_MRU_SPLIT_DGRAD', '1') == '1'
+
 ENC_UNITS = [(1, 8, 64), (2, 64, 128), (3, 128, 256), (4, 256, 512)]                 # (unit, C_h, D); inp = 3 ch
 DEC_UNITS = [(0, 512, 384), (2, 384, 256), (4, 256, 128), (6, 128, 128), (8, 128, 64)]      # (unit_num, C_h, D)
 DISC_UNITS = [(1, 8, 128), (2, 128, 256), (3, 256, 512), (4, 512, 768)]
@@ -163,6 +166,18 @@ class _MRUBlocks(object):
     def _conv_dgrad(self, pre, dy, out, n_off=0, nn=None, nstore=None, accumulate=False, k_real=None):
         w = self._w(pre)
         k = w.shape[0]
+        n_all = w.shape[2] - n_off if nn is None else nn
+        n_st = n_all if nstore is None else nstore
+        wide = n_all // 64 * 64
+        # [h, sketch] inputs: 128 + 3 (or 256 + 3 ...) channels.  As one launch the 3 extra columns cost a whole 64-column
+        # tile of matrix work (131 -> 192 columns computed); split: the multiple of 64 on the tile kernel, the rest (<= 4
+        # columns) on the narrow kernel (SSC_MRU_SPLIT_DGRAD=0: one launch)
+        if _SPLIT_DGRAD and k_real is None and n_off == 0 and 0 < n_all - wide <= 4 and wide >= 64 and n_st - wide <= 4 \
+                and dy.shape[-1] % 32 == 0:
+            hip.conv_dgrad(View(dy), w, 1, (k - 1) // 2, out, n_off=0, nn=wide, nstore=wide, accumulate=accumulate)
+            hip.conv_dgrad(View(dy), w, 1, (k - 1) // 2, out, n_off=wide, nn=n_all - wide, nstore=n_st - wide,
+                           accumulate=accumulate, coff=wide)
+            return
         hip.conv_dgrad(View(dy), w, 1, (k - 1) // 2, out, n_off=n_off, nn=nn, nstore=nstore, accumulate=accumulate,
                        k_real=k_real)
 
