@@ -136,7 +136,7 @@ class Pix2PixGenerator(object):
     def backward(self, ctx, dpre, on_section=None, side_stream=None):
         """dpre [N,H,W,4]: gradient w.r.t. the pre-tanh output.  Writes every generator gradient.
         ``on_section(name)`` is called when a contiguous block of the flat gradient buffer is final
-        ('decoders' = noise head + decoders, 'text', 'encoders') so the caller can start its all-reduce.
+        ('decoders' = noise head + decoders, 'text', 'encoder_5', 'encoders' = encoder_1..4) so the caller can start its all-reduce.
         With ``side_stream`` the decoder filter gradients (off the critical path: nothing downstream reads
         them) are held back and launched on that stream next to the caption branch's BPTT, whose small
         recurrent GEMMs leave most CUs idle."""
@@ -254,10 +254,13 @@ class Pix2PixGenerator(object):
             if forked:
                 self._join()
             gcur = dx
+            if k == 5 and not text_pending:
+                done('encoder_5')       # its filter, scale and offset gradients are final (trainer._sections)
         hip.conv_wgrad(View(ctx['xs']), View(gcur), s.grad('generator/encoder_1/conv/filter'), 2, 1)
         if text_pending:
             self.text.join_backward()
             done('text')
+            done('encoder_5')
         done('encoders')
 
 

@@ -78,7 +78,7 @@ class GanTrainer(object):
         self.reducer = GradReducer(process_group)
         self.world = self.reducer.world
         g = self.store.generator.offsets
-        self._g_sections = self._sections(g)
+        self._g_sections = self._sections(g, split_encoder_5=(block_type == 'Pix2Pix'))
         self._sn_pending = None
         # hipGraph replay of whole D-/G-steps (the ~550 launches of a step are host-bound otherwise):
         # a step shape is run eagerly the first time, captured the second time, replayed afterwards
@@ -121,14 +121,22 @@ class GanTrainer(object):
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
-    def _sections(offsets):
+    def _sections(offsets, split_encoder_5=False):
         """Contiguous flat ranges in the order the generator backward finishes them."""
         names = list(offsets.keys())
         i_emb = names.index('generator/TextLSTM/embedding')
         i_fc = names.index('generator/fully_connected/weights')
         end = offsets[names[-1]][0] + (offsets[names[-1]][1] + 63) // 64 * 64
         o_emb, o_fc = offsets[names[i_emb]][0], offsets[names[i_fc]][0]
-        return {'decoders': (o_fc, end), 'text': (o_emb, o_fc), 'encoders': (0, o_emb)}
+        sec = {'decoders': (o_fc, end), 'text': (o_emb, o_fc), 'encoders': (0, o_emb)}
+        # Pix2Pix: encoder_5 (17 of the encoders' 28 MB) is final one layer into the encoder backward, and it sits last among
+        # the encoders in the flat buffer: its all-reduce starts then, beside the backward of encoder_4..1, and only the
+        # remaining 11 MB are exchanged after the backward pass has ended
+        e5 = 'generator/encoder_5/conv/filter'
+        if split_encoder_5 and e5 in offsets and names.index(e5) < i_emb and all(n.startswith('generator/encoder_5/') for n in names[names.index(e5):i_emb]):
+            sec['encoder_5'] = (offsets[e5][0], o_emb)
+            sec['encoders'] = (0, offsets[e5][0])
+        return sec
 
     def decay(self, counter):
         """graph_single.py:139 in fp32: max(0.2, 1 - counter/max_iter*0.9)."""

@@ -36,7 +36,7 @@ def main():
             (it, la, lb)
     segs = [g for g in b._graphs.values() if isinstance(g, list)]
     assert len(segs) == 2 and all(sum(1 for op in ops if op[0] == 'reduce') >= 1 for ops in segs)
-    assert sum(1 for op in [o for ops in segs for o in ops] if op[0] == 'reduce') == 4      # D: 1, G: 3 sections
+    assert sum(1 for op in [o for ops in segs for o in ops] if op[0] == 'reduce') == 5      # D: 1, G: 4 sections
     worst = max(float((a.store[n] - b.store[n]).abs().max()) for n in a.store.names())
     assert worst < 4e-3, worst
     torch.cuda.synchronize()
