@@ -1627,7 +1627,9 @@ static bool fwd_is_utg(const ssc_conv_desc& d) {
         const char* e = getenv("SSC_UTG_WASTE");
         waste = (e != nullptr) ? atof(e) : 1.2;
     }
-    return !off && vec && d.k_real >= 1 && d.k_real <= C && (double)padded <= waste * (double)C &&
+    // ... or no more K-tiles than the generic kernel's walk over taps * C would take (few channels: one chunk per tap either way)
+    const long kt_chunks = (long)d.TH * d.TW * (padded / BK), kt_flat = ((long)d.TH * d.TW * C + BK - 1) / BK;
+    return !off && vec && d.k_real >= 1 && d.k_real <= C && ((double)padded <= waste * (double)C || kt_chunks <= kt_flat) &&
            (long)d.NB * d.x.H * d.x.W * (d.x.C0 > d.x.C1 ? d.x.C0 : d.x.C1) < 0x1fffffffL &&
            (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x1fffffffL;
 }
