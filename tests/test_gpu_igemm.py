@@ -146,34 +146,35 @@ def test_conv_forward_row_tap(stride, h):
 
 def test_large_launches_tail_split():
     """Launches with more tiles than the chip holds at once (1152-1536 tiles of 64x128 on 768 resident workgroups): the
-    partly filled last round is cut into K slices and summed by ts_fixup_kernel (igemm.hip, tail split), for the plain
-    grid, the 4 sub-pixel phases of the transposed conv, and the accumulating data-gradient epilogue.  Reference:
-    torch's own convolutions on the GPU (fp32)."""
-    import torch.nn.functional as F
+    partly filled last round is cut into K slices that are combined inside the launch (igemm.hip, tail split), for the plain
+    grid, the 4 sub-pixel phases of the transposed conv, and the accumulating data-gradient epilogue.  Reference: the CPU
+    oracle (oracle/tf_ops.py) and its autograd."""
     hip = _hip()
-    torch.backends.cudnn.allow_tf32 = False
     # conv 3x3 SAME, M = 8*96*96 = 73728 -> 1152 row tiles
-    x = rnd(8, 32, 96, 96, seed=41).cuda()
-    w = rnd(3, 3, 32, 128, seed=42, std=0.05).cuda()
-    ref = F.conv2d(torch.relu(x), w.permute(3, 2, 0, 1), padding=1)
+    x = rnd(8, 32, 96, 96, seed=41)
+    w = rnd(3, 3, 32, 128, seed=42, std=0.05)
+    ref = T.conv2d_same(torch.relu(x), w, 1)
     out = torch.full((8, 96, 96, 128), float('nan'), device='cuda')
-    hip.conv_forward(hip.View(nhwc(x), None, None, 1), w, 1, 0, out, same=True)
+    hip.conv_forward(hip.View(nhwc(x).cuda(), None, None, 1), w.cuda(), 1, 0, out, same=True)
     close(nchw(out), ref)
     # transposed conv k=4 s=2: 4 phases x (8*48*48 / 64) = 1152 tiles
-    xd = rnd(8, 64, 48, 48, seed=43).cuda()
-    f = rnd(4, 4, 128, 64, seed=44, std=0.05).cuda()
-    refd = F.conv_transpose2d(xd, f.permute(3, 2, 0, 1), stride=2, padding=1)
+    xd = rnd(8, 64, 48, 48, seed=43)
+    f = rnd(4, 4, 128, 64, seed=44, std=0.05)
+    refd = T.conv2d_transpose_same_s2(xd, f)
     outd = torch.full((8, 96, 96, 128), float('nan'), device='cuda')
-    hip.deconv_forward(hip.View(nhwc(xd)), f, outd)
+    hip.deconv_forward(hip.View(nhwc(xd).cuda()), f.cuda(), outd)
     close(nchw(outd), refd)
-    # data gradient of a stride-1 conv, accumulated onto an existing tensor
-    w2 = rnd(3, 3, 128, 64, seed=47, std=0.05).cuda()
-    dy = rnd(8, 64, 96, 96, seed=45).cuda()
+    # data gradient of a stride-1 3x3 SAME conv (128 -> 64 channels), accumulated onto an existing tensor
+    w2 = rnd(3, 3, 128, 64, seed=47, std=0.05)
+    xin = rnd(8, 128, 96, 96, seed=48).requires_grad_(True)
+    y = T.conv2d_same(xin, w2, 1)
+    dy = rnd(*y.shape, seed=45)
+    y.backward(dy)
     base = rnd(8, 96, 96, 128, seed=46).cuda()
-    refg = F.conv_transpose2d(dy, w2.permute(3, 2, 0, 1), padding=1)
     dx = base.clone()
-    hip.conv_dgrad(hip.View(nhwc(dy)), w2, 1, 1, dx, accumulate=True)
-    close(nchw(dx - base), refg)
+    hip.conv_dgrad(hip.View(nhwc(dy).cuda()), w2.cuda(), 1, 1, dx, accumulate=True)
+    close(nchw(dx - base), xin.grad)
+    assert hip.sk_timeouts() == 0
 
 
 def test_conv_forward_splitk_small_m():
