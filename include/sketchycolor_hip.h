@@ -92,8 +92,17 @@ typedef struct ssc_conv_desc {
     const float* sb_stats;/* [2][Nstore]: mean, 1/std */
     int32_t sb_ldx;       /* row stride of x */
     int32_t sb_act;       /* SSC_ACT_* of the consumer */
+    int32_t sk_tag;       /* caller's id of this launch (31 bits): a hand-off that times out reports 0x80000000 | sk_tag */
+    int32_t _pad0;
 } ssc_conv_desc;
-#define SSC_SK_FLAG_WORDS 8192   /* >= resident workgroups of the largest grid; the last word reports a hand-off timeout */
+#define SSC_SK_FLAG_WORDS 8192   /* >= resident workgroups of the largest grid; the last word reports a hand-off timeout:
+                                    0 = none, else 0x80000000 | sk_tag of the first launch whose owner workgroup gave up
+                                    waiting for a K slice.  The output of that launch is WRONG (a partial sum): callers must
+                                    read the word wherever they read results back (losses, snapshots) and fail; the flags
+                                    are to be zeroed before the array is used again. */
+/* hand-off wait bound in milliseconds (default 20000: only a deadlock guard -- the owner waits for workgroups that were
+ * dispatched before it) and a test hook that makes the producers withhold their flags so that the bound is reached */
+int ssc_sk_configure(int timeout_ms, int test_withhold);
 
 /*
  * Implicit-GEMM filter gradient:

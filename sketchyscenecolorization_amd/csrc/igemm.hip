@@ -28,6 +28,9 @@ int ssc_conv_narrow_forward_ws(const ssc_conv_desc* dp, float* ws, int64_t ws_by
 int ssc_conv_fewchan_forward(const ssc_conv_desc* dp, int num_cu, void* stream);
 
 #define BK 32
+// in-launch K-slice hand-off (conv_ut_kernel): {wait bound in ticks of the 100 MHz wall clock (lo, hi), test hook: producers
+// withhold their flags, -}.  ssc_sk_configure writes it.
+__device__ unsigned g_sk_cfg[4] = {2000000000u, 0u, 0u, 0u};
 #ifndef SSC_BDMA
 #define SSC_BDMA 1       // filter tiles of conv_ut_kernel by LDS-DMA (global_load_lds) instead of through registers
 #endif
@@ -897,22 +900,33 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(flags + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && g_sk_cfg[2] == 0u) __hip_atomic_store(flags + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        // owner: the other slices of this tile are workgroups slot-(sk-1) .. slot-1
+        // owner: the other slices of this tile are workgroups slot-(sk-1) .. slot-1.  The wait is bounded (a deadlock guard:
+        // everything waited for was dispatched earlier); an owner that gives up REPORTS it -- the timeout word gets
+        // 0x80000000 | sk_tag, which the host must read wherever it reads results (hip.check_sk) -- because what it then
+        // stores is a partial sum.  A flag that was never seen set is not cleared (its late producer would otherwise leave
+        // a 1 behind for the next launch to trust); the host zeroes the array after a reported timeout.
         if (tid == 0) {
             const unsigned long long t0 = wall_clock64();
+            const unsigned long long bound = ((unsigned long long)g_sk_cfg[1] << 32) | g_sk_cfg[0];
+            bool gave_up = false;
             for (int q = sk - 1; q >= 1; --q) {
+                bool seen = true;
                 while (__hip_atomic_load(flags + slot - q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (wall_clock64() - t0 > 200000000ull) {       // 2 s of the 100 MHz counter: report, do not hang
-                        __hip_atomic_store(flags + (SSC_SK_FLAG_WORDS - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (gave_up || wall_clock64() - t0 > bound) {
+                        gave_up = true;
+                        seen = false;
                         break;
                     }
                 }
-                __hip_atomic_store(flags + slot - q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // leave them zero
+                if (seen) __hip_atomic_store(flags + slot - q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // leave them zero
             }
+            if (gave_up)
+                __hip_atomic_store(flags + (SSC_SK_FLAG_WORDS - 1), 0x80000000u | (unsigned)d.sk_tag, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // one L1 invalidate after the last flag
         }
         __syncthreads();
@@ -1842,6 +1856,12 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
         }
     }
     return ssc_conv_forward(&d, ws, ws_bytes, stream);
+}
+
+extern "C" int ssc_sk_configure(int timeout_ms, int test_withhold) {
+    const unsigned long long ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 20000) * 100000ull;     // 100 MHz
+    const unsigned cfg[4] = {(unsigned)(ticks & 0xffffffffu), (unsigned)(ticks >> 32), test_withhold ? 1u : 0u, 0u};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sk_cfg), cfg, sizeof(cfg), 0, hipMemcpyHostToDevice);
 }
 
 extern "C" int ssc_conv_forward_plan(const ssc_conv_desc* dp, int64_t ws_bytes, int* out5) {

@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ('out_stride', C.c_int32), ('ooff_y', C.c_int32), ('ooff_x', C.c_int32),
                 ('epi', C.c_int32), ('accumulate', C.c_int32), ('stat_partial', C.c_void_p), ('sk_flags', C.c_void_p),
                 ('sb_x', C.c_void_p), ('sb_ab', C.c_void_p), ('sb_stats', C.c_void_p), ('sb_ldx', C.c_int32),
-                ('sb_act', C.c_int32)]
+                ('sb_act', C.c_int32), ('sk_tag', C.c_int32), ('_pad0', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -79,6 +79,7 @@ SIGNATURES = {
     'ssc_conv_forward_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, _I],
     'ssc_conv_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, _I],
     'ssc_conv_forward_plan': [C.POINTER(ConvDesc), _L, C.POINTER(C.c_int)],
+    'ssc_sk_configure': [_I, _I],
     'ssc_nchw_to_nhwc': [_P, _P, _I, _I, _I, _I, _I, _P],
     'ssc_nhwc_to_nchw': [_P, _P, _I, _I, _I, _I, _I, _P],
     'ssc_sketch_preprocess_u8': [_P, _I, _I, _I, _I, _P, _P],
@@ -252,23 +253,90 @@ def _kernel_name(fn, d):
 
 
 SK_FLAG_WORDS = 8192
+_SK_MAX_STREAMS = 32
 _sk_flags = {}
+_sk_pool = {}           # device -> [_SK_MAX_STREAMS, SK_FLAG_WORDS] int32: every stream's flag array is a row of it
+_sk_tags = {}           # sk_tag -> copy of the descriptor of that launch (bounded: tags wrap at _SK_TAG_RING)
+_SK_TAG_RING = 1 << 14
+_sk_configured = False
+
+
+class HandoffTimeout(RuntimeError):
+    """An owner workgroup of a conv launch gave up waiting for a K slice: that launch stored a partial sum."""
+
+
+def _sk_configure():
+    """SSC_SK_TIMEOUT_MS (default 20000: a deadlock guard only), SSC_SK_TEST_WITHHOLD=1 (test hook: producers never raise
+    their flags, so every sliced tile reaches the bound)."""
+    global _sk_configured
+    if not _sk_configured:
+        _sk_configured = True
+        ms, wh = int(os.environ.get('SSC_SK_TIMEOUT_MS', '0')), int(os.environ.get('SSC_SK_TEST_WITHHOLD', '0'))
+        if ms > 0 or wh:
+            check(lib().ssc_sk_configure(ms, wh), 'ssc_sk_configure')
 
 
 def sk_flags():
     """Stream-K hand-off flags of the CURRENT stream (ssc_conv_desc.sk_flags): zero when created, left zero by every
     kernel that uses them; one array per device and stream because launches on different streams run concurrently."""
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    dev = torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream().cuda_stream)
     f = _sk_flags.get(key)
     if f is None:
-        f = torch.zeros(SK_FLAG_WORDS, dtype=torch.int32, device='cuda')
+        _sk_configure()
+        pool = _sk_pool.get(dev)
+        if pool is None:
+            pool = _sk_pool[dev] = torch.zeros((_SK_MAX_STREAMS, SK_FLAG_WORDS), dtype=torch.int32, device='cuda')
+        n = sum(1 for k in _sk_flags if k[0] == dev)
+        # beyond the pool (never seen: a trainer uses five streams) a stream gets an array of its own
+        f = pool[n] if n < _SK_MAX_STREAMS else torch.zeros(SK_FLAG_WORDS, dtype=torch.int32, device='cuda')
         _sk_flags[key] = f
     return f
 
 
+def _sk_tag(d):
+    """Tag a launch that may split tiles inside the kernel and remember its descriptor for the error message."""
+    tag = (LAUNCHES % _SK_TAG_RING) + 1
+    d.sk_tag = tag
+    _sk_tags[tag] = ConvDesc.from_buffer_copy(d)
+
+
 def sk_timeouts():
-    """Number of flag arrays whose last word reports a hand-off that timed out (must be 0; tests check it)."""
-    return sum(int(f[-1].item() != 0) for f in _sk_flags.values())
+    """Number of flag arrays whose last word reports a hand-off that timed out (must be 0)."""
+    n = 0
+    for pool in _sk_pool.values():
+        n += int((pool[:, -1] != 0).sum().item())
+    return n + sum(int(f[-1].item() != 0) for f in _sk_flags.values() if f.dim() == 1 and f._base is None)
+
+
+def check_sk(where=''):
+    """Raise HandoffTimeout if any conv launch since the last check reported a hand-off timeout (igemm.hip: the owner of a
+    sliced tile then stored a partial sum -- a silently wrong activation or gradient otherwise).  One small reduction and one
+    host read: called wherever results are read back anyway (loss fetch, snapshot, end of a benchmark, smoke).  The flag
+    arrays are zeroed before raising, so a caller that catches the error can go on (e.g. with SSC_STREAMK=0)."""
+    bad = []
+    for pool in _sk_pool.values():
+        words = pool[:, -1]
+        if bool((words != 0).any().item()):
+            bad += [int(w) & 0x7fffffff for w in words.cpu().tolist() if w != 0]
+            pool.zero_()
+    for f in _sk_flags.values():
+        if f.dim() == 1 and f._base is None and int(f[-1].item()) != 0:
+            bad.append(int(f[-1].item()) & 0x7fffffff)
+            f.zero_()
+    if not bad:
+        return
+    what = []
+    for tag in bad:
+        d = _sk_tags.get(tag)
+        if d is None:
+            what.append('launch tag %d' % tag)
+        else:
+            what.append('%s M=%d N=%d K=%d (launch tag %d)' % (_kernel_name('ssc_conv_forward_kernel_name', d),
+                                                              d.NB * d.PH * d.PW * d.nphase, d.Nn, d.TH * d.TW * d.k_real, tag))
+    raise HandoffTimeout('in-launch K-slice hand-off timed out%s: %s -- the outputs of these launches are partial sums; '
+                         'set SSC_STREAMK=0 to run without in-launch combining' % (' (' + where + ')' if where else '',
+                                                                                 '; '.join(what)))
 
 
 class BnBwdSums(object):
@@ -296,11 +364,17 @@ def _run_conv(d, bn=None, bnbwd=None):
     activated norm; its backward sums come out of the epilogue when the launch qualifies."""
     ws = workspace()
     d.sk_flags = sk_flags().data_ptr() if SK_ENABLED else None
+    if SK_ENABLED:
+        _sk_tag(d)
 
     def launch():
         if bnbwd is not None:
             sums, act = bnbwd
             C2 = 2 * sums.x2d.shape[1]
+            # the epilogue indexes the normed tensor and its tables with the conv's own column count and pixel rows
+            assert d.Nstore == d.ldc == sums.x2d.shape[1], (d.Nstore, d.ldc, sums.x2d.shape)
+            assert sums.ab.numel() == 2 * d.Nstore and sums.stats.numel() == 2 * d.Nstore
+            assert sums.x2d.shape[0] == d.NB * d.OH * d.OW, (sums.x2d.shape, d.NB, d.OH, d.OW)
             part = sums.buf[sums.rows:]
             n = C.c_int(0)
             check(lib().ssc_conv_forward_bnbwd(C.byref(d), ptr(ws), ws.numel() * 4, ptr(sums.x2d), sums.x2d.stride(0),

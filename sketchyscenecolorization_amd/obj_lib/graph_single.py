@@ -109,6 +109,10 @@ class TowerGraph(object):
         # examples: no rank reads and decodes the other towers' share); anything else is the global batch and is cut
         # by split_inputs as in the reference (graph_single.py:128-135)
         self.per_tower = all(getattr(x, 'per_tower', False) for x in inputs)
+        if self.per_tower and world > 1 and len(set(int(p) for p in batch_portion[:world])) > 1:
+            # split_inputs gives tower i batch_size * batch_portion[i] samples; per-tower queues all dequeue batch_size
+            raise ValueError('per-tower input queues dequeue batch_size examples on every rank: a non-uniform '
+                             'batch_portion %s needs global-batch inputs (split_inputs)' % (list(batch_portion),))
 
     def _dequeue(self):
         vals = [_value(x) for x in self.inputs]
@@ -145,6 +149,11 @@ class TowerGraph(object):
             else:
                 self.last['loss_g'] = self._tower_mean(self.tr.g_step(self._dequeue(), c))
         out = []
+        if 'loss_g' in kinds or 'loss_d' in kinds:
+            # the loss is read back here anyway: also read the conv launches' hand-off timeout words, so that a launch that
+            # stored a partial sum fails the run instead of training on (ssc_conv_desc.sk_flags, hip.check_sk)
+            from .. import hip
+            hip.check_sk('Session.run')
         for k in kinds:
             if k in ('loss_g', 'loss_d'):
                 out.append(np.float32(float(self.last[k])))

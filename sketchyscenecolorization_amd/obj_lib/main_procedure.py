@@ -31,6 +31,8 @@ SIZE = {True: (64, 64), False: (192, 192)}
 
 # ----------------------------------------------------------------------------- checkpoints (tf.train.Saver look-alike)
 def save_checkpoint(store, ckpt_dir, name, global_step):
+    from .. import hip
+    hip.check_sk('save_checkpoint')         # never snapshot weights behind a launch that reported a partial sum
     os.makedirs(ckpt_dir, exist_ok=True)
     path = os.path.join(ckpt_dir, '%s-%d' % (name, global_step))
     torch.save(store.state_dict(), path)
@@ -151,6 +153,8 @@ class RecordQueue(object):
 
 def _write_png(path, arr_uint8):
     from PIL import Image
+    from .. import hip
+    hip.check_sk('before writing %s' % os.path.basename(path))
     Image.fromarray(arr_uint8).save(path)
 
 

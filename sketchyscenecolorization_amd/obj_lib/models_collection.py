@@ -81,13 +81,26 @@ def generate_pix2pix(z, text_vocab_indices, LSTM_hybrid, output_channel, num_cla
     return tower.generate(z, text, noise_vec), noise_vec
 
 
-def _discriminate(block_type, discrim_inputs, discrim_targets, reuse, data_format, scope_name):
+def _tower_vocab(block_type, img, vocab_size=None):
+    """The discriminator has no vocabulary of its own, but it lives in the tower its generator registered (keyed by
+    vocab_size): the caller's value if given, else the one tower of this block type and size that exists, else Config's."""
+    if vocab_size is not None:
+        return vocab_size
+    have = [k[1] for k in _REGISTRY if k[0] == block_type and k[2] == img]
+    if len(have) == 1:
+        return have[0]
+    if len(have) > 1:
+        raise ValueError('towers with vocab_size %s exist for %s at %d: pass vocab_size=' % (sorted(have), block_type, img))
+    return getattr(Config, 'vocab_size', 58)
+
+
+def _discriminate(block_type, discrim_inputs, discrim_targets, reuse, data_format, scope_name, vocab_size=None):
     assert data_format == 'NCHW'
     if type(discrim_targets) is list:
         discrim_targets = discrim_targets[-1]
     a, b = _as_device(discrim_inputs), _as_device(discrim_targets)
     n, _, h, w = a.shape
-    tr = get_trainer(block_type, 58, h)
+    tr = get_trainer(block_type, _tower_vocab(block_type, h, vocab_size), h)
     xd = tr.bufs.get((scope_name or 'discriminator') + '/api_xd', (n, h, w, 8), zero_on_alloc=True)
     hip.nchw_to_nhwc(a, xd, 0)
     hip.nchw_to_nhwc(b, xd, 3)
@@ -99,15 +112,15 @@ def _discriminate(block_type, discrim_inputs, discrim_targets, reuse, data_forma
 
 
 def discriminate_pix2pix(discrim_inputs, discrim_targets, num_classes, labels=None, reuse=False,
-                         data_format='NCHW', scope_name=None):
+                         data_format='NCHW', scope_name=None, vocab_size=None):
     """models_collection.py:789-841: PatchGAN logits [N,1,h,w] + spectral-normed class logits [N,25]."""
-    return _discriminate('Pix2Pix', discrim_inputs, discrim_targets, reuse, data_format, scope_name)
+    return _discriminate('Pix2Pix', discrim_inputs, discrim_targets, reuse, data_format, scope_name, vocab_size)
 
 
 def discriminate_residual(discrim_inputs, discrim_targets, num_classes, labels=None, reuse=False,
-                          data_format='NCHW', scope_name=None):
+                          data_format='NCHW', scope_name=None, vocab_size=None):
     """models_collection.py:844-893: five stride-2 bottlenecks -> patch logits [N,1,h/32,w/32] + class logits."""
-    return _discriminate('Residual', discrim_inputs, discrim_targets, reuse, data_format, scope_name)
+    return _discriminate('Residual', discrim_inputs, discrim_targets, reuse, data_format, scope_name, vocab_size)
 
 
 def generate_residual(z, text_vocab_indices, LSTM_hybrid, output_channel, num_classes, vocab_size, reuse=False,
@@ -146,9 +159,9 @@ def generate_mru(z, text_vocab_indices, LSTM_hybrid, output_channel, num_classes
 
 
 def discriminate_mru(discrim_inputs, discrim_targets, num_classes, labels=None, reuse=False,
-                     data_format='NCHW', scope_name=None):
+                     data_format='NCHW', scope_name=None, vocab_size=None):
     """models_collection.py:676-786: MRU discriminator (spectral norm everywhere, prelu; the sketch is unused)."""
-    return _discriminate('MRU', discrim_inputs, discrim_targets, reuse, data_format, scope_name)
+    return _discriminate('MRU', discrim_inputs, discrim_targets, reuse, data_format, scope_name, vocab_size)
 
 
 generator_mru = generate_mru

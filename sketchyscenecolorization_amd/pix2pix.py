@@ -259,7 +259,10 @@ class Pix2PixGenerator(object):
             xin = View(e[k - 1], None, ab[k - 1], ACT_LRELU)
             dyv = View(gcur)
             gin = B.get(tag + '/gb/e%d_in' % k, e[k - 1].shape)
-            hip.conv_dgrad(dyv, w, 2, 1, gin, bnbwd=(sums_e[k - 1].take(ACT_LRELU) if sums_e[k - 1] else None))
+            # (a sums object that already missed a source -- the merged decoder launches -- falls back to the separate pass
+            # anyway: do not make this epilogue re-read e[k-1] for rows nobody will use)
+            live = sums_e[k - 1] is not None and not sums_e[k - 1].missed
+            hip.conv_dgrad(dyv, w, 2, 1, gin, bnbwd=(sums_e[k - 1].take(ACT_LRELU) if live else None))
             forked = self._fork(lambda xin=xin, dyv=dyv, k=k:
                                 hip.conv_wgrad(xin, dyv, s.grad('generator/encoder_%d/conv/filter' % k), 2, 1))
             dx = B.get(tag + '/gb/de%d' % (k - 1), e[k - 1].shape)

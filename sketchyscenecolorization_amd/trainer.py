@@ -99,7 +99,9 @@ class GanTrainer(object):
         self._aux_stream = torch.cuda.Stream() if overlap_real else None
         # discriminator backward of the real and of the fake pair side by side (Pix2Pix / Residual discriminators: their
         # backward touches a gradient only through store.grad(); the MRU one keeps per-call spectral-norm state)
-        self._dbwd_concurrent = (overlap_real and block_type in ('Pix2Pix', 'Residual') and
+        # Not together with the filter-gradient side stream: both passes' filter gradients would then land on
+        # hip.WGRAD_STREAM, which neither pass's stream waits for before the two buffers are added.
+        self._dbwd_concurrent = (overlap_real and block_type in ('Pix2Pix', 'Residual') and self._wgrad_stream is None and
                                  os.environ.get('SSC_DBWD_CONCURRENT', '1') == '1')
         self._text_stream = torch.cuda.Stream() if (overlap_real and os.environ.get('SSC_TEXT_STREAM', '1') == '1') else None
         # generator forward of the next G-step inside the D-step (train_iteration)
@@ -425,10 +427,10 @@ class GanTrainer(object):
         hip.call('ssc_acgan_loss', cr['logits'], batch['class_id_d'], N, K, 1, 1.0, loss_d, dlog_r)
         if self._dbwd_concurrent and self._aux_stream is not None and hip.PROFILE is None:
             # The two backward passes of the discriminator step (real pair, fake pair) share nothing but the filters they
-            # read: run them side by side -- real on the second stream into a second gradient buffer, fake in line -- so
-            # that each chain's launch tails and partly filled rounds are filled by the other, then add the buffers.  The
-            # fake pair's pass goes to the second buffer: it touches a subset of the variables (no class head), the rest of
-            # that buffer stays zero from its allocation.
+            # read: run them side by side -- the fake pair on the second stream into a second gradient buffer, the real
+            # pair in line -- so that each chain's launch tails and partly filled rounds are filled by the other, then add
+            # the buffers.  The fake pair's pass goes to the second buffer: it touches a subset of the variables (no class
+            # head), the rest of that buffer stays zero from its allocation.
             sc = s.discriminator
             if getattr(sc, 'grad2', None) is None:
                 sc.grad2 = torch.zeros_like(sc.grad)
@@ -443,6 +445,7 @@ class GanTrainer(object):
                     sc.g, sc.g2 = sc.g2, sc.g
             self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False)
             main.wait_stream(self._aux_stream)
+            hip.join_wgrad()        # (no side-stream filter gradients in this mode; kept so that the add can never run early)
             hip.call('ssc_axpy', sc.grad, sc.grad2, 1.0, sc.numel)
         else:
             self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False)

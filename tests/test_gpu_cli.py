@@ -186,3 +186,19 @@ def test_cli_other_optimizers(tmp_path, monkeypatch, opt):
     run = os.path.join('outputs', sorted(os.listdir('outputs'))[0])
     scal = [json.loads(l) for l in open(os.path.join(run, 'log', 'scalars.jsonl'))]
     assert len(scal) == 2 and all(np.isfinite(s['total_loss/g']) for s in scal)
+
+
+def test_cli_train_fails_on_handoff_timeout(tmp_path):
+    """A conv launch whose K-slice hand-off times out stores a partial sum: the CLI must die with the launch's name, not go
+    on training with a finite loss.  Forced through the test hook (producers withhold their flags, every tile sliced in 2,
+    20 ms bound) in a process of its own."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSC_SK_TEST_WITHHOLD='1', SSC_SK_TIMEOUT_MS='20', SSC_TS_FORCE='0,2', PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, 'obj_colorization_main.py'), '--mode', 'train', '-bt', 'Pix2Pix',
+                        '-si', '1', '-bs', '8', '-mi', '3', '-smf', '2', '-swf', '1'], cwd=str(tmp_path), env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert 'hand-off timed out' in r.stderr and 'conv_fwd<' in r.stderr, r.stderr[-3000:]
+    assert not glob.glob(os.path.join(str(tmp_path), 'outputs', '*', 'snapshot', 'model_*'))

@@ -547,3 +547,40 @@ def test_recurrent_step_both_kernel_forms(rows, div2, form):
     close(ho, h_ref, tol=2e-5)
     a_ref = torch.cat([torch.sigmoid(i), torch.tanh(j), torch.sigmoid(f + 1.0), torch.sigmoid(o)], dim=1)
     close(acts[keep.squeeze(1).cuda()], a_ref[keep.squeeze(1)], tol=2e-5)
+
+
+def test_handoff_timeout_is_reported_and_fatal():
+    """igemm.hip, owner side of the in-launch K-slice hand-off: an owner that gives up waiting stores a partial sum, so it must
+    say so -- the timeout word carries the launch's tag, hip.check_sk raises HandoffTimeout naming the launch and zeroes the
+    flags, a flag that was never seen set is not cleared by the owner, and the next launch (hook off) is exact again."""
+    from sketchyscenecolorization_amd import hip
+    from sketchyscenecolorization_amd.hip import ACT_NONE, View
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(32, 48, 48, 128, device='cuda', generator=g)      # encoder_3 at batch 32: 512 whole tiles + 64 x 4 slices
+    w = torch.randn(4, 4, 128, 256, device='cuda', generator=g) * 0.05
+    v = View(x, None, None, ACT_NONE)
+    hip.SK_ENABLED = False
+    ref = torch.zeros(32, 24, 24, 256, device='cuda')
+    hip.conv_forward(v, w, 2, 1, ref)
+    hip.SK_ENABLED = True
+    hip.sk_flags()
+    hip.check_sk()
+    try:
+        assert hip.lib().ssc_sk_configure(30, 1) == 0       # 30 ms bound, producers withhold their flags
+        out = torch.zeros_like(ref)
+        hip.conv_forward(v, w, 2, 1, out)
+        torch.cuda.synchronize()
+        assert hip.sk_timeouts() == 1
+        # (with the hook the producers did write their partial tiles -- only the flags are withheld -- so `out` may even be
+        # right here; after a real timeout it is a partial sum, which is why the report must be fatal)
+        with pytest.raises(hip.HandoffTimeout) as ei:
+            hip.check_sk('unit test')
+        assert 'conv_fwd<' in str(ei.value) and 'M=18432 N=256 K=2048' in str(ei.value), str(ei.value)
+    finally:
+        assert hip.lib().ssc_sk_configure(0, 0) == 0
+    assert hip.sk_timeouts() == 0 and int(hip.sk_flags().abs().sum()) == 0     # zeroed by check_sk
+    out = torch.zeros_like(ref)
+    hip.conv_forward(v, w, 2, 1, out)
+    torch.cuda.synchronize()
+    hip.check_sk()
+    assert float((out - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
