@@ -393,14 +393,16 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(max(args.warmup, 0 if args.no_graphs else 3)):   # graphs: eager, capture, first replay
-        tr.train_iteration(bd, bg, counter=i)
+    # every iteration also hands over the NEXT iteration's discriminator batch (here: the same resident one), as an input
+    # pipeline that is one batch ahead does: its real pass runs inside this iteration's G-step (trainer.real_ahead)
+    for i in range(max(args.warmup, 0 if args.no_graphs else 5)):   # graphs: eager, capture, first replay (of every variant)
+        tr.train_iteration(bd, bg, counter=i, next_batch_d=bd)
     barrier()
     preheat_steps = 0
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.preheat_seconds:       # untimed; same step count on every rank
         for _ in range(10):
-            tr.train_iteration(bd, bg, counter=args.warmup)
+            tr.train_iteration(bd, bg, counter=args.warmup, next_batch_d=bd)
         preheat_steps += 10
         barrier()
         if world > 1:       # agree on continuing so that no rank leaves the loop alone
@@ -420,7 +422,7 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        tr.train_iteration(bd, bg, counter=args.warmup + i)
+        tr.train_iteration(bd, bg, counter=args.warmup + i, next_batch_d=bd)
         marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
@@ -429,7 +431,7 @@ def main():
     if not args.no_graphs and prof is not None:
         hip.PROFILE = prof
         for i in range(args.prof_steps):
-            tr.train_iteration(bd, bg, counter=args.warmup + args.steps + i)
+            tr.train_iteration(bd, bg, counter=args.warmup + args.steps + i, next_batch_d=bd)
         torch.cuda.synchronize()
         prof_steps = args.prof_steps
     hip.PROFILE = None

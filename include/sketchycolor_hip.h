@@ -130,6 +130,11 @@ int ssc_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
 /* implicit GEMM (igemm.hip).  ws: split-K slab workspace (may be NULL). */
 int ssc_conv_forward(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, void* stream);
 int ssc_conv_wgrad(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void* stream);
+/* filter gradients of the large layers on a 128 x 128 accumulator tile (wgrad128.hip); ssc_conv_wgrad dispatches to it when
+ * _supported: the gathered channels a multiple of 128 inside one source (or exactly 64: two taps per tile), no channel
+ * padding on the gathered side, >= 128 real dense channels, every tensor below 2 GiB */
+int ssc_conv_wgrad128_supported(const ssc_wgrad_desc* d);
+int ssc_conv_wgrad128(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void* stream);
 /* conv + the batch-statistics norm of its output [M*nphase rows, Nstore == ldc columns] folded to ab = [a; b] (y = a*x + b)
  * and stats = [mean; rstd] (models_collection.py:36-46 after :389 / :402): the column sums come out of the conv epilogue
  * when the launch allows it, else ssc_bn_stats reads the output back */
@@ -184,6 +189,8 @@ int ssc_distance_map_u8(const uint8_t* sk, int N, int R, float* out, int32_t* ws
 /* host-side CRC-32C (Castagnoli) of n bytes: TFRecord record framing (tf.TFRecordReader, input_pipeline.py:57-59) */
 uint32_t ssc_crc32c(const uint8_t* data, int64_t n);
 int ssc_fill(float* dst, float value, int64_t n, void* stream);
+/* profiling aid: *dst = the device's 100 MHz wall clock at the time the launch runs (a one-lane kernel; capturable) */
+int ssc_timestamp(uint64_t* dst, void* stream);
 /* ---- MRU blocks (mru.py:353-461 mru_conv_block_v3, :527-591 mru_deconv_block_v2), NHWC fp32 -------------------- */
 /* mean_pool (mru.py:15-19): out[n, y, x, c] = mean of the 2x2 block */
 int ssc_mean_pool2(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int C, void* stream);

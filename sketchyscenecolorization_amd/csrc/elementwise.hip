@@ -279,6 +279,14 @@ extern "C" int ssc_image_postprocess_u8(const float* src, int ldc, int coff, int
     return CHECK_LAUNCH();
 }
 
+// profiling aid: dst[0] = the 100 MHz wall clock when this launch runs (one lane).  Captured into a replayed hipGraph it tells
+// when a branch of the graph really starts, without a profiler's per-dispatch overhead (scripts/branch_marks.py)
+__global__ void timestamp_kernel(unsigned long long* dst) { dst[0] = wall_clock64(); }
+extern "C" int ssc_timestamp(uint64_t* dst, void* stream) {
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(dst));
+    return (int)hipGetLastError();
+}
+
 extern "C" int ssc_fill(float* dst, float value, int64_t n, void* stream) {
     if (n <= 0) return 0;
     long blocks = (n + 255) / 256;

@@ -68,6 +68,8 @@ SIGNATURES = {
     'ssc_device_info': [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, _I],
     'ssc_conv_forward': [C.POINTER(ConvDesc), _P, _L, _P],
     'ssc_conv_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
+    'ssc_conv_wgrad128_supported': [C.POINTER(WgradDesc)],
+    'ssc_conv_wgrad128': [C.POINTER(WgradDesc), _P, _L, _P],
     'ssc_conv_forward_bn': [C.POINTER(ConvDesc), _P, _L, _P, _P, _F, _P, _P, _P],
     'ssc_bn_finalize': [_P, _I, _I, _L, _P, _P, _F, _P, _P, _P],
     'ssc_conv_forward_bnbwd': [C.POINTER(ConvDesc), _P, _L, _P, _I, _P, _P, _I, _P, _L, C.POINTER(C.c_int), _P],
@@ -88,6 +90,7 @@ SIGNATURES = {
     'ssc_decode_paired_u8': [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     'ssc_distance_map_u8': [_P, _I, _I, _P, _P, _L, _P],
     'ssc_fill': [_P, _F, _L, _P],
+    'ssc_timestamp': [_P, _P],
     'ssc_affine_act': [_P, _I, _P, _I, _I, _P, _I, _L, _I, _P],
     'ssc_residual_merge': [_P, _P, _P, _P, _I, _P, _L, _I, _P],
     'ssc_bn_stats': [_P, _L, _I, _I, _P, _P, _F, _P, _P, _P, _L, _P],
@@ -697,6 +700,32 @@ def decode_paired_u8(img_u8, sk_u8, size, noise=None, img_out=None, sk_out=None,
     check(lib().ssc_decode_paired_u8(ptr(img_u8), ptr(sk_u8), ptr(skf), n, r, size, ptr(noise), ptr(img_out),
                                      ptr(sk_out), ptr(mnmx), stream_ptr()), 'decode_paired_u8')
     return img_out, sk_out
+
+
+# Branch marks (profiling aid, scripts/branch_marks.py): when MARKS is a dict, mark(name) launches a one-lane kernel on the
+# current stream that stores the device wall clock into a slot of its own -- captured into the step graphs, the slots show
+# after a replay when each branch of the graph really ran.
+MARKS = None
+_mark_buf = None
+
+
+def mark(name):
+    global _mark_buf
+    if MARKS is None:
+        return
+    if _mark_buf is None:
+        _mark_buf = torch.zeros(256, dtype=torch.int64, device='cuda')
+    if name not in MARKS:
+        MARKS[name] = len(MARKS)
+    check(lib().ssc_timestamp(C.c_void_p(_mark_buf.data_ptr() + 8 * MARKS[name]), stream_ptr()), 'ssc_timestamp')
+
+
+def read_marks():
+    """{name: microseconds since the earliest mark} of the last run / replay."""
+    v = _mark_buf.cpu().tolist()
+    t = {n: v[i] for n, i in MARKS.items() if v[i] != 0}
+    t0 = min(t.values())
+    return {n: (x - t0) / 100.0 for n, x in sorted(t.items(), key=lambda kv: kv[1])}
 
 
 def fill(t, value):

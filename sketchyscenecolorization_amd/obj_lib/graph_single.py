@@ -133,21 +133,26 @@ class TowerGraph(object):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
         return t / self.world
 
-    def run(self, fetches, g_follows=False):
+    def run(self, fetches, g_follows=False, d_follows=False):
         """g_follows (with opt_d): the next run is opt_g -- its batch is dequeued now (same order as the reference's
-        queue: D batch, then G batch) so that the trainer can run its generator forward inside the D-step."""
+        queue: D batch, then G batch) so that the trainer can run its generator forward inside the D-step.
+        d_follows (with opt_g): the next run is opt_d -- its batch is dequeued now (again the queue order is unchanged:
+        ..., G batch, next D batch) so that the trainer can run that step's real pass inside this G-step."""
         kinds = [f.kind for f in fetches]
         c = self.counter.value if isinstance(self.counter, Counter) else int(_value(self.counter))
         if 'opt_d' in kinds:
-            d_batch = self._dequeue()
+            d_batch, self._d_next = getattr(self, '_d_next', None), None
+            use_real = d_batch is not None
+            if d_batch is None:
+                d_batch = self._dequeue()
             self._g_next = self._dequeue() if (g_follows and getattr(self.tr, 'run_ahead', False)) else None
-            self.last['loss_d'] = self._tower_mean(self.tr.d_step(d_batch, c, ahead=self._g_next))
+            self.last['loss_d'] = self._tower_mean(self.tr.d_step(d_batch, c, ahead=self._g_next, use_real=use_real))
         if 'opt_g' in kinds:
             g_next, self._g_next = getattr(self, '_g_next', None), None
-            if g_next is not None:
-                self.last['loss_g'] = self._tower_mean(self.tr.g_step(g_next, c, use_ahead=True))
-            else:
-                self.last['loss_g'] = self._tower_mean(self.tr.g_step(self._dequeue(), c))
+            g_batch = g_next if g_next is not None else self._dequeue()
+            self._d_next = self._dequeue() if (d_follows and getattr(self.tr, 'real_ahead', False)) else None
+            self.last['loss_g'] = self._tower_mean(self.tr.g_step(g_batch, c, use_ahead=g_next is not None,
+                                                                   next_d=self._d_next))
         out = []
         if 'loss_g' in kinds or 'loss_d' in kinds:
             # the loss is read back here anyway: also read the conv launches' hand-off timeout words, so that a launch that

@@ -242,7 +242,9 @@ def train(**kwargs):
             if np.isnan(np.sum(loss_d_out)):
                 print("NaN occurred during training D")
                 return -1
-        _, loss_g_out, counter_out, _ = sess.run([opt_g, loss_g, fetch_counter, fetch_add])
+        # d_follows: the trainer may run the next iteration's real D pass inside this G-step (trainer.real_ahead)
+        _, loss_g_out, counter_out, _ = sess.run([opt_g, loss_g, fetch_counter, fetch_add],
+                                                 d_follows=(Diters >= 1 and i + 1 < max_iter_step))
         if np.isnan(np.sum(loss_g_out)):
             print("NaN occurred during training G")
             return -1

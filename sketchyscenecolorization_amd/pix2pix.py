@@ -67,6 +67,7 @@ class Pix2PixGenerator(object):
                 hip.conv_forward(View(e[k - 1], None, ab[k - 1], ACT_LRELU), s['generator/encoder_%d/conv/filter' % k],
                                  2, 1, e[k], bn=(s['generator/encoder_%d/scale' % k], s['generator/encoder_%d/offset' % k],
                                                  ab[k], st[k]))
+        hip.mark(tag + '/encoders: last')
         ctx = {'tag': tag, 'N': N, 'H': H, 'W': W, 'xs': xs, 'e': e, 'ab': ab, 'st': st, 'noise_vec': noise_vec}
         hh, ww = e[5].shape[1], e[5].shape[2]
         P = hh * ww
@@ -86,6 +87,7 @@ class Pix2PixGenerator(object):
         hip.call('ssc_miu_permute_fwd', pre, N, cd, P, noise)
         ctx['noise_pre'], ctx['noise'] = pre, noise
         # decoders
+        hip.mark(tag + '/caption fusion: last')
         d, abd, std = [None] * 6, [None] * 6, [None] * 6
         dch = [None, 3, 64, 128, 256, 512]
         views = {}
@@ -214,6 +216,7 @@ class Pix2PixGenerator(object):
         hip.call('ssc_miu_permute_bwd', ctx['noise_pre'], g_noise, N, cd, P, dpre_fc)
         hip.matmul_tn(ctx['noise_vec'], dpre_fc, s.grad('generator/fully_connected/weights'))
         hip.call('ssc_group_rowsum', dpre_fc, cd * P, 1, N, cd * P, s.grad('generator/fully_connected/biases'), 0)
+        hip.mark(tag + '/bwd decoders dgrad: last')
         if held:
             main = torch.cuda.current_stream()
             side_stream.wait_stream(main)
@@ -228,8 +231,10 @@ class Pix2PixGenerator(object):
         if self.lstm_hybrid:
             tstream = self.text_stream_bwd if hip.PROFILE is None else None
             dy5 = self.text.backward(ctx['tctx'], g_feat, side_stream=tstream)
+            hip.mark(tag + '/bwd caption branch: last (main stream)')
             if held:
                 main.wait_stream(side_stream)
+                hip.mark(tag + '/bwd held decoder wgrads joined')
                 done('decoders')
             if tstream is None:
                 done('text')
@@ -280,6 +285,7 @@ class Pix2PixGenerator(object):
             if k == 5 and not text_pending:
                 done('encoder_5')       # its filter, scale and offset gradients are final (trainer._sections)
         hip.conv_wgrad(View(ctx['xs']), View(gcur), s.grad('generator/encoder_1/conv/filter'), 2, 1)
+        hip.mark(tag + '/bwd encoders: last')
         if text_pending:
             self.text.join_backward()
             done('text')
@@ -296,17 +302,19 @@ class Pix2PixDiscriminator(object):
         self.chans = [8, 64, 128, 256, 512, 1]
         self.strides = [None, 2, 2, 2, 1, 1]
 
-    def prepare_sn(self):
-        """One power iteration on fully_connected/weights (sn.py), shared by every call of this step."""
+    def prepare_sn(self, tag='d/sn', u=None):
+        """One power iteration on fully_connected/weights (sn.py), shared by every call of this step.
+        tag / u: buffers and starting vector of a pass that runs beside another step's (the discriminator's real pass run
+        ahead inside the generator step starts from the u that step is about to assign: trainer._d_real_pass)."""
         s, B = self.s, self.b
         W = s['discriminator/fully_connected/weights']
         m, n = W.shape
         if not self.sn:
             return {'wbar': W}
-        sn = {'v': B.get('d/sn/v', (m,)), 'u_new': B.get('d/sn/u_new', (1, n)), 'wbar': B.get('d/sn/wbar', (m, n)),
-              'aux': B.get('d/sn/aux', (4,)), 'gwbar': B.get('d/sn/gwbar', (m, n)), 'n_acc': 0}
-        hip.call('ssc_sn_forward', W, s['discriminator/fully_connected/u'], m, n, sn['v'], sn['u_new'], sn['wbar'],
-                 sn['aux'])
+        sn = {'v': B.get(tag + '/v', (m,)), 'u_new': B.get(tag + '/u_new', (1, n)), 'wbar': B.get(tag + '/wbar', (m, n)),
+              'aux': B.get(tag + '/aux', (4,)), 'gwbar': B.get(tag + '/gwbar', (m, n)), 'n_acc': 0,
+              'scratch': B.get(tag + '/scratch', (m,)), 'u': (u if u is not None else s['discriminator/fully_connected/u'])}
+        hip.call('ssc_sn_forward', W, sn['u'], m, n, sn['v'], sn['u_new'], sn['wbar'], sn['aux'])
         return sn
 
     def forward(self, xd, sn, tag):
@@ -430,5 +438,5 @@ class Pix2PixDiscriminator(object):
             if not accumulate:
                 hip.fill(gW, 0.0)
             return
-        hip.call('ssc_sn_backward', W, s['discriminator/fully_connected/u'], sn['v'], sn['u_new'], sn['aux'],
-                 sn['gwbar'], m, n, gW, int(accumulate), B.get('d/sn/scratch', (m,)))
+        hip.call('ssc_sn_backward', W, sn['u'], sn['v'], sn['u_new'], sn['aux'], sn['gwbar'], m, n, gW, int(accumulate),
+                 sn['scratch'])

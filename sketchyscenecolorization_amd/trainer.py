@@ -109,6 +109,19 @@ class GanTrainer(object):
         self._ahead_stream = torch.cuda.Stream() if self.run_ahead else None
         self._ahead = None
         self._ahead_pending = False
+        # ... and, the other way round, the REAL half of the next D-step inside the G-step: D(real) forward + backward depend on
+        # the discriminator's variables (untouched by a G-step), the next real batch and the spectral-norm u the G-step is
+        # about to assign -- not on the generator.  The G-step is one dependent chain (D forward -> losses -> D data gradient
+        # -> G backward, with ~12 tiny launches at each transition and the caption branch's BPTT chain in the middle:
+        # scripts/timeline_dump.py shows ~1.5 ms of its 7 ms with no full-size launch in flight); the D-step already runs
+        # three chains.  Moving 3.3 ms of independent full-size work under the G-step fills those holes.  Pix2Pix pair, one
+        # GPU (a fork may not cross the end of a graph segment, and with world > 1 the G-step is cut at every gradient section).
+        self.real_ahead = (overlap_real and block_type == 'Pix2Pix' and self._dbwd_concurrent and not self.segment_graphs and
+                           os.environ.get('SSC_REAL_AHEAD', '1') == '1')
+        self._real_stream = torch.cuda.Stream() if self.real_ahead else None
+        self._real = None               # what the run-ahead real pass left for the D-step: {'sn', 'cr'}
+        self._real_pending, self._real_key = False, None
+        self.loss_real = torch.zeros(1, dtype=torch.float64, device=device)      # its loss terms
         self.use_graphs_infer = os.environ.get('SSC_INFER_GRAPHS', '1') == '1'   # hipGraph replay of generate / generate_u8
         self.G.text_stream = self._text_stream          # forward half: every generator
         if block_type == 'Pix2Pix':
@@ -271,15 +284,17 @@ class GanTrainer(object):
             sbatch['text'] = batch['text']
         return sbatch
 
-    def _run_step(self, kind, batch, counter, ahead=None, use_ahead=False):
+    def _run_step(self, kind, batch, counter, ahead=None, use_ahead=False, real=None, use_real=False):
         """Eager, capture or replay of one D-/G-step.  ``ahead``: the NEXT generator step's batch, whose generator
-        forward this discriminator step also runs (on a side stream); ``use_ahead``: this generator step starts from it."""
+        forward this discriminator step also runs (on a side stream); ``use_ahead``: this generator step starts from it.
+        ``real``: the NEXT discriminator step's batch, whose real pass this generator step also runs; ``use_real``: this
+        discriminator step starts from it."""
         scope, idx, lr = ((self.store.discriminator, 1, self.lr_d) if kind == 'd' else
                           (self.store.generator, 0, self.lr_g))
         if kind == 'd':
-            impl = (lambda b: self._d_impl(b, ahead)) if ahead is not None else self._d_impl
+            impl = lambda b: self._d_impl(b, ahead, use_real)
         else:
-            impl = (lambda b: self._g_impl(b, True)) if use_ahead else self._g_impl
+            impl = lambda b: self._g_impl(b, use_ahead, real)
         if not self.use_graphs or hip.PROFILE is not None:
             self._adam_prepare(scope, idx, lr * self.decay(counter))
             return impl(batch)
@@ -292,9 +307,17 @@ class GanTrainer(object):
         if ahead is not None:           # the generator step's inputs must be in place before this graph reads them
             ahead = self._static_batch('g', ahead)
             key = key + ('ahead', ahead['text']['S'] if isinstance(ahead['text'], dict) else -1)
-            impl = lambda b, a=ahead: self._d_impl(b, a)
         elif use_ahead:
             key = key + ('use_ahead',)
+        if real is not None:            # likewise the next discriminator step's inputs (its graph will find them in place)
+            real = self._static_batch('d', real)
+            key = key + ('real',)
+        elif use_real:
+            key = key + ('use_real',)
+        if kind == 'd':
+            impl = lambda b, a=ahead: self._d_impl(b, a, use_real)
+        else:
+            impl = lambda b, r=real: self._g_impl(b, use_ahead, r)
         self._adam_prepare(scope, idx, lr * self.decay(counter))
         g = self._graphs.get(key)
         if g is None:
@@ -341,33 +364,46 @@ class GanTrainer(object):
         return xd_f, gctx
 
     # ------------------------------------------------------------------ steps
-    def d_step(self, batch, counter=0, ahead=None):
+    @staticmethod
+    def _batch_key(batch):
+        return (batch['images_d'].data_ptr(), batch['sketches'].data_ptr(), batch['class_id_d'].data_ptr())
+
+    def d_step(self, batch, counter=0, ahead=None, use_real=False):
         """One discriminator update; returns the device scalar loss_d (a view of self.loss).
         ahead: the batch of the generator step that follows -- its generator forward then runs inside this step
-        (``run_ahead``; call ``g_step(that batch, use_ahead=True)`` next)."""
+        (``run_ahead``; call ``g_step(that batch, use_ahead=True)`` next).
+        use_real: the preceding ``g_step(..., next_d=batch)`` ran this step's real pass (``real_ahead``); taken only if
+        ``batch`` is the batch that call was given (same tensors)."""
+        use_real = bool(use_real and self._real_pending and hip.PROFILE is None and self._real is not None and
+                        self._real_key == self._batch_key(batch))
+        self._real_pending = False
         if ahead is not None and self.run_ahead and hip.PROFILE is None:
             self._ahead_pending = True
-            return self._run_step('d', batch, counter, ahead=ahead)
+            return self._run_step('d', batch, counter, ahead=ahead, use_real=use_real)
         self._ahead_pending = False
-        return self._run_step('d', batch, counter)
+        return self._run_step('d', batch, counter, use_real=use_real)
 
-    def _d_impl(self, batch, ahead=None):
+    def _d_impl(self, batch, ahead=None, use_real=False):
         if ahead is not None:
             # The generator does not change during a discriminator step, so the generator forward of the generator step
             # that follows can run now, on its own stream, in whatever the discriminator step leaves idle (launch tails,
             # partly filled rounds).  No nested fork: the word half of its caption branch stays in line.
             main = torch.cuda.current_stream()
+            hip.mark('d/start')
             self._ahead_stream.wait_stream(main)
             with torch.cuda.stream(self._ahead_stream):
                 ts, self.G.text_stream = self.G.text_stream, None
                 try:
+                    hip.mark('d/ahead G forward: first')
                     self._ahead = self._pack_fake(ahead, 'ga')
+                    hip.mark('d/ahead G forward: last')
                 finally:
                     self.G.text_stream = ts
-        loss_d = self.d_gradients(batch)
+        loss_d = self.d_gradients(batch, use_real)
         if ahead is not None:       # joined before the gradient all-reduce: a fork may not cross the end of a graph segment
             torch.cuda.current_stream().wait_stream(self._ahead_stream)
         self._apply_d_launch()
+        hip.mark('d/end')
         return loss_d
 
     def apply_d(self, counter=0):
@@ -381,14 +417,66 @@ class GanTrainer(object):
         self._allreduce_wait()
         self._adam_launch(sc, 1)
 
-    def d_gradients(self, batch):
+    def d_gradients(self, batch, use_real=False):
         """loss_d and d loss_d / d discriminator variables (compute_gradients, graph_single.py:309-312)."""
         hip.WGRAD_STREAM = self._wgrad_stream
         try:
-            return self._d_gradients(batch)
+            return self._d_gradients_fake_only(batch) if use_real else self._d_gradients(batch)
         finally:
             hip.join_wgrad()
             hip.WGRAD_STREAM = None
+
+    def _d_real_pass(self, batch, u=None):
+        """The real half of a discriminator step: D(real) forward, its loss terms (into ``loss_real``) and its backward into the
+        discriminator's gradient buffer.  Runs on the current stream; ``u``: spectral-norm vector to start from (inside a
+        generator step: the u that step will assign at its end)."""
+        B = self.bufs
+        N, _, H, W = batch['sketches'].shape
+        sn = self.D.prepare_sn(tag='d/sn_r', u=u)
+        xd_r = B.get('xd_real', (N, H, W, 8), zero_on_alloc=True)
+        hip.nchw_to_nhwc(batch['sketches'], xd_r, 0)
+        hip.nchw_to_nhwc(batch['images_d'], xd_r, 3)
+        cr = self.D.forward(xd_r, sn, 'dr')
+        lr = self.loss_real
+        lr.zero_()
+        rows = cr['disc'].shape[0] * cr['disc'].shape[1] * cr['disc'].shape[2]
+        dl5_r = B.get('dl5_r', cr['disc'].shape, zero_on_alloc=True)
+        hip.call('ssc_softplus_loss', cr['disc'], 4, rows, -1.0, 1.0 / rows, lr, dl5_r, 1.0 / rows)
+        K = cr['logits'].shape[1]
+        dlog_r = B.get('dlog_r', (N, K))
+        hip.call('ssc_acgan_loss', cr['logits'], batch['class_id_d'], N, K, 1, 1.0, lr, dlog_r)
+        self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False)
+        return {'sn': sn, 'cr': cr}
+
+    def _d_gradients_fake_only(self, batch):
+        """d_gradients when the real pass of this step ran ahead (inside the preceding generator step): generator forward,
+        D(fake) forward + backward into the second gradient buffer, the two buffers added."""
+        B, s = self.bufs, self.store
+        sn, cr = self._real['sn'], self._real['cr']
+        xd_f, gctx = self._pack_fake(batch)
+        cf = self.D.forward(xd_f, sn, 'df')
+        loss_d = self.loss[1:2]
+        loss_d.zero_()
+        rows = cf['disc'].shape[0] * cf['disc'].shape[1] * cf['disc'].shape[2]
+        dl5_f = B.get('dl5_f', cf['disc'].shape, zero_on_alloc=True)
+        hip.call('ssc_softplus_loss', cf['disc'], 4, rows, 1.0, 1.0 / rows, loss_d, dl5_f, 1.0 / rows)
+        loss_d.add_(self.loss_real)
+        sc = s.discriminator
+        if getattr(sc, 'grad2', None) is None:
+            sc.grad2 = torch.zeros_like(sc.grad)
+            sc.g2 = type(sc.g)((n, sc.grad2[o:o + k].view(shp)) for n, (o, k, shp) in sc.offsets.items())
+        sc.g, sc.g2 = sc.g2, sc.g
+        try:
+            self.D.backward(cf, dl5_f, None, sn, True, False, accumulate=False)
+        finally:
+            sc.g, sc.g2 = sc.g2, sc.g
+        hip.call('ssc_axpy', sc.grad, sc.grad2, 1.0, sc.numel)
+        self.D.finish_sn_backward(sn)
+        hip.call('ssc_l2_reg', s['discriminator/fully_connected/weights'],
+                 s['discriminator/fully_connected/weights'].numel(), 1e-6, loss_d,
+                 s.grad('discriminator/fully_connected/weights'))
+        self.last = {'gctx': gctx, 'cr': cr, 'cf': cf}
+        return loss_d
 
     def _d_gradients(self, batch):
         B, s = self.bufs, self.store
@@ -406,15 +494,20 @@ class GanTrainer(object):
             # GEMMs) leaves idle
             self._aux_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._aux_stream):
+                hip.mark('d/D(real) forward: first')
                 sn = self.D.prepare_sn()
                 cr = real_branch(sn)
+                hip.mark('d/D(real) forward: last')
+            hip.mark('d/G forward: first')
             xd_f, gctx = self._pack_fake(batch)
+            hip.mark('d/G forward: last')
             torch.cuda.current_stream().wait_stream(self._aux_stream)
         else:
             sn = self.D.prepare_sn()
             xd_f, gctx = self._pack_fake(batch)
             cr = real_branch(sn)
         cf = self.D.forward(xd_f, sn, 'df')
+        hip.mark('d/D(fake) forward: last')
         loss_d = self.loss[1:2]
         loss_d.zero_()
         rows = cr['disc'].shape[0] * cr['disc'].shape[1] * cr['disc'].shape[2]
@@ -440,10 +533,14 @@ class GanTrainer(object):
             with torch.cuda.stream(self._aux_stream):
                 sc.g, sc.g2 = sc.g2, sc.g
                 try:
+                    hip.mark('d/D backward (fake): first')
                     self.D.backward(cf, dl5_f, None, sn, True, False, accumulate=False)
+                    hip.mark('d/D backward (fake): last')
                 finally:
                     sc.g, sc.g2 = sc.g2, sc.g
+            hip.mark('d/D backward (real): first')
             self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False)
+            hip.mark('d/D backward (real): last')
             main.wait_stream(self._aux_stream)
             hip.join_wgrad()        # (no side-stream filter gradients in this mode; kept so that the add can never run early)
             hip.call('ssc_axpy', sc.grad, sc.grad2, 1.0, sc.numel)
@@ -458,18 +555,24 @@ class GanTrainer(object):
         self.last = {'gctx': gctx, 'cr': cr, 'cf': cf}
         return loss_d
 
-    def g_step(self, batch, counter=0, use_ahead=False):
+    def g_step(self, batch, counter=0, use_ahead=False, next_d=None):
         """One generator update (+ spectral-norm u assignment); returns the device scalar loss_g.
-        use_ahead: start from the forward pass the preceding ``d_step(..., ahead=batch)`` ran for this batch."""
+        use_ahead: start from the forward pass the preceding ``d_step(..., ahead=batch)`` ran for this batch.
+        next_d: the batch of the discriminator step that follows -- its real pass then runs inside this step
+        (``real_ahead``; call ``d_step(that batch, use_real=True)`` next)."""
+        real = next_d if (next_d is not None and self.real_ahead and hip.PROFILE is None) else None
+        self._real_pending = real is not None
+        self._real_key = self._batch_key(real) if real is not None else None
         if use_ahead and self._ahead_pending and hip.PROFILE is None:
             self._ahead_pending = False
-            return self._run_step('g', batch, counter, use_ahead=True)
+            return self._run_step('g', batch, counter, use_ahead=True, real=real)
         self._ahead_pending = False
-        return self._run_step('g', batch, counter)
+        return self._run_step('g', batch, counter, real=real)
 
-    def _g_impl(self, batch, use_ahead=False):
-        loss_g = self.g_gradients(batch, use_ahead)
+    def _g_impl(self, batch, use_ahead=False, real=None):
+        loss_g = self.g_gradients(batch, use_ahead, real)
         self._apply_g_launch()
+        hip.mark('g/end')
         return loss_g
 
     def apply_g(self, counter=0):
@@ -487,16 +590,16 @@ class GanTrainer(object):
                 self.store['discriminator/fully_connected/u'].copy_(self._sn_pending['u_new'])
             self._sn_pending = None
 
-    def g_gradients(self, batch, use_ahead=False):
+    def g_gradients(self, batch, use_ahead=False, real=None):
         """loss_g and d loss_g / d generator variables; section all-reduces start as they finish."""
         hip.WGRAD_STREAM = self._wgrad_stream
         try:
-            return self._g_gradients(batch, use_ahead)
+            return self._g_gradients(batch, use_ahead, real)
         finally:
             hip.join_wgrad()
             hip.WGRAD_STREAM = None
 
-    def _g_gradients(self, batch, use_ahead=False):
+    def _g_gradients(self, batch, use_ahead=False, real=None):
         B, s = self.bufs, self.store
         N, _, H, W = batch['sketches'].shape
         if use_ahead:       # the forward pass of this batch was run during the discriminator step (_d_impl)
@@ -518,6 +621,15 @@ class GanTrainer(object):
             sn = self.D.prepare_sn()
             img4 = B.get('img4', (N, H, W, 4), zero_on_alloc=True)
             hip.nchw_to_nhwc(batch['images'], img4, 0)
+        if real is not None:
+            # the next discriminator step's real pass, on its own stream under this whole step (joined at its end); it starts
+            # from the u this step assigns after its optimizer launch (u_new of the power iteration above)
+            self._real_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._real_stream):
+                hip.mark('g/next D(real) pass: first')
+                self._real = self._d_real_pass(real, u=(sn['u_new'] if self.D.sn else None))
+                hip.mark('g/next D(real) pass: last')
+        hip.mark('g/start (D forward)')
         cf = self.D.forward(xd_f, sn, 'df')
         loss_g = self.loss[0:1]
         loss_g.zero_()
@@ -527,7 +639,9 @@ class GanTrainer(object):
         K = cf['logits'].shape[1]
         dlog_f = B.get('dlog_f', (N, K))
         hip.call('ssc_acgan_loss', cf['logits'], batch['class_id'], N, K, 0, 0.5, loss_g, dlog_f)
+        hip.mark('g/D data gradient: first')
         dgen = self.D.backward(cf, dl5_f, dlog_f, sn, False, True, accumulate=False)
+        hip.mark('g/G backward: first')
         dpre = B.get('dpre', (N, H, W, 4))
         hip.call('ssc_gen_output_grad', xd_f.view(-1)[3:], 8, img4, 4, dgen, 4, N * H * W, 100.0, loss_g, dpre)
         sc = s.generator
@@ -536,6 +650,8 @@ class GanTrainer(object):
             self.G.backward(gctx, dpre, on_section=lambda name: self._section_done(sc, name), side_stream=side)
         else:
             self.G.backward(gctx, dpre, on_section=lambda name: self._section_done(sc, name))
+        if real is not None:
+            torch.cuda.current_stream().wait_stream(self._real_stream)
         self._sn_pending = sn if self.D.sn else None
         self.last = {'gctx': gctx, 'cf': cf}
         return loss_g
@@ -550,12 +666,14 @@ class GanTrainer(object):
         lo, hi = self._g_sections[name]
         self._allreduce_async(sc.grad, lo, hi)
 
-    def train_iteration(self, batch_d, batch_g, counter=0):
+    def train_iteration(self, batch_d, batch_g, counter=0, next_batch_d=None):
         """D-step then G-step on independent batches (main_procedure.py:178-232).  Knowing both batches up front, the
         generator forward of the G-step is run inside the D-step (``run_ahead``; results identical: the generator's
-        variables do not change in between)."""
-        ld = self.d_step(batch_d, counter, ahead=batch_g)
-        lg = self.g_step(batch_g, counter, use_ahead=True)
+        variables do not change in between).  Knowing the NEXT iteration's discriminator batch as well, its real pass is run
+        inside this G-step (``real_ahead``; identical again: a G-step does not touch the discriminator's variables) -- pass
+        that same batch as ``batch_d`` of the next call."""
+        ld = self.d_step(batch_d, counter, ahead=batch_g, use_real=True)
+        lg = self.g_step(batch_g, counter, use_ahead=True, next_d=next_batch_d)
         return lg, ld
 
     def _infer(self, kind, sketches, text, noise_vec, labels, thicken):

@@ -584,3 +584,85 @@ def test_handoff_timeout_is_reported_and_fatal():
     torch.cuda.synchronize()
     hip.check_sk()
     assert float((out - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def _wgrad_name(hip, d):
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+    hip.lib().ssc_conv_wgrad_kernel_name(ctypes.byref(d), buf, 64)
+    return buf.value.decode()
+
+
+@pytest.mark.parametrize('case', [
+    # n, h, ci, co, k, stride, pad, act of x, norm on x
+    (3, 20, 128, 256, 4, 2, 1, 2, True),        # one tap per 128-column tile (encoder_3's shape), K tail (300 pixels)
+    (2, 24, 64, 128, 4, 2, 1, 2, False),        # 64 gathered channels: two taps per tile (encoder_2, discriminator layer_2)
+    (2, 15, 64, 192, 3, 1, 1, 1, True),         # 9 taps of 64 channels: the last tile holds one tap; Nn = 1.5 tiles
+    (1, 24, 256, 128, 4, 1, 1, 2, True),        # stride 1, 23 x 23 lattice (discriminator layer_4's form)
+    (2, 12, 128, 130, 1, 1, 0, 0, False),       # 1 x 1, plain gathered side, ragged dense width (even, not a multiple of 4 x 32)
+])
+def test_wgrad128_conv(case):
+    """conv filter gradient on the 128 x 128 kernel (wgrad128.hip; graph_single.py:24-30) vs the oracle's autograd: folded norm +
+    activation on the gathered side, dy by LDS-DMA, out-of-image taps / pixels beyond the last / columns beyond the tensor
+    through the descriptors' range check."""
+    hip = _hip()
+    n, h, ci, co, k, stride, pad, act, norm = case
+    x = rnd(n, ci, h, h, seed=81)
+    w = rnd(k, k, ci, co, seed=82, std=0.05).requires_grad_(True)
+    ab = torch.cat([1.0 + 0.1 * rnd(ci, seed=83), 0.2 * rnd(ci, seed=84)]) if norm else None
+    xa = x * ab[:ci].view(1, -1, 1, 1) + ab[ci:].view(1, -1, 1, 1) if norm else x
+    xa = act_ref(xa, act)
+    y = T.conv2d_valid_pad(xa, w, stride, pad)
+    dy = rnd(*y.shape, seed=85)
+    y.backward(dy)
+    cop = (co + 3) // 4 * 4
+    dyp = torch.zeros(n, y.shape[2], y.shape[3], cop)
+    dyp[..., :co] = nhwc(dy)
+    xv = hip.View(nhwc(x).cuda(), None, ab.cuda() if norm else None, act)
+    dw = torch.full((k, k, ci, co), float('nan'), device='cuda')
+    hip.conv_wgrad(xv, hip.View(dyp.cuda()), dw, stride, pad)
+    close(dw, w.grad)
+    d = hip.WgradDesc()
+    d.g, d.d = xv.c(), hip.View(dyp.cuda()).c()
+    d.out = dw.data_ptr()
+    d.NB, d.PH, d.PW, d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = n, y.shape[2], y.shape[3], k, k, stride, -pad, -pad
+    d.Cg_real, d.Nn, d.ldc, d.accumulate = ci, co, co, 0
+    assert _wgrad_name(hip, d) == 'conv_wgrad128<128x128>'
+    # accumulate: out += (splitk == 1 path and the reduce kernel's)
+    dw2 = dw.clone()
+    hip.conv_wgrad(xv, hip.View(dyp.cuda()), dw2, stride, pad, accumulate=True)
+    close(dw2, 2 * w.grad)
+
+
+def test_wgrad128_deconv_two_sources():
+    """Transposed-conv filter gradient (decoder_3's form): gathered side = dy (plain), dense side = concat[decoder, encoder] with a
+    folded norm + relu on each source (the transform runs on the dense tile; a column tile lies inside one source)."""
+    hip = _hip()
+    n, h, c0, c1, co = 2, 10, 128, 128, 128
+    ci = c0 + c1
+    x = rnd(n, ci, h, h, seed=91)
+    f = rnd(4, 4, co, ci, seed=92, std=0.05).requires_grad_(True)
+    ab = torch.cat([1.0 + 0.1 * rnd(ci, seed=93), 0.2 * rnd(ci, seed=94)])
+    xa = torch.relu(x * ab[:ci].view(1, -1, 1, 1) + ab[ci:].view(1, -1, 1, 1))
+    y = T.conv2d_transpose_same_s2(xa, f)
+    dy = rnd(*y.shape, seed=95)
+    y.backward(dy)
+    ab0 = torch.cat([ab[:c0], ab[ci:ci + c0]]).cuda()
+    ab1 = torch.cat([ab[c0:ci], ab[ci + c0:]]).cuda()
+    v = hip.View(nhwc(x[:, :c0]).cuda(), nhwc(x[:, c0:]).cuda(), ab0, 1, ab1)
+    df = torch.full((4, 4, co, ci), float('nan'), device='cuda')
+    hip.deconv_wgrad(v, hip.View(nhwc(dy).cuda()), df)
+    close(df, f.grad)
+    # decoder_5's form: 512 + 64 dense channels (the last column tile is half empty and starts the second source)
+    c0, c1, co, h = 512, 64, 128, 6
+    ci = c0 + c1
+    x = rnd(n, ci, h, h, seed=96)
+    f = rnd(4, 4, co, ci, seed=97, std=0.05).requires_grad_(True)
+    xa = torch.relu(x)
+    y = T.conv2d_transpose_same_s2(xa, f)
+    dy = rnd(*y.shape, seed=98)
+    y.backward(dy)
+    v = hip.View(nhwc(x[:, :c0]).cuda(), nhwc(x[:, c0:]).cuda(), None, 1, None)
+    df = torch.full((4, 4, co, ci), float('nan'), device='cuda')
+    hip.deconv_wgrad(v, hip.View(nhwc(dy).cuda()), df)
+    close(df, f.grad)

@@ -157,6 +157,34 @@ def test_train_iteration_run_ahead_matches_separate_steps(block_type):
     assert worst < 4e-3, worst      # see test_hipgraph_replay_matches_eager
 
 
+def test_real_pass_run_ahead_matches_separate_steps():
+    """g_step(..., next_d=batch) runs the NEXT discriminator step's real pass (D(real) forward, its loss terms, its backward)
+    inside the generator step, from the spectral-norm u that step is about to assign; d_step(batch, use_real=True) then only
+    adds the fake pass.  A G-step does not touch the discriminator's variables, so losses and weights must equal the separate
+    steps -- eagerly, while capturing and in replay; a D batch other than the announced one falls back to the whole step."""
+    from sketchyscenecolorization_amd.synthetic import synthetic_batch
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    a = GanTrainer(img=64, seed=9, max_iter_step=50)
+    b = GanTrainer(img=64, seed=9, max_iter_step=50, use_graphs=True)
+    assert b.real_ahead
+    ds = [synthetic_batch(2, 31 + k, 64) for k in range(4)]
+    gs = [synthetic_batch(2, 41 + k, 64) for k in range(4)]
+    took = 0
+    for it in range(9):
+        bd, bg = ds[it % 4], gs[it % 4]
+        la = (float(a.d_step(bd, it)), float(a.g_step(bg, it)))
+        # iteration 5 announces a batch that is then NOT the one used: the D-step of iteration 6 must ignore the stale pass
+        nxt = ds[(it + 1) % 4] if it != 5 else ds[(it + 2) % 4]
+        before = b._real_pending
+        lg, ld = b.train_iteration(bd, bg, it, next_batch_d=nxt)
+        took += int(before and it != 6)
+        lb = (float(ld), float(lg))
+        assert abs(la[0] - lb[0]) < 1e-4 * max(1.0, abs(la[0])) and abs(la[1] - lb[1]) < 1e-4 * max(1.0, abs(la[1])), (it, la, lb)
+    assert took >= 6 and any('use_real' in k for k in b._graphs)
+    worst = max(float((a.store[n] - b.store[n]).abs().max()) for n in a.store.names())
+    assert worst < 4e-3, worst      # see test_hipgraph_replay_matches_eager
+
+
 def test_full_size_overlapped_trainer_equals_inline_trainer_bitwise():
     """BASELINE configs[2] size (batch 32, 192x192).  Trainer A launches every kernel in line on one stream; trainer B is
     the default: hipGraph replay, discriminator-real / caption-word / run-ahead branches on their own streams.  Every
@@ -166,12 +194,16 @@ def test_full_size_overlapped_trainer_equals_inline_trainer_bitwise():
     from sketchyscenecolorization_amd.trainer import GanTrainer
     a = GanTrainer(img=192, seed=3, max_iter_step=1000, use_graphs=False, overlap_real=False)
     b = GanTrainer(img=192, seed=3, max_iter_step=1000, use_graphs=True)
-    assert b.run_ahead and b._text_stream is not None and a._aux_stream is None
-    for it in range(6):
-        bd, bg = synthetic_batch(32, 100 + it % 3, 192), synthetic_batch(32, 200 + it % 3, 192)
+    assert b.run_ahead and b.real_ahead and b._text_stream is not None and a._aux_stream is None
+    ds = [synthetic_batch(32, 100 + k, 192) for k in range(3)]
+    gs = [synthetic_batch(32, 200 + k, 192) for k in range(3)]
+    for it in range(8):
+        bd, bg = ds[it % 3], gs[it % 3]
         la = (float(a.d_step(bd, it)), float(a.g_step(bg, it)))
-        lg, ld = b.train_iteration(bd, bg, it)
+        # the next iteration's discriminator batch rides along: its real pass runs inside this G-step (real_ahead)
+        lg, ld = b.train_iteration(bd, bg, it, next_batch_d=ds[(it + 1) % 3])
         assert abs(la[0] - float(ld)) < 1e-9 * max(1.0, abs(la[0])) and abs(la[1] - float(lg)) < 1e-9 * max(1.0, abs(la[1]))
+    assert any('use_real' in k for k in b._graphs) and any('real' in k for k in b._graphs)
     for n in a.store.names():
         assert torch.equal(a.store[n], b.store[n]), n
 
