@@ -36,6 +36,22 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 #define SSC_RSRC_FLAGS 0x00020000
 
+#ifdef SSC_WG128_TIMING
+// diagnostic build (scripts/wg128_timing.sh): cycle-counter stamps of one wave per workgroup at the phase borders of every K
+// step, summed into g_wg128_t: [0] barrier release -> first operands in registers, [1] -> last MFMA issued, [2] -> counted wait
+// passed, [3] -> barrier passed, [4] K steps counted, [5] whole kernel (wave 0 of every workgroup).  The stamps perturb the
+// kernel (read the SHARES, not the cycles).  Finding: with the dense tile's DMA in the second quarter of the step a wave sat
+// 15 % (one workgroup per CU) to 36 % (two) of its time in the counted wait in front of the barrier -- a 16 KB LDS-DMA fill
+// takes ~1.1 us from issue to landed (MI355X_MICROARCH.md, ldsdma-fill); issuing the DMA first (every load of the loop by
+// inline asm under a hand count, because hipcc's own vmcnt does not know the DMA) moved the wait to the register loads of the
+// gathered tile and the kernel's rate did not change (113.7 vs 115.9 TFLOP/s): the step is bound by the latency of its
+// ~32 KB of loads per workgroup against ~1.8 us of MFMA work, not by their placement.
+__device__ unsigned long long g_wg128_t[8];
+#define TSTAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define TSTAMP(v)
+#endif
+
 // 16 bytes per lane through a buffer descriptor: an offset at or beyond its num_records comes back as zeros.  (The builtin's
 // result is taken with `auto`: assigned to an ext_vector_type it is converted as a SCALAR -- a splat of the first dword.)
 __device__ __forceinline__ float4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
@@ -66,6 +82,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(co
     float* Bs = smem + 2 * T_SZ;           // [2][BK][TB]  dense side
     int2* ptab = reinterpret_cast<int2*>(smem + 4 * T_SZ);      // [2][TPT][256]: {byte offset of pixel@tap | 0x80000000, 1.0f | 0}
 
+    TSTAMP(t_kernel0);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -248,11 +265,17 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(co
             // speed is the speed of ONE wave's instruction stream.
             constexpr int NG = BK / 2, PF = 4;
             f32x2v av[8], bv[8];
+            TSTAMP(t_a);
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
                 av[q] = *reinterpret_cast<const f32x2v*>(Ab + q * 2 * TB);
                 bv[q] = *reinterpret_cast<const f32x2v*>(Bb + q * 2 * TB);
             }
+#ifdef SSC_WG128_TIMING
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            TSTAMP(t_b);
 #pragma unroll
             for (int q = 0; q < NG; ++q) {
                 if (q + PF < NG) {
@@ -277,15 +300,32 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(co
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            TSTAMP(t_c);
             if (DMODE == 0) {       // counted wait + bare barrier: the gathered loads of K-tile j + 2 stay in flight
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NP) : "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+            TSTAMP(t_d);
             __builtin_amdgcn_s_barrier();
+#ifdef SSC_WG128_TIMING
+            {
+                TSTAMP(t_e);
+                if (tid == 0) {
+                    atomicAdd(&g_wg128_t[0], t_b - t_a);
+                    atomicAdd(&g_wg128_t[1], t_c - t_b);
+                    atomicAdd(&g_wg128_t[2], t_d - t_c);
+                    atomicAdd(&g_wg128_t[3], t_e - t_d);
+                    atomicAdd(&g_wg128_t[4], 1ull);
+                }
+            }
+#endif
         }
     }
 
+#ifdef SSC_WG128_TIMING
+    if (tid == 0) atomicAdd(&g_wg128_t[5], __builtin_readcyclecounter() - t_kernel0);
+#endif
     // ---- epilogue: tile row 2 * (row of the 32 x 32 block) + i, tile column 2 * l31 + jj ----
     float* outp = (splitk > 1) ? (slab_base + (long)ks * slab_stride) : d.out;
     const bool accum = (splitk == 1) && d.accumulate;
@@ -422,6 +462,16 @@ static int launch_wg128_t(const ssc_wgrad_desc& d, int splitk, float* ws, hipStr
     if (dp) return gp ? launch_wg128<true, 1, TPT>(d, splitk, ws, st) : launch_wg128<false, 1, TPT>(d, splitk, ws, st);
     return gp ? launch_wg128<true, 2, TPT>(d, splitk, ws, st) : launch_wg128<false, 2, TPT>(d, splitk, ws, st);
 }
+
+#ifdef SSC_WG128_TIMING
+extern "C" int ssc_wg128_timing(unsigned long long* out8, int reset) {
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wg128_t), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wg128_t), 8 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int ssc_conv_wgrad128(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream) {
     const ssc_wgrad_desc& d = *dp;
