@@ -32,7 +32,7 @@ class GanTrainer(object):
 
     def __init__(self, img=192, vocab_size=58, lstm_hybrid=True, lr_g=2e-4, lr_d=1e-4, max_iter_step=100000,
                  seed=0, sn=True, process_group=None, device='cuda', use_graphs=False, block_type='Pix2Pix',
-                 segment_graphs=None, overlap_wgrad=None, optimizer='Adam', overlap_real=True):
+                 segment_graphs=None, overlap_wgrad=None, optimizer='Adam', overlap_real=True, real_ahead=None):
         if not torch.cuda.is_available():
             raise RuntimeError('GanTrainer needs an MI355X (HIP) device: there is no CPU fallback')
         hip.lib()
@@ -114,10 +114,17 @@ class GanTrainer(object):
         # about to assign -- not on the generator.  The G-step is one dependent chain (D forward -> losses -> D data gradient
         # -> G backward, with ~12 tiny launches at each transition and the caption branch's BPTT chain in the middle:
         # scripts/timeline_dump.py shows ~1.5 ms of its 7 ms with no full-size launch in flight); the D-step already runs
-        # three chains.  Moving 3.3 ms of independent full-size work under the G-step fills those holes.  Pix2Pix pair, one
-        # GPU (a fork may not cross the end of a graph segment, and with world > 1 the G-step is cut at every gradient section).
-        self.real_ahead = (overlap_real and block_type == 'Pix2Pix' and self._dbwd_concurrent and not self.segment_graphs and
-                           os.environ.get('SSC_REAL_AHEAD', '1') == '1')
+        # three chains.  Moving 3.3 ms of independent full-size work under the G-step does fill those holes -- and empties the
+        # D-step of the co-running chain that filled ITS launch tails: measured (scripts/branch_marks.py) D-step 10.45 -> 7.53
+        # ms, G-step 6.97 -> 9.90 ms, the iteration 17.42 -> 17.43 ms; 1798 vs 1813 images/s over three interleaved runs.  Two
+        # full-size chains side by side run at the speed of one after the other wherever they meet (the launches fill the LDS
+        # of every CU on their own), so work moved between the steps is zero-sum.  Built, tested bit for bit, OFF by default
+        # (SSC_REAL_AHEAD=1 / real_ahead=True).  Pix2Pix pair, one GPU (a fork may not cross the end of a graph segment, and
+        # with world > 1 the G-step is cut at every gradient section).
+        if real_ahead is None:
+            real_ahead = os.environ.get('SSC_REAL_AHEAD', '0') == '1'
+        self.real_ahead = bool(real_ahead and overlap_real and block_type == 'Pix2Pix' and self._dbwd_concurrent and
+                               not self.segment_graphs)
         self._real_stream = torch.cuda.Stream() if self.real_ahead else None
         self._real = None               # what the run-ahead real pass left for the D-step: {'sn', 'cr'}
         self._real_pending, self._real_key = False, None

@@ -165,7 +165,7 @@ def test_real_pass_run_ahead_matches_separate_steps():
     from sketchyscenecolorization_amd.synthetic import synthetic_batch
     from sketchyscenecolorization_amd.trainer import GanTrainer
     a = GanTrainer(img=64, seed=9, max_iter_step=50)
-    b = GanTrainer(img=64, seed=9, max_iter_step=50, use_graphs=True)
+    b = GanTrainer(img=64, seed=9, max_iter_step=50, use_graphs=True, real_ahead=True)
     assert b.real_ahead
     ds = [synthetic_batch(2, 31 + k, 64) for k in range(4)]
     gs = [synthetic_batch(2, 41 + k, 64) for k in range(4)]
@@ -193,7 +193,7 @@ def test_full_size_overlapped_trainer_equals_inline_trainer_bitwise():
     from sketchyscenecolorization_amd.synthetic import synthetic_batch
     from sketchyscenecolorization_amd.trainer import GanTrainer
     a = GanTrainer(img=192, seed=3, max_iter_step=1000, use_graphs=False, overlap_real=False)
-    b = GanTrainer(img=192, seed=3, max_iter_step=1000, use_graphs=True)
+    b = GanTrainer(img=192, seed=3, max_iter_step=1000, use_graphs=True, real_ahead=True)
     assert b.run_ahead and b.real_ahead and b._text_stream is not None and a._aux_stream is None
     ds = [synthetic_batch(32, 100 + k, 192) for k in range(3)]
     gs = [synthetic_batch(32, 200 + k, 192) for k in range(3)]
