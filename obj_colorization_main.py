@@ -98,6 +98,7 @@ def start_or_resume_training(params):
         first_iter = box[0]
     params.update(log_dir=log_dir, ckpt_dir=ckpt_dir, iter_from=first_iter)
     if int(os.environ.get('RANK', 0)) == 0:
+        os.makedirs(log_dir, exist_ok=True)     # a released model dropped into outputs/<stamp>/snapshot has no log/ yet
         with open(os.path.join(log_dir, 'param_%d.json' % first_iter), 'w') as fp:
             json.dump(params, fp, indent=4)
     Config.set_from_dict(params)
