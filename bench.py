@@ -382,6 +382,18 @@ def main():
 
     tr = GanTrainer(img=args.img, seed=0, process_group=pg, use_graphs=not args.no_graphs, block_type=args.block_type)
     assert tr.world == world
+    allreduce_plan = tr.allreduce_plan() if world > 1 else None
+    # every rank on a GPU of its own (PCI bus ids gathered from all ranks): a launcher that put two ranks on one device would
+    # still "scale" on paper
+    devices_by_rank = [torch.cuda.get_device_properties(torch.cuda.current_device()).pci_bus_id
+                       if hasattr(torch.cuda.get_device_properties(torch.cuda.current_device()), 'pci_bus_id')
+                       else torch.cuda.current_device()]
+    if under_launcher and world > 1:
+        box = [None] * world
+        torch.distributed.all_gather_object(box, (devices_by_rank[0], torch.cuda.current_device()))
+        devices_by_rank = [b[0] if b[0] is not None else b[1] for b in box]
+        if not rehearsal and len(set(box)) != world:
+            raise SystemExit('bench.py: %d ranks but only %d distinct devices: %s' % (world, len(set(box)), box))
     bd = synthetic_batch(args.batch, 1234 + rank, args.img)
     bg = synthetic_batch(args.batch, 5678 + rank, args.img)
     if not args.no_graphs:
@@ -466,6 +478,7 @@ def main():
                           'launcher': ('torch.distributed.run, REHEARSAL: all ranks on one GPU over gloo (not a measurement)'
                                        if rehearsal else
                                        'torch.distributed.run, backend nccl (RCCL)' if under_launcher else 'in-process'),
+                          'allreduce': allreduce_plan, 'devices_by_rank': devices_by_rank,
                           'block_type': args.block_type, 'loss_g': loss_g, 'loss_d': loss_d,
                           'launch': 'eager' if args.no_graphs else 'hipGraph replay'},
                'step_tflops_as_written': flops_step / (ms * 1e-3) / 1e12,

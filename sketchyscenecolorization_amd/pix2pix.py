@@ -352,10 +352,12 @@ class Pix2PixDiscriminator(object):
         hip.call('ssc_fc_small_fwd', img, sn['wbar'], s['discriminator/fully_connected/biases'], N, 512, K, logits)
         return {'tag': tag, 'N': N, 'l': l, 'ab': ab, 'st': st, 'img': img, 'logits': logits, 'disc': l[5], 'P4': P4}
 
-    def backward(self, ctx, dl5, dlogits, sn, need_params, need_input, accumulate):
+    def backward(self, ctx, dl5, dlogits, sn, need_params, need_input, accumulate, after_layer=None):
         """dl5 [N,h5,w5,4] (channel 0 real), dlogits [N,K] or None.
         need_params: write (accumulate=False) or add (True) the filter/norm gradients.
-        need_input: return d loss / d discrim_targets as NHWC [N,H,W,4]."""
+        need_input: return d loss / d discrim_targets as NHWC [N,H,W,4].
+        after_layer(k): called when layer k's filter / scale / offset gradients have been launched (the trainer starts the
+        all-reduce of a finished section of the flat gradient buffer there)."""
         s, B = self.s, self.b
         tag, N, l, ab, st = ctx['tag'], ctx['N'], ctx['l'], ctx['ab'], ctx['st']
         gname = lambda k, what: s.grad('discriminator/layer_%d/%s' % (k, what))
@@ -411,6 +413,8 @@ class Pix2PixDiscriminator(object):
             w = s['discriminator/layer_%d/conv/filter' % k]
             if need_params:
                 hip.conv_wgrad(xin, dyv, gname(k, 'conv/filter'), self.strides[k], 1, accumulate=accumulate)
+                if after_layer is not None:
+                    after_layer(k)
             if k > 1:
                 gin = B.get(tag + '/gb/g%d' % (k - 1), l[k - 1].shape)
                 sums = None

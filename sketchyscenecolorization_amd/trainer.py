@@ -79,6 +79,11 @@ class GanTrainer(object):
         self.world = self.reducer.world
         g = self.store.generator.offsets
         self._g_sections = self._sections(g, split_encoder_5=(block_type == 'Pix2Pix'))
+        # discriminator (Pix2Pix pair): layer_4's filter is 8.4 of its 11.1 MB and sits, with layer_5 and the class head, at the
+        # end of the flat buffer: final three layers before the backward pass ends, so that exchange runs beside them
+        d = self.store.discriminator.offsets
+        self._d_late = d['discriminator/layer_4/conv/filter'][0] if 'discriminator/layer_4/conv/filter' in d else None
+        self._d_late_sent = False
         self._sn_pending = None
         # hipGraph replay of whole D-/G-steps (the ~550 launches of a step are host-bound otherwise):
         # a step shape is run eagerly the first time, captured the second time, replayed afterwards
@@ -406,6 +411,7 @@ class GanTrainer(object):
                     hip.mark('d/ahead G forward: last')
                 finally:
                     self.G.text_stream = ts
+        self._ahead_forked = ahead is not None
         loss_d = self.d_gradients(batch, use_real)
         if ahead is not None:       # joined before the gradient all-reduce: a fork may not cross the end of a graph segment
             torch.cuda.current_stream().wait_stream(self._ahead_stream)
@@ -420,9 +426,20 @@ class GanTrainer(object):
 
     def _apply_d_launch(self):
         sc = self.store.discriminator
-        self._allreduce_async(sc.grad, 0, sc.numel)
+        # (the late section -- layer_4, layer_5, class head -- may already be on its way: _d_gradients)
+        self._allreduce_async(sc.grad, 0, self._d_late if self._d_late_sent else sc.numel)
+        self._d_late_sent = False
         self._allreduce_wait()
         self._adam_launch(sc, 1)
+
+    def allreduce_plan(self):
+        """Bytes per iteration and per exchange: what a SCALE line of bench.py can be checked against."""
+        gs = {k: 4 * (hi - lo) for k, (lo, hi) in self._g_sections.items()}
+        dn = 4 * self.store.discriminator.numel
+        ds = {'all': dn} if self._d_late is None or self.block_type != 'Pix2Pix' else \
+            {'layer_4 + layer_5 + class head': dn - 4 * self._d_late, 'layer_1..3': 4 * self._d_late}
+        return {'generator_sections_bytes': gs, 'discriminator_sections_bytes': ds,
+                'bytes_per_iteration': sum(gs.values()) + sum(ds.values()), 'collective': 'sum all-reduce, fp32'}
 
     def d_gradients(self, batch, use_real=False):
         """loss_d and d loss_d / d discriminator variables (compute_gradients, graph_single.py:309-312)."""
@@ -525,7 +542,7 @@ class GanTrainer(object):
         K = cr['logits'].shape[1]
         dlog_r = B.get('dlog_r', (N, K))
         hip.call('ssc_acgan_loss', cr['logits'], batch['class_id_d'], N, K, 1, 1.0, loss_d, dlog_r)
-        if self._dbwd_concurrent and self._aux_stream is not None and hip.PROFILE is None:
+        if self._dbwd_concurrent and self._aux_stream is not None and hip.PROFILE is None and self.world == 1:
             # The two backward passes of the discriminator step (real pair, fake pair) share nothing but the filters they
             # read: run them side by side -- the fake pair on the second stream into a second gradient buffer, the real
             # pair in line -- so that each chain's launch tails and partly filled rounds are filled by the other, then add
@@ -553,6 +570,29 @@ class GanTrainer(object):
             hip.call('ssc_axpy', sc.grad, sc.grad2, 1.0, sc.numel)
         else:
             self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False)
+            if self.world > 1 and self.block_type == 'Pix2Pix' and self._d_late is not None:
+                # more than one tower: the two passes in line, and the late section of the flat buffer -- layer_4's filter
+                # (8.4 of the 11.1 MB), layer_5, the class head -- goes to the all-reduce as soon as the second pass has
+                # added its layer_4 gradient, beside the backward of layers 3..1 (the class head's gradient is complete after
+                # the real pass: the fake pair has no class term)
+                sc = s.discriminator
+
+                def late(k):
+                    if k == 4:
+                        hip.join_wgrad()
+                        if getattr(self, '_ahead_forked', False):       # a fork may not cross the end of a graph segment
+                            torch.cuda.current_stream().wait_stream(self._ahead_stream)
+                        self.D.finish_sn_backward(sn)
+                        hip.call('ssc_l2_reg', s['discriminator/fully_connected/weights'],
+                                 s['discriminator/fully_connected/weights'].numel(), 1e-6, loss_d,
+                                 s.grad('discriminator/fully_connected/weights'))
+                        self._allreduce_async(sc.grad, self._d_late, sc.numel)
+                        self._d_late_sent = True
+
+                self.D.backward(cf, dl5_f, None, sn, True, False, accumulate=True, after_layer=late)
+                hip.join_wgrad()
+                self.last = {'gctx': gctx, 'cr': cr, 'cf': cf}
+                return loss_d
             self.D.backward(cf, dl5_f, None, sn, True, False, accumulate=True)
         hip.join_wgrad()
         self.D.finish_sn_backward(sn)

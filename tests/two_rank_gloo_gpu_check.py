@@ -60,6 +60,17 @@ def worker(rank, port, out_dir):
     torch.cuda.synchronize()
     segs = [g for g in T._graphs.values() if isinstance(g, list)]
     assert len(segs) == 2, len(segs)
+    # the discriminator's exchange is sectioned: layer_4 + layer_5 + class head (the end of the flat buffer) first, beside the
+    # backward of layers 3..1, then the rest; together exactly the flat buffer, and what allreduce_plan() declares
+    dn = T.store.discriminator.numel
+    d_red = [[(op[2], op[3]) for op in g if op[0] == 'reduce' and op[1] is T.store.discriminator.grad] for g in segs]
+    d_red = [r for r in d_red if r]
+    assert d_red == [[(T._d_late, dn), (0, T._d_late)]], d_red
+    plan = T.allreduce_plan()
+    assert sum(plan['discriminator_sections_bytes'].values()) == 4 * dn
+    g_red = [[(op[2], op[3]) for op in g if op[0] == 'reduce' and op[1] is T.store.generator.grad] for g in segs]
+    g_red = [r for r in g_red if r][0]
+    assert sum(hi - lo for lo, hi in g_red) * 4 == sum(plan['generator_sections_bytes'].values())
     w2 = max(float((T.store[n] - E.store[n]).abs().max()) for n in T.store.names())
     assert w2 == 0.0, ('segmented graphs vs eager, world 2', w2)
 
