@@ -200,3 +200,82 @@ def test_cli_nan_loss_returns_minus_one_and_restarts_from_snapshot(tmp_path, mon
     p2 = json.load(open(os.path.join(run_dir, 'log', 'param_2.json')))     # snapshot model_1 -> first iteration 2
     assert p2['iter_from'] == 2 and p2['resume_from'] == runs[0]
     assert os.path.exists(os.path.join(run_dir, 'snapshot', 'model_3.ckpt-3'))
+
+
+@pytest.mark.parametrize('mode', ['test', 'val'])
+def test_cli_test_and_val_192_match_oracle(mode, tmp_path, monkeypatch):
+    """main_procedure.test (:361-492) and validation (:245-358) at the full 192x192 size through the CLI: the PNGs they write
+    equal the oracle's generator on the same weights / sketches / captions / noise after the truncating cast.
+    test: data/captions/<cat>/test.json + data/images/<cat>/sketch/<name>, incl. a 'house' (thickened strokes) and a 'road'
+    (no margin) sketch; val: the seeded synthetic batch the procedure falls back to without data/tfrecord/val."""
+    from PIL import Image, ImageDraw
+    import obj_colorization_main as cli
+    from oracle import pix2pix as O
+    from sketchyscenecolorization_amd.data_processing.default_vocab import default_vocab_dict
+    from sketchyscenecolorization_amd.data_processing.text_processing import preprocess_sentence
+    from sketchyscenecolorization_amd.obj_lib import main_procedure as mp
+    from sketchyscenecolorization_amd.obj_lib.input_pipeline import resize_and_padding_mask_image, thicken_drawings
+    from sketchyscenecolorization_amd.params import ParamStore
+    from sketchyscenecolorization_amd.synthetic import synthetic_batch
+    monkeypatch.chdir(tmp_path)
+    ts = '2019-06-07-08-09-10'
+    run = os.path.join('outputs', ts)
+    p = O.init_params(8, img=192)
+    store = ParamStore('Pix2Pix', 58, 192, 'cuda', seed=3)
+    store.load_dict(p)
+    mp.save_checkpoint(store, os.path.join(run, 'snapshot'), 'model_9.ckpt', 9)
+    bs = 3
+    noises = {1: torch.randn(1, 256, generator=torch.Generator().manual_seed(21)),
+              bs: torch.randn(bs, 256, generator=torch.Generator().manual_seed(22))}
+    real_randn = torch.randn
+
+    def fake_randn(*shape, **kw):
+        if len(shape) == 2 and shape[1] == 256 and shape[0] in noises:
+            return noises[shape[0]].to(kw.get('device', 'cpu'))
+        return real_randn(*shape, **kw)
+
+    def check(png, ref_nchw, k=0):
+        out = np.array(Image.open(png))
+        ref_u8 = mp._postprocess(ref_nchw)[k]
+        diff = np.abs(out.astype(np.int32) - ref_u8.astype(np.int32))
+        assert out.shape == (192, 192, 3) and diff.max() <= 1 and (diff > 0).mean() < 0.05, (png, diff.max(), (diff > 0).mean())
+
+    if mode == 'test':
+        cases = {'house': ('h1.png', 'the house is red with a brown roof'), 'road': ('r7.png', 'the road is grey'),
+                 'car': ('c3.png', 'the car is yellow with blue window')}
+        for cate, (name, cap) in cases.items():
+            os.makedirs(os.path.join('data', 'captions', cate))
+            os.makedirs(os.path.join('data', 'images', cate, 'sketch'))
+            json.dump({name: cap}, open(os.path.join('data', 'captions', cate, 'test.json'), 'w'))
+            im = Image.new('L', (260, 300), 255)
+            d = ImageDraw.Draw(im)
+            d.rectangle([30, 90, 220, 210], outline=0, width=3)
+            d.line([30, 90, 125, 30, 220, 90], fill=0, width=3)
+            im.save(os.path.join('data', 'images', cate, 'sketch', name))
+        monkeypatch.setattr(torch, 'randn', fake_randn)
+        cli.main(['--mode', 'test', '-rf', ts, '-bt', 'Pix2Pix'])
+        monkeypatch.setattr(torch, 'randn', real_randn)
+        cats = sorted(cases)                # _categories(): the listing of data/captions
+        for cate, (name, cap) in cases.items():
+            sk = resize_and_padding_mask_image(Image.open(os.path.join('data', 'images', cate, 'sketch', name)).convert('RGB'),
+                                               192, margin_size=0 if cate == 'road' else 10)
+            if cate in ('house', 'road'):
+                sk = thicken_drawings(sk)
+            x = torch.from_numpy(mp._normalise(sk.astype(np.float32)))
+            idx = np.array([preprocess_sentence(cap, default_vocab_dict(), 15)], dtype=np.int32)
+            ref = O.generate_pix2pix(p, x, torch.from_numpy(idx), noises[1])
+            stem = os.path.join(run, 'test_results', '%s_%s' % (cate, name[:-4]))
+            check(stem + '_output.png', ref)
+            assert np.array_equal(np.array(Image.open(stem + '_input.png')), mp._postprocess(x)[0])
+        assert cats == ['car', 'house', 'road']
+    else:
+        monkeypatch.setattr(torch, 'randn', fake_randn)
+        cli.main(['--mode', 'val', '-rf', ts, '-bt', 'Pix2Pix', '-bs', str(bs)])
+        monkeypatch.setattr(torch, 'randn', real_randn)
+        b = synthetic_batch(bs, 4321, 192, 58)
+        ref = O.generate_pix2pix(p, b['sketches'].cpu(), torch.from_numpy(b['text']), noises[bs])
+        cls = b['class_id'].cpu().numpy()
+        for i in range(bs):
+            stem = os.path.join(run, 'validation_results', 'with_text', '%s_%04d' % (mp.CATEGORIES[int(cls[i])], i))
+            check(stem + '_output.png', ref, i)
+            assert np.array_equal(np.array(Image.open(stem + '_target.png')), mp._postprocess(b['images'])[i])
