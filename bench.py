@@ -452,6 +452,16 @@ def main():
     gen_fb = None
     if args.block_type == 'Pix2Pix' and not args.no_graphs and world == 1:
         gen_fb = generator_fwd_bwd(tr, bg, args)
+        if args.batch == 32 and not args.no_secondary:
+            # the same graph at larger batches: BASELINE.json's 70 % target names the generator forward + backward at 192x192
+            # without a batch; the train step's batch (32) is the one reported above, these show where the kernels go once a
+            # launch holds more tiles per CU (labelled by batch, never merged into the batch-32 figure)
+            from sketchyscenecolorization_amd.synthetic import synthetic_batch as _sb
+            by_batch = {}
+            for nb in (64, 128):
+                r = generator_fwd_bwd(tr, _sb(nb, 4321, args.img), args, iters=10)
+                by_batch[str(nb)] = {k: r[k] for k in ('ms', 'images_per_sec', 'tflops_executed', 'frac_of_fp32_mfma_peak_executed')}
+            gen_fb['by_batch'] = by_batch
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -743,6 +743,28 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                         for (int j = 0; j < SN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][q][i], bv[g & 1][q][j], acc[i][j], 0, 0, 0);
             };
+#if SSC_UT_SGB == 2
+            // hand-placed: full scheduling barriers between the pieces (the compiler orders only inside one); MFMAs strictly
+            // round robin over the accumulators
+            fetch(0, 0);
+            fetch(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(0);
+            stage(cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (BDMA && !ADMA) dma_b(min(kt + 1, last), cur ^ 1);
+            fetch(2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_loads(min(kt + 2, last));
+            fetch(3, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(3);
+            __builtin_amdgcn_sched_barrier(0);
+#else
             fetch(0, 0);
             fetch(1, 1);
             mfmas(0);
@@ -757,7 +779,8 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             fetch(3, 1);
             mfmas(2);
             mfmas(3);
-#if SSC_UT_SGB
+#endif
+#if SSC_UT_SGB == 1
             // interleave hint: one MFMA, then a few of the independent staging instructions
 #pragma unroll
             for (int q = 0; q < NFG * FG * SM * SN; ++q) {
