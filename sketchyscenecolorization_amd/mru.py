@@ -103,6 +103,15 @@ class _MRUBlocks(object):
         hip.concat_parts(out, [dict(x=raw, ab=abn, act=ACT_MIU)])
         return out, (abn, st)
 
+    def _na_part(self, tag, scope, raw, labels):
+        """norm_activ of ``raw`` as a PART of a concat (hip.concat_parts): the norm + activation are applied while the concat is
+        written, the normalised tensor itself is never materialised (its only consumer is that concat)."""
+        s, B = self.s, self.b
+        if not self.cond_norm:
+            return dict(x=raw, ab=s[scope + '/prelu/param'].view(1), act=ACT_PRELU), None
+        abn, st = self._cbn(tag, scope, raw, labels)
+        return dict(x=raw, ab=abn, act=ACT_MIU), (abn, st)
+
     def _cbn(self, tag, scope, raw, labels):
         s, B = self.s, self.b
         N, C = raw.shape[0], raw.shape[-1]
@@ -187,9 +196,9 @@ class _MRUBlocks(object):
         B = self.b
         N, h, w, ch = ht.shape
         rec = {'kind': 'conv', 'pre': pre, 'tag': tag, 'xin': xin, 'ht': ht, 'ch': ch, 'd': d}
-        na, rec['aux_in'] = self._na_fwd(tag, pre + '/norm_activation_in', ht, labels)
+        na, rec['aux_in'] = self._na_part(tag, pre + '/norm_activation_in', ht, labels)
         full = B.get(tag + '/' + pre + '/full', (N, h, w, ch + 4), zero_on_alloc=True)
-        hip.concat_parts(full, [dict(x=na), dict(x=xin, C=3)])
+        hip.concat_parts(full, [na, dict(x=xin, C=3)])
         rg = self._conv(tag, pre + '/update_gate', View(full), ch, 'rg', epi=2)
         mm = B.get(tag + '/' + pre + '/rg_mm', (N, 2, ch))
         hip.minmax_hw(rg, mm)
