@@ -219,7 +219,10 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const ssc_conv_desc d, 
 typedef const __attribute__((address_space(4))) float* cfloatp;
 typedef const __attribute__((address_space(4))) f32x4* cf32x4p;
 
-template <int MODE, int NOUT>
+// KS: 0 = taps from the descriptor (<= 4x4); 7 = the 7x7 conv form with the tap loops unrolled (the MRU generator's last conv,
+// 64 -> 3, models_collection.py:372-374: 3.2 ms per launch on narrow_fwd_kernel<BIGK> -- one 88 KB workgroup per CU, every
+// filter value an LDS read -- against ~0.8 ms here: a (16+6)^2 patch of 16 channels per image, two images = 77 KB).
+template <int MODE, int NOUT, int KS>
 __global__ __launch_bounds__(256) void narrow_sc_kernel(const ssc_conv_desc d, float* __restrict__ slabs,
                                                         long slab_stride, int csplit) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void narrow_sc_kernel(const ssc_conv_desc d, f
     const long w_ns = (d.bmode == 0) ? 0 : (long)d.wC1;
     const cfloatp wsc = (cfloatp)(d.w + ((d.bmode == 0) ? (long)d.n_off : (long)d.n_off * d.wC1));
 
-    constexpr int MAXE = 6;             // ceil(19 * 19 * 4 / 256) patch float4 per thread
+    constexpr int MAXE = (KS == 7) ? 8 : 6;     // ceil(19 * 19 * 4 / 256) (22 * 22 * 4 / 256) patch float4 per thread
     const int c4s = (tid & 3) * 4;
     // per-thread patch positions: fixed for the whole kernel
     int poff[MAXE];                     // pixel index into the source, or -1: outside the image / the patch
@@ -328,6 +331,25 @@ __global__ __launch_bounds__(256) void narrow_sc_kernel(const ssc_conv_desc d, f
                     }
                 }
             }
+        } else if (KS == 7) {       // unflipped 7x7 taps (ky0 = kx0 = 0, kstep = 1: the host checks), fully unrolled
+#pragma unroll
+            for (int ty = 0; ty < 7; ++ty) {
+#pragma unroll
+                for (int tx = 0; tx < 7; ++tx) {
+                    const float* xp = patch + ((ly + ty) * PXD + lx + tx) * SPAD;
+                    const cfloatp ws = wsc + (ty * 7 + tx) * w_ts + cb;
+#pragma unroll
+                    for (int c4 = 0; c4 < SCH; c4 += 4) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(xp + c4);
+#pragma unroll
+                        for (int n = 0; n < NOUT; ++n) {
+                            const f32x4 w = *(cf32x4p)(ws + n * w_ns + c4);
+                            acc[0][n] = __builtin_elementwise_fma(x.xy, w.xy, acc[0][n]);
+                            acc[0][n] = __builtin_elementwise_fma(x.zw, w.zw, acc[0][n]);
+                        }
+                    }
+                }
+            }
         } else {
             for (int ty = 0; ty < d.TH; ++ty) {
                 for (int tx = 0; tx < d.TW; ++tx) {
@@ -388,7 +410,11 @@ static bool narrow_sc_ok(const ssc_conv_desc& d) {
     // measured (scripts/conv_microbench.py, batch 32): 128 -> 3 transposed 135 -> 127 us, the 64 -> 3 data gradient 79 -> 59 us,
     // but the 512 -> 1 conv form 41 -> 56 us (one output: a scalar fetch feeds a single packed FMA) -- transposed form only.
     // What bounds it now is the scalar data path: with constant weights the same launch takes 83 us, without the accumulate 49.
-    if (d.nphase != 4) return false;
+    // ... and the unflipped 7x7 conv form with >= 2 outputs and an [n][k] filter (hip.conv_forward(..., w_nk=...): the MRU
+    // generator's last conv hands over a transposed copy of its [7,7,64,3] filter)
+    const bool conv7 = d.nphase == 1 && d.bmode == 1 && nout >= 2 && d.TH == 7 && d.TW == 7 && d.KH == 7 && d.KW == 7 &&
+                       d.ky0 == 0 && d.kx0 == 0 && d.kstep == 1 && ((d.x.C0 + d.x.C1) % SCH) == 0 && (d.x.C0 % SCH) == 0;
+    if (d.nphase != 4 && !conv7) return false;
     // pixel offsets are 32-bit in this form
     return (long)d.NB * d.x.H * d.x.W < 0x7fffffffL;
 }
@@ -434,9 +460,24 @@ static int launch_narrow(const ssc_conv_desc& d, hipStream_t st, float* ws, int6
         }                                                                                                          \
         hipLaunchKernelGGL((narrow_fwd_kernel<MODE, NO, BIG>), grid, dim3(256), lds, st, d, ws, out_count, csplit); \
     }
-#define NARROW_SC_LAUNCH(NO) hipLaunchKernelGGL((narrow_sc_kernel<1, NO>), grid, dim3(256), lds, st, d, ws, out_count, csplit);
+#define NARROW_SC_LAUNCH(NO) hipLaunchKernelGGL((narrow_sc_kernel<1, NO, 0>), grid, dim3(256), lds, st, d, ws, out_count, csplit);
+#define NARROW_SC7_LAUNCH(NO)                                                                                      \
+    {                                                                                                              \
+        static bool attr7 = false;                                                                                 \
+        if (!attr7) {                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_sc_kernel<0, NO, 7>),                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                      \
+            attr7 = true;                                                                                          \
+        }                                                                                                          \
+        hipLaunchKernelGGL((narrow_sc_kernel<0, NO, 7>), grid, dim3(256), lds, st, d, ws, out_count, csplit);      \
+    }
     if (lds > 96 * 1024) return -5;
-    if (sc) {       // transposed form only (narrow_sc_ok)
+    if (sc && MODE == 0) {      // the 7x7 conv form (narrow_sc_ok): no channel split
+        if (csplit_out != nullptr) *csplit_out = 1;
+        grid.z = d.NB;
+        csplit = 1;
+        if (nout == 2) NARROW_SC7_LAUNCH(2) else if (nout == 3) NARROW_SC7_LAUNCH(3) else NARROW_SC7_LAUNCH(4)
+    } else if (sc) {            // transposed form
         if (nout == 1) NARROW_SC_LAUNCH(1) else if (nout == 2) NARROW_SC_LAUNCH(2) else if (nout == 3) NARROW_SC_LAUNCH(3) else NARROW_SC_LAUNCH(4)
     } else if (MODE == 0 && (d.TH > 4 || d.TW > 4 || d.KH * d.KW > 16)) {
         constexpr bool BIG = true;
@@ -447,6 +488,7 @@ static int launch_narrow(const ssc_conv_desc& d, hipStream_t st, float* ws, int6
     }
 #undef NARROW_LAUNCH
 #undef NARROW_SC_LAUNCH
+#undef NARROW_SC7_LAUNCH
     return (int)hipGetLastError();
 }
 

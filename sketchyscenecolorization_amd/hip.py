@@ -447,9 +447,12 @@ def same_pad_before(size, k, stride):
     return max((out - 1) * stride + k - size, 0) // 2
 
 
-def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, accumulate=False, same=False, bn=None):
+def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, accumulate=False, same=False, bn=None,
+                 w_nk=None):
     """tf.pad + tf.nn.conv2d(VALID): x View, w [KH,KW,Cin_real,Cout] -> out[..., coff:coff+Cout].
-    same=True: tf.nn.conv2d(padding='SAME') -- output ceil(in/stride), asymmetric pad (mru.py:125, conv_ex)."""
+    same=True: tf.nn.conv2d(padding='SAME') -- output ceil(in/stride), asymmetric pad (mru.py:125, conv_ex).
+    w_nk: the same filter as [KH,KW,Cout,Cin] (a transposed copy, e.g. ``transpose_filter``): the launch then reads the [n][k]
+    orientation, which the few-output kernels take through scalar loads."""
     KH, KW, ci, co = w.shape
     d = ConvDesc()
     d.x = x.c()
@@ -465,11 +468,22 @@ def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, 
     d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x, d.nphase = KH, KW, stride, -pad, -pad, 1
     d.ky0, d.kx0, d.kstep = 0, 0, 1
     d.KH, d.KW, d.wC0, d.wC1, d.bmode, d.k_real = KH, KW, ci, co, 0, ci
+    if w_nk is not None:
+        assert tuple(w_nk.shape) == (KH, KW, co, ci) and w_nk.is_contiguous()
+        d.w, d.wC0, d.wC1, d.bmode = w_nk.data_ptr(), co, ci, 1
     assert ci <= x.C
     d.n_off, d.Nn, d.Nstore = 0, co, (nstore if nstore is not None else co)
     d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 1, 0, 0
     d.epi, d.accumulate = epi, int(accumulate)
     _run_conv(d, _bn_arg(bn, d, coff, out))
+
+
+def transpose_filter(w, out):
+    """out [KH,KW,Cout,Cin] <- w [KH,KW,Cin,Cout] (one small launch; for conv_forward(..., w_nk=out))."""
+    KH, KW, ci, co = w.shape
+    assert tuple(out.shape) == (KH, KW, co, ci) and w.is_contiguous() and out.is_contiguous()
+    nhwc_to_nchw(w.view(KH * KW, 1, ci, co), out.view(KH * KW, co, 1, ci))
+    return out
 
 
 def _bn_arg(bn, d, coff, out):

@@ -434,8 +434,12 @@ class MRUGenerator(_MRUBlocks):
             out = B.get(tag + '/gen', (N, H, W, 4), zero_on_alloc=True)
             out_coff = 0
         nstore = 4 if out.shape[3] == 4 and out_coff == 0 else 3
-        hip.conv_forward(View(ht), s['generator/Conv_1/weights'], 1, 0, out, coff=out_coff, nstore=nstore,
-                         bias=s['generator/Conv_1/biases'], epi=1, same=True)
+        # the 7x7 64 -> 3 conv on the few-output kernel with its filter through scalar loads: that form wants the input
+        # channels of a (tap, output) contiguous, i.e. a transposed copy of the 9408-float filter (one tiny launch)
+        w7 = s['generator/Conv_1/weights']
+        w7t = hip.transpose_filter(w7, B.get(tag + '/Conv_1/w_nk', (w7.shape[0], w7.shape[1], w7.shape[3], w7.shape[2])))
+        hip.conv_forward(View(ht), w7, 1, 0, out, coff=out_coff, nstore=nstore,
+                         bias=s['generator/Conv_1/biases'], epi=1, same=True, w_nk=w7t)
         ctx.update(out=out, out_coff=out_coff, feat=feat, dec=dec, noise=noise, noise_pre=pre)
         return ctx
 
