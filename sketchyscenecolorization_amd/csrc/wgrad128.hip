@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include "sketchycolor_hip.h"
 #include "igemm_util.h"
+#include <type_traits>
 
 #ifndef SSC_WG128_BK
 #define SSC_WG128_BK 32    // pixels per K step: 32 (68 KB of LDS, two workgroups per CU) or 16 (36 KB)
@@ -30,6 +31,14 @@
 #define BK SSC_WG128_BK
 #define NP (BK / 8)      // 16-byte pieces of a staged tile per thread
 #define KPB (256 / BK)   // K steps per block of the pixel table
+#ifndef SSC_WG128_DEEP
+#define SSC_WG128_DEEP 0        // 1: dense tiles two K steps ahead (ring of 3 LDS buffers), gathered tiles three ahead (two
+                                // register sets): 88 KB of LDS, one workgroup per CU (dense side by DMA only).  Measured
+                                // (encoder_3's filter gradient, one workgroup per CU either way): 112.9 vs 113.0 TFLOP/s, at
+                                // 8x the batch 121.8 vs 126.6 with two per CU -- memory latency is NOT what the K step waits
+                                // for (the cycle-stamp build's "counted wait" share was its own perturbation); off
+#endif
+#define NBB (SSC_WG128_DEEP ? 3 : 2)    // LDS buffers of the dense side
 #define TB 128          // tile edge (both sides)
 
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -79,8 +88,8 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(co
     constexpr int T_SZ = BK * TB;          // floats per operand tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                      // [2][BK][TB]  gathered side, [pixel][column]
-    float* Bs = smem + 2 * T_SZ;           // [2][BK][TB]  dense side
-    int2* ptab = reinterpret_cast<int2*>(smem + 4 * T_SZ);      // [2][TPT][256]: {byte offset of pixel@tap | 0x80000000, 1.0f | 0}
+    float* Bs = smem + 2 * T_SZ;           // [NBB][BK][TB]  dense side
+    int2* ptab = reinterpret_cast<int2*>(smem + (2 + NBB) * T_SZ);      // [2][TPT][256]: {byte offset of pixel@tap | 0x80000000, 1.0f | 0}
 
     TSTAMP(t_kernel0);
     const int tid = threadIdx.x;
@@ -232,6 +241,85 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(co
                 (DMODE == 2) ? xform4_nomask(rb[s], ba, bb, d_slope) : rb[s];
     };
 
+#if SSC_WG128_DEEP
+    // ---- deep-prefetch form (DMODE 0): at step j the registers of K-tile j + 1 (loaded at step j - 2) go to LDS, the dense tile
+    // of K-tile j + 2 starts its DMA into the ring, the gathered loads of K-tile j + 3 refill the registers just drained ----
+    float4 ra2[2][NP];
+    float ram2[2][NP];
+    auto load_a2 = [&](int j, int set, int s) {
+        ra2[set][s] = bload16(rsA, (unsigned)pe[s].x + a_cb);
+        ram2[set][s] = __builtin_bit_cast(float, pe[s].y);
+    };
+    auto stage_a2 = [&](int buf, int set, int s) {
+        *reinterpret_cast<float4*>(As + buf * T_SZ + (a_r + 8 * s) * TB + a_q * 4) =
+            GPLAIN ? ra2[set][s] : xform4(ra2[set][s], aa, ab, g_slope, ram2[set][s]);
+    };
+    if (nk > 0 && DMODE == 0) {
+        fill_ptab(0);
+#pragma unroll
+        for (int s = 0; s < NP; ++s) dma_b_piece(0, 0, s);
+#pragma unroll
+        for (int s = 0; s < NP; ++s) dma_b_piece(1, 1, s);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NP; ++s) { ptab_piece(0, s); load_a2(0, 0, s); }
+#pragma unroll
+        for (int s = 0; s < NP; ++s) { ptab_piece(1, s); load_a2(1, 1, s); }
+#pragma unroll
+        for (int s = 0; s < NP; ++s) stage_a2(0, 0, s);
+#pragma unroll
+        for (int s = 0; s < NP; ++s) { ptab_piece(2, s); load_a2(2, 0, s); }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP) : "memory");      // both dense tiles have landed (older than the 2 NP loads)
+        __syncthreads();
+        const float* a_rd = As + lhi * TB + wm * 64 + 2 * l31;
+        const float* b_rd = Bs + lhi * TB + wn * 64 + 2 * l31;
+        int ring = 0;       // j % 3
+        auto body = [&](int j, auto PAR) {
+            constexpr int P = decltype(PAR)::value;         // j & 1
+            const float* Ab = a_rd + P * T_SZ;
+            const float* Bb = b_rd + ring * T_SZ;
+            const int ring2 = ring == 0 ? 2 : ring - 1;     // (j + 2) % 3
+            if ((j % KPB) == KPB / 2 - 1) fill_ptab(j / KPB + 1);
+            constexpr int NG = BK / 2, PF = 4;
+            f32x2v av[8], bv[8];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                av[q] = *reinterpret_cast<const f32x2v*>(Ab + q * 2 * TB);
+                bv[q] = *reinterpret_cast<const f32x2v*>(Bb + q * 2 * TB);
+            }
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                if (q + PF < NG) {
+                    av[(q + PF) & 7] = *reinterpret_cast<const f32x2v*>(Ab + (q + PF) * 2 * TB);
+                    bv[(q + PF) & 7] = *reinterpret_cast<const f32x2v*>(Bb + (q + PF) * 2 * TB);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 7][i], bv[q & 7][jj], acc[i][jj], 0, 0, 0);
+                if (q < NP) {
+                    stage_a2(P ^ 1, P ^ 1, q);                      // K-tile j + 1 (set (j + 1) & 1) -> As[(j + 1) & 1]
+                } else if (q < 2 * NP) {
+                    dma_b_piece(j + 2, ring2, q - NP);
+                    ptab_piece(j + 3, q - NP);
+                } else if (q < 3 * NP) {
+                    load_a2(j + 3, P ^ 1, q - 2 * NP);              // the set just drained
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the dense tile of K-tile j + 1 (its DMA was issued a whole step ago) has landed: younger than it are the loads of
+            // K-tile j + 2, the DMA of K-tile j + 2 and the loads of K-tile j + 3
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * NP) : "memory");
+            __builtin_amdgcn_s_barrier();
+            ring = ring == 2 ? 0 : ring + 1;
+        };
+        for (int j = 0; j < nk; j += 2) {
+            body(j, std::integral_constant<int, 0>());
+            if (j + 1 < nk) body(j + 1, std::integral_constant<int, 1>());
+        }
+    } else
+#endif
     if (nk > 0) {
         fill_ptab(0);
         if (DMODE == 0) {
@@ -432,7 +520,7 @@ void ssc_launch_wgrad_reduce(const float* ws, long count, int splitk, float* out
 
 template <bool GPLAIN, int DMODE, int TPT>
 static int launch_wg128(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
-    constexpr size_t lds = 4 * BK * TB * sizeof(float) + 2 * TPT * 256 * sizeof(int2);
+    constexpr size_t lds = (2 + NBB) * BK * TB * sizeof(float) + 2 * TPT * 256 * sizeof(int2);
     const int Cg = d.g.C0 + d.g.C1;
     const long Mtot = (long)d.TH * d.TW * Cg;
     const long P = (long)d.NB * d.PH * d.PW;
