@@ -508,7 +508,12 @@ static int wg128_splitk(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws)
         const long wgs = tiles * sk;
         const long on_cu = (wgs + ncu - 1) / ncu;                       // workgroups on the busiest CU
         double cost = (double)on_cu * (double)(per + 5);
-        if (on_cu == 1) cost *= 1.25;                                   // a lone wave per SIMD hides nothing
+        static double occ1 = -1.0;      // SSC_WG128_OCC1: penalty of one workgroup per CU (tuning aid)
+        if (occ1 < 0.0) {
+            const char* e = getenv("SSC_WG128_OCC1");
+            occ1 = (e != nullptr) ? atof(e) : 0.9;      // in the train step one workgroup per CU co-runs better: 1824 vs 1818 images/s (1.25)
+        }
+        if (on_cu == 1) cost *= occ1;
         if (sk > 1) cost += (double)sk * (double)out_elems * 4.0 * 2.0 / 3.0e6 / 3.4 + 2.0;     // slab bytes at ~3 TB/s in K-tile units (3.4 us)
         if (force > 0) cost = (double)(sk > force ? sk - force : force - sk);
         if (cost < best_cost) { best_cost = cost; best = sk; }
