@@ -512,7 +512,8 @@ def main():
             out['step_frac_of_fp32_peak'] = out['step_tflops_executed'] / PEAK_FP32_MFMA_TFLOPS
             traffic = mfma_busy = valu_busy = traffic_note = None
             tree = _csrc_hash()
-            tpath = os.path.join(ROOT, 'profiles', 'r02_pmc.json')
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc.json') and f[0] == 'r')
+            tpath = os.path.join(ROOT, 'profiles', cands[-1] if cands else 'r03_pmc.json')      # the latest round's passes
             if os.path.exists(tpath) and args.batch == 32 and args.img == 192 and args.block_type == 'Pix2Pix':
                 with open(tpath) as f:
                     pm = json.load(f)
@@ -522,12 +523,12 @@ def main():
                         traffic = tk.get('hbm_bytes_per_launch')
                         mfma_busy, valu_busy = tk.get('mfma_busy_frac'), tk.get('valu_busy_frac')
                 else:
-                    traffic_note = ('profiles/r02_pmc.json was collected on kernel tree %s, this run is %s: not attached'
-                                    % (pm.get('csrc_hash'), tree))
+                    traffic_note = ('%s was collected on kernel tree %s, this run is %s: not attached'
+                                    % (os.path.basename(tpath), pm.get('csrc_hash'), tree))
             out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                                'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc '
-                                               'passes, profiles/r02_pmc.json; attached only when its csrc_hash matches)',
+                                               'passes, profiles/rNN_pmc.json of the latest round; attached only when its csrc_hash matches)',
                                'traffic_note': traffic_note, 'csrc_hash': tree,
                                'algorithmic_bytes_per_launch': nb / cnt,
                                'traffic_ratio': (traffic / (nb / cnt)) if traffic else None,

@@ -14,6 +14,8 @@ def demangled_short(name):
     # rocpd stores demangled names: "void conv_fwd_kernel<2, 2, 1, 2, 0, true, true>(...)"
     if name.startswith('lstm_step_fwd_kernel') or 'lstm_step_fwd_kernel(' in name:
         return 'lstm_step_fwd<64x64>'
+    if 'conv_wgrad128_kernel' in name:
+        return 'conv_wgrad128<128x128>'
     m = re.match(r'void (conv_fwd_kernel|conv_ut_kernel|conv_wgrad_kernel|narrow_fwd_kernel)<([^>]*)>', name)
     if not m:
         return None
@@ -49,7 +51,7 @@ def main(base, dst, bench_json=None):
             pk = json.loads(lines[-1]).get('roofline', {}).get('per_kernel', {})
             alg = {k: v.get('algorithmic_bytes_per_launch') for k, v in pk.items()}
     res = {'source': 'rocprofv3 --kernel-trace --pmc <one pass each> of `python bench.py --steps 2 --warmup 1 --no-graphs '
-                     '--no-kernel-events` (scripts/run_profile_r02_pmc.sh), 1x MI355X, batch 32, 192x192',
+                     '--no-kernel-events` (scripts/run_profile_pmc.sh), 1x MI355X, batch 32, 192x192',
            'csrc_hash': _bench._csrc_hash(),
            'correction': 'FETCH_SIZE (KB) x2 (gfx950 tallies the 128-B requests of coalesced 16-B/lane reads at 64 B, '
                          'MI355X_MICROARCH.md section HBM); WRITE_SIZE (KB) as reported',
