@@ -84,7 +84,8 @@ __device__ __forceinline__ float4 xform4_nomask(float4 v, const float4& a, const
 // registers (A/B), 2 = folded norm + activation through registers.  TPT: taps per tile (2: a 64-channel gathered tensor).
 template <bool GPLAIN, int DMODE, int TPT>
 __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(const ssc_wgrad_desc d, const Magics mg,
-                                                                float* __restrict__ slab_base, long slab_stride, int splitk) {
+                                                                float* __restrict__ slab_base, long slab_stride, int splitk,
+                                                                int xcd) {
     constexpr int T_SZ = BK * TB;          // floats per operand tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                      // [2][BK][TB]  gathered side, [pixel][column]
@@ -102,7 +103,21 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(co
     const int Mtot = ntap * Cg;
     const unsigned P = (unsigned)((long)d.NB * d.PH * d.PW);
     const int PHW = d.PH * d.PW;
-    const int m0 = blockIdx.x * TB, n0 = blockIdx.y * TB, ks = blockIdx.z;
+    // workgroup -> (row tile, column tile, K slice).  All tiles of a K slice read the same pixels; dealt round robin to the 8
+    // XCDs (id % 8) each L2 fetches every slice.  xcd (host flag, grid a multiple of 8): ids with the same id % 8 walk a
+    // contiguous run of (row tile, column tile, slice) order -- whole slices per XCD.
+    int mt_i = blockIdx.x, nt_i = blockIdx.y, ks = blockIdx.z;
+    if (xcd) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned t2 = (lin & 7u) * (total >> 3) + (lin >> 3);
+        const unsigned per_slice = gridDim.x * gridDim.y;
+        ks = (int)(t2 / per_slice);
+        const unsigned r = t2 - (unsigned)ks * per_slice;
+        nt_i = (int)(r / gridDim.x);
+        mt_i = (int)(r - (unsigned)nt_i * gridDim.x);
+    }
+    const int m0 = mt_i * TB, n0 = nt_i * TB;
 
     // ---- gathered side: the tile's tap(s), source, descriptor ----
     int tap0, c0;
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(co
         tap0 = div32(m0, mg.mC, mg.oneC);
         c0 = m0 - tap0 * Cg;
     } else {
-        tap0 = blockIdx.x * 2;
+        tap0 = mt_i * 2;
         c0 = 0;
     }
     const bool g_first = c0 < gC0;
@@ -538,7 +553,13 @@ static int launch_wg128(const ssc_wgrad_desc& d, int splitk, float* ws, hipStrea
     }
     const long out_count = Mtot * d.ldc;
     dim3 grid((unsigned)((Mtot + TB - 1) / TB), (unsigned)((d.Nn + TB - 1) / TB), (unsigned)splitk);
-    hipLaunchKernelGGL((conv_wgrad128_kernel<GPLAIN, DMODE, TPT>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk);
+    static int xcd_on = -1;     // SSC_WG128_XCD=0: plain grid order (A/B)
+    if (xcd_on < 0) {
+        const char* e = getenv("SSC_WG128_XCD");
+        xcd_on = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    const int xcd = (xcd_on && splitk > 1 && (((long)grid.x * grid.y * grid.z) & 7) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((conv_wgrad128_kernel<GPLAIN, DMODE, TPT>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, xcd);
     if (splitk > 1) ssc_launch_wgrad_reduce(ws, out_count, splitk, d.out, d.accumulate, st);
     return (int)hipGetLastError();
 }
