@@ -190,3 +190,84 @@ def test_config_matches_reference_module_goldens():
         for k in fields():
             delattr(C, k)
         C.set_from_dict(saved)
+
+
+def test_tower_graph_dequeue_order_with_run_ahead_and_real_ahead():
+    """TowerGraph.run keeps the reference's queue order (D batch, G batch, next D batch, ...) while handing the trainer the G
+    batch one step early (g_follows -> run_ahead) and the next D batch one step early (d_follows -> real_ahead); a D-step only
+    claims the run-ahead real pass for the very batch that was announced."""
+    from sketchyscenecolorization_amd.obj_lib.graph_single import Counter, Fetch, TowerGraph
+
+    class StubTrainer(object):
+        run_ahead = real_ahead = True
+        lr_g = 1e-4
+
+        def __init__(self):
+            self.calls = []
+
+        def decay(self, c):
+            return 1.0
+
+        def d_step(self, batch, c, ahead=None, use_real=False):
+            self.calls.append(('d', batch['id'], None if ahead is None else ahead['id'], use_real))
+            return torch.tensor(0.5)
+
+        def g_step(self, batch, c, use_ahead=False, next_d=None):
+            self.calls.append(('g', batch['id'], use_ahead, None if next_d is None else next_d['id']))
+            return torch.tensor(0.25)
+
+    import sketchyscenecolorization_amd.obj_lib.graph_single as gs
+    n = {'v': 0}
+
+    def deq():
+        n['v'] += 1
+        return {'id': n['v']}
+
+    tr = StubTrainer()
+    g = TowerGraph(tr, [None] * 6, Counter(0), 0, 1, 2, [1])
+    g._dequeue = deq
+    od, og, lg, ld = Fetch(g, 'opt_d'), Fetch(g, 'opt_g'), Fetch(g, 'loss_g'), Fetch(g, 'loss_d')
+    real_check = gs.__dict__.get('hip')
+    import sketchyscenecolorization_amd.hip as hip_mod
+    saved = hip_mod.check_sk
+    hip_mod.check_sk = lambda where='': None         # no device in this test
+    try:
+        for it in range(3):
+            g.run([od, ld], g_follows=True)
+            g.run([og, lg], d_follows=(it < 2))
+    finally:
+        hip_mod.check_sk = saved
+    assert tr.calls == [('d', 1, 2, False), ('g', 2, True, 3),        # D0 dequeues 1 (+ G0 = 2 early); G0 dequeues D1 = 3 early
+                        ('d', 3, 4, True), ('g', 4, True, 5),
+                        ('d', 5, 6, True), ('g', 6, True, None)], tr.calls
+    assert n['v'] == 6                                                  # the same six dequeues, in the reference's order
+
+
+def test_independent_bundle_writer_against_the_reader(tmp_path):
+    """tests/golden/bundle_writer.py (own varint / protobuf / block / CRC code, CRC of large tensors by a gcc-compiled helper
+    that is checked against the bitwise form) -> tf_checkpoint.read_checkpoint: several data blocks, scalars, int64, a tensor
+    larger than a block, corrupted data rejected."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import bundle_writer as W
+    from sketchyscenecolorization_amd import tf_checkpoint as C
+    rng = np.random.RandomState(0)
+    t = {'generator/v%03d/weights' % i: rng.randn(3, 5).astype(np.float32) for i in range(400)}
+    t['generator/big/filter'] = rng.randn(300, 1000).astype(np.float32)
+    t['global_step'] = np.array(7, np.int64)
+    t['beta2_power'] = np.float32(0.9 ** 7)
+    pre = os.path.join(str(tmp_path), 'model_7.ckpt-7')
+    index_bytes, data_bytes = W.write_bundle(pre, t, block_bytes=1024)
+    assert index_bytes > 10000 and data_bytes == sum(np.asarray(v).nbytes for v in t.values())
+    r = C.read_checkpoint(pre)
+    assert set(r) == set(t)
+    for k in t:
+        assert r[k].shape == np.asarray(t[k]).shape and np.array_equal(r[k], np.asarray(t[k])), k
+    assert W.crc32c(bytes(range(256)) * 40) == W.crc32c_bitwise(bytes(range(256)) * 40)
+    raw = bytearray(open(pre + '.data-00000-of-00001', 'rb').read())
+    raw[5000] ^= 0x01
+    open(pre + '.data-00000-of-00001', 'wb').write(bytes(raw))
+    import pytest
+    with pytest.raises(IOError):
+        C.read_checkpoint(pre)
