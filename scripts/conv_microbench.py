@@ -29,9 +29,13 @@ elif layer == 'dg3':      # data gradient of encoder_3 (4 sub-pixel phases of 2x
     dx = torch.empty(N, 48, 48, 128, device='cuda')
     fn = lambda: hip.conv_dgrad(View(dy), w, 2, 1, dx)
     flops = 2.0 * N * 48 * 48 * 128 * 4 * 256
-elif layer == 'wg3':
+elif layer in ('wg3', 'wg3p', 'wg3n', 'wg3m'):   # weight gradient of encoder_3; p: plain operands, n: norm + lrelu on x, m: + mask on dy
     x, dy, dw = r(N, 48, 48, 128), r(N, 24, 24, 256), torch.empty(4, 4, 128, 256, device='cuda')
-    fn = lambda: hip.conv_wgrad(View(x, None, None, 2), View(dy), dw, 2, 1)
+    ab = torch.cat([torch.ones(128, device='cuda'), torch.zeros(128, device='cuda')])
+    ab2 = torch.cat([torch.ones(256, device='cuda'), torch.zeros(256, device='cuda')])
+    xv = {'wg3': View(x, None, None, 2), 'wg3p': View(x), 'wg3n': View(x, None, ab, 2), 'wg3m': View(x, None, ab, 2)}[layer]
+    gv = View(dy) if layer != 'wg3m' else View(dy, None, ab2, 2)
+    fn = lambda: hip.conv_wgrad(xv, gv, dw, 2, 1)
     flops = 2.0 * N * 24 * 24 * 256 * 16 * 128
 elif layer == 'dec1':     # generator's last transposed conv 2 x 64 -> 3 (narrow kernel, folded norm + relu on both sources)
     x0, x1, f = r(N, 96, 96, 64), r(N, 96, 96, 64), r(4, 4, 3, 128) * 0.02

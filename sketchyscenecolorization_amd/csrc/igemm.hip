@@ -1011,6 +1011,13 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     }
 }
 
+// streaming 16-byte load (split-K slabs are read once)
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ntload4(const float4* p) {
+    const nt_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // sum split-K slabs; applies the epilogue that the partial passes skipped
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splitk,
                                    float* __restrict__ out, long count, int ldc, int Nn, int Nstore,
@@ -1026,6 +1033,59 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_st
     else if (epi == 2) v = fmaxf(v, 0.2f * v);
     if (accumulate) v += out[i];
     out[i] = v;
+}
+
+// the same sum, four columns per thread (16-byte loads, four slabs in flight; the additions keep the scalar kernel's order,
+// so both give the same bits): ldc, Nn, Nstore multiples of 4 and 16-byte aligned bases
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(const float4* __restrict__ slabs, long slab_stride4, int splitk,
+                                                            float4* __restrict__ out, long count4, int ldc4, int Nn4,
+                                                            int Nstore4, const float4* bias, int epi, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count4) return;
+    const int col = (int)(i % ldc4);
+    if (col >= Nstore4) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* p = slabs + i;
+    int s = 0;
+    for (; s + 4 <= splitk; s += 4) {
+        const float4 a = ntload4(p), b = ntload4(p + slab_stride4),
+                     c = ntload4(p + 2 * slab_stride4), e = ntload4(p + 3 * slab_stride4);
+        p += 4 * slab_stride4;
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+        v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+    }
+    for (; s < splitk; ++s, p += slab_stride4) {
+        const float4 a = ntload4(p);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (bias != nullptr && col < Nn4) {
+        const float4 b = bias[col];
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (epi == 1) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+    else if (epi == 2) { v.x = fmaxf(v.x, 0.2f * v.x); v.y = fmaxf(v.y, 0.2f * v.y); v.z = fmaxf(v.z, 0.2f * v.z); v.w = fmaxf(v.w, 0.2f * v.w); }
+    if (accumulate) {
+        const float4 o = out[i];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    out[i] = v;
+}
+
+static void launch_slab_reduce(const float* ws, long out_count, int splitk, const ssc_conv_desc& d, hipStream_t st) {
+    const int thr = 256;
+    const bool v4 = (out_count % 4) == 0 && (d.ldc % 4) == 0 && (d.Nn % 4) == 0 && (d.Nstore % 4) == 0 &&
+                    (((uintptr_t)ws | (uintptr_t)d.out | (uintptr_t)d.bias) & 15) == 0;
+    if (v4) {
+        const long c4 = out_count / 4;
+        hipLaunchKernelGGL(slab_reduce4_kernel, dim3((unsigned)((c4 + thr - 1) / thr)), dim3(thr), 0, st, (const float4*)ws,
+                           c4, splitk, (float4*)d.out, c4, d.ldc / 4, d.Nn / 4, d.Nstore / 4, (const float4*)d.bias, d.epi,
+                           d.accumulate);
+    } else {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
+                           out_count, splitk, d.out, out_count, d.ldc, d.Nn, d.Nstore, d.bias, d.epi, d.accumulate);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1340,6 +1400,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// one thread per four elements: 16-byte loads, four slabs in flight, the scalar kernel's order of additions (same bits)
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float4* __restrict__ slabs, long slab_stride4, int splitk,
+                                                             float4* __restrict__ out, long count4, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* p = slabs + i;
+    int s = 0;
+    for (; s + 4 <= splitk; s += 4) {
+        const float4 a = ntload4(p), b = ntload4(p + slab_stride4),
+                     c = ntload4(p + 2 * slab_stride4), e = ntload4(p + 3 * slab_stride4);
+        p += 4 * slab_stride4;
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+        v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+    }
+    for (; s < splitk; ++s, p += slab_stride4) {
+        const float4 a = ntload4(p);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (accumulate) {
+        const float4 o = out[i];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    out[i] = v;
+}
+
 static void launch_wgrad_reduce(const float* ws, long count, int splitk, float* out, int accumulate, hipStream_t st) {
     static int skip = -1;       // SSC_DIAG_SKIP_WGRAD_REDUCE=1: timing diagnostic only (wrong gradients): what do the slab sums cost
     if (skip < 0) {
@@ -1347,7 +1435,11 @@ static void launch_wgrad_reduce(const float* ws, long count, int splitk, float* 
         skip = (e != nullptr && e[0] == '1') ? 1 : 0;
     }
     if (skip) return;
-    if (count >= 262144 || splitk < 8) {
+    if ((count >= 262144 || splitk < 8) && (count % 4) == 0 && (((uintptr_t)ws | (uintptr_t)out) & 15) == 0) {
+        const long c4 = count / 4;
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, st, (const float4*)ws, c4,
+                           splitk, (float4*)out, c4, accumulate);
+    } else if (count >= 262144 || splitk < 8) {
         hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, count,
                            splitk, out, count, accumulate);
     } else if (count >= 65536 || splitk < 32) {
@@ -1511,9 +1603,7 @@ static int launch_fwd_v(const ssc_conv_desc& d, int splitk, float* ws, hipStream
     hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB>), grid, dim3(256), lds, st, d, mg, ws,
                        out_count, splitk);
     if (splitk > 1) {
-        const int thr = 256;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
-                           out_count, splitk, d.out, out_count, d.ldc, d.Nn, d.Nstore, d.bias, d.epi, d.accumulate);
+        launch_slab_reduce(ws, out_count, splitk, d, st);
     }
     return (int)hipGetLastError();
 }
@@ -1638,9 +1728,7 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
     hipLaunchKernelGGL((conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>), grid, dim3(256), lds, st, d, mg, ws, out_count,
                        splitk, 0, 0, (unsigned*)nullptr);
     if (splitk > 1) {
-        const int thr = 256;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
-                           out_count, splitk, d.out, out_count, d.ldc, d.Nn, d.Nstore, d.bias, d.epi, d.accumulate);
+        launch_slab_reduce(ws, out_count, splitk, d, st);
     }
     return (int)hipGetLastError();
 }
