@@ -140,6 +140,16 @@ int ssc_conv_wgrad128(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void
  * when the launch allows it, else ssc_bn_stats reads the output back */
 int ssc_conv_forward_bn(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, const float* scale, const float* offset,
                         float eps, float* ab, float* stats, void* stream);
+/* the one-output patch head over a 512-channel tensor (discriminate_pix2pix layer_5, models_collection.py:812-817: 4x4,
+ * stride 1, 512 -> 1) as streaming kernels (head1.hip): forward (ws: 64 B per input pixel), its data gradient (the
+ * hip.conv_dgrad descriptor: one-channel dy, "NK" filter, flipped taps) and its filter gradient (ws: up to 256 x 32 KB slabs).
+ * ssc_conv_forward / ssc_conv_wgrad dispatch to them when _supported; SSC_HEAD1=0 keeps the general kernels. */
+int ssc_head1_forward_supported(const ssc_conv_desc* d);
+int ssc_head1_forward(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, void* stream);
+int ssc_head1_dgrad_supported(const ssc_conv_desc* d);
+int ssc_head1_dgrad(const ssc_conv_desc* d, void* stream);
+int ssc_head1_wgrad_supported(const ssc_wgrad_desc* d);
+int ssc_head1_wgrad(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void* stream);
 /* direct (vector-ALU, LDS patch) form for <= 4 output channels; ssc_conv_forward dispatches to it (narrow.hip) */
 int ssc_conv_narrow_supported(const ssc_conv_desc* d);
 int ssc_conv_narrow_forward(const ssc_conv_desc* d, void* stream);

@@ -1,5 +1,5 @@
 """Single-layer microbenchmark of the implicit-GEMM kernel (for rocprofv3 --pmc passes).
-usage: conv_microbench.py <layer> [iters] [batch];  layers: enc2 enc3 enc4 d4 dec3 dg3 wg3 dec1 dl1g logit d1 d1p e1 dec1g"""
+usage: conv_microbench.py <layer> [iters] [batch];  layers: enc2 enc3 enc4 d4 dec3 dg3 wg3 dec1 dl1g logit logitd logitw d1 d1p e1 dec1g"""
 import sys
 import torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -53,6 +53,16 @@ elif layer == 'logit':    # PatchGAN logit conv 512 -> 1, 4x4 stride 1
     ab = torch.cat([torch.ones(512, device='cuda'), torch.zeros(512, device='cuda')])
     out = torch.empty(N, 22, 22, 4, device='cuda')
     fn = lambda: hip.conv_forward(View(x, None, ab, 2), w, 1, 1, out, nstore=4)
+    flops = 2.0 * N * 22 * 22 * 16 * 512
+elif layer == 'logitd':   # its data gradient: one-channel dy -> 512 channels
+    dy, w = r(N, 22, 22, 4), r(4, 4, 512, 1) * 0.02
+    g4 = torch.empty(N, 23, 23, 512, device='cuda')
+    fn = lambda: hip.conv_dgrad(View(dy), w, 1, 1, g4, k_real=1)
+    flops = 2.0 * N * 22 * 22 * 16 * 512
+elif layer == 'logitw':   # its filter gradient
+    x, dy, dw = r(N, 23, 23, 512), r(N, 22, 22, 4), torch.empty(4, 4, 512, 1, device='cuda')
+    ab = torch.cat([torch.ones(512, device='cuda'), torch.zeros(512, device='cuda')])
+    fn = lambda: hip.conv_wgrad(View(x, None, ab, 2), View(dy), dw, 1, 1)
     flops = 2.0 * N * 22 * 22 * 16 * 512
 elif layer in ('d1', 'd1p'):    # discriminator's first conv: 8-channel input (6 real); d1p: filter padded to 8 rows per tap (row-tap form)
     cr = 6 if layer == 'd1' else 8

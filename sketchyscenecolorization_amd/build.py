@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libsketchycolor_hip.so')
 EXTRA_FLAGS = {'igemm.hip': ['-Xclang', '-target-feature', '-Xclang', '-load-store-opt']} if os.environ.get('SSC_NO_LSOPT') == '1' else {}     # per-source compiler flags
-SOURCES = ['igemm.hip', 'wgrad128.hip', 'narrow.hip', 'fewchan.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip', 'mru_ops.hip']
+SOURCES = ['igemm.hip', 'wgrad128.hip', 'narrow.hip', 'head1.hip', 'fewchan.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip', 'mru_ops.hip']
 
 
 def _hipcc():

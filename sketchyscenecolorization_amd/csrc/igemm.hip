@@ -1778,6 +1778,10 @@ static void copy_name(const char* src, char* dst, int len) {
 }
 
 extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, int len) {
+    if (ssc_head1_forward_supported(dp) || ssc_head1_dgrad_supported(dp)) {
+        copy_name(ssc_head1_dgrad_supported(dp) ? "head1_dgrad" : "head1_fwd", buf, len);
+        return 0;
+    }
     if (ssc_conv_narrow_supported(dp)) {
         copy_name(dp->nphase == 4 ? "narrow_fwd<transposed>" : "narrow_fwd<conv>", buf, len);
         return 0;
@@ -1905,6 +1909,10 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
     if (d.nphase == 4 && (d.TH != 2 || d.TW != 2 || d.KH != 4 || d.KW != 4 || d.kstep != -2 || d.out_stride != 2 ||
                           d.in_stride != 1))
         return -3;
+    // the one-output patch head over a 512-channel tensor and its data gradient (head1.hip): streaming kernels
+    if (ws != nullptr && ssc_head1_forward_supported(dp) && (int64_t)d.NB * d.x.H * d.x.W * 16 * 4 <= ws_bytes)
+        return ssc_head1_forward(dp, ws, ws_bytes, stream);
+    if (ssc_head1_dgrad_supported(dp)) return ssc_head1_dgrad(dp, stream);
     if (ssc_conv_narrow_supported(dp)) {        // <= 4 output channels
         int csplit = 1;
         const int rc = ssc_conv_narrow_forward_ws(dp, ws, ws_bytes, stream, &csplit);
@@ -2042,6 +2050,10 @@ static Plan plan_wgrad(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws) 
 extern "C" int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* dp, char* buf, int len) {
     static const char* names[5] = {"conv_wgrad<128x128>", "conv_wgrad<64x128>", "conv_wgrad<128x64>",
                                    "conv_wgrad<64x64>", "conv_wgrad<128x32>"};
+    if (ssc_head1_wgrad_supported(dp)) {
+        copy_name("head1_wgrad", buf, len);
+        return 0;
+    }
     if (ssc_conv_wgrad128_supported(dp)) {
         copy_name("conv_wgrad128<128x128>", buf, len);
         return 0;
@@ -2059,6 +2071,8 @@ extern "C" int ssc_conv_wgrad(const ssc_wgrad_desc* dp, float* ws, int64_t ws_by
     // the filter-gradient slab is dense [TH*TW*Cg_real][ldc]; rows/cols skipped by the kernel
     // (padding channels) do not exist in it, so every slab entry is written when ldc == Nn.
     if (d.ldc != d.Nn) return -3;
+    if (ws != nullptr && ws_bytes >= (int64_t)16 * 512 * 4 && ssc_head1_wgrad_supported(dp))     // the one-output patch head
+        return ssc_head1_wgrad(dp, ws, ws_bytes, stream);
     if (ssc_conv_wgrad128_supported(dp)) return ssc_conv_wgrad128(dp, ws, ws_bytes, stream);     // the large layers
     const Plan p = plan_wgrad(d, ws_bytes, ws != nullptr);
     switch (p.cfg) {

@@ -75,6 +75,12 @@ SIGNATURES = {
     'ssc_conv_forward_bnbwd': [C.POINTER(ConvDesc), _P, _L, _P, _I, _P, _P, _I, _P, _L, C.POINTER(C.c_int), _P],
     'ssc_bn_act_backward_pre': [_P, _L, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _F, _I, _P,
                                 _L, _P],
+    'ssc_head1_forward_supported': [C.POINTER(ConvDesc)],
+    'ssc_head1_forward': [C.POINTER(ConvDesc), _P, _L, _P],
+    'ssc_head1_dgrad_supported': [C.POINTER(ConvDesc)],
+    'ssc_head1_dgrad': [C.POINTER(ConvDesc), _P],
+    'ssc_head1_wgrad_supported': [C.POINTER(WgradDesc)],
+    'ssc_head1_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
     'ssc_conv_narrow_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_narrow_forward': [C.POINTER(ConvDesc), _P],
     'ssc_conv_fewchan_supported': [C.POINTER(ConvDesc)],

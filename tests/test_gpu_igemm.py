@@ -666,3 +666,54 @@ def test_wgrad128_deconv_two_sources():
     df = torch.full((4, 4, co, ci), float('nan'), device='cuda')
     hip.deconv_wgrad(v, hip.View(nhwc(dy).cuda()), df)
     close(df, f.grad)
+
+
+@pytest.mark.parametrize('case', [
+    # n, h, k, pad, act of x, norm on x
+    (3, 23, 4, 1, 2, True),         # discriminator layer_5 (models_collection.py:812-817): 23 x 23 x 512 -> 22 x 22 x 1
+    (2, 9, 3, 1, 1, False),         # 3 x 3 SAME-like, relu, no norm: 9 taps (lanes 9..15 idle)
+    (1, 7, 4, 0, 0, True),          # no padding: every tap in range
+])
+def test_head1_patch_head(case):
+    """The one-output patch head (head1.hip) in its three forms -- forward, data gradient, filter gradient -- vs the oracle conv
+    and its autograd; the launcher must pick the streaming kernels for these descriptors."""
+    import ctypes
+    hip = _hip()
+    n, h, k, pad, act, norm = case
+    ci = 512
+    x = rnd(n, ci, h, h, seed=101).requires_grad_(True)
+    w = rnd(k, k, ci, 1, seed=102, std=0.05).requires_grad_(True)
+    ab = torch.cat([1.0 + 0.1 * rnd(ci, seed=103), 0.2 * rnd(ci, seed=104)]) if norm else None
+    xa = x * ab[:ci].view(1, -1, 1, 1) + ab[ci:].view(1, -1, 1, 1) if norm else x
+    xa = act_ref(xa, act)
+    xa.retain_grad()
+    y = T.conv2d_valid_pad(xa, w, 1, pad)
+    dy = rnd(*y.shape, seed=105)
+    y.backward(dy)
+    oh = y.shape[2]
+    xv = hip.View(nhwc(x.detach()).cuda(), None, ab.cuda() if norm else None, act)
+    # forward: channel 0 of a 4-float row, the other stored columns 0
+    out = torch.full((n, oh, oh, 4), float('nan'), device='cuda')
+    hip.conv_forward(xv, w.detach().cuda(), 1, pad, out, nstore=4)
+    close(out[..., 0], y.detach()[:, 0])
+    assert float(out[..., 1:].abs().max()) == 0.0
+    # data gradient w.r.t. the activated tensor
+    dyp = torch.zeros(n, oh, oh, 4)
+    dyp[..., 0] = dy[:, 0]
+    g = torch.full((n, h, h, ci), float('nan'), device='cuda')
+    hip.conv_dgrad(hip.View(dyp.cuda()), w.detach().cuda(), 1, pad, g, k_real=1)
+    close(g, nhwc(xa.grad))
+    # filter gradient, then accumulated on top of itself
+    dw = torch.full((k, k, ci, 1), float('nan'), device='cuda')
+    hip.conv_wgrad(xv, hip.View(dyp.cuda()), dw, 1, pad)
+    close(dw, w.grad)
+    hip.conv_wgrad(xv, hip.View(dyp.cuda()), dw, 1, pad, accumulate=True)
+    close(dw, 2 * w.grad)
+    # the launcher's choice
+    d = hip.WgradDesc()
+    d.g, d.d = xv.c(), hip.View(dyp.cuda()).c()
+    d.out = dw.data_ptr()
+    d.NB, d.PH, d.PW, d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = n, oh, oh, k, k, 1, -pad, -pad
+    d.Cg_real, d.Nn, d.ldc, d.accumulate = ci, 1, 1, 0
+    assert _wgrad_name(hip, d) == 'head1_wgrad'
+    assert hip.lib().ssc_head1_wgrad_supported(ctypes.byref(d)) == 1
