@@ -150,6 +150,18 @@ int ssc_head1_dgrad_supported(const ssc_conv_desc* d);
 int ssc_head1_dgrad(const ssc_conv_desc* d, void* stream);
 int ssc_head1_wgrad_supported(const ssc_wgrad_desc* d);
 int ssc_head1_wgrad(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void* stream);
+/* the head's data gradient fused with the backward of the batch norm + activation of its input tensor x [pixels][512]
+ * (layer_4: models_collection.py:806-811): the gradient w.r.t. act(norm(x)) is recomputed in both passes of the norm backward
+ * and never stored.  d = the hip.conv_dgrad descriptor (out ignored), ab = [a; b], stats = [mean; rstd], rowb [NB][512] or
+ * NULL = a per-image term (the class head's gradient through its spatial mean) added with rowb_scale; dx [pixels][512];
+ * dscale / doffset [512] or NULL; ws >= (2 * 512 + 2) * 512 floats.  -1: not this shape (callers then use ssc_conv_forward +
+ * ssc_bn_act_backward_pre) */
+int ssc_head1_dgrad_bn_backward(const ssc_conv_desc* d, const float* x, const float* ab, const float* stats, int act,
+                                const float* rowb, float rowb_scale, float* dx, float* dscale, float* doffset, float* ws,
+                                int64_t ws_bytes, void* stream);
+/* rows of partial sums [nblk][2][C] of a norm backward -> coef [2][C] = [mean dz; mean dz*xhat], dscale / doffset (may be NULL) */
+int ssc_bn_bwd_finalize(const float* partial, int nblk, int C, int64_t M, float* coef, float* dscale, float* doffset,
+                        void* stream);
 /* direct (vector-ALU, LDS patch) form for <= 4 output channels; ssc_conv_forward dispatches to it (narrow.hip) */
 int ssc_conv_narrow_supported(const ssc_conv_desc* d);
 int ssc_conv_narrow_forward(const ssc_conv_desc* d, void* stream);

@@ -696,6 +696,15 @@ extern "C" int ssc_bn_act_backward_pre(const float* x, int64_t M, int C, int ldx
     return CHECK_LAUNCH();
 }
 
+// the second step of the norm backward on its own: rows of partial sums [nblk][2][C] -> coef = [mean dz; mean dz*xhat] and the
+// scale / offset gradients (head1.hip takes the sums inside its fused data-gradient pass)
+extern "C" int ssc_bn_bwd_finalize(const float* partial, int nblk, int C, int64_t M, float* coef, float* dscale, float* doffset,
+                                   void* stream) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, (long)M,
+                       coef, dscale, doffset);
+    return CHECK_LAUNCH();
+}
+
 extern "C" int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, const float* ab, const float* stats,
                                    const float* scale, const float* g1, int ldg1, int act1, const float* g2,
                                    int ldg2, int act2, int has_bn, float* dx, int lddx, float* dscale,

@@ -14,6 +14,9 @@
 
 #define CHECK_LAUNCH() ((int)hipGetLastError())
 
+// elementwise.hip: rows of [sum dz | sum dz*xhat] -> coef = their means, scale / offset gradients
+extern "C" int ssc_bn_bwd_finalize(const float* partial, int nblk, int C, int64_t M, float* coef, float* dscale, float* doffset,
+                                   void* stream);
 // igemm.hip: dw (+)= the sum of `splitk` slabs of `count` floats, in a fixed order
 void ssc_launch_wgrad_reduce(const float* ws, long count, int splitk, float* out, int accumulate, hipStream_t st);
 
@@ -42,6 +45,11 @@ __device__ __forceinline__ void h1_decode(const H1Geo& g, int q, int& n, int& iy
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// lane t's value to every lane through an SGPR (v_readlane_b32; t is a compile-time constant after unrolling)
+__device__ __forceinline__ float h1_bcast(float v, int t) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+}
 
 // this lane's 8 raw channels of pixel q, and act(a*x+b) of them (split so that a pixel's loads fly during the FMAs of the
 // previous one)
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256) void head1_dgrad_kernel(const float* __restric
         float acc[CPL] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-            const float s = __shfl(mine, t);
+            const float s = h1_bcast(mine, t);
 #pragma unroll
             for (int j = 0; j < CPL; ++j) acc[j] = fmaf(s, wr[t][j], acc[j]);
         }
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(256) void head1_wgrad_kernel(const float* __restric
         h1_act(u0, u1, a0, a1, b0, b1, g.slope, v);
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-            const float s = __shfl(mine, t);
+            const float s = h1_bcast(mine, t);
 #pragma unroll
             for (int j = 0; j < CPL; ++j) acc[t][j] = fmaf(v[j], s, acc[t][j]);
         }
@@ -258,7 +266,6 @@ __global__ __launch_bounds__(256) void head1_wgrad_kernel(const float* __restric
         float* o = slabs + (long)blockIdx.x * ntap * HC;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-            if (t >= ntap) break;
             float4 s0 = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
             float4 s1 = make_float4(acc[t][4], acc[t][5], acc[t][6], acc[t][7]);
             for (int k = 0; k < 3; ++k) {
@@ -267,9 +274,152 @@ __global__ __launch_bounds__(256) void head1_wgrad_kernel(const float* __restric
                 s0.x += u0.x; s0.y += u0.y; s0.z += u0.z; s0.w += u0.w;
                 s1.x += u1.x; s1.y += u1.y; s1.z += u1.z; s1.w += u1.w;
             }
-            *reinterpret_cast<float4*>(o + t * HC + 4 * lane) = s0;
-            *reinterpret_cast<float4*>(o + t * HC + 256 + 4 * lane) = s1;
+            if (t < ntap) {
+                *reinterpret_cast<float4*>(o + t * HC + 4 * lane) = s0;
+                *reinterpret_cast<float4*>(o + t * HC + 256 + 4 * lane) = s1;
+            }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- data gradient fused
+// with the backward of the norm + activation that follows the wide tensor x (layer_4's batch norm + lrelu): the gradient
+// g = sum_tap dy*w (+ rowb[n]*rowb_scale, the class head's term) is recomputed in both passes and never stored.
+//   pass 1: rows of [sum dz | sum dz*xhat] per workgroup, dz = g * act'(a*x+b), xhat = (x - mean) * rstd
+//   pass 2 (after ssc_bn_bwd_finalize): dx = a * (dz - c1 - xhat*c2)          (bn_bwd_apply_kernel's formula)
+struct H1Bn {
+    const float* x;         // [npix][HC]
+    const float* ab;        // [2][HC]
+    const float* stats;     // [2][HC]: mean, rstd
+    const float* rowb;      // [NB][HC] or NULL
+    float rowb_scale;
+    int act;
+};
+__device__ __forceinline__ float h1_dact(float z, int act) {
+    if (act == SSC_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == SSC_ACT_LRELU) return z > 0.f ? 1.f : 0.2f;
+    return 1.f;
+}
+__device__ __forceinline__ void h1_load_wt(const float* __restrict__ w, const H1Geo& g, int ky0, int kx0, int kstep, int lane,
+                                           float (&wr)[MAXT][CPL]) {
+    const int ntap = g.TH * g.TW;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int ty = t / g.TW, tx = t - ty * g.TW;
+        const int ft = (ky0 + kstep * ty) * g.TW + kx0 + kstep * tx;
+        float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0;
+        if (t < ntap) {
+            u0 = ld4(w + (long)ft * HC + 4 * lane);
+            u1 = ld4(w + (long)ft * HC + 256 + 4 * lane);
+        }
+        wr[t][0] = u0.x; wr[t][1] = u0.y; wr[t][2] = u0.z; wr[t][3] = u0.w;
+        wr[t][4] = u1.x; wr[t][5] = u1.y; wr[t][6] = u1.z; wr[t][7] = u1.w;
+    }
+}
+// dz and x of this lane's 8 channels of pixel q (sample n): mine = this lane's tap value of dy
+__device__ __forceinline__ void h1_dz(const H1Bn& b, int q, int n, int lane, float mine, const float (&wr)[MAXT][CPL],
+                                      const float (&a)[CPL], const float (&bb)[CPL], const float4& x0, const float4& x1,
+                                      float (&xv)[CPL], float (&dz)[CPL]) {
+    float gsum[CPL] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const float s = h1_bcast(mine, t);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) gsum[j] = fmaf(s, wr[t][j], gsum[j]);
+    }
+    if (b.rowb != nullptr) {
+        const float4 r0 = ld4(b.rowb + (long)n * HC + 4 * lane), r1 = ld4(b.rowb + (long)n * HC + 256 + 4 * lane);
+        const float rr[CPL] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) gsum[j] = fmaf(rr[j], b.rowb_scale, gsum[j]);
+    }
+    xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) dz[j] = gsum[j] * h1_dact(fmaf(a[j], xv[j], bb[j]), b.act);
+}
+__device__ __forceinline__ void h1_lane8(const float* p, int lane, float (&v)[CPL]) {
+    const float4 u0 = ld4(p + 4 * lane), u1 = ld4(p + 256 + 4 * lane);
+    v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w; v[4] = u1.x; v[5] = u1.y; v[6] = u1.z; v[7] = u1.w;
+}
+
+__global__ __launch_bounds__(256) void head1_bnbwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                  H1Geo g, int ky0, int kx0, int kstep, int npix, H1Bn b,
+                                                                  float* __restrict__ partial) {
+    __shared__ float sh[3][2][HC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wv, nwave = gridDim.x * 4;
+    float wr[MAXT][CPL];
+    h1_load_wt(w, g, ky0, kx0, kstep, lane, wr);
+    float a[CPL], bb[CPL], mu[CPL], rs[CPL];
+    h1_lane8(b.ab, lane, a); h1_lane8(b.ab + HC, lane, bb); h1_lane8(b.stats, lane, mu); h1_lane8(b.stats + HC, lane, rs);
+    const int lty = lane / g.TW, ltx = lane - lty * g.TW;
+    float s1[CPL] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[CPL] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0;
+    if (wave < npix) h1_load(b.x, wave, lane, u0, u1);
+    for (int q = wave; q < npix; q += nwave) {
+        float4 n0 = u0, n1 = u1;
+        if (q + nwave < npix) h1_load(b.x, q + nwave, lane, n0, n1);
+        int n, iy, ix;
+        h1_decode(g, q, n, iy, ix);
+        const float mine = h1_narrow_at(dy, g, n, iy, ix, lty, ltx);
+        float xv[CPL], dz[CPL];
+        h1_dz(b, q, n, lane, mine, wr, a, bb, u0, u1, xv, dz);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            s1[j] += dz[j];
+            s2[j] += dz[j] * (xv[j] - mu[j]) * rs[j];
+        }
+        u0 = n0;
+        u1 = n1;
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int c = (j < 4 ? 4 * lane + j : 256 + 4 * lane + j - 4);
+            sh[wv - 1][0][c] = s1[j];
+            sh[wv - 1][1][c] = s2[j];
+        }
+    }
+    __syncthreads();
+    if (wv == 0) {
+        float* o = partial + (long)blockIdx.x * 2 * HC;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int c = (j < 4 ? 4 * lane + j : 256 + 4 * lane + j - 4);
+            o[c] = ((s1[j] + sh[0][0][c]) + sh[1][0][c]) + sh[2][0][c];
+            o[HC + c] = ((s2[j] + sh[0][1][c]) + sh[1][1][c]) + sh[2][1][c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void head1_bnbwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                H1Geo g, int ky0, int kx0, int kstep, int npix, H1Bn b,
+                                                                const float* __restrict__ coef, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+    float wr[MAXT][CPL];
+    h1_load_wt(w, g, ky0, kx0, kstep, lane, wr);
+    float a[CPL], bb[CPL], mu[CPL], rs[CPL], c1[CPL], c2[CPL];
+    h1_lane8(b.ab, lane, a); h1_lane8(b.ab + HC, lane, bb); h1_lane8(b.stats, lane, mu); h1_lane8(b.stats + HC, lane, rs);
+    h1_lane8(coef, lane, c1); h1_lane8(coef + HC, lane, c2);
+    const int lty = lane / g.TW, ltx = lane - lty * g.TW;
+    float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0;
+    if (wave < npix) h1_load(b.x, wave, lane, u0, u1);
+    for (int q = wave; q < npix; q += nwave) {
+        float4 n0 = u0, n1 = u1;
+        if (q + nwave < npix) h1_load(b.x, q + nwave, lane, n0, n1);
+        int n, iy, ix;
+        h1_decode(g, q, n, iy, ix);
+        const float mine = h1_narrow_at(dy, g, n, iy, ix, lty, ltx);
+        float xv[CPL], dz[CPL], o[CPL];
+        h1_dz(b, q, n, lane, mine, wr, a, bb, u0, u1, xv, dz);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) o[j] = a[j] * (dz[j] - c1[j] - (xv[j] - mu[j]) * rs[j] * c2[j]);
+        float* p = dx + (long)q * HC + 4 * lane;
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(p + 256) = make_float4(o[4], o[5], o[6], o[7]);
+        u0 = n0;
+        u1 = n1;
     }
 }
 
@@ -394,5 +544,40 @@ extern "C" int ssc_head1_wgrad(const ssc_wgrad_desc* dp, float* ws, int64_t ws_b
     }
     hipLaunchKernelGGL(head1_wgrad_kernel, dim3(blocks), dim3(256), lds, st, d.g.s0, d.g.ab0, d.d.s0, g, npix, ws);
     ssc_launch_wgrad_reduce(ws, (long)d.TH * d.TW * HC, blocks, d.out, d.accumulate, st);     // slabs are [TH*TW][HC]
+    return CHECK_LAUNCH();
+}
+
+// data gradient of the patch head fused with the backward of the batch norm + activation of the wide tensor x [npix][512]
+// (ab = [a; b], stats = [mean; rstd]): dx = d loss / d x; dscale / doffset (may be NULL) the norm's parameter gradients;
+// rowb [NB][512] (may be NULL): a per-image gradient term added to every pixel, scaled by rowb_scale.
+// ws: (blocks * 2 + 2) * 512 floats.  `dp` is the hip.conv_dgrad descriptor of the head (its `out` is not written).
+extern "C" int ssc_head1_dgrad_bn_backward(const ssc_conv_desc* dp, const float* x, const float* ab, const float* stats, int act,
+                                           const float* rowb, float rowb_scale, float* dx, float* dscale, float* doffset,
+                                           float* ws, int64_t ws_bytes, void* stream) {
+    ssc_conv_desc t = *dp;
+    t.out = dx;             // only its alignment is looked at
+    if (!ssc_head1_dgrad_supported(&t)) return -1;
+    if (x == nullptr || ab == nullptr || stats == nullptr || dx == nullptr || !al16(x) || !al16(ab) || !al16(stats) ||
+        (rowb != nullptr && !al16(rowb)))
+        return -1;
+    const ssc_conv_desc& d = *dp;
+    const int npix = d.NB * d.OH * d.OW;
+    int blocks = (int)wave_blocks(npix);
+    if (blocks > 512) blocks = 512;
+    if (ws == nullptr || !al16(ws) || ((int64_t)blocks * 2 + 2) * HC * 4 > ws_bytes) return -2;
+    const H1Geo g = make_geo(d.NB, d.OH, d.OW, d.x.H, d.x.W, d.x.C0, d.TH, d.TW, -d.ioff_y - (d.TH - 1), -d.ioff_x - (d.TW - 1),
+                             nullptr);
+    const int ky0 = d.ky0 + d.kstep * (d.TH - 1), kx0 = d.kx0 + d.kstep * (d.TW - 1), kstep = -d.kstep;
+    H1Bn b;
+    b.x = x; b.ab = ab; b.stats = stats; b.rowb = rowb; b.rowb_scale = rowb_scale; b.act = act;
+    float* partial = ws;
+    float* coef = ws + (long)blocks * 2 * HC;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(head1_bnbwd_partial_kernel, dim3(blocks), dim3(256), 0, st, d.x.s0, d.w, g, ky0, kx0, kstep, npix, b,
+                       partial);
+    const int rc = ssc_bn_bwd_finalize(partial, blocks, HC, (int64_t)npix, coef, dscale, doffset, stream);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(head1_bnbwd_apply_kernel, dim3(wave_blocks(npix)), dim3(256), 0, st, d.x.s0, d.w, g, ky0, kx0, kstep, npix,
+                       b, coef, dx);
     return CHECK_LAUNCH();
 }

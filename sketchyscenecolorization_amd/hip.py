@@ -81,6 +81,8 @@ SIGNATURES = {
     'ssc_head1_dgrad': [C.POINTER(ConvDesc), _P],
     'ssc_head1_wgrad_supported': [C.POINTER(WgradDesc)],
     'ssc_head1_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
+    'ssc_head1_dgrad_bn_backward': [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _F, _P, _P, _P, _P, _L, _P],
+    'ssc_bn_bwd_finalize': [_P, _I, _I, _L, _P, _P, _P, _P],
     'ssc_conv_narrow_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_narrow_forward': [C.POINTER(ConvDesc), _P],
     'ssc_conv_fewchan_supported': [C.POINTER(ConvDesc)],
@@ -521,7 +523,8 @@ def deconv_forward(x, f, out, coff=0, nstore=None, epi=0, bn=None):
     _run_conv(d, _bn_arg(bn, d, coff, out))
 
 
-def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=None, accumulate=False, bnbwd=None, coff=0):
+def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=None, accumulate=False, bnbwd=None, coff=0,
+               _desc_only=False):
     """Gradient of a conv w.r.t. its input channels [n_off, n_off+nn): dy View -> out[..., coff:coff+nstore] [N,Hin,Win,*].
     stride 2: the k=4 pad-1 conv (4 sub-pixel phases).  stride 1: any square kernel, ``pad`` = padding before
     (SAME: (k-1)//2, the extra element after), input size taken from ``out``."""
@@ -547,7 +550,27 @@ def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=No
     d.n_off, d.Nn, d.Nstore = n_off, nn, (nstore if nstore is not None else nn)
     d.OH, d.OW, d.ldc, d.ooff_y, d.ooff_x = OH, OW, ldc, 0, 0
     d.epi, d.accumulate = 0, int(accumulate)
+    if _desc_only:
+        return d
     _run_conv(d, bnbwd=bnbwd)
+
+
+def head1_dgrad_bn_backward(dy, w, pad, x4d, ab, stats, act, dx4d, dscale=None, doffset=None, rowb=None):
+    """Data gradient of a one-output conv head (w [k,k,512,1], stride 1) fused with the backward of the batch norm + activation
+    of its input x4d [N,H,W,512]: dx4d <- d loss / d x4d, the gradient w.r.t. act(norm(x)) is never stored (head1.hip).
+    rowb = (v [N,512], scale): a per-image term added to that gradient.  Returns False (nothing launched) when the shape is
+    not the head's: callers then run conv_dgrad + bn_act_backward."""
+    if tuple(w.shape[2:]) != (512, 1) or x4d.shape[-1] != 512 or ab is None:
+        return False
+    d = conv_dgrad(dy, w, 1, pad, dx4d, k_real=1, _desc_only=True)
+    if not lib().ssc_head1_dgrad_supported(C.byref(d)):
+        return False
+    ws = workspace()
+    check(lib().ssc_head1_dgrad_bn_backward(C.byref(d), ptr(x4d), ptr(ab), ptr(stats), act,
+                                            ptr(rowb[0]) if rowb else None, float(rowb[1]) if rowb else 0.0, ptr(dx4d),
+                                            ptr(dscale), ptr(doffset), ptr(ws), ws.numel() * 4, stream_ptr()),
+          'ssc_head1_dgrad_bn_backward')
+    return True
 
 
 def deconv_dgrad(dy, f, out, n_off=0, nn=None, accumulate=False, bnbwd=None):

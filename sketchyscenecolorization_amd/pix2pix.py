@@ -293,6 +293,9 @@ class Pix2PixGenerator(object):
         done('encoders')
 
 
+_HEAD1_FUSED = os.environ.get('SSC_HEAD1_FUSED', '0') == '1'
+
+
 class Pix2PixDiscriminator(object):
     """discriminate_pix2pix: 70x70-style PatchGAN + spectral-normed auxiliary classifier."""
 
@@ -363,11 +366,9 @@ class Pix2PixDiscriminator(object):
         gname = lambda k, what: s.grad('discriminator/layer_%d/%s' % (k, what))
         # layer 5 (Cout = 1)
         x5 = View(l[4], None, ab[4], ACT_LRELU)
-        dyv = View(dl5)
+        dy5 = View(dl5)
         if need_params:
-            hip.conv_wgrad(x5, dyv, gname(5, 'conv/filter'), 1, 1, accumulate=accumulate)
-        g4 = B.get(tag + '/gb/g4', l[4].shape)
-        hip.conv_dgrad(dyv, s['discriminator/layer_5/conv/filter'], 1, 1, g4, k_real=1)
+            hip.conv_wgrad(x5, dy5, gname(5, 'conv/filter'), 1, 1, accumulate=accumulate)
         rowb = None
         if dlogits is not None:
             dimg = B.get(tag + '/gb/dimg', (N, 512))
@@ -384,7 +385,7 @@ class Pix2PixDiscriminator(object):
             # the class head reads the spatial mean of layer 4: its gradient dimg / P4 is added to g4 by the norm backward
             # below while it reads g4 (no pass of its own over the tensor)
             rowb = (dimg, 1.0 / ctx['P4'], ctx['P4'])
-        gcur = g4
+        gcur = None         # layer 5's data gradient: taken inside layer 4's norm backward when the fused launch applies
         dgen = None
         sums = None         # partial sums of layer k's norm backward, taken by the launch that produced gcur (hip.BnBwdSums)
         for k in (4, 3, 2, 1):
@@ -396,8 +397,21 @@ class Pix2PixDiscriminator(object):
                     ds, do = tmp_s[0], tmp_s[1]
                 elif need_params:
                     ds, do = gname(k, 'scale'), gname(k, 'offset')
-                hip.bn_act_backward(_rows(l[k]), ab[k], st[k], _rows(gcur), ACT_LRELU, _rows(dx), dscale=ds, doffset=do,
-                                    pre=sums, rowb=(rowb if k == 4 else None))
+                fused = False
+                if k == 4:
+                    # d loss / d act(norm(l4)) = layer 5's data gradient + the class head's term.  SSC_HEAD1_FUSED=1 recomputes
+                    # it inside the two passes of the norm backward instead of storing it: 44 vs 55 us alone, but 0.1 ms
+                    # SLOWER per iteration in the replayed step (its vector-ALU work competes with the matrix kernels of the
+                    # chains running beside it; the separate launches are memory traffic those leave idle) -- off by default
+                    fused = _HEAD1_FUSED and hip.head1_dgrad_bn_backward(dy5, s['discriminator/layer_5/conv/filter'], 1, l[4], ab[4], st[4],
+                                                        ACT_LRELU, dx, dscale=ds, doffset=do,
+                                                        rowb=(rowb[:2] if rowb else None))
+                    if not fused:
+                        gcur = B.get(tag + '/gb/g4', l[4].shape)
+                        hip.conv_dgrad(dy5, s['discriminator/layer_5/conv/filter'], 1, 1, gcur, k_real=1)
+                if not fused:
+                    hip.bn_act_backward(_rows(l[k]), ab[k], st[k], _rows(gcur), ACT_LRELU, _rows(dx), dscale=ds, doffset=do,
+                                        pre=sums, rowb=(rowb if k == 4 else None))
                 if need_params and accumulate:
                     hip.call('ssc_axpy', gname(k, 'scale'), ds, 1.0, self.chans[k])
                     hip.call('ssc_axpy', gname(k, 'offset'), do, 1.0, self.chans[k])

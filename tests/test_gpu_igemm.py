@@ -717,3 +717,47 @@ def test_head1_patch_head(case):
     d.Cg_real, d.Nn, d.ldc, d.accumulate = ci, 1, 1, 0
     assert _wgrad_name(hip, d) == 'head1_wgrad'
     assert hip.lib().ssc_head1_wgrad_supported(ctypes.byref(d)) == 1
+
+
+@pytest.mark.parametrize('with_rowb', [True, False])
+def test_head1_dgrad_fused_with_norm_backward(with_rowb):
+    """ssc_head1_dgrad_bn_backward (the head's data gradient recomputed inside layer_4's norm backward, never stored) against
+    the two separate launches (conv_dgrad, then bn_act_backward with the class head's per-image term) and the oracle's autograd."""
+    hip = _hip()
+    n, h, k, pad, ci = 3, 23, 4, 1, 512
+    x = rnd(n, ci, h, h, seed=111).requires_grad_(True)
+    w = rnd(k, k, ci, 1, seed=112, std=0.05)
+    scale = (1.0 + 0.1 * rnd(ci, seed=113)).requires_grad_(True)
+    offset = (0.2 * rnd(ci, seed=114)).requires_grad_(True)
+    y4 = T.lrelu(T.batchnorm(x, scale, offset), 0.2)
+    out = T.conv2d_valid_pad(y4, w, 1, pad)
+    dy = rnd(*out.shape, seed=115)
+    v = rnd(n, ci, seed=116) if with_rowb else None
+    loss = (out * dy).sum()
+    if with_rowb:       # a term through the spatial mean of y4, as the class head's
+        loss = loss + (y4.mean(dim=(2, 3)) * v).sum()
+    loss.backward()
+    oh = out.shape[2]
+    xd = nhwc(x.detach()).cuda()
+    ab, st = torch.empty(2 * ci, device='cuda'), torch.empty(2 * ci, device='cuda')
+    hip.bn_stats(xd.view(-1, ci), scale.detach().cuda(), offset.detach().cuda(), ab, st)
+    dyp = torch.zeros(n, oh, oh, 4)
+    dyp[..., 0] = dy[:, 0]
+    dyv = hip.View(dyp.cuda())
+    wd = w.cuda()
+    rowb = (v.cuda(), 1.0 / (h * h)) if with_rowb else None
+    dx = torch.full((n, h, h, ci), float('nan'), device='cuda')
+    ds, do = torch.full((ci,), float('nan'), device='cuda'), torch.full((ci,), float('nan'), device='cuda')
+    assert hip.head1_dgrad_bn_backward(dyv, wd, pad, xd, ab, st, 2, dx, dscale=ds, doffset=do, rowb=rowb)
+    close(dx, nhwc(x.grad))
+    close(ds, scale.grad)
+    close(do, offset.grad)
+    # the separate launches
+    g4 = torch.empty(n, h, h, ci, device='cuda')
+    hip.conv_dgrad(dyv, wd, 1, pad, g4, k_real=1)
+    dx2, ds2, do2 = torch.empty_like(dx), torch.empty_like(ds), torch.empty_like(do)
+    hip.bn_act_backward(xd.view(-1, ci), ab, st, g4.view(-1, ci), 2, dx2.view(-1, ci), dscale=ds2, doffset=do2,
+                        rowb=(rowb + (h * h,) if rowb else None))
+    close(dx, dx2, tol=2e-5)
+    close(ds, ds2, tol=2e-5)
+    close(do, do2, tol=2e-5)
