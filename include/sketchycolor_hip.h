@@ -140,7 +140,7 @@ int ssc_conv_wgrad128(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void
  * when the launch allows it, else ssc_bn_stats reads the output back */
 int ssc_conv_forward_bn(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, const float* scale, const float* offset,
                         float eps, float* ab, float* stats, void* stream);
-/* the one-output patch head over a 512-channel tensor (discriminate_pix2pix layer_5, models_collection.py:812-817: 4x4,
+/* the one-output patch head over a 512-channel tensor (discriminate_pix2pix layer_5, models_collection.py:833-835: 4x4,
  * stride 1, 512 -> 1) as streaming kernels (head1.hip): forward (ws: 64 B per input pixel), its data gradient (the
  * hip.conv_dgrad descriptor: one-channel dy, "NK" filter, flipped taps) and its filter gradient (ws: up to 256 x 32 KB slabs).
  * ssc_conv_forward / ssc_conv_wgrad dispatch to them when _supported; SSC_HEAD1=0 keeps the general kernels. */
@@ -151,7 +151,7 @@ int ssc_head1_dgrad(const ssc_conv_desc* d, void* stream);
 int ssc_head1_wgrad_supported(const ssc_wgrad_desc* d);
 int ssc_head1_wgrad(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void* stream);
 /* the head's data gradient fused with the backward of the batch norm + activation of its input tensor x [pixels][512]
- * (layer_4: models_collection.py:806-811): the gradient w.r.t. act(norm(x)) is recomputed in both passes of the norm backward
+ * (layer_4: models_collection.py:823-830): the gradient w.r.t. act(norm(x)) is recomputed in both passes of the norm backward
  * and never stored.  d = the hip.conv_dgrad descriptor (out ignored), ab = [a; b], stats = [mean; rstd], rowb [NB][512] or
  * NULL = a per-image term (the class head's gradient through its spatial mean) added with rowb_scale; dx [pixels][512];
  * dscale / doffset [512] or NULL; ws >= (2 * 512 + 2) * 512 floats.  -1: not this shape (callers then use ssc_conv_forward +

@@ -1,4 +1,4 @@
-// head1.hip -- the PatchGAN logit conv (512 -> 1, 4x4, stride 1, pad 1; models_collection.py:812-817 discriminate_pix2pix
+// head1.hip -- the PatchGAN logit conv (512 -> 1, 4x4, stride 1, pad 1; models_collection.py:833-835 discriminate_pix2pix
 // layer_5) in its three forms.  With one output channel the GEMM forms degenerate (N = 1 forward, K = 16 for the data gradient,
 // a matrix-vector product for the filter gradient): 0.25 GFLOP against 35 MB of activations, i.e. HBM-bound streaming work.
 // All three kernels walk the PIXELS of the 512-channel tensor once, a wavefront per pixel, lane l holding channels

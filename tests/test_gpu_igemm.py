@@ -670,7 +670,7 @@ def test_wgrad128_deconv_two_sources():
 
 @pytest.mark.parametrize('case', [
     # n, h, k, pad, act of x, norm on x
-    (3, 23, 4, 1, 2, True),         # discriminator layer_5 (models_collection.py:812-817): 23 x 23 x 512 -> 22 x 22 x 1
+    (3, 23, 4, 1, 2, True),         # discriminator layer_5 (models_collection.py:833-835): 23 x 23 x 512 -> 22 x 22 x 1
     (2, 9, 3, 1, 1, False),         # 3 x 3 SAME-like, relu, no norm: 9 taps (lanes 9..15 idle)
     (1, 7, 4, 0, 0, True),          # no padding: every tap in range
 ])
