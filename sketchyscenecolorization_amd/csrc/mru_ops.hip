@@ -70,6 +70,8 @@ __device__ __forceinline__ void st4u(float* p, const float4& v) {
     *reinterpret_cast<f4u*>(p) = u;
 }
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// the multiply-high decodes are exact for rows < 2^32 and pix * W < 2^32
+static inline bool pw_ok(long rows, long P, int W) { return rows < 0xffffffffL && P * (long)(W > 0 ? W : 1) < 0xffffffffL; }
 #define PW_EACH(expr_x, expr_y, expr_z, expr_w) make_float4(expr_x, expr_y, expr_z, expr_w)
 
 static inline unsigned grid_for(long total) {
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(256) void pool2_v4_kernel(const float* __restrict__
 }
 static bool pool2_v4(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int C, float scale, int accumulate,
                      hipStream_t st) {
-    if ((C & 3) || (ldx & 3) || (ldo & 3) || !al16(x) || !al16(out)) return false;
+    if ((C & 3) || (ldx & 3) || (ldo & 3) || !al16(x) || !al16(out) || !pw_ok((long)N * (H / 2) * (W / 2), (long)(H / 2) * (W / 2), W / 2))
+        return false;
     const PwMap m = pw_map(C / 4, (long)(H / 2) * (W / 2), W / 2);
     hipLaunchKernelGGL(pool2_v4_kernel, dim3(pw_blocks((long)N * (H / 2) * (W / 2), m)), dim3(256), 0, st, x, ldx, out, ldo, N,
                        H, W, C, scale, accumulate, m);
@@ -424,7 +427,7 @@ extern "C" int ssc_concat_parts(const ssc_cat_desc* desc, void* stream) {
             base += q.C;
             ngt += cv.ng[k];
         }
-        if (ok) {
+        if (ok && pw_ok((long)d.N * d.H * d.W, (long)d.H * d.W, d.W)) {
             cv.ngt = ngt;
             const PwMap m = pw_map(ngt, (long)d.H * d.W, d.W);
             hipLaunchKernelGGL(concat_parts_v4_kernel, dim3(pw_blocks((long)d.N * d.H * d.W, m)), dim3(256), 0,
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(256) void mru_gate_merge_v4_kernel(const float* __r
 
 extern "C" int ssc_mru_gate_merge(const float* ht, const float* rg, const float* mnmx, const float* img, float* out,
                                   int N, int64_t P, int C, void* stream) {
-    if ((C & 3) == 0 && al16(ht) && al16(rg) && al16(mnmx) && al16(img) && al16(out)) {
+    if ((C & 3) == 0 && al16(ht) && al16(rg) && al16(mnmx) && al16(img) && al16(out) && pw_ok((long)N * P, 1, 1)) {
         const PwMap m = pw_map(C / 4, (long)P, 1);
         hipLaunchKernelGGL(mru_gate_merge_v4_kernel, dim3(pw_blocks((long)N * P, m)), dim3(256), 0, (hipStream_t)stream, ht, rg,
                            mnmx, img, out, N, (long)P, C, m);
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256) void mru_blend_v4_kernel(const float* __restri
 extern "C" int ssc_mru_blend(const float* ht, const float* ht_ab, int ht_lowres, const float* h2, const float* h2_ab,
                              const float* zg, const float* mnmx, float* out, int N, int H, int W, int C, void* stream) {
     if ((C & 3) == 0 && al16(ht) && al16(h2) && al16(zg) && al16(mnmx) && al16(out) && al16(h2_ab) &&
-        (ht_ab == nullptr || al16(ht_ab))) {
+        (ht_ab == nullptr || al16(ht_ab)) && pw_ok((long)N * H * W, (long)H * W, W)) {
         const PwMap m = pw_map(C / 4, (long)H * W, W);
         hipLaunchKernelGGL(mru_blend_v4_kernel, dim3(pw_blocks((long)N * H * W, m)), dim3(256), 0, (hipStream_t)stream, ht,
                            ht_ab, ht_lowres, h2, h2_ab, zg, mnmx, out, N, H, W, C, m);
@@ -815,7 +818,7 @@ extern "C" int ssc_cbn_act_backward(const float* x, const float* abn, const floa
     hipLaunchKernelGGL(cbn_bwd_fold_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, part, nsplit, N, C, sn);
     hipLaunchKernelGGL(cbn_bwd_final_kernel, dim3(((n_labels + 1) * C + 255) / 256), dim3(256), 0, st, sn, scale_m,
                        labels, N, C, n_labels, 1.f / ((float)N * (float)P), dscale_m, doffset_m, accumulate_params, kk);
-    if ((C & 3) == 0 && al16(x) && al16(abn) && al16(stats)) {
+    if ((C & 3) == 0 && al16(x) && al16(abn) && al16(stats) && pw_ok((long)N * P, 1, 1)) {
         const PwMap m = pw_map(C / 4, (long)P, 1);
         hipLaunchKernelGGL(cbn_bwd_apply_v4_kernel, dim3(pw_blocks((long)N * P, m)), dim3(256), 0, st, x, abn, stats, kk, gy,
                            ldg, act, N, (long)P, C, dx, lddx, accumulate_dx, m);
@@ -1060,7 +1063,7 @@ extern "C" int ssc_minmax_gate_backward(const float* g, const float* mnmx, const
                            part);
     }
     hipLaunchKernelGGL(gate_bwd_fold_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, part, mnmx, nsplit, N, C, coef);
-    if ((C & 3) == 0 && al16(g) && al16(mnmx) && al16(gr) && al16(dpre) && al16(coef)) {
+    if ((C & 3) == 0 && al16(g) && al16(mnmx) && al16(gr) && al16(dpre) && al16(coef) && pw_ok((long)N * P, 1, 1)) {
         const PwMap m = pw_map(C / 4, (long)P, 1);
         hipLaunchKernelGGL(gate_bwd_apply_v4_kernel, dim3(pw_blocks((long)N * P, m)), dim3(256), 0, st, g, mnmx, coef, gr, N,
                            (long)P, C, dpre, m);
@@ -1103,7 +1106,7 @@ __global__ __launch_bounds__(256) void gate_merge_bwd_v4_kernel(const float* __r
 
 extern "C" int ssc_mru_gate_merge_backward(const float* ghtp, const float* rg, const float* mnmx, const float* img,
                                            float* gr, float* gimg, int N, int64_t P, int C, void* stream) {
-    if ((C & 3) == 0 && al16(ghtp) && al16(rg) && al16(mnmx) && al16(img) && al16(gr) && al16(gimg)) {
+    if ((C & 3) == 0 && al16(ghtp) && al16(rg) && al16(mnmx) && al16(img) && al16(gr) && al16(gimg) && pw_ok((long)N * P, 1, 1)) {
         const PwMap m = pw_map(C / 4, (long)P, 1);
         hipLaunchKernelGGL(gate_merge_bwd_v4_kernel, dim3(pw_blocks((long)N * P, m)), dim3(256), 0, (hipStream_t)stream, ghtp,
                            rg, mnmx, img, gr, gimg, N, (long)P, C, m);
@@ -1176,7 +1179,7 @@ extern "C" int ssc_mru_blend_backward(const float* gout, const float* ht, const 
                                       const float* h2, const float* h2_ab, const float* zg, const float* mnmx,
                                       float* ghp, float* gh, float* gz, int N, int H, int W, int C, void* stream) {
     if ((C & 3) == 0 && al16(gout) && al16(ht) && al16(h2) && al16(h2_ab) && al16(zg) && al16(mnmx) && al16(ghp) && al16(gh) &&
-        al16(gz) && (ht_ab == nullptr || al16(ht_ab))) {
+        al16(gz) && (ht_ab == nullptr || al16(ht_ab)) && pw_ok((long)N * H * W, (long)H * W, W)) {
         const PwMap m = pw_map(C / 4, (long)H * W, W);
         hipLaunchKernelGGL(blend_bwd_v4_kernel, dim3(pw_blocks((long)N * H * W, m)), dim3(256), 0, (hipStream_t)stream, gout, ht,
                            ht_ab, ht_lowres, h2, h2_ab, zg, mnmx, ghp, gh, gz, N, H, W, C, m);
@@ -1226,7 +1229,8 @@ __global__ __launch_bounds__(256) void in2_gate_bwd_v4_kernel(float* __restrict_
 
 extern "C" int ssc_mru_in2_gate_backward(float* G, int ldG, const float* rg, const float* mnmx, const float* ht_low,
                                          float* gr, int N, int H, int W, int C, void* stream) {
-    if ((C & 3) == 0 && (ldG & 3) == 0 && al16(G) && al16(rg) && al16(mnmx) && al16(ht_low) && al16(gr)) {
+    if ((C & 3) == 0 && (ldG & 3) == 0 && al16(G) && al16(rg) && al16(mnmx) && al16(ht_low) && al16(gr) &&
+        pw_ok((long)N * H * W, (long)H * W, W)) {
         const PwMap m = pw_map(C / 4, (long)H * W, W);
         hipLaunchKernelGGL(in2_gate_bwd_v4_kernel, dim3(pw_blocks((long)N * H * W, m)), dim3(256), 0, (hipStream_t)stream, G, ldG,
                            rg, mnmx, ht_low, gr, N, H, W, C, m);
