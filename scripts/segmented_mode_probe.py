@@ -16,14 +16,19 @@ from sketchyscenecolorization_amd.trainer import GanTrainer             # noqa: 
 with socket.socket() as sock:
     sock.bind(('127.0.0.1', 0))
     port = sock.getsockname()[1]
-dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
-                        device_id=torch.device('cuda', 0))
-for seg in (False, True):
-    tr = GanTrainer(img=192, seed=0, use_graphs=True, segment_graphs=seg, process_group=dist.group.WORLD if seg else None)
+NODIST = os.environ.get('SSC_PROBE_NODIST') == '1'      # no process group at all (the collectives become no-ops): for rocprofv3
+if not NODIST:
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+for seg in ((True,) if os.environ.get('SSC_PROBE_SEG_ONLY') == '1' else (False, True)):
+    tr = GanTrainer(img=192, seed=0, use_graphs=True, segment_graphs=seg, process_group=dist.group.WORLD if (seg and not NODIST) else None)
     if seg:
         tr.reducer.world = 2
         tr.reducer.stream = torch.cuda.Stream()
-        tr.world = 1
+        tr.world = int(os.environ.get("SSC_PROBE_WORLD", "2"))     # 2: the many-tower code paths (sectioned discriminator all-reduce)
+    if seg and (NODIST or os.environ.get('SSC_PROBE_NOREDUCE') == '1'):      # the same segments, no collective call in between
+        tr.reducer.reduce_async = lambda *a: None
+        tr.reducer.wait = lambda: None
     bd, bg = synthetic_batch(32, 1, 192), synthetic_batch(32, 2, 192)
     bd, bg = tr.input_buffers('d', bd), tr.input_buffers('g', bg)
     for i in range(60):

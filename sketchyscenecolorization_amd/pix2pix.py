@@ -355,15 +355,23 @@ class Pix2PixDiscriminator(object):
         hip.call('ssc_fc_small_fwd', img, sn['wbar'], s['discriminator/fully_connected/biases'], N, 512, K, logits)
         return {'tag': tag, 'N': N, 'l': l, 'ab': ab, 'st': st, 'img': img, 'logits': logits, 'disc': l[5], 'P4': P4}
 
-    def backward(self, ctx, dl5, dlogits, sn, need_params, need_input, accumulate, after_layer=None):
+    def backward(self, ctx, dl5, dlogits, sn, need_params, need_input, accumulate, after_layer=None, stop_after=None,
+                 resume=None):
         """dl5 [N,h5,w5,4] (channel 0 real), dlogits [N,K] or None.
         need_params: write (accumulate=False) or add (True) the filter/norm gradients.
         need_input: return d loss / d discrim_targets as NHWC [N,H,W,4].
         after_layer(k): called when layer k's filter / scale / offset gradients have been launched (the trainer starts the
-        all-reduce of a finished section of the flat gradient buffer there)."""
+        all-reduce of a finished section of the flat gradient buffer there).
+        stop_after=k: return after layer k's part (its norm backward, filter gradient and the data gradient into layer k-1)
+        with the state to go on from; resume=that state: the rest of the pass.  The trainer runs the two passes of a
+        discriminator step side by side in two such halves when the gradient of layers 4, 5 and the class head goes to the
+        all-reduce between them (more than one tower)."""
         s, B = self.s, self.b
         tag, N, l, ab, st = ctx['tag'], ctx['N'], ctx['l'], ctx['ab'], ctx['st']
         gname = lambda k, what: s.grad('discriminator/layer_%d/%s' % (k, what))
+        if resume is not None:
+            return self._backward_layers(ctx, resume['layers'], resume['gcur'], resume['sums'], None, None, need_params,
+                                         need_input, accumulate, after_layer, None)
         # layer 5 (Cout = 1)
         x5 = View(l[4], None, ab[4], ACT_LRELU)
         dy5 = View(dl5)
@@ -385,10 +393,17 @@ class Pix2PixDiscriminator(object):
             # the class head reads the spatial mean of layer 4: its gradient dimg / P4 is added to g4 by the norm backward
             # below while it reads g4 (no pass of its own over the tensor)
             rowb = (dimg, 1.0 / ctx['P4'], ctx['P4'])
-        gcur = None         # layer 5's data gradient: taken inside layer 4's norm backward when the fused launch applies
+        return self._backward_layers(ctx, (4, 3, 2, 1), None, None, dy5, rowb, need_params, need_input, accumulate, after_layer,
+                                     stop_after)
+
+    def _backward_layers(self, ctx, layers, gcur, sums, dy5, rowb, need_params, need_input, accumulate, after_layer, stop_after):
+        """Layers ``layers`` of the backward pass.  gcur: gradient w.r.t. the activated output of layers[0] (None for layer 4:
+        layer 5's data gradient, taken here); sums: the norm-backward sums that came with it."""
+        s, B = self.s, self.b
+        tag, N, l, ab, st = ctx['tag'], ctx['N'], ctx['l'], ctx['ab'], ctx['st']
+        gname = lambda k, what: s.grad('discriminator/layer_%d/%s' % (k, what))
         dgen = None
-        sums = None         # partial sums of layer k's norm backward, taken by the launch that produced gcur (hip.BnBwdSums)
-        for k in (4, 3, 2, 1):
+        for k in layers:
             dx = B.get(tag + '/gb/dl%d' % k, l[k].shape)
             if k >= 2:
                 ds = do = None
@@ -439,6 +454,8 @@ class Pix2PixDiscriminator(object):
                                                (hip.BnBwdSums.rows_needed(x2d.shape[0]), 2 * x2d.shape[1])))
                 hip.conv_dgrad(dyv, w, self.strides[k], 1, gin, bnbwd=(sums.take(ACT_LRELU) if sums else None))
                 gcur = gin
+                if stop_after == k:
+                    return {'layers': tuple(j for j in layers if j < k), 'gcur': gcur, 'sums': sums}
             elif need_input:
                 dgen = B.get(tag + '/gb/dgen', (N, l[0].shape[1], l[0].shape[2], 4))
                 hip.conv_dgrad(dyv, w, 2, 1, dgen, n_off=3, nn=3, nstore=4)

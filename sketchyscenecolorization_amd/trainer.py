@@ -84,6 +84,9 @@ class GanTrainer(object):
         d = self.store.discriminator.offsets
         self._d_late = d['discriminator/layer_4/conv/filter'][0] if 'discriminator/layer_4/conv/filter' in d else None
         self._d_late_sent = False
+        self._g_merge = int(os.environ.get('SSC_G_SECTIONS', '0')) if os.environ.get('SSC_G_SECTIONS', '0') in ('1', '2') else 0
+        self._g_done = set()
+        self._seg_eager_adam = os.environ.get('SSC_SEG_EAGER_ADAM', '1') == '1'
         self._sn_pending = None
         # hipGraph replay of whole D-/G-steps (the ~550 launches of a step are host-bound otherwise):
         # a step shape is run eagerly the first time, captured the second time, replayed afterwards
@@ -234,6 +237,8 @@ class GanTrainer(object):
                 op[1].replay()
             elif op[0] == 'reduce':
                 self.reducer.reduce_async(op[1], op[2], op[3])
+            elif op[0] == 'adam':
+                self._adam_launch_now(op[1], op[2])
             else:
                 self.reducer.wait()
 
@@ -245,6 +250,16 @@ class GanTrainer(object):
         self.lr_dev[idx:idx + 1].fill_(float(lr_t))
 
     def _adam_launch(self, scope, idx):
+        if self._seg is not None and self._seg_eager_adam:
+            # segmented capture: the optimizer launch that follows the last exchange is issued eagerly at replay instead of
+            # becoming a one-kernel graph segment of its own (a graph launch costs far more than the launch it would hold)
+            self._seg_end_graph()
+            self._seg['ops'].append(('adam', scope, idx))
+            self._seg_begin_graph()
+            return
+        self._adam_launch_now(scope, idx)
+
+    def _adam_launch_now(self, scope, idx):
         lr_dev, gs = self.lr_dev[idx:idx + 1], 1.0 / self.world
         if self.optimizer == 'adam':
             hip.call('ssc_adam_tf', scope.flat, scope.grad, None, scope.adam_v, scope.numel, 0.0, lr_dev, self.beta1,
@@ -542,32 +557,60 @@ class GanTrainer(object):
         K = cr['logits'].shape[1]
         dlog_r = B.get('dlog_r', (N, K))
         hip.call('ssc_acgan_loss', cr['logits'], batch['class_id_d'], N, K, 1, 1.0, loss_d, dlog_r)
-        if self._dbwd_concurrent and self._aux_stream is not None and hip.PROFILE is None and self.world == 1:
+        if self._dbwd_concurrent and self._aux_stream is not None and hip.PROFILE is None:
             # The two backward passes of the discriminator step (real pair, fake pair) share nothing but the filters they
             # read: run them side by side -- the fake pair on the second stream into a second gradient buffer, the real
             # pair in line -- so that each chain's launch tails and partly filled rounds are filled by the other, then add
             # the buffers.  The fake pair's pass goes to the second buffer: it touches a subset of the variables (no class
-            # head), the rest of that buffer stays zero from its allocation.
+            # head), the rest of that buffer stays zero from its allocation.  (17.42 vs 17.70 ms per iteration in line.)
             sc = s.discriminator
             if getattr(sc, 'grad2', None) is None:
                 sc.grad2 = torch.zeros_like(sc.grad)
                 sc.g2 = type(sc.g)((n, sc.grad2[o:o + k].view(shp)) for n, (o, k, shp) in sc.offsets.items())
             main = torch.cuda.current_stream()
-            self._aux_stream.wait_stream(main)
-            with torch.cuda.stream(self._aux_stream):
-                sc.g, sc.g2 = sc.g2, sc.g
-                try:
-                    hip.mark('d/D backward (fake): first')
-                    self.D.backward(cf, dl5_f, None, sn, True, False, accumulate=False)
-                    hip.mark('d/D backward (fake): last')
-                finally:
+
+            def both(**kw):
+                """One stretch of the two passes side by side; returns what each returned."""
+                self._aux_stream.wait_stream(main)
+                with torch.cuda.stream(self._aux_stream):
                     sc.g, sc.g2 = sc.g2, sc.g
-            hip.mark('d/D backward (real): first')
-            self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False)
-            hip.mark('d/D backward (real): last')
-            main.wait_stream(self._aux_stream)
-            hip.join_wgrad()        # (no side-stream filter gradients in this mode; kept so that the add can never run early)
-            hip.call('ssc_axpy', sc.grad, sc.grad2, 1.0, sc.numel)
+                    try:
+                        hip.mark('d/D backward (fake): first')
+                        rf = self.D.backward(cf, dl5_f, None, sn, True, False, accumulate=False, **kw.get('fake', {}))
+                        hip.mark('d/D backward (fake): last')
+                    finally:
+                        sc.g, sc.g2 = sc.g2, sc.g
+                hip.mark('d/D backward (real): first')
+                rr = self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False, **kw.get('real', {}))
+                hip.mark('d/D backward (real): last')
+                main.wait_stream(self._aux_stream)
+                hip.join_wgrad()    # (no side-stream filter gradients in this mode; kept so that the add can never run early)
+                return rr, rf
+
+            late = self._d_late if (self.world > 1 and self.block_type == 'Pix2Pix') else None
+            if late is None:
+                both()
+                hip.call('ssc_axpy', sc.grad, sc.grad2, 1.0, sc.numel)
+            else:
+                # more than one tower: the two passes side by side in two stretches.  After the first (layer_5, the class head,
+                # layer_4 and the data gradient into layer_3) the late section of the flat buffer -- layer_4's filter (8.4 of
+                # the 11.1 MB), layer_5, the class head -- is complete in both buffers: added, and on its way to the all-reduce
+                # beside the second stretch (layers 3..1 of both passes).  A fork may not cross the end of a graph segment, so
+                # the two chains meet at that point; they are the same work on two batches and arrive together.
+                cont_r, cont_f = both(real={'stop_after': 4}, fake={'stop_after': 4})
+                hip.call('ssc_axpy', sc.grad[late:], sc.grad2[late:], 1.0, sc.numel - late)
+                if getattr(self, '_ahead_forked', False):
+                    torch.cuda.current_stream().wait_stream(self._ahead_stream)
+                self.D.finish_sn_backward(sn)
+                hip.call('ssc_l2_reg', s['discriminator/fully_connected/weights'],
+                         s['discriminator/fully_connected/weights'].numel(), 1e-6, loss_d,
+                         s.grad('discriminator/fully_connected/weights'))
+                self._allreduce_async(sc.grad, late, sc.numel)
+                self._d_late_sent = True
+                both(real={'resume': cont_r}, fake={'resume': cont_f})
+                hip.call('ssc_axpy', sc.grad, sc.grad2, 1.0, late)
+                self.last = {'gctx': gctx, 'cr': cr, 'cf': cf}
+                return loss_d
         else:
             self.D.backward(cr, dl5_r, dlog_r, sn, True, False, accumulate=False)
             if self.world > 1 and self.block_type == 'Pix2Pix' and self._d_late is not None:
@@ -711,6 +754,20 @@ class GanTrainer(object):
                      s['generator/fully_connected/weights'].numel(), 1e-6, self.loss[0:1],
                      s.grad('generator/fully_connected/weights'))
         lo, hi = self._g_sections[name]
+        if self._g_merge:
+            # fewer, larger exchanges (SSC_G_SECTIONS=2 | 1): every exchange ends a graph segment, and the side chains of the
+            # backward pass (held filter gradients, the caption branch) cannot run across a segment end.  2: decoders + text as one
+            # exchange when both are final, all encoders at the end; 1: one exchange at the end.
+            self._g_done.add(name)
+            sec = self._g_sections
+            if self._g_merge == 2 and {'decoders', 'text'} <= self._g_done and 'dt' not in self._g_done:
+                self._g_done.add('dt')
+                self._allreduce_async(sc.grad, sec['text'][0], sec['decoders'][1])
+            if name == 'encoders':
+                hi = sec['text'][0] if self._g_merge == 2 else sec['decoders'][1]
+                self._allreduce_async(sc.grad, 0, hi)
+                self._g_done = set()
+            return
         self._allreduce_async(sc.grad, lo, hi)
 
     def train_iteration(self, batch_d, batch_g, counter=0, next_batch_d=None):
