@@ -679,6 +679,7 @@ class GanTrainer(object):
             else:
                 self.store['discriminator/fully_connected/u'].copy_(self._sn_pending['u_new'])
             self._sn_pending = None
+            hip.LAUNCHES += 1       # the assign may be a torch copy: the graph segment that holds it is not empty (_seg_end_graph)
 
     def g_gradients(self, batch, use_ahead=False, real=None):
         """loss_g and d loss_g / d generator variables; section all-reduces start as they finish."""
