@@ -208,6 +208,39 @@ def test_full_size_overlapped_trainer_equals_inline_trainer_bitwise():
         assert torch.equal(a.store[n], b.store[n]), n
 
 
+def test_discriminator_backward_in_two_stretches_is_the_same_pass():
+    """Pix2PixDiscriminator.backward(stop_after=4) + backward(resume=...) -- the form the trainer uses with more than one tower,
+    where the gradient of layer_4, layer_5 and the class head goes to the all-reduce between the stretches -- launches exactly
+    the kernels of the one-call pass: every gradient and the gradient w.r.t. the generated image bitwise equal."""
+    p, tr, b, dev = make(2, 192)
+    from sketchyscenecolorization_amd import hip
+    xd = torch.zeros(2, 192, 192, 8, device='cuda')
+    hip.nchw_to_nhwc(dev['sketches'], xd, 0)
+    hip.nchw_to_nhwc(dev['images_d'], xd, 3)
+    outs = []
+    for two in (False, True):
+        sn = tr.D.prepare_sn()
+        c = tr.D.forward(xd, sn, 'dr')
+        dl5 = torch.zeros_like(c['disc'])
+        dl5[..., 0] = torch.randn(c['disc'].shape[:3], device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))
+        dlog = torch.randn(c['logits'].shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(6))
+        tr.store.discriminator.grad.fill_(float('nan'))
+        if two:
+            cont = tr.D.backward(c, dl5, dlog, sn, True, True, accumulate=False, stop_after=4)
+            assert cont['layers'] == (3, 2, 1)
+            dgen = tr.D.backward(c, dl5, dlog, sn, True, True, accumulate=False, resume=cont)
+        else:
+            dgen = tr.D.backward(c, dl5, dlog, sn, True, True, accumulate=False)
+        torch.cuda.synchronize()
+        conv = {n: tr.store.discriminator.g[n].clone() for n in tr.store.discriminator.g
+                if 'fully_connected' not in n}      # (the class head's gradient is finished by finish_sn_backward, not here)
+        outs.append((dgen.clone(), conv))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for n in outs[0][1]:
+        assert not torch.isnan(outs[0][1][n]).any(), n
+        assert torch.equal(outs[0][1][n], outs[1][1][n]), n
+
+
 def test_segmented_graphs_with_rccl_world1_match_eager():
     """The multi-GPU step protocol on one GPU: a 1-rank RCCL process group, steps captured as graph SEGMENTS with the
     all-reduces issued eagerly on the side stream between them (what world > 1 uses).  Must equal the eager trainer.
