@@ -17,6 +17,7 @@ import json
 import os
 
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')     # kernel arguments in device memory (measured: 1570 vs 1540 images/s with 0)
+os.environ.setdefault('SSC_KEEP_GRAPHS', '1')           # captured graphs stay readable: kernel launches per step are counted from them
 import sys
 import time
 
@@ -66,6 +67,21 @@ def cpu_baseline(img, n=4):
                       % (nb, img, img, best, n, dt),
             'images_per_sec_by_threads': {str(th): r[0] for th, r in by_threads.items()},
             'host_cores': all_cores}
+
+
+def _graph_launches(graphs):
+    """Kernel nodes over the hipGraphs one step replays (a segmented step is a list of ops)."""
+    from sketchyscenecolorization_amd import hip
+    tot = 0
+    for g in graphs:
+        if isinstance(g, list):
+            part = [hip.graph_kernel_nodes(op[1]) for op in g if op[0] == 'graph']
+        else:
+            part = [hip.graph_kernel_nodes(g)]
+        if any(v is None for v in part):
+            return None
+        tot += sum(part)
+    return tot
 
 
 def run_forward_workload(args):
@@ -132,6 +148,12 @@ def run_forward_workload(args):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if wl == 'bg768_train':
+        launches = _graph_launches(list(tr._graphs.values()))
+    elif wl == 'bg768':
+        launches = None if args.no_graphs else _graph_launches([graph])
+    else:
+        launches = _graph_launches(list(tower._graphs.values()))
     prof = []
     hip.PROFILE = prof
     step()
@@ -151,6 +173,7 @@ def run_forward_workload(args):
            'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
            'config': {'workload': '%s, %dx%d, batch %d' % (name, img, img, n),
                       'launch': 'eager' if args.no_graphs else 'hipGraph replay'},
+           'launches_per_step': launches,
            'step_tflops_executed': sum(v[0] for v in agg.values()) / (ms * 1e-3) / 1e12,
            'step_frac_of_fp32_peak': sum(v[0] for v in agg.values()) / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
            'step_tflops_as_written': flop_img * n / (ms * 1e-3) / 1e12,
@@ -231,7 +254,8 @@ def secondary_workloads(args):
             out[name] = {'workload': j['config']['workload'], 'images_per_sec': j['value'], 'ms': j['ms_per_step'],
                          'frac_executed': j.get('step_frac_of_fp32_peak'),
                          'frac_as_written': j.get('step_frac_of_fp32_peak_as_written'),
-                         'steps': j['steps'], 'launch': j['config'].get('launch'), 'wall_s': time.time() - t0}
+                         'steps': j['steps'], 'launch': j['config'].get('launch'),
+                         'launches_per_step': j.get('launches_per_step'), 'wall_s': time.time() - t0}
         except Exception as e:     # noqa: BLE001 -- a secondary workload must never cost the headline line
             out[name] = {'error': repr(e)[:300]}
     return out
@@ -270,17 +294,13 @@ def self_launch(args, argv):
 
 
 def _csrc_hash():
-    """sha256 over the kernel sources + the C-ABI header: PMC figures are only attached to a bench line measured on the
-    same kernels (profiles/*.json carry the hash of the tree they were collected on)."""
-    import hashlib
-    h = hashlib.sha256()
-    base = os.path.join(ROOT, 'sketchyscenecolorization_amd', 'csrc')
-    for f in sorted(os.listdir(base)) + [os.path.join(ROOT, 'include', 'sketchycolor_hip.h')]:
-        fp = f if os.path.isabs(f) else os.path.join(base, f)
-        if fp.endswith(('.hip', '.h')):
-            with open(fp, 'rb') as fh:
-                h.update(os.path.basename(fp).encode() + b'\0' + fh.read())
-    return h.hexdigest()[:16]
+    """Hash of the kernel sources + the C-ABI header, as compiled into the library that is RUNNING (hip.lib() has already
+    refused a binary whose hash is not the tree's): PMC figures are only attached to a bench line measured on the same kernels
+    (profiles/*.json carry the hash of the binary they were collected on)."""
+    from sketchyscenecolorization_amd import build, hip
+    have, tree = hip.build_hash(), build.tree_hash()
+    assert have == tree, (have, tree)
+    return have
 
 
 def run_stub_cpu(args, rank, world):
@@ -448,6 +468,8 @@ def main():
         prof_steps = args.prof_steps
     hip.PROFILE = None
     loss_g, loss_d = [float(v) for v in tr.loss.tolist()]
+    # kernel launches of one iteration: the kernel nodes of the graphs a train_iteration replays (one D-step, one G-step)
+    launches_per_step = None if args.no_graphs else _graph_launches(list(tr._graphs.values()))
     hip.check_sk('bench.py timed region')       # a conv launch that stored a partial sum (hand-off timeout) fails the run
     gen_fb = None
     if args.block_type == 'Pix2Pix' and not args.no_graphs and world == 1:
@@ -475,7 +497,7 @@ def main():
         flops_step = (4 * f_g + 8 * f_d) * args.batch       # per GPU, as-written reference FLOPs
         out = {'metric': 'train images/sec (192x192, gen+disc fwd+bwd)', 'value': value, 'unit': 'images/sec',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'preheat_steps': preheat_steps,
-               'ms_per_step': ms,
+               'ms_per_step': ms, 'launches_per_step': launches_per_step,
                'ms_per_step_median': step_ms[len(step_ms) // 2] if step_ms else None,
                'ms_per_step_min_max': [step_ms[0], step_ms[-1]] if step_ms else None,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32',
@@ -545,13 +567,29 @@ def main():
                                                   'flop_per_launch': v[0] / v[2],
                                                   'algorithmic_bytes_per_launch': v[3] / v[2]}
                                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+        # The quantities BASELINE.json's target is stated on go INSIDE `roofline` (the driver's record keeps that object whole
+        # and only the names of other extra keys): the train step's and the generator forward + backward graph's fraction of
+        # the fp32-MFMA peak on executed FLOPs at the configured batch, and one line per secondary workload.
+        rl = out.setdefault('roofline', {'bound': 'mfma', 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s'})
+        tg = rl['targets'] = {'step_frac_of_fp32_peak_executed': out.get('step_frac_of_fp32_peak'),
+                              'step_ms': ms, 'step_images_per_sec': value, 'batch_per_gpu': args.batch}
         if gen_fb is not None:
             out['generator_fwd_bwd'] = gen_fb
+            tg['generator_fwd_bwd_frac_executed'] = gen_fb['frac_of_fp32_mfma_peak_executed']
+            tg['generator_fwd_bwd_ms'] = gen_fb['ms']
+            tg['generator_fwd_bwd_tflops_executed'] = gen_fb['tflops_executed']
+            if 'by_batch' in gen_fb:
+                tg['generator_fwd_bwd_frac_executed_by_batch'] = {
+                    k: v['frac_of_fp32_mfma_peak_executed'] for k, v in gen_fb['by_batch'].items()}
         if (not args.no_secondary and world == 1 and not under_launcher and args.block_type == 'Pix2Pix' and
                 args.batch == 32 and args.img == 192 and not args.no_graphs):
             del tr
             torch.cuda.empty_cache()
             out['secondary'] = secondary_workloads(args)
+            rl['secondary'] = {k: ({'images_per_sec': v['images_per_sec'], 'ms': v['ms'], 'frac_executed': v['frac_executed'],
+                                    'launches_per_step': v.get('launches_per_step')}
+                                   if 'error' not in v else {'error': v['error'][:120]})
+                               for k, v in out['secondary'].items()}
         if not args.no_cpu_baseline and world == 1 and args.block_type == 'Pix2Pix':
             out['cpu_baseline'] = cpu_baseline(args.img)
         print(json.dumps(out), flush=True)

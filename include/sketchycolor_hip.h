@@ -125,6 +125,9 @@ typedef struct ssc_wgrad_desc {
 
 /* library / device info */
 int ssc_version(void);
+/* the 16-hex-digit sha256 prefix of the sources (csrc + this header) the binary was built from: callers compare it with the hash
+ * of the tree they run from (sketchyscenecolorization_amd/build.py tree_hash) and refuse a stale binary */
+int ssc_build_hash(char* buf, int len);
 int ssc_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
 
 /* implicit GEMM (igemm.hip).  ws: split-K slab workspace (may be NULL). */

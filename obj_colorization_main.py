@@ -6,7 +6,8 @@ choices, the same run directory ``outputs/<UTC Y-m-d-H-M-S>/{log,snapshot,valida
 inference_results}``, ``log/param_<first iteration>.json`` and the restart-after-NaN loop.
 
     python obj_colorization_main.py --mode train --block_type Pix2Pix --batch_size 32 --max_iter 1000
-    python -m torch.distributed.run --nproc-per-node 8 obj_colorization_main.py --mode train -bt Pix2Pix -gpu 8
+    python obj_colorization_main.py --mode train -bt Pix2Pix -gpu 8      # starts itself as 8 ranks, one per GPU
+    python -m torch.distributed.run --nproc-per-node 8 obj_colorization_main.py --mode train -bt Pix2Pix -gpu 8   # same
     python obj_colorization_main.py --mode inference -rf <timestamp> --infer_name car.png \
         --instruction 'the car is yellow with blue window'
 """
@@ -131,6 +132,13 @@ def main(argv=None):
         if args.mode == 'inference':
             assert args.infer_name != '' and args.instruction != '', '--infer_name and --instruction are required'
         return evaluate(args.mode, params)
+    # -gpu N without a launcher: the towers are processes here, so the command starts itself once per GPU
+    from sketchyscenecolorization_amd.dist_utils import launch_towers
+    rc = launch_towers(args.num_gpu)
+    if rc is not None:
+        if rc != 0:
+            raise SystemExit(rc)
+        return
     status, stamp = start_or_resume_training(params)
     while status == -1:         # a NaN loss ends train() with -1: continue from the last snapshot
         print('Training ended with status -1. Restarting..')

@@ -196,7 +196,7 @@ class BGTrainer(object):
                 impl()
                 return self._gctx
             try:
-                g = torch.cuda.CUDAGraph()
+                g = hip.new_graph()
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     impl()
             except Exception as e:      # never lose a training run to graph capture

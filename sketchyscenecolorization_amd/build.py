@@ -9,6 +9,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libsketchycolor_hip.so')
 EXTRA_FLAGS = {'igemm.hip': ['-Xclang', '-target-feature', '-Xclang', '-load-store-opt']} if os.environ.get('SSC_NO_LSOPT') == '1' else {}     # per-source compiler flags
+LAST_BUILD = None       # 'rebuilt' | 'reused' after build_library()
 SOURCES = ['igemm.hip', 'wgrad128.hip', 'narrow.hip', 'head1.hip', 'fewchan.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip', 'mru_ops.hip']
 
 
@@ -19,21 +20,59 @@ def _hipcc():
     return 'hipcc'
 
 
+HASH_MARKER = b'SSC_CSRC_HASH='
+
+
+def tree_hash(csrc=None, header=None):
+    """sha256 (16 hex digits) over the kernel sources + the C-ABI header.  It is compiled INTO the library
+    (-DSSC_CSRC_HASH, exported as ssc_build_hash) so that a binary can be tied to the sources it was built from: hip.lib()
+    refuses a library whose hash is not the tree's, bench.py / scripts/pmc_summary.py stamp their output with it."""
+    import hashlib
+    csrc = csrc or CSRC
+    header = header or os.path.join(ROOT, 'include', 'sketchycolor_hip.h')
+    h = hashlib.sha256()
+    for fp in [os.path.join(csrc, f) for f in sorted(os.listdir(csrc))] + [header]:
+        if fp.endswith(('.hip', '.h')):
+            with open(fp, 'rb') as fh:
+                h.update(os.path.basename(fp).encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
+def library_hash(path=None):
+    """The source hash a built library carries (read from the file, no dlopen); None when it has none."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return None
+    with open(path, 'rb') as fh:
+        blob = fh.read()
+    i = blob.find(HASH_MARKER)
+    if i < 0:
+        return None
+    return blob[i + len(HASH_MARKER):i + len(HASH_MARKER) + 16].decode('ascii', 'replace')
+
+
 def is_stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'igemm_util.h'), os.path.join(ROOT, 'include', 'sketchycolor_hip.h')]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    """The library is rebuilt when it is missing or was built from other sources (by content hash, not by mtime: a snapshot
+    copy or a checkout changes every mtime, and a stale binary newer than its sources would pass an mtime test)."""
+    return library_hash() != tree_hash()
 
 
 def build_library(force=False, verbose=True):
     """Compile every HIP source for gfx950 and link the C-ABI shared library."""
+    global LAST_BUILD
     if not force and not is_stale():
+        LAST_BUILD = 'reused'
         return LIB_PATH
+    LAST_BUILD = 'rebuilt'
     os.makedirs(LIB_DIR, exist_ok=True)
+    th = tree_hash()
+    import hashlib
     objs = []
     procs = []
+    hdrs = b''
+    for hp in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(ROOT, 'include', 'sketchycolor_hip.h')]:
+        with open(hp, 'rb') as fh:
+            hdrs += fh.read()
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         if not os.path.exists(src):
@@ -41,14 +80,22 @@ def build_library(force=False, verbose=True):
         obj = os.path.join(LIB_DIR, s.replace('.hip', '.o'))
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'),
                '-Wno-unused-value', '-Wno-unused-function'] + os.environ.get('SSC_EXTRA_HIPCC_FLAGS', '').split() + \
-              EXTRA_FLAGS.get(s, []) + ['-c', src, '-o', obj]
+              EXTRA_FLAGS.get(s, []) + (['-DSSC_CSRC_HASH="%s"' % th] if s == 'elementwise.hip' else []) + ['-c', src, '-o', obj]
+        objs.append(obj)
+        # an object is reused when its source, the shared headers and its command line are what it was compiled from
+        with open(src, 'rb') as fh:
+            key = hashlib.sha256(fh.read() + b'\0' + hdrs + b'\0' + ' '.join(cmd).encode()).hexdigest()
+        kf = obj + '.key'
+        if not force and os.path.exists(obj) and os.path.exists(kf) and open(kf).read() == key:
+            continue
         if verbose:
             print(' '.join(cmd), flush=True)
-        procs.append((subprocess.Popen(cmd), cmd))
-        objs.append(obj)
-    for p, cmd in procs:
+        procs.append((subprocess.Popen(cmd), cmd, kf, key))
+    for p, cmd, kf, key in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
+        with open(kf, 'w') as fh:
+            fh.write(key)
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
     if verbose:
         print(' '.join(cmd), flush=True)

@@ -780,7 +780,22 @@ extern "C" int ssc_residual_merge(const float* x1, const float* ab1, const float
 }
 
 // ------------------------------------------------------------------ info
-extern "C" int ssc_version(void) { return 100; }
+extern "C" int ssc_version(void) { return 101; }
+
+// The sha256 prefix of the kernel sources + C-ABI header this binary was compiled from (build.py passes it; a build made by
+// hand without it says so).  The marker string lets build.py read it from the file without loading the library.
+#ifndef SSC_CSRC_HASH
+#define SSC_CSRC_HASH "unstamped-build."
+#endif
+extern "C" __attribute__((used, visibility("default"))) const char ssc_build_hash_marker[] = "SSC_CSRC_HASH=" SSC_CSRC_HASH;
+
+extern "C" int ssc_build_hash(char* buf, int len) {
+    const char* h = ssc_build_hash_marker + 14;
+    int i = 0;
+    for (; i < len - 1 && h[i]; ++i) buf[i] = h[i];
+    if (len > 0) buf[i] = 0;
+    return 0;
+}
 
 extern "C" int ssc_device_info(int* cu_count, int* wave_size, char* arch, int arch_len) {
     int dev = 0;

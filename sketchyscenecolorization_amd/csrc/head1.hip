@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sketchycolor_hip.h"
+#include "host_util.h"
 
 #define CHECK_LAUNCH() ((int)hipGetLastError())
 
@@ -535,12 +536,11 @@ extern "C" int ssc_head1_wgrad(const ssc_wgrad_desc* dp, float* ws, int64_t ws_b
     if (ws == nullptr || (int64_t)blocks * MAXT * HC * 4 > ws_bytes) return -2;
     const H1Geo g = make_geo(d.NB, d.g.H, d.g.W, d.PH, d.PW, d.d.C0, d.TH, d.TW, d.ioff_y, d.ioff_x, &d.g);
     hipStream_t st = (hipStream_t)stream;
-    static bool attr = false;
+    static unsigned long long attr_done = 0;
     const size_t lds = (size_t)3 * MAXT * HC * sizeof(float);
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head1_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr = true;
+    {
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&head1_wgrad_kernel), (int)lds, &attr_done);
+        if (arc != 0) return arc;
     }
     hipLaunchKernelGGL(head1_wgrad_kernel, dim3(blocks), dim3(256), lds, st, d.g.s0, d.g.ab0, d.d.s0, g, npix, ws);
     ssc_launch_wgrad_reduce(ws, (long)d.TH * d.TW * HC, blocks, d.out, d.accumulate, st);     // slabs are [TH*TW][HC]

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include "sketchycolor_hip.h"
 #include "igemm_util.h"
+#include "host_util.h"
 
 // wgrad128.hip
 extern "C" int ssc_conv_wgrad128_supported(const ssc_wgrad_desc* dp);
@@ -1465,16 +1466,7 @@ template __global__ void conv_wgrad_kernel<1, 4, 2, 1, false, true, true>(const 
 // ---------------------------------------------------------------------------------------------
 // host launchers (C ABI)
 // ---------------------------------------------------------------------------------------------
-static int g_num_cu = 0;
-static int num_cu() {
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return g_num_cu;
-}
+static int num_cu() { return ssc_num_cu(); }
 
 // Tile configurations.  `res` = workgroups resident per CU (LDS-limited), `penalty` = relative cost of the
 // staging instructions per MFMA (fp32 MFMA does not overlap VALU on gfx950).
@@ -1593,11 +1585,10 @@ static int launch_fwd_v(const ssc_conv_desc& d, int splitk, float* ws, hipStream
     const long mt = (M + BM - 1) / BM;
     const int nt = (d.Nstore + BN - 1) / BN;
     const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    static unsigned long long attr_done = 0;
+    {
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB>), (int)lds, &attr_done);
+        if (arc != 0) return arc;
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
     hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, SM, SN, BMODE, VECB>), grid, dim3(256), lds, st, d, mg, ws,
@@ -1695,11 +1686,10 @@ static int launch_fwd_ut(const ssc_conv_desc& d, int splitk, float* ws, hipStrea
     const long mt = (M + BM - 1) / BM;
     const int nt = (d.Nstore + BN - 1) / BN;
     const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    static unsigned long long attr_done = 0;
+    {
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_ut_kernel<WM, WN, SM, SN, BMODE, PLAIN, KM>), (int)lds, &attr_done);
+        if (arc != 0) return arc;
     }
     // whole tiles + K slices combined inside the launch, as the planner laid them out (plan_launch / cu_timeline)
     if (splitk == 1 && ws != nullptr && d.sk_flags != nullptr && g_launch_ts_s > 1) {
@@ -1966,11 +1956,10 @@ static int launch_wgrad_v(const ssc_wgrad_desc& d, int splitk, float* ws, hipStr
     const int mt = (Mtot + BM - 1) / BM;
     const int nt = (d.Nn + BN - 1) / BN;
     const long out_count = (long)d.TH * d.TW * d.Cg_real * d.ldc;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<WM, WN, SM, SN, GPLAIN, DPLAIN, DDMA>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    static unsigned long long attr_done = 0;
+    {
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_kernel<WM, WN, SM, SN, GPLAIN, DPLAIN, DDMA>), (int)lds, &attr_done);
+        if (arc != 0) return arc;
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)splitk);
     // SSC_WG_XCD=1: whole K slices per XCD.  Measured (scripts/wg_xcd_ab.sh): FETCH_SIZE of the encoder_3 filter gradient 113 ->

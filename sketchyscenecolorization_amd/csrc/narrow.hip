@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "sketchycolor_hip.h"
+#include "host_util.h"
 
 #define NT 16            // lattice tile edge (16x16 = 256 lanes)
 #define NCH 32           // channels per chunk
@@ -452,23 +453,19 @@ static int launch_narrow(const ssc_conv_desc& d, hipStream_t st, float* ws, int6
     grid.z *= csplit;
 #define NARROW_LAUNCH(NO)                                                                                          \
     {                                                                                                              \
-        static bool attr = false;                                                                                  \
-        if (!attr) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_fwd_kernel<MODE, NO, BIG>),            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                      \
-            attr = true;                                                                                           \
-        }                                                                                                          \
+        static unsigned long long attr_done = 0;                                                                   \
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&narrow_fwd_kernel<MODE, NO, BIG>), 96 * 1024, \
+                                        &attr_done);                                                               \
+        if (arc != 0) return arc;                                                                                  \
         hipLaunchKernelGGL((narrow_fwd_kernel<MODE, NO, BIG>), grid, dim3(256), lds, st, d, ws, out_count, csplit); \
     }
 #define NARROW_SC_LAUNCH(NO) hipLaunchKernelGGL((narrow_sc_kernel<1, NO, 0>), grid, dim3(256), lds, st, d, ws, out_count, csplit);
 #define NARROW_SC7_LAUNCH(NO)                                                                                      \
     {                                                                                                              \
-        static bool attr7 = false;                                                                                 \
-        if (!attr7) {                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_sc_kernel<0, NO, 7>),                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                      \
-            attr7 = true;                                                                                          \
-        }                                                                                                          \
+        static unsigned long long attr7_done = 0;                                                                  \
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&narrow_sc_kernel<0, NO, 7>), 96 * 1024,     \
+                                        &attr7_done);                                                              \
+        if (arc != 0) return arc;                                                                                  \
         hipLaunchKernelGGL((narrow_sc_kernel<0, NO, 7>), grid, dim3(256), lds, st, d, ws, out_count, csplit);      \
     }
     if (lds > 96 * 1024) return -5;

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include "sketchycolor_hip.h"
 #include "igemm_util.h"
+#include "host_util.h"
 #include <type_traits>
 
 #ifndef SSC_WG128_BK
@@ -488,16 +489,7 @@ extern "C" int ssc_conv_wgrad128_supported(const ssc_wgrad_desc* dp) {
     return 1;
 }
 
-static int wg128_num_cu() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                ? prop.multiProcessorCount : 256;
-    }
-    return n;
-}
+static int wg128_num_cu() { return ssc_num_cu(); }
 
 // K slices: every workgroup carries the same number of K-tiles; two workgroups fit a CU (LDS).  Cost of a layout = K-tiles on
 // the busiest CU (+ a fixed cost per workgroup: table, first tiles, 64 accumulator registers to store) + the slab traffic.
@@ -545,11 +537,10 @@ static int launch_wg128(const ssc_wgrad_desc& d, int splitk, float* ws, hipStrea
     const long Mtot = (long)d.TH * d.TW * Cg;
     const long P = (long)d.NB * d.PH * d.PW;
     const Magics mg = make_magics((unsigned)Cg, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW, (unsigned long)P);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad128_kernel<GPLAIN, DMODE, TPT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    static unsigned long long attr_done = 0;
+    {
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_wgrad128_kernel<GPLAIN, DMODE, TPT>), (int)lds, &attr_done);
+        if (arc != 0) return arc;
     }
     const long out_count = Mtot * d.ldc;
     dim3 grid((unsigned)((Mtot + TB - 1) / TB), (unsigned)((d.Nn + TB - 1) / TB), (unsigned)splitk);

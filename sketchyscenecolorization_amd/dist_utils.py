@@ -20,6 +20,33 @@ def init_distributed():
     return dist
 
 
+def launch_towers(num_gpu, argv=None):
+    """``--num_gpu N`` without a launcher: the reference loops its N towers inside one process (obj_colorization_main.py:
+    189-190, graph_single.py:146-166); here a tower is a process, so the command re-executes itself as N ranks under
+    torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and returns their exit code.  Returns None when there is
+    nothing to do: one tower, or already inside a launcher (WORLD_SIZE set).  ``argv``: [script, args...], default sys.argv."""
+    import subprocess
+    import sys
+    if num_gpu <= 1 or 'WORLD_SIZE' in os.environ:
+        return None
+    argv = list(sys.argv if argv is None else argv)
+    if os.environ.get('SSC_DIST_ONE_DEVICE') != '1':
+        n_dev = torch.cuda.device_count()
+        if n_dev < num_gpu:
+            raise SystemExit('--num_gpu %d but only %d GPU(s) visible' % (num_gpu, n_dev))
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(num_gpu),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(argv[0])] + argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC (RCCL across processes)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    print('num_gpu=%d: starting %d ranks (one per GPU): %s' % (num_gpu, num_gpu, ' '.join(cmd)), flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def tower_slice(global_n, batch_size, rank, world, batch_portion=None):
     """Sample range [lo, hi) of tower ``rank`` (input_pipeline.split_inputs semantics)."""
     portion = [1] * world if batch_portion is None else list(batch_portion)

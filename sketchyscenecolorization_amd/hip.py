@@ -55,9 +55,36 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('libsketchycolor_hip.so is missing (%s): run `python -c "import __graft_entry__ as g; '
                                'g.build()"` or `python -m sketchyscenecolorization_amd.build`' % LIB_PATH)
-        _lib = C.CDLL(LIB_PATH)
-        _declare(_lib)
+        l = C.CDLL(LIB_PATH)
+        _declare(l)
+        check_build_hash(l)
+        _lib = l
     return _lib
+
+
+def build_hash(l=None):
+    """The source hash compiled into the loaded library (ssc_build_hash)."""
+    buf = C.create_string_buffer(32)
+    (l if l is not None else lib()).ssc_build_hash(buf, 32)
+    return buf.value.decode()
+
+
+def check_build_hash(l=None, tree=None):
+    """Raise when the library was built from other kernel sources than the tree it is used from (a stale binary would run --
+    and be profiled, benchmarked, tested -- under the name of sources it does not contain).  SSC_ALLOW_STALE_LIB=1 turns the
+    error into a warning (A/B runs of an older build against new host code)."""
+    from . import build
+    have = build_hash(l)
+    want = tree if tree is not None else build.tree_hash()
+    if have != want:
+        msg = ('%s was built from kernel sources %s, the tree is %s: rebuild (python -m sketchyscenecolorization_amd.build)'
+               % (LIB_PATH, have, want))
+        if os.environ.get('SSC_ALLOW_STALE_LIB') == '1':
+            import warnings
+            warnings.warn(msg)
+        else:
+            raise RuntimeError(msg)
+    return have
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -65,6 +92,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 # name -> argtypes (restype is always int); mirrors include/sketchycolor_hip.h
 SIGNATURES = {
     'ssc_version': [],
+    'ssc_build_hash': [C.c_char_p, _I],
     'ssc_device_info': [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, _I],
     'ssc_conv_forward': [C.POINTER(ConvDesc), _P, _L, _P],
     'ssc_conv_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
@@ -267,8 +295,10 @@ SK_FLAG_WORDS = 8192
 _SK_MAX_STREAMS = 32
 _sk_flags = {}
 _sk_pool = {}           # device -> [_SK_MAX_STREAMS, SK_FLAG_WORDS] int32: every stream's flag array is a row of it
-_sk_tags = {}           # sk_tag -> copy of the descriptor of that launch (bounded: tags wrap at _SK_TAG_RING)
-_SK_TAG_RING = 1 << 14
+_sk_tags = {}           # sk_tag -> copy of the descriptor of that launch
+_sk_eager = []          # tags of launches issued eagerly, oldest first: only the last _SK_TAG_RING of them are remembered
+_sk_next = [0]          # tags only grow (31 bits: the flag word is 0x80000000 | tag), so a tag frozen into a captured graph
+_SK_TAG_RING = 1 << 14  # never comes to name a later launch; the descriptors of captured launches are kept for good
 _sk_configured = False
 
 
@@ -307,9 +337,16 @@ def sk_flags():
 
 def _sk_tag(d):
     """Tag a launch that may split tiles inside the kernel and remember its descriptor for the error message."""
-    tag = (LAUNCHES % _SK_TAG_RING) + 1
+    _sk_next[0] = (_sk_next[0] % 0x7ffffffe) + 1
+    tag = _sk_next[0]
     d.sk_tag = tag
     _sk_tags[tag] = ConvDesc.from_buffer_copy(d)
+    if not torch.cuda.is_current_stream_capturing():
+        _sk_eager.append(tag)
+        if len(_sk_eager) > _SK_TAG_RING:
+            for old in _sk_eager[:_SK_TAG_RING // 2]:
+                _sk_tags.pop(old, None)
+            del _sk_eager[:_SK_TAG_RING // 2]
 
 
 def sk_timeouts():
@@ -330,10 +367,12 @@ def check_sk(where=''):
         words = pool[:, -1]
         if bool((words != 0).any().item()):
             bad += [int(w) & 0x7fffffff for w in words.cpu().tolist() if w != 0]
+            torch.cuda.synchronize()        # launches still running on the other streams wait on flags of this pool
             pool.zero_()
     for f in _sk_flags.values():
         if f.dim() == 1 and f._base is None and int(f[-1].item()) != 0:
             bad.append(int(f[-1].item()) & 0x7fffffff)
+            torch.cuda.synchronize()
             f.zero_()
     if not bad:
         return
@@ -743,6 +782,34 @@ def decode_paired_u8(img_u8, sk_u8, size, noise=None, img_out=None, sk_out=None,
     check(lib().ssc_decode_paired_u8(ptr(img_u8), ptr(sk_u8), ptr(skf), n, r, size, ptr(noise), ptr(img_out),
                                      ptr(sk_out), ptr(mnmx), stream_ptr()), 'decode_paired_u8')
     return img_out, sk_out
+
+
+def new_graph():
+    """A hipGraph object for a step capture.  SSC_KEEP_GRAPHS=1 keeps the captured graph beside its executable so that
+    graph_kernel_nodes() can count what a replay launches (bench.py reports it)."""
+    return torch.cuda.CUDAGraph(keep_graph=True) if os.environ.get('SSC_KEEP_GRAPHS') == '1' else torch.cuda.CUDAGraph()
+
+
+def graph_kernel_nodes(g):
+    """Number of kernel nodes of a captured torch.cuda.CUDAGraph (needs SSC_KEEP_GRAPHS=1 at capture); None when the graph was
+    not kept."""
+    try:
+        raw = g.raw_cuda_graph()
+    except Exception:       # noqa: BLE001 -- not kept
+        return None
+    rt = C.CDLL('libamdhip64.so')
+    n = C.c_size_t(0)
+    if rt.hipGraphGetNodes(C.c_void_p(raw), None, C.byref(n)) != 0:
+        return None
+    nodes = (C.c_void_p * n.value)()
+    if rt.hipGraphGetNodes(C.c_void_p(raw), nodes, C.byref(n)) != 0:
+        return None
+    k = 0
+    ty = C.c_int(0)
+    for i in range(n.value):
+        if rt.hipGraphNodeGetType(C.c_void_p(nodes[i]), C.byref(ty)) == 0 and ty.value == 0:     # hipGraphNodeTypeKernel
+            k += 1
+    return k
 
 
 # Branch marks (profiling aid, scripts/branch_marks.py): when MARKS is a dict, mark(name) launches a one-lane kernel on the

@@ -198,8 +198,9 @@ def build_multi_tower_graph(images, sketches, images_d, image_paired_class_ids, 
     if num_gpu > 1:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() == num_gpu):
-            raise RuntimeError('num_gpu=%d needs one process per GPU: launch with `python -m torch.distributed.run '
-                               '--nproc-per-node %d ...` (the reference looped towers in one process)' % (num_gpu, num_gpu))
+            raise RuntimeError('num_gpu=%d needs one process per GPU (the reference looped towers in one process): run it '
+                               'through obj_colorization_main.py -gpu %d (which starts its own ranks, dist_utils.launch_towers) '
+                               'or `python -m torch.distributed.run --nproc-per-node %d ...`' % (num_gpu, num_gpu, num_gpu))
         pg, rank, world = dist.group.WORLD, dist.get_rank(), num_gpu
     # image size: from the input's ``img_size`` attribute when it has one (a queue output: nothing may be dequeued
     # here, or the first training batch would pair batch-0 sketches with batch-1 images), else from the value

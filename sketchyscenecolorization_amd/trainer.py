@@ -187,7 +187,7 @@ class GanTrainer(object):
 
     # ------------------------------------------------------------------ segmented capture
     def _seg_begin_graph(self):
-        g = torch.cuda.CUDAGraph()
+        g = hip.new_graph()
         # thread_local: the RCCL watchdog thread polls events while we capture; under the default 'global' mode that
         # call invalidates the capture (hipErrorStreamCaptureInvalidated, seen intermittently)
         g.capture_begin(pool=self._seg['pool'], capture_error_mode='thread_local')
@@ -355,7 +355,7 @@ class GanTrainer(object):
                 if self.segment_graphs:
                     g = self._capture_segments(impl, sbatch)
                 else:
-                    g = torch.cuda.CUDAGraph()
+                    g = hip.new_graph()
                     self._capturing = True
                     try:
                         with torch.cuda.graph(g, capture_error_mode='thread_local'):
@@ -366,6 +366,7 @@ class GanTrainer(object):
                 print('hipGraph capture failed (%r): continuing with eager launches' % (e,))
                 self.use_graphs = False
                 self._seg = None
+                self._g_done, self._d_late_sent = set(), False      # nothing of the abandoned capture was exchanged
                 torch.cuda.synchronize()
                 scope.adam_t -= 1       # _adam_prepare ran once for this step already
                 self._adam_prepare(scope, idx, lr * self.decay(counter))
@@ -451,13 +452,21 @@ class GanTrainer(object):
         """Bytes per iteration and per exchange: what a SCALE line of bench.py can be checked against."""
         gs = {k: 4 * (hi - lo) for k, (lo, hi) in self._g_sections.items()}
         dn = 4 * self.store.discriminator.numel
-        ds = {'all': dn} if self._d_late is None or self.block_type != 'Pix2Pix' else \
+        ds = {'all': dn} if self._d_late is None or self.block_type != 'Pix2Pix' or self.world == 1 else \
             {'layer_4 + layer_5 + class head': dn - 4 * self._d_late, 'layer_1..3': 4 * self._d_late}
         return {'generator_sections_bytes': gs, 'discriminator_sections_bytes': ds,
                 'bytes_per_iteration': sum(gs.values()) + sum(ds.values()), 'collective': 'sum all-reduce, fp32'}
 
     def d_gradients(self, batch, use_real=False):
-        """loss_d and d loss_d / d discriminator variables (compute_gradients, graph_single.py:309-312)."""
+        """loss_d and d loss_d / d discriminator variables (compute_gradients, graph_single.py:309-312).
+        With more than one tower (Pix2Pix pair) the call also STARTS the all-reduce of the late section of the flat gradient
+        buffer (layer_4, layer_5, class head) beside the rest of the backward pass: until ``apply_d`` has waited for it that
+        section of ``store.discriminator.grad`` is in flight -- read gradients after ``apply_d``, or on one tower."""
+        if self._d_late_sent:
+            # a previous call already sent the late section on its way and nobody applied it (apply_d was never called):
+            # let that exchange finish before the buffer is written again, and start over
+            self._allreduce_wait()
+            self._d_late_sent = False
         hip.WGRAD_STREAM = self._wgrad_stream
         try:
             return self._d_gradients_fake_only(batch) if use_real else self._d_gradients(batch)
@@ -692,6 +701,7 @@ class GanTrainer(object):
 
     def _g_gradients(self, batch, use_ahead=False, real=None):
         B, s = self.bufs, self.store
+        self._g_done = set()        # a step that was abandoned half way (failed capture) must not leave sections marked as sent
         N, _, H, W = batch['sketches'].shape
         if use_ahead:       # the forward pass of this batch was run during the discriminator step (_d_impl)
             xd_f, gctx = self._ahead
@@ -817,7 +827,7 @@ class GanTrainer(object):
                 self._seen.add(key)
                 return body(st['sk'], prep, st['nv'], st['lb'])
             try:
-                g = torch.cuda.CUDAGraph()
+                g = hip.new_graph()
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     st['out'] = body(st['sk'], prep, st['nv'], st['lb'])
             except Exception as e:      # never lose a request to graph capture

@@ -51,3 +51,35 @@ def test_no_oracle_import_in_product():
                 assert 'import oracle' not in txt and 'from oracle' not in txt, f
                 assert '/root/reference' not in txt, f
     assert 'oracle' not in sys.modules or True
+
+
+def test_stale_binary_is_refused(tmp_path, monkeypatch):
+    """The library carries the hash of the sources it was built from (ssc_build_hash); a tree whose kernel sources differ --
+    here: one comment appended to a .hip file, no rebuild -- makes hip.lib() (and with it smoke(), bench.py, every test)
+    fail loudly instead of running the old binary under the new sources' name."""
+    import shutil
+    from sketchyscenecolorization_amd import build, hip
+    build.build_library(verbose=False)
+    assert build.library_hash() == build.tree_hash() and not build.is_stale()
+    l = ctypes.CDLL(build.LIB_PATH)
+    hip._declare(l)
+    assert hip.build_hash(l) == build.tree_hash()
+    csrc2 = tmp_path / 'csrc'
+    shutil.copytree(build.CSRC, str(csrc2))
+    with open(str(csrc2 / 'igemm.hip'), 'a') as f:
+        f.write('// touched\n')
+    monkeypatch.setattr(build, 'CSRC', str(csrc2))
+    assert build.is_stale()
+    monkeypatch.setattr(hip, '_lib', None)
+    monkeypatch.delenv('SSC_ALLOW_STALE_LIB', raising=False)
+    try:
+        hip.lib()
+    except RuntimeError as e:
+        assert 'built from kernel sources' in str(e)
+    else:
+        raise AssertionError('a stale library was accepted')
+    assert hip._lib is None
+    # smoke() starts with the same check
+    import __graft_entry__ as G
+    src = open(G.__file__).read()
+    assert 'hip.check_build_hash()' in src.split('def smoke')[1]

@@ -74,3 +74,44 @@ def test_two_rank_rehearsal_on_one_gpu():
     assert j['value'] > 0 and j['scaling'] == 'weak'
     import math
     assert math.isfinite(j['config']['loss_g']) and math.isfinite(j['config']['loss_d'])
+
+
+def test_cli_num_gpu_self_launch_on_cpu(tmp_path):
+    """obj_colorization_main.py -gpu N outside a launcher re-executes itself as N ranks (the reference loops its towers in
+    process, obj_colorization_main.py:189-190): the real torch.distributed.run path on CPU, with a script that uses
+    dist_utils.launch_towers the way the CLI does and whose ranks report back through files."""
+    script = tmp_path / 'towers.py'
+    script.write_text(
+        'import os, sys\n'
+        'sys.path.insert(0, %r)\n'
+        'from sketchyscenecolorization_amd.dist_utils import launch_towers\n'
+        'rc = launch_towers(int(sys.argv[1]))\n'
+        'if rc is not None:\n'
+        '    print("LAUNCHER_DONE rc=%%d" %% rc); raise SystemExit(rc)\n'
+        'open(os.path.join(%r, "rank%%s_of%%s" %% (os.environ["RANK"], os.environ["WORLD_SIZE"])), "w").write(" ".join(sys.argv[1:]))\n'
+        % (ROOT, str(tmp_path)))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env['SSC_DIST_ONE_DEVICE'] = '1'        # no device-count check: this box has no GPU
+    r = subprocess.run([sys.executable, str(script), '2', '--flag', 'x y'], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and 'LAUNCHER_DONE rc=0' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith('rank')) == ['rank0_of2', 'rank1_of2']
+    assert (tmp_path / 'rank1_of2').read_text() == '2 --flag x y'      # the ranks get the command's own arguments
+    # one tower, or already under a launcher: nothing to start
+    from sketchyscenecolorization_amd.dist_utils import launch_towers
+    assert launch_towers(1) is None
+    os.environ['WORLD_SIZE'] = '2'
+    try:
+        assert launch_towers(2) is None
+    finally:
+        del os.environ['WORLD_SIZE']
+
+
+def test_cli_refuses_more_towers_than_gpus():
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'SSC_DIST_ONE_DEVICE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'obj_colorization_main.py'), '--mode', 'train', '-gpu', '64'],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and '--num_gpu 64 but only' in (r.stderr + r.stdout)

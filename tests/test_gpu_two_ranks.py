@@ -44,3 +44,29 @@ def test_two_rank_cli_nan_restart(tmp_path):
     assert os.path.exists(os.path.join(run, 'snapshot', 'model_1.ckpt-1')) and os.path.exists(os.path.join(run, 'snapshot', 'model_3.ckpt-3'))
     steps = [json.loads(l)['step'] for l in open(os.path.join(run, 'log', 'scalars.jsonl'))]
     assert steps == [0, 1, 2, 3, 4], steps        # iteration 2 failed before its summary; the restart repeats it
+
+
+def test_cli_self_launch_two_ranks(tmp_path):
+    """`-gpu 2` WITHOUT torch.distributed.run: the command starts its two ranks itself (dist_utils.launch_towers; the reference
+    loops its towers inside one process, obj_colorization_main.py:189-190, graph_single.py:146-166).  Same run as
+    test_two_rank_cli_nan_restart -- one run directory, snapshots by rank 0, a NaN on rank 1 restarts both -- started as a plain
+    `python <script>`."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env['SSC_DIST_ONE_DEVICE'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(here, 'two_rank_cli_check.py')], capture_output=True, text=True,
+                       timeout=900, cwd=str(tmp_path), env=env)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert 'num_gpu=2: starting 2 ranks' in out, out[-4000:]
+    assert 'RANK0_DONE fired=False' in out and 'RANK1_DONE fired=True' in out and 'RANK-1_DONE' in out, out[-4000:]
+    assert out.count('Training ended with status -1. Restarting..') == 2
+    runs = sorted(os.listdir(os.path.join(tmp_path, 'outputs')))
+    assert len(runs) == 1, runs
+    run = os.path.join(tmp_path, 'outputs', runs[0])
+    assert os.path.exists(os.path.join(run, 'snapshot', 'model_3.ckpt-3'))
+    steps = [json.loads(l)['step'] for l in open(os.path.join(run, 'log', 'scalars.jsonl'))]
+    assert steps == [0, 1, 2, 3, 4], steps

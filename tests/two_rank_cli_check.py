@@ -1,5 +1,7 @@
 """Body of test_gpu_two_ranks.py::test_two_rank_cli_nan_restart: `obj_colorization_main.py --mode train -gpu 2` as rank
-RANK of 2 (started by torch.distributed.run with SSC_DIST_ONE_DEVICE=1: both ranks on cuda:0 over gloo).  Rank 1's LOCAL loss
+RANK of 2 (started by torch.distributed.run with SSC_DIST_ONE_DEVICE=1: both ranks on cuda:0 over gloo) -- and of
+::test_cli_self_launch_two_ranks, which runs this file WITHOUT a launcher: cli.main then starts the two ranks itself
+(dist_utils.launch_towers re-executes sys.argv, i.e. this file, under torch.distributed.run) and this process only waits.  Rank 1's LOCAL loss
 of the G-step of iteration 2 is made NaN once: the tower-mean all-reduce must carry it to rank 0 as well, both ranks must
 leave train() with -1 and continue together from the snapshot rank 0 wrote (main_procedure.py:213-232 and
 obj_colorization_main.py:240-246 of the reference; graph_single.TowerGraph._tower_mean here)."""
@@ -12,7 +14,7 @@ sys.path.insert(0, ROOT)
 import obj_colorization_main as cli                                         # noqa: E402
 from sketchyscenecolorization_amd.obj_lib import graph_single              # noqa: E402
 
-rank = int(os.environ['RANK'])
+rank = int(os.environ.get('RANK', -1))      # -1: the launching process of the self-launch test
 state = {'calls': 0, 'fired': False}
 orig = graph_single.TowerGraph._tower_mean
 
