@@ -120,7 +120,7 @@ def run_forward_workload(args):
         if not args.no_graphs:
             eager()
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
+            graph = hip.new_graph()
             with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 eager()
             step = lambda: (graph.replay() if hip.PROFILE is None else eager())

@@ -93,8 +93,34 @@ typedef struct ssc_conv_desc {
     int32_t sb_ldx;       /* row stride of x */
     int32_t sb_act;       /* SSC_ACT_* of the consumer */
     int32_t sk_tag;       /* caller's id of this launch (31 bits): a hand-off that times out reports 0x80000000 | sk_tag */
-    int32_t _pad0;
+    /* set by ssc_conv_forward_bnbwd2 (callers leave sb2_x NULL): the output columns [sb2_col0, Nstore) are the gradient w.r.t. a
+       SECOND normed tensor (the data gradient of a layer that reads concat[x, x2] -- relu(concat[decoder_{k+1}, encoder_k]),
+       models_collection.py:512-531 -- in one launch); the sb_* set then describes columns [0, sb2_col0) only (tables of
+       sb2_col0 entries), this set the remaining Nstore - sb2_col0, its rows of sums going to stat_partial2 */
+    int32_t sb2_col0;
+    const float* sb2_x;
+    const float* sb2_ab;
+    const float* sb2_stats;
+    float* stat_partial2;
+    int32_t sb2_ldx;
+    int32_t sb2_act;
+    /* set by ssc_conv_forward_bn (callers leave fin_cnt NULL): the fold of the batch statistics -- sum the rows of stat_partial
+       per channel, mean / variance -> (a, b) and (mean, 1/std) -- happens INSIDE the launch instead of in a launch of its own:
+       the rows are written through to memory, the last workgroup of every group of fin_gs rows (an agent-scope ticket per group
+       and column tile) sums its group in row order into fin_grp, the last group to finish sums the groups in order and writes
+       ab / stats.  Fixed groups, fixed orders: deterministic.  fin_cnt: (groups + 1) x column tiles counters, zero on entry,
+       left zero (the words behind the SSC_SK_FLAG_WORDS hand-off flags of the stream's flag array). */
+    uint32_t* fin_cnt;
+    double* fin_grp;      /* [groups][2][Nstore] */
+    const float* fin_scale;
+    const float* fin_offset;
+    float* fin_ab;        /* [2][Nstore] */
+    float* fin_stats;     /* [2][Nstore] */
+    int64_t fin_M;        /* elements per channel */
+    float fin_eps;
+    int32_t fin_gs;       /* rows per group */
 } ssc_conv_desc;
+#define SSC_FIN_CNT_WORDS 8192   /* counters of the in-launch statistics fold: words [SSC_SK_FLAG_WORDS, + SSC_FIN_CNT_WORDS) of sk_flags */
 #define SSC_SK_FLAG_WORDS 8192   /* >= resident workgroups of the largest grid; the last word reports a hand-off timeout:
                                     0 = none, else 0x80000000 | sk_tag of the first launch whose owner workgroup gave up
                                     waiting for a K slice.  The output of that launch is WRONG (a partial sum): callers must
@@ -323,6 +349,40 @@ int ssc_bn_act_backward_pre(const float* x, int64_t M, int C, int ldx, const flo
                             float* dx, int lddx, float* dscale, float* doffset, const float* pre, int nrows,
                             const float* rowb, float rowb_scale, int rowb_P, float* ws, int64_t ws_bytes, void* stream);
 /*
+ * The norm backward in two steps, so that its streaming pass can ride inside another launch.  `job` describes the site exactly
+ * as the arguments of ssc_bn_act_backward_pre do (host memory, read during the call).
+ *   ssc_bn_bwd_sums     partial sums (from `pre` / nrows when given, else a pass over x, g1, g2) -> coef [2][C] = mean dz,
+ *                       mean dz*xhat, and the scale / offset gradients.  coef is the caller's buffer: it must stay untouched
+ *                       until the apply pass has run (the workspace is not a place for it).
+ *   ssc_bn_bwd_apply    dx = a*(dz - coef0 - xhat*coef1) (has_bn) or dx = dz, as a launch of its own.
+ *   ssc_conv_wgrad_hosting   ssc_conv_wgrad + that apply pass: the filter gradient of the layer ABOVE the site needs neither
+ *                       dx nor anything the pass writes, so the pass runs as the first workgroups of the filter-gradient
+ *                       launch (HBM traffic beside its MFMA work; conv_wgrad128_kernel and conv_wgrad_kernel host it).  Where
+ *                       the launch cannot host (the one-output head's streaming kernel) the pass is launched in front of it:
+ *                       same results either way, and the same bits as ssc_bn_act_backward_pre.
+ */
+typedef struct ssc_bn_apply_job {
+    const float* x;       /* the normed tensor (raw), [M][ldx] */
+    int64_t M;
+    int32_t C, ldx;
+    const float* ab;      /* [2][C] folded norm (has_bn) */
+    const float* stats;   /* [2][C] mean, 1/std (has_bn) */
+    const float* g1;      /* gradient w.r.t. act1(z) */
+    const float* g2;      /* second consumer's gradient (through act2) or NULL */
+    int32_t ldg1, act1, ldg2, act2;
+    int32_t has_bn;       /* 0: dx = dz (activation only) */
+    int32_t rowb_P;       /* with rowb: g1[r] += rowb[r / rowb_P] * rowb_scale */
+    const float* rowb;
+    float rowb_scale;
+    int32_t lddx;
+    const float* coef;    /* [2][C], written by ssc_bn_bwd_sums (has_bn) */
+    float* dx;            /* [M][lddx] */
+} ssc_bn_apply_job;
+int ssc_bn_bwd_sums(const ssc_bn_apply_job* job, const float* pre, int nrows, float* coef, float* dscale, float* doffset,
+                    float* ws, int64_t ws_bytes, void* stream);
+int ssc_bn_bwd_apply(const ssc_bn_apply_job* job, void* stream);
+int ssc_conv_wgrad_hosting(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, const ssc_bn_apply_job* job, void* stream);
+/*
  * ssc_conv_forward for a launch whose output g is the gradient w.r.t. act(a*x+b) of a batch-statistics-normed
  * tensor x ([rows][ldx], addressed like the output): when the launch qualifies (uniform-tap kernel, no split-K
  * slabs, whole 16-byte aligned rows) its epilogue also writes rows of `partial` ([2][Nstore] each: sum dz,
@@ -332,6 +392,24 @@ int ssc_bn_act_backward_pre(const float* x, int64_t M, int C, int ldx, const flo
 int ssc_conv_forward_bnbwd(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, const float* x, int ldx,
                            const float* ab, const float* stats, int act, float* partial, int64_t partial_bytes,
                            int* nrows, void* stream);
+
+/*
+ * The same for a launch whose output columns are the gradients w.r.t. TWO normed tensors side by side: columns [0, C0) belong to
+ * x0 ([rows][ldx0], C0 channels), columns [C0, Nstore) to x1.  C0 must be a multiple of 128 (a column tile never straddles the
+ * two).  Each tensor gets its own rows of partial sums ([2][C0] / [2][Nstore - C0] each); *nrows is the row count of either
+ * (0: the launch did not qualify, take the sums with ssc_bn_act_backward).
+ */
+typedef struct ssc_bnbwd_site {
+    const float* x;       /* the normed tensor (raw values), rows addressed like the launch's output */
+    const float* ab;      /* [2][C]: a, b */
+    const float* stats;   /* [2][C]: mean, 1/std */
+    float* partial;       /* rows of [2][C] sums */
+    int64_t partial_bytes;
+    int32_t ldx;
+    int32_t act;          /* SSC_ACT_* of the consumer whose gradient the columns are */
+} ssc_bnbwd_site;
+int ssc_conv_forward_bnbwd2(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, const ssc_bnbwd_site* site0,
+                            const ssc_bnbwd_site* site1, int C0, int* nrows, void* stream);
 
 /* --- caption branch (text_lstm.hip): encode_feat_with_text, models_collection.py:150-248 --- */
 /* tf.nn.embedding_lookup (:182) and its (dense) gradient; tok rows are time-major [T*N] */

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sketchycolor_hip.h"
+#include "bn_bwd.h"
 
 #define CHECK_LAUNCH() ((int)hipGetLastError())
 
@@ -315,12 +316,6 @@ static inline void col_grid(int64_t M, int C, int& tcg, int& rl, int& nblk_rows,
     nblk_rows = (int)nb;
 }
 
-__device__ __forceinline__ float dact(float z, int act) {
-    if (act == SSC_ACT_RELU) return z > 0.f ? 1.f : 0.f;
-    if (act == SSC_ACT_LRELU) return z > 0.f ? 1.f : 0.2f;
-    return 1.f;
-}
-
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long M, int C, int ldx,
                                                                 int tcg, float* __restrict__ partial) {
     __shared__ float4 sh[2][256];
@@ -519,40 +514,6 @@ extern "C" int ssc_colsum(const float* x, int ld, int64_t M, int C, float* out, 
 }
 
 // ------------------------------------------------------------------ norm + activation backward
-struct BnBwdArgs {
-    const float* x; long M; int C; int ldx;
-    const float* ab; const float* stats;
-    const float* g1; int ldg1; int act1;
-    const float* g2; int ldg2; int act2;
-    int has_bn;
-    const float* rowb; float rowb_scale; int rowb_P;    // g1[r][c] += rowb[r / rowb_P][c] * rowb_scale (NULL: nothing added)
-};
-
-__device__ __forceinline__ void bn_bwd_dz(const BnBwdArgs& a, long r, int c, const float4& aa, const float4& bb,
-                                          float4& xv, float4& dz) {
-    xv = *reinterpret_cast<const float4*>(a.x + r * a.ldx + c);
-    float4 z;
-    if (a.has_bn) {
-        z.x = fmaf(aa.x, xv.x, bb.x); z.y = fmaf(aa.y, xv.y, bb.y);
-        z.z = fmaf(aa.z, xv.z, bb.z); z.w = fmaf(aa.w, xv.w, bb.w);
-    } else {
-        z = xv;
-    }
-    float4 g = *reinterpret_cast<const float4*>(a.g1 + r * a.ldg1 + c);
-    if (a.rowb != nullptr) {        // a per-image term broadcast over the pixels (the class head's gradient through its spatial mean)
-        const float4 t = *reinterpret_cast<const float4*>(a.rowb + (r / a.rowb_P) * a.C + c);
-        g.x = fmaf(t.x, a.rowb_scale, g.x); g.y = fmaf(t.y, a.rowb_scale, g.y);
-        g.z = fmaf(t.z, a.rowb_scale, g.z); g.w = fmaf(t.w, a.rowb_scale, g.w);
-    }
-    dz.x = g.x * dact(z.x, a.act1); dz.y = g.y * dact(z.y, a.act1);
-    dz.z = g.z * dact(z.z, a.act1); dz.w = g.w * dact(z.w, a.act1);
-    if (a.g2 != nullptr) {
-        const float4 h = *reinterpret_cast<const float4*>(a.g2 + r * a.ldg2 + c);
-        dz.x += h.x * dact(z.x, a.act2); dz.y += h.y * dact(z.y, a.act2);
-        dz.z += h.z * dact(z.z, a.act2); dz.w += h.w * dact(z.w, a.act2);
-    }
-}
-
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(BnBwdArgs a, int tcg, float* __restrict__ partial) {
     __shared__ float4 sh[2][256];
     const int rl = 256 / tcg;
@@ -629,37 +590,49 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const float* __restrict__ coef,
                                                             float* __restrict__ dx, int lddx) {
-    const int cg = a.C / 4;
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long tot = a.M * cg;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (; i < tot; i += stride) {
-        const long r = i / cg;
-        const int c = (int)(i - r * cg) * 4;
-        float4 aa = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.has_bn) {
-            aa = *reinterpret_cast<const float4*>(a.ab + c);
-            bb = *reinterpret_cast<const float4*>(a.ab + a.C + c);
-        }
-        float4 xv, dz;
-        bn_bwd_dz(a, r, c, aa, bb, xv, dz);
-        float4 o = dz;
-        if (a.has_bn) {
-            const float4 mu = *reinterpret_cast<const float4*>(a.stats + c);
-            const float4 rs = *reinterpret_cast<const float4*>(a.stats + a.C + c);
-            const float4 c1 = *reinterpret_cast<const float4*>(coef + c);
-            const float4 c2 = *reinterpret_cast<const float4*>(coef + a.C + c);
-            o.x = aa.x * (dz.x - c1.x - (xv.x - mu.x) * rs.x * c2.x);
-            o.y = aa.y * (dz.y - c1.y - (xv.y - mu.y) * rs.y * c2.y);
-            o.z = aa.z * (dz.z - c1.z - (xv.z - mu.z) * rs.z * c2.z);
-            o.w = aa.w * (dz.w - c1.w - (xv.w - mu.w) * rs.w * c2.w);
-        }
-        *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
-    }
+    bn_bwd_apply_blocks(a, coef, dx, lddx, (int)blockIdx.x, (int)gridDim.x);
 }
 
-// pre / nrows: the rows [nrows][2][C] of partial sums already taken by the epilogues of the launches that produced g1 (and g2)
-// (ssc_conv_forward_bnbwd); NULL / 0: take them here with a pass over x, g1, g2.
+// Step 1 of a norm backward: the two per-channel sums -> coef, dscale, doffset.  pre / nrows: rows [nrows][2][C] of partial
+// sums already taken by the epilogues of the launches that produced g1 (and g2) (ssc_conv_forward_bnbwd); NULL / 0: take them
+// here with a pass over x, g1, g2.
+extern "C" int ssc_bn_bwd_sums(const ssc_bn_apply_job* job, const float* pre, int nrows, float* coef, float* dscale,
+                               float* doffset, float* ws, int64_t ws_bytes, void* stream) {
+    ssc_bn_apply_job j = *job;
+    j.coef = coef;
+    if (!j.has_bn || coef == nullptr || !bn_job_ok(j)) return -1;
+    if (j.rowb != nullptr && pre != nullptr && nrows > 0) return -3;    // sums taken elsewhere cannot include rowb
+    hipStream_t st = (hipStream_t)stream;
+    const BnBwdArgs a = bn_args_of(j);
+    int tcg, rl, nbr, nbc;
+    col_grid(j.M, j.C, tcg, rl, nbr, nbc);
+    const float* partial = ws;
+    if (pre != nullptr && nrows > 0) {
+        partial = pre;
+        nbr = nrows;
+    } else {
+        if ((int64_t)nbr * 2 * j.C * (int64_t)sizeof(float) > ws_bytes) return -2;
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, a, tcg, ws);
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((j.C + 3) / 4), dim3(256), 0, st, partial, nbr, j.C, (long)j.M, coef, dscale,
+                       doffset);
+    return CHECK_LAUNCH();
+}
+
+// Step 2 as a launch of its own
+extern "C" int ssc_bn_bwd_apply(const ssc_bn_apply_job* job, void* stream) {
+    if (!bn_job_ok(*job)) return -1;
+    const BnBwdArgs a = bn_args_of(*job);
+    long tot = (long)job->M * (job->C / 4);
+    long blocks = (tot + 1023) / 1024;      // four rows in flight per thread (bn_bwd_apply_blocks)
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, job->coef, job->dx,
+                       job->lddx);
+    return CHECK_LAUNCH();
+}
+
+// both steps back to back (coef in the workspace, behind the partial rows)
 extern "C" int ssc_bn_act_backward_pre(const float* x, int64_t M, int C, int ldx, const float* ab, const float* stats,
                                        const float* g1, int ldg1, int act1, const float* g2, int ldg2, int act2, int has_bn,
                                        float* dx, int lddx, float* dscale, float* doffset, const float* pre, int nrows,
@@ -667,33 +640,20 @@ extern "C" int ssc_bn_act_backward_pre(const float* x, int64_t M, int C, int ldx
                                        void* stream) {
     if ((C & 3) || (ldx & 3) || (ldg1 & 3) || (lddx & 3) || (g2 != nullptr && (ldg2 & 3))) return -1;
     if (rowb != nullptr && (rowb_P <= 0 || (pre != nullptr && nrows > 0))) return -3;   // sums taken elsewhere cannot include rowb
-    hipStream_t st = (hipStream_t)stream;
-    BnBwdArgs a;
-    a.x = x; a.M = (long)M; a.C = C; a.ldx = ldx; a.ab = ab; a.stats = stats;
-    a.g1 = g1; a.ldg1 = ldg1; a.act1 = act1; a.g2 = g2; a.ldg2 = ldg2; a.act2 = act2; a.has_bn = has_bn;
-    a.rowb = rowb; a.rowb_scale = rowb_scale; a.rowb_P = rowb_P;
-    float* coef = nullptr;
+    ssc_bn_apply_job j;
+    j.x = x; j.M = M; j.C = C; j.ldx = ldx; j.ab = ab; j.stats = stats; j.g1 = g1; j.g2 = g2; j.ldg1 = ldg1; j.act1 = act1;
+    j.ldg2 = ldg2; j.act2 = act2; j.has_bn = has_bn; j.rowb_P = rowb_P; j.rowb = rowb; j.rowb_scale = rowb_scale; j.lddx = lddx;
+    j.coef = nullptr; j.dx = dx;
     if (has_bn) {
         int tcg, rl, nbr, nbc;
         col_grid(M, C, tcg, rl, nbr, nbc);
         if (((int64_t)nbr * 2 * C + 2 * C) * (int64_t)sizeof(float) > ws_bytes) return -2;
-        coef = ws + (int64_t)nbr * 2 * C;
-        const float* partial = ws;
-        if (pre != nullptr && nrows > 0) {
-            partial = pre;
-            nbr = nrows;
-        } else {
-            hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, a, tcg, ws);
-        }
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, nbr, C, (long)M, coef,
-                           dscale, doffset);
+        float* coef = ws + (int64_t)nbr * 2 * C;
+        const int rc = ssc_bn_bwd_sums(&j, pre, nrows, coef, dscale, doffset, ws, (int64_t)nbr * 2 * C * (int64_t)sizeof(float), stream);
+        if (rc != 0) return rc;
+        j.coef = coef;
     }
-    long tot = (long)M * (C / 4);
-    long blocks = (tot + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, coef, dx, lddx);
-    return CHECK_LAUNCH();
+    return ssc_bn_bwd_apply(&j, stream);
 }
 
 // the second step of the norm backward on its own: rows of partial sums [nblk][2][C] -> coef = [mean dz; mean dz*xhat] and the

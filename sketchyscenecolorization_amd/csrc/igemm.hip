@@ -25,12 +25,23 @@
 // wgrad128.hip
 extern "C" int ssc_conv_wgrad128_supported(const ssc_wgrad_desc* dp);
 extern "C" int ssc_conv_wgrad128(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream);
+int ssc_conv_wgrad128_job(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, const ssc_bn_apply_job* job, void* stream);
 // narrow.hip
 int ssc_conv_narrow_forward_ws(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, void* stream, int* csplit_out);
 // fewchan.hip
 int ssc_conv_fewchan_forward(const ssc_conv_desc* dp, int num_cu, void* stream);
 
 #define BK 32
+// 8-byte write-through (agent-scope relaxed atomic) stores: data another workgroup of the same launch will read
+__device__ __forceinline__ void st_agent2(float* p, float a, float b) {
+    union { float f[2]; unsigned long long u; } cv;
+    cv.f[0] = a; cv.f[1] = b;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), cv.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_d(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
 // in-launch K-slice hand-off (conv_ut_kernel): {wait bound in ticks of the 100 MHz wall clock (lo, hi), test hook: producers
 // withhold their flags, -}.  ssc_sk_configure writes it.
 __device__ unsigned g_sk_cfg[4] = {2000000000u, 0u, 0u, 0u};
@@ -905,18 +916,29 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         // ... or, when the output is the gradient w.r.t. the activated norm of a tensor x (sb_x: same layout as the output),
         // the two sums of that norm's backward: sum dz and sum dz * xhat with dz = out * act'(a x + b) (ssc_conv_forward_bnbwd);
         // the column group of a thread is the same in every pass of the loop below (256 % (BN / 4) == 0)
-        const float* const sbx = (stat != nullptr) ? d.sb_x : nullptr;
+        // two normed tensors side by side (ssc_conv_forward_bnbwd2): this workgroup's column tile lies in one of them; cb = its
+        // first column, sbC = its channel count (the width of its tables and of its rows of sums)
+        const bool sb_two = (stat != nullptr) && d.sb2_x != nullptr;
+        const bool sb_second = sb_two && n0 >= d.sb2_col0;
+        const int cb = sb_second ? d.sb2_col0 : 0;
+        const int sbC = sb_two ? (sb_second ? Nst - d.sb2_col0 : d.sb2_col0) : Nst;
+        float* const statw = sb_second ? d.stat_partial2 : stat;
+        const float* const sbx = (stat != nullptr) ? (sb_second ? d.sb2_x : d.sb_x) : nullptr;
+        const int sb_ldx = sb_second ? d.sb2_ldx : d.sb_ldx;
         float4 sb_a = make_float4(1.f, 1.f, 1.f, 1.f), sb_b = make_float4(0.f, 0.f, 0.f, 0.f), sb_mu = sb_b, sb_rs = sb_a;
         float sb_neg = 1.f;         // act'(z) for z <= 0
         if (sbx != nullptr) {
             const int c = n0 + (tid % (BN / 4)) * 4;
             if (c < Nst) {
-                sb_a = *reinterpret_cast<const float4*>(d.sb_ab + c);
-                sb_b = *reinterpret_cast<const float4*>(d.sb_ab + Nst + c);
-                sb_mu = *reinterpret_cast<const float4*>(d.sb_stats + c);
-                sb_rs = *reinterpret_cast<const float4*>(d.sb_stats + Nst + c);
+                const float* const tab = sb_second ? d.sb2_ab : d.sb_ab;
+                const float* const tst = sb_second ? d.sb2_stats : d.sb_stats;
+                sb_a = *reinterpret_cast<const float4*>(tab + (c - cb));
+                sb_b = *reinterpret_cast<const float4*>(tab + sbC + (c - cb));
+                sb_mu = *reinterpret_cast<const float4*>(tst + (c - cb));
+                sb_rs = *reinterpret_cast<const float4*>(tst + sbC + (c - cb));
             }
-            sb_neg = d.sb_act == SSC_ACT_RELU ? 0.f : (d.sb_act == SSC_ACT_LRELU ? 0.2f : 1.f);
+            const int sact = sb_second ? d.sb2_act : d.sb_act;
+            sb_neg = sact == SSC_ACT_RELU ? 0.f : (sact == SSC_ACT_LRELU ? 0.2f : 1.f);
         }
 #pragma unroll
         for (int p = 0; p < BM * BN / 1024; ++p) {
@@ -935,7 +957,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                     ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
                     ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
                 } else {
-                    const float4 xv = *reinterpret_cast<const float4*>(sbx + rowpix[row] * d.sb_ldx + col);
+                    const float4 xv = *reinterpret_cast<const float4*>(sbx + rowpix[row] * sb_ldx + (col - cb));
                     float4 dz;
                     dz.x = v.x * (fmaf(sb_a.x, xv.x, sb_b.x) > 0.f ? 1.f : sb_neg);
                     dz.y = v.y * (fmaf(sb_a.y, xv.y, sb_b.y) > 0.f ? 1.f : sb_neg);
@@ -979,9 +1001,85 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                 const int col = n0 + tid * 4;
                 if (col < Nst) {
                     const long blk = (long)phase * ((M + BM - 1) / BM) + m0 / BM;
-                    float* sp = stat + blk * 2 * Nst;
-                    *reinterpret_cast<float4*>(sp + col) = s;
-                    *reinterpret_cast<float4*>(sp + Nst + col) = q;
+                    float* sp = statw + blk * 2 * sbC;
+                    if (d.fin_cnt != nullptr) {     // other workgroups will read this row: 8-byte write-through stores
+                        st_agent2(sp + (col - cb), s.x, s.y);
+                        st_agent2(sp + (col - cb) + 2, s.z, s.w);
+                        st_agent2(sp + sbC + (col - cb), q.x, q.y);
+                        st_agent2(sp + sbC + (col - cb) + 2, q.z, q.w);
+                    } else {
+                        *reinterpret_cast<float4*>(sp + (col - cb)) = s;
+                        *reinterpret_cast<float4*>(sp + sbC + (col - cb)) = q;
+                    }
+                }
+            }
+            // In-launch fold of the batch statistics (ssc_conv_desc.fin_*): two levels of "the last one to arrive sums".  Rows
+            // travel write-through (above); a ticket is taken only after the row's stores have completed; the reader takes one
+            // agent-scope acquire after it saw the last ticket, then plain loads (MI355X guide, inter-workgroup visibility).
+            if (d.fin_cnt != nullptr && sbx == nullptr) {
+                int* const fl = reinterpret_cast<int*>(smem + BM * C_LD + 2 * 256 * 4);
+                const int mtiles = (int)((M + BM - 1) / BM);
+                const int nrows = mtiles * d.nphase;
+                const int gs = d.fin_gs, ngr = (nrows + gs - 1) / gs;
+                const int ctile = n0 / BN, ntile = (Nst + BN - 1) / BN;
+                const int blk = phase * mtiles + (int)(m0 / BM);
+                const int grp = blk / gs;
+                const int want = min(gs, nrows - grp * gs);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    const unsigned t = __hip_atomic_fetch_add(d.fin_cnt + grp * ntile + ctile, 1u, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = t == (unsigned)(want - 1);
+                    if (last) {
+                        __hip_atomic_store(d.fin_cnt + grp * ntile + ctile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    fl[0] = last;
+                    fl[1] = 0;
+                }
+                __syncthreads();
+                if (fl[0]) {        // this workgroup saw the last row of its group: sum the group, column by column, in row order
+                    const int col = n0 + tid;
+                    if (tid < BN && col < Nst) {
+                        double ss = 0.0, qq = 0.0;
+                        const float* rp = stat + (long)grp * gs * 2 * Nst + col;
+                        for (int r = 0; r < want; ++r) {
+                            ss += (double)rp[(long)r * 2 * Nst];
+                            qq += (double)rp[(long)r * 2 * Nst + Nst];
+                        }
+                        st_agent_d(d.fin_grp + ((long)grp * 2 + 0) * Nst + col, ss);
+                        st_agent_d(d.fin_grp + ((long)grp * 2 + 1) * Nst + col, qq);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) {
+                        const unsigned t2 = __hip_atomic_fetch_add(d.fin_cnt + ngr * ntile + ctile, 1u, __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_AGENT);
+                        const int last2 = t2 == (unsigned)(ngr - 1);
+                        if (last2) {
+                            __hip_atomic_store(d.fin_cnt + ngr * ntile + ctile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        }
+                        fl[1] = last2;
+                    }
+                    __syncthreads();
+                    if (fl[1] && tid < BN && col < Nst) {      // the last group: sum the groups in order, fold (bn_stats_finalize_kernel)
+                        double ss = 0.0, qq = 0.0;
+                        for (int g = 0; g < ngr; ++g) {
+                            ss += d.fin_grp[((long)g * 2 + 0) * Nst + col];
+                            qq += d.fin_grp[((long)g * 2 + 1) * Nst + col];
+                        }
+                        const double mean = ss / (double)d.fin_M;
+                        double var = qq / (double)d.fin_M - mean * mean;
+                        if (var < 0.0) var = 0.0;
+                        const float rstd = (float)(1.0 / sqrt(var + (double)d.fin_eps));
+                        const float a = rstd * d.fin_scale[col];
+                        d.fin_ab[col] = a;
+                        d.fin_ab[Nst + col] = d.fin_offset[col] - (float)mean * a;
+                        d.fin_stats[col] = (float)mean;
+                        d.fin_stats[Nst + col] = rstd;
+                    }
                 }
             }
         }
@@ -1011,6 +1109,7 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         }
     }
 }
+
 
 // streaming 16-byte load (split-K slabs are read once)
 typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
@@ -1509,6 +1608,15 @@ static double makespan(long blocks, double w, int res, int ncu) {
 
 struct Plan { int cfg; int splitk; double cost; long ts_full; int ts_s; };
 
+static bool inlaunch_splitk() {
+    static int on = -1;     // SSC_INLAUNCH_SPLITK=1: split-K of every tile combined in the launch (A/B; default: slabs + a reduce launch)
+    if (on < 0) {
+        const char* e = getenv("SSC_INLAUNCH_SPLITK");
+        on = (e != nullptr && e[0] == '1') ? 1 : 0;      // off: measured slower (17.79 vs 17.71 ms per Pix2Pix step, 7.05 vs
+    }                                                    // 6.90 ms generator forward + backward): few owners do the combining
+    return on != 0;                                      // while the reduce launch spreads it over the chip
+}
+
 static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long M, long N, long nphase, long nkt,
                         long out_elems, int64_t ws_bytes, bool have_ws, bool can_ts = false) {
     const int ncu = num_cu();
@@ -1567,6 +1675,15 @@ static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long
             best.splitk = 1;
             best.ts_full = full;
             best.ts_s = (int)sl;
+        } else if (best.splitk > 1 && ff < 0 && inlaunch_splitk() && blocks * best.splitk < SSC_SK_FLAG_WORDS - 1 &&
+                   (int64_t)blocks * best.splitk * t.BM * t.BN * 4 <= ws_bytes) {
+            // Split-K of EVERY tile (few tiles, long K: the recurrent GEMMs, encoder_5): the slices are combined inside the
+            // launch by the same hand-off (no whole tiles, every tile cut into splitk slices) instead of through slabs and a
+            // reduce launch of its own -- one launch less on a dependent chain, and the owner's epilogue can take the
+            // batch statistics, which a slab pass cannot
+            best.ts_full = 0;
+            best.ts_s = best.splitk;
+            best.splitk = 1;
         }
     }
     return best;
@@ -1802,6 +1919,8 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
     ssc_conv_desc d = *dp;
     d.stat_partial = nullptr;
     d.sb_x = nullptr;
+    d.sb2_x = nullptr;
+    d.fin_cnt = nullptr;
     const long M = (long)d.NB * d.PH * d.PW;
     const long Mall = M * d.nphase;
     static int off = -1;        // SSC_FUSE_STATS=0: always the separate pass (A/B)
@@ -1818,14 +1937,34 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
         if (p.cfg > 0 && p.splitk == 1) {
             const long mt = (M + FWD_CFGS[p.cfg].BM - 1) / FWD_CFGS[p.cfg].BM;
             const int64_t need = (int64_t)mt * d.nphase * 2 * d.Nstore * 4;
-            if (need * 4 <= ws_bytes) {     // the partial rows sit at the end of the workspace, the conv keeps the rest
-                ws_conv = (ws_bytes - need) & ~(int64_t)255;
+            // the fold itself inside the launch too (ssc_conv_desc.fin_*): group rows behind the partial rows, counters behind
+            // the stream's hand-off flags
+            static int fin_on = -1;     // SSC_FIN_INLAUNCH=0: the fold as a launch of its own (A/B)
+            if (fin_on < 0) {
+                const char* e = getenv("SSC_FIN_INLAUNCH");
+                fin_on = (e != nullptr && e[0] == '0') ? 0 : 1;
+            }
+            const long nrows = mt * d.nphase;
+            const int gs = nrows <= 1024 ? 32 : 64;
+            const long ngr = (nrows + gs - 1) / gs;
+            const long ntile = (d.Nstore + FWD_CFGS[p.cfg].BN - 1) / FWD_CFGS[p.cfg].BN;
+            const int64_t grp_bytes = (int64_t)ngr * 2 * d.Nstore * 8;
+            const bool fin = fin_on && d.sk_flags != nullptr && (ngr + 1) * ntile <= SSC_FIN_CNT_WORDS && nrows >= 2;
+            const int64_t reserve = ((need + 255) & ~(int64_t)255) + (fin ? grp_bytes + 256 : 0);
+            if (reserve * 4 <= ws_bytes) {     // the partial rows sit at the end of the workspace, the conv keeps the rest
+                ws_conv = (ws_bytes - reserve) & ~(int64_t)255;
                 const Plan p2 = plan_fwd(d, ws_conv, true);
                 if (p2.cfg == p.cfg && p2.splitk == 1) {
                     d.stat_partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_conv);
                     fused = true;
+                    if (fin) {
+                        d.fin_cnt = d.sk_flags + SSC_SK_FLAG_WORDS;
+                        d.fin_grp = reinterpret_cast<double*>(reinterpret_cast<char*>(d.stat_partial) + ((need + 255) & ~(int64_t)255));
+                        d.fin_scale = scale; d.fin_offset = offset; d.fin_ab = ab; d.fin_stats = stats;
+                        d.fin_M = Mall; d.fin_eps = eps; d.fin_gs = gs;
+                    }
                     const int rc = ssc_conv_forward(&d, ws, ws_conv, stream);
-                    if (rc != 0) return rc;
+                    if (rc != 0 || fin) return rc;
                     return ssc_bn_finalize(d.stat_partial, (int)(mt * d.nphase), d.Nstore, Mall, scale, offset, eps, ab, stats,
                                            stream);
                 }
@@ -1848,6 +1987,8 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
     ssc_conv_desc d = *dp;
     d.stat_partial = nullptr;
     d.sb_x = nullptr;
+    d.sb2_x = nullptr;
+    d.fin_cnt = nullptr;
     *nrows = 0;
     const long M = (long)d.NB * d.PH * d.PW;
     static int off = -1;        // SSC_FUSE_BNBWD=0: always the separate pass (A/B)
@@ -1867,6 +2008,43 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
             if ((int64_t)mt * d.nphase * 2 * d.Nstore * 4 <= partial_bytes) {
                 d.stat_partial = partial;
                 d.sb_x = x; d.sb_ldx = ldx; d.sb_ab = ab; d.sb_stats = stats; d.sb_act = act;
+                *nrows = (int)(mt * d.nphase);
+            }
+        }
+    }
+    return ssc_conv_forward(&d, ws, ws_bytes, stream);
+}
+
+extern "C" int ssc_conv_forward_bnbwd2(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, const ssc_bnbwd_site* s0,
+                                       const ssc_bnbwd_site* s1, int C0, int* nrows, void* stream) {
+    ssc_conv_desc d = *dp;
+    d.stat_partial = nullptr;
+    d.sb_x = nullptr;
+    d.sb2_x = nullptr;
+    d.fin_cnt = nullptr;
+    *nrows = 0;
+    const long M = (long)d.NB * d.PH * d.PW;
+    static int off = -1;        // SSC_FUSE_BNBWD=0: always the separate pass (A/B)
+    if (off < 0) {
+        const char* e = getenv("SSC_FUSE_BNBWD");
+        off = (e != nullptr && e[0] == '0') ? 1 : 0;
+    }
+    const int C1 = d.Nstore - C0;
+    if (!off && ws != nullptr && s0 != nullptr && s1 != nullptr && s0->x && s1->x && s0->ab && s1->ab && s0->stats && s1->stats &&
+        s0->partial && s1->partial && C0 > 0 && C1 > 0 && (C0 % 128) == 0 && (C1 & 3) == 0 &&
+        !ssc_conv_narrow_supported(dp) && !ssc_conv_fewchan_supported(dp) && d.epi == 0 && !d.accumulate &&
+        d.bias == nullptr && d.Nstore == d.ldc && d.Nn == d.Nstore && ((s0->ldx | s1->ldx) & 3) == 0 &&
+        ((reinterpret_cast<unsigned long>(d.out) | reinterpret_cast<unsigned long>(s0->x) |
+          reinterpret_cast<unsigned long>(s1->x)) & 15) == 0 &&
+        (fwd_is_ut(d) || fwd_is_utg(d))) {
+        const Plan p = plan_fwd(d, ws_bytes, true);
+        if (p.cfg > 0 && p.splitk == 1 && FWD_CFGS[p.cfg].BN <= 128) {
+            const long mt = (M + FWD_CFGS[p.cfg].BM - 1) / FWD_CFGS[p.cfg].BM;
+            if ((int64_t)mt * d.nphase * 2 * C0 * 4 <= s0->partial_bytes && (int64_t)mt * d.nphase * 2 * C1 * 4 <= s1->partial_bytes) {
+                d.stat_partial = s0->partial;
+                d.sb_x = s0->x; d.sb_ldx = s0->ldx; d.sb_ab = s0->ab; d.sb_stats = s0->stats; d.sb_act = s0->act;
+                d.stat_partial2 = s1->partial; d.sb2_col0 = C0;
+                d.sb2_x = s1->x; d.sb2_ldx = s1->ldx; d.sb2_ab = s1->ab; d.sb2_stats = s1->stats; d.sb2_act = s1->act;
                 *nrows = (int)(mt * d.nphase);
             }
         }
@@ -2050,6 +2228,26 @@ extern "C" int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* dp, char* buf, i
     const Plan p = plan_wgrad(*dp, (int64_t)1 << 40, true);
     copy_name(names[p.cfg < 0 ? 0 : p.cfg], buf, len);
     return 0;
+}
+
+// filter gradient + the apply pass of a norm backward (bn_bwd.h): inside the launch where the kernel hosts it, in front of it
+// otherwise
+extern "C" int ssc_conv_wgrad_hosting(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, const ssc_bn_apply_job* job,
+                                      void* stream) {
+    static int off = -1;        // SSC_SIDE_APPLY=0: always a launch of its own (A/B)
+    if (off < 0) {
+        const char* e = getenv("SSC_SIDE_APPLY");
+        off = (e != nullptr && e[0] == '0') ? 1 : 0;
+    }
+    if (job == nullptr) return ssc_conv_wgrad(dp, ws, ws_bytes, stream);
+    const ssc_wgrad_desc& d = *dp;
+    const bool head1 = ws != nullptr && ws_bytes >= (int64_t)16 * 512 * 4 && ssc_head1_wgrad_supported(dp);
+    if (!off && !head1 && !((d.g.C0 & 3) || (d.g.C1 & 3) || (d.d.C0 & 3) || (d.d.C1 & 3)) && d.d.H == d.PH && d.d.W == d.PW &&
+        d.ldc == d.Nn && ssc_conv_wgrad128_supported(dp))
+        return ssc_conv_wgrad128_job(dp, ws, ws_bytes, job, stream);
+    const int rc = ssc_bn_bwd_apply(job, stream);
+    if (rc != 0) return rc;
+    return ssc_conv_wgrad(dp, ws, ws_bytes, stream);
 }
 
 extern "C" int ssc_conv_wgrad(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream) {

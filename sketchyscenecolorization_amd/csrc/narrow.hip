@@ -411,6 +411,11 @@ static bool narrow_sc_ok(const ssc_conv_desc& d) {
     // measured (scripts/conv_microbench.py, batch 32): 128 -> 3 transposed 135 -> 127 us, the 64 -> 3 data gradient 79 -> 59 us,
     // but the 512 -> 1 conv form 41 -> 56 us (one output: a scalar fetch feeds a single packed FMA) -- transposed form only.
     // What bounds it now is the scalar data path: with constant weights the same launch takes 83 us, without the accumulate 49.
+    // Round 4, two lattice points per lane (32 x 16 tiles, each patch pixel read once per point, 8-channel chunks): with the
+    // filter slice in LDS read as broadcasts 17.89 vs 17.78 ms per train step, with scalar filter loads (one fetch per 4 packed
+    // FMAs) 291 vs 127 us for this layer and 115 vs 59 us for the 64 -> 3 data gradient -- the LDS -> VGPR return path
+    // (128 B / clk per CU, broadcast or not) bounds the first, 134 VGPRs + the lgkmcnt shared by scalar and LDS returns the
+    // second.  Not kept (profiles/NOTEBOOK_r04.md).
     // ... and the unflipped 7x7 conv form with >= 2 outputs and an [n][k] filter (hip.conv_forward(..., w_nk=...): the MRU
     // generator's last conv hands over a transposed copy of its [7,7,64,3] filter)
     const bool conv7 = d.nphase == 1 && d.bmode == 1 && nout >= 2 && d.TH == 7 && d.TW == 7 && d.KH == 7 && d.KW == 7 &&

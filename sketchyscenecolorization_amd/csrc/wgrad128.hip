@@ -24,6 +24,7 @@
 #include "sketchycolor_hip.h"
 #include "igemm_util.h"
 #include "host_util.h"
+#include "bn_bwd.h"
 #include <type_traits>
 
 #ifndef SSC_WG128_BK
@@ -86,7 +87,12 @@ __device__ __forceinline__ float4 xform4_nomask(float4 v, const float4& a, const
 template <bool GPLAIN, int DMODE, int TPT>
 __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(const ssc_wgrad_desc d, const Magics mg,
                                                                 float* __restrict__ slab_base, long slab_stride, int splitk,
-                                                                int xcd) {
+                                                                int xcd, const BnApplySide side) {
+    // side job (bn_bwd.h): the first side.blocks workgroups stream the apply pass of a norm backward and leave
+    if ((int)blockIdx.x < side.blocks) {
+        bn_bwd_apply_blocks(side.a, side.coef, side.dx, side.lddx, (int)blockIdx.x, side.blocks);
+        return;
+    }
     constexpr int T_SZ = BK * TB;          // floats per operand tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                      // [2][BK][TB]  gathered side, [pixel][column]
@@ -107,16 +113,17 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(co
     // workgroup -> (row tile, column tile, K slice).  All tiles of a K slice read the same pixels; dealt round robin to the 8
     // XCDs (id % 8) each L2 fetches every slice.  xcd (host flag, grid a multiple of 8): ids with the same id % 8 walk a
     // contiguous run of (row tile, column tile, slice) order -- whole slices per XCD.
-    int mt_i = blockIdx.x, nt_i = blockIdx.y, ks = blockIdx.z;
-    if (xcd) {
-        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const unsigned t2 = (lin & 7u) * (total >> 3) + (lin >> 3);
-        const unsigned per_slice = gridDim.x * gridDim.y;
+    // (1-D grid: side blocks first -- a multiple of 8, so id % 8 is still the XCD --, then row tile fastest, column tile, slice)
+    int mt_i, nt_i, ks;
+    {
+        const unsigned gx = (unsigned)((Mtot + TB - 1) / TB), gy = (unsigned)((d.Nn + TB - 1) / TB);
+        const unsigned per_slice = gx * gy, total = per_slice * (unsigned)splitk;
+        const unsigned lin = blockIdx.x - (unsigned)side.blocks;
+        const unsigned t2 = xcd ? (lin & 7u) * (total >> 3) + (lin >> 3) : lin;
         ks = (int)(t2 / per_slice);
         const unsigned r = t2 - (unsigned)ks * per_slice;
-        nt_i = (int)(r / gridDim.x);
-        mt_i = (int)(r - (unsigned)nt_i * gridDim.x);
+        nt_i = (int)(r / gx);
+        mt_i = (int)(r - (unsigned)nt_i * gx);
     }
     const int m0 = mt_i * TB, n0 = nt_i * TB;
 
@@ -531,7 +538,7 @@ static int wg128_splitk(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws)
 void ssc_launch_wgrad_reduce(const float* ws, long count, int splitk, float* out, int accumulate, hipStream_t st);   // igemm.hip
 
 template <bool GPLAIN, int DMODE, int TPT>
-static int launch_wg128(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
+static int launch_wg128(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st, const BnApplySide& side) {
     constexpr size_t lds = (2 + NBB) * BK * TB * sizeof(float) + 2 * TPT * 256 * sizeof(int2);
     const int Cg = d.g.C0 + d.g.C1;
     const long Mtot = (long)d.TH * d.TW * Cg;
@@ -543,29 +550,30 @@ static int launch_wg128(const ssc_wgrad_desc& d, int splitk, float* ws, hipStrea
         if (arc != 0) return arc;
     }
     const long out_count = Mtot * d.ldc;
-    dim3 grid((unsigned)((Mtot + TB - 1) / TB), (unsigned)((d.Nn + TB - 1) / TB), (unsigned)splitk);
+    const long wgs = ((Mtot + TB - 1) / TB) * ((d.Nn + TB - 1) / TB) * splitk;
     static int xcd_on = -1;     // SSC_WG128_XCD=0: plain grid order (A/B)
     if (xcd_on < 0) {
         const char* e = getenv("SSC_WG128_XCD");
         xcd_on = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
-    const int xcd = (xcd_on && splitk > 1 && (((long)grid.x * grid.y * grid.z) & 7) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((conv_wgrad128_kernel<GPLAIN, DMODE, TPT>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, xcd);
+    const int xcd = (xcd_on && splitk > 1 && (wgs & 7) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((conv_wgrad128_kernel<GPLAIN, DMODE, TPT>), dim3((unsigned)(wgs + side.blocks)), dim3(256), lds, st, d, mg,
+                       ws, out_count, splitk, xcd, side);
     if (splitk > 1) ssc_launch_wgrad_reduce(ws, out_count, splitk, d.out, d.accumulate, st);
     return (int)hipGetLastError();
 }
 
 template <int TPT>
-static int launch_wg128_t(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
+static int launch_wg128_t(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st, const BnApplySide& side) {
     const bool gp = view_plain(d.g), dp = view_plain(d.d);
     static int dma = -1;        // SSC_WGRAD_DMA=0: plain dense tiles through registers (A/B)
     if (dma < 0) {
         const char* e = getenv("SSC_WGRAD_DMA");
         dma = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
-    if (dp && dma) return gp ? launch_wg128<true, 0, TPT>(d, splitk, ws, st) : launch_wg128<false, 0, TPT>(d, splitk, ws, st);
-    if (dp) return gp ? launch_wg128<true, 1, TPT>(d, splitk, ws, st) : launch_wg128<false, 1, TPT>(d, splitk, ws, st);
-    return gp ? launch_wg128<true, 2, TPT>(d, splitk, ws, st) : launch_wg128<false, 2, TPT>(d, splitk, ws, st);
+    if (dp && dma) return gp ? launch_wg128<true, 0, TPT>(d, splitk, ws, st, side) : launch_wg128<false, 0, TPT>(d, splitk, ws, st, side);
+    if (dp) return gp ? launch_wg128<true, 1, TPT>(d, splitk, ws, st, side) : launch_wg128<false, 1, TPT>(d, splitk, ws, st, side);
+    return gp ? launch_wg128<true, 2, TPT>(d, splitk, ws, st, side) : launch_wg128<false, 2, TPT>(d, splitk, ws, st, side);
 }
 
 #ifdef SSC_WG128_TIMING
@@ -578,9 +586,17 @@ extern "C" int ssc_wg128_timing(unsigned long long* out8, int reset) {
 }
 #endif
 
-extern "C" int ssc_conv_wgrad128(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream) {
+// job != NULL: the launch also carries the apply pass of that norm backward (ssc_conv_wgrad_hosting)
+int ssc_conv_wgrad128_job(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, const ssc_bn_apply_job* job, void* stream) {
     const ssc_wgrad_desc& d = *dp;
     if (!ssc_conv_wgrad128_supported(dp)) return -10;
+    if (job != nullptr && !bn_job_ok(*job)) return -11;
     const int sk = wg128_splitk(d, ws_bytes, ws != nullptr);
-    return wg128_tpt(d) == 2 ? launch_wg128_t<2>(d, sk, ws, (hipStream_t)stream) : launch_wg128_t<1>(d, sk, ws, (hipStream_t)stream);
+    const BnApplySide side = job != nullptr ? bn_side_of(*job, wg128_num_cu()) : bn_side_none();
+    return wg128_tpt(d) == 2 ? launch_wg128_t<2>(d, sk, ws, (hipStream_t)stream, side)
+                             : launch_wg128_t<1>(d, sk, ws, (hipStream_t)stream, side);
+}
+
+extern "C" int ssc_conv_wgrad128(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream) {
+    return ssc_conv_wgrad128_job(dp, ws, ws_bytes, nullptr, stream);
 }

@@ -34,7 +34,24 @@ class ConvDesc(C.Structure):
                 ('out_stride', C.c_int32), ('ooff_y', C.c_int32), ('ooff_x', C.c_int32),
                 ('epi', C.c_int32), ('accumulate', C.c_int32), ('stat_partial', C.c_void_p), ('sk_flags', C.c_void_p),
                 ('sb_x', C.c_void_p), ('sb_ab', C.c_void_p), ('sb_stats', C.c_void_p), ('sb_ldx', C.c_int32),
-                ('sb_act', C.c_int32), ('sk_tag', C.c_int32), ('_pad0', C.c_int32)]
+                ('sb_act', C.c_int32), ('sk_tag', C.c_int32), ('sb2_col0', C.c_int32),
+                ('sb2_x', C.c_void_p), ('sb2_ab', C.c_void_p), ('sb2_stats', C.c_void_p), ('stat_partial2', C.c_void_p),
+                ('sb2_ldx', C.c_int32), ('sb2_act', C.c_int32),
+                ('fin_cnt', C.c_void_p), ('fin_grp', C.c_void_p), ('fin_scale', C.c_void_p), ('fin_offset', C.c_void_p),
+                ('fin_ab', C.c_void_p), ('fin_stats', C.c_void_p), ('fin_M', C.c_int64), ('fin_eps', C.c_float),
+                ('fin_gs', C.c_int32)]
+
+
+class BnApplyJob(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('M', C.c_int64), ('C', C.c_int32), ('ldx', C.c_int32), ('ab', C.c_void_p),
+                ('stats', C.c_void_p), ('g1', C.c_void_p), ('g2', C.c_void_p), ('ldg1', C.c_int32), ('act1', C.c_int32),
+                ('ldg2', C.c_int32), ('act2', C.c_int32), ('has_bn', C.c_int32), ('rowb_P', C.c_int32), ('rowb', C.c_void_p),
+                ('rowb_scale', C.c_float), ('lddx', C.c_int32), ('coef', C.c_void_p), ('dx', C.c_void_p)]
+
+
+class BnBwdSite(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('ab', C.c_void_p), ('stats', C.c_void_p), ('partial', C.c_void_p),
+                ('partial_bytes', C.c_int64), ('ldx', C.c_int32), ('act', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -101,6 +118,8 @@ SIGNATURES = {
     'ssc_conv_forward_bn': [C.POINTER(ConvDesc), _P, _L, _P, _P, _F, _P, _P, _P],
     'ssc_bn_finalize': [_P, _I, _I, _L, _P, _P, _F, _P, _P, _P],
     'ssc_conv_forward_bnbwd': [C.POINTER(ConvDesc), _P, _L, _P, _I, _P, _P, _I, _P, _L, C.POINTER(C.c_int), _P],
+    'ssc_conv_forward_bnbwd2': [C.POINTER(ConvDesc), _P, _L, C.POINTER(BnBwdSite), C.POINTER(BnBwdSite), _I,
+                                C.POINTER(C.c_int), _P],
     'ssc_bn_act_backward_pre': [_P, _L, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _F, _I, _P,
                                 _L, _P],
     'ssc_head1_forward_supported': [C.POINTER(ConvDesc)],
@@ -111,6 +130,9 @@ SIGNATURES = {
     'ssc_head1_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
     'ssc_head1_dgrad_bn_backward': [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _F, _P, _P, _P, _P, _L, _P],
     'ssc_bn_bwd_finalize': [_P, _I, _I, _L, _P, _P, _P, _P],
+    'ssc_bn_bwd_sums': [C.POINTER(BnApplyJob), _P, _I, _P, _P, _P, _P, _L, _P],
+    'ssc_bn_bwd_apply': [C.POINTER(BnApplyJob), _P],
+    'ssc_conv_wgrad_hosting': [C.POINTER(WgradDesc), _P, _L, C.POINTER(BnApplyJob), _P],
     'ssc_conv_narrow_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_narrow_forward': [C.POINTER(ConvDesc), _P],
     'ssc_conv_fewchan_supported': [C.POINTER(ConvDesc)],
@@ -292,9 +314,10 @@ def _kernel_name(fn, d):
 
 
 SK_FLAG_WORDS = 8192
+FIN_CNT_WORDS = 8192    # counters of the in-launch statistics fold, behind the hand-off flags (SSC_FIN_CNT_WORDS)
 _SK_MAX_STREAMS = 32
 _sk_flags = {}
-_sk_pool = {}           # device -> [_SK_MAX_STREAMS, SK_FLAG_WORDS] int32: every stream's flag array is a row of it
+_sk_pool = {}           # device -> [_SK_MAX_STREAMS, SK_FLAG_WORDS + FIN_CNT_WORDS] int32: every stream's flag array is a row of it
 _sk_tags = {}           # sk_tag -> copy of the descriptor of that launch
 _sk_eager = []          # tags of launches issued eagerly, oldest first: only the last _SK_TAG_RING of them are remembered
 _sk_next = [0]          # tags only grow (31 bits: the flag word is 0x80000000 | tag), so a tag frozen into a captured graph
@@ -327,10 +350,10 @@ def sk_flags():
         _sk_configure()
         pool = _sk_pool.get(dev)
         if pool is None:
-            pool = _sk_pool[dev] = torch.zeros((_SK_MAX_STREAMS, SK_FLAG_WORDS), dtype=torch.int32, device='cuda')
+            pool = _sk_pool[dev] = torch.zeros((_SK_MAX_STREAMS, SK_FLAG_WORDS + FIN_CNT_WORDS), dtype=torch.int32, device='cuda')
         n = sum(1 for k in _sk_flags if k[0] == dev)
         # beyond the pool (never seen: a trainer uses five streams) a stream gets an array of its own
-        f = pool[n] if n < _SK_MAX_STREAMS else torch.zeros(SK_FLAG_WORDS, dtype=torch.int32, device='cuda')
+        f = pool[n] if n < _SK_MAX_STREAMS else torch.zeros(SK_FLAG_WORDS + FIN_CNT_WORDS, dtype=torch.int32, device='cuda')
         _sk_flags[key] = f
     return f
 
@@ -353,8 +376,8 @@ def sk_timeouts():
     """Number of flag arrays whose last word reports a hand-off that timed out (must be 0)."""
     n = 0
     for pool in _sk_pool.values():
-        n += int((pool[:, -1] != 0).sum().item())
-    return n + sum(int(f[-1].item() != 0) for f in _sk_flags.values() if f.dim() == 1 and f._base is None)
+        n += int((pool[:, SK_FLAG_WORDS - 1] != 0).sum().item())
+    return n + sum(int(f[SK_FLAG_WORDS - 1].item() != 0) for f in _sk_flags.values() if f.dim() == 1 and f._base is None)
 
 
 def check_sk(where=''):
@@ -364,14 +387,14 @@ def check_sk(where=''):
     arrays are zeroed before raising, so a caller that catches the error can go on (e.g. with SSC_STREAMK=0)."""
     bad = []
     for pool in _sk_pool.values():
-        words = pool[:, -1]
+        words = pool[:, SK_FLAG_WORDS - 1]
         if bool((words != 0).any().item()):
             bad += [int(w) & 0x7fffffff for w in words.cpu().tolist() if w != 0]
             torch.cuda.synchronize()        # launches still running on the other streams wait on flags of this pool
             pool.zero_()
     for f in _sk_flags.values():
-        if f.dim() == 1 and f._base is None and int(f[-1].item()) != 0:
-            bad.append(int(f[-1].item()) & 0x7fffffff)
+        if f.dim() == 1 and f._base is None and int(f[SK_FLAG_WORDS - 1].item()) != 0:
+            bad.append(int(f[SK_FLAG_WORDS - 1].item()) & 0x7fffffff)
             torch.cuda.synchronize()
             f.zero_()
     if not bad:
@@ -418,7 +441,29 @@ def _run_conv(d, bn=None, bnbwd=None):
         _sk_tag(d)
 
     def launch():
-        if bnbwd is not None:
+        if isinstance(bnbwd, list):
+            # two normed tensors side by side: the columns [0, C0) are the gradient w.r.t. the first, the rest w.r.t. the second
+            (s0, a0), (s1, a1) = bnbwd
+            C0, C1 = s0.x2d.shape[1], s1.x2d.shape[1]
+            assert d.Nstore == d.ldc == C0 + C1, (d.Nstore, d.ldc, C0, C1)
+            sites = []
+            for sm, act in ((s0, a0), (s1, a1)):
+                assert sm.x2d.shape[0] == d.NB * d.OH * d.OW and sm.ab.numel() == 2 * sm.x2d.shape[1]
+                part = sm.buf[sm.rows:]
+                st = BnBwdSite()
+                st.x, st.ab, st.stats, st.partial = sm.x2d.data_ptr(), sm.ab.data_ptr(), sm.stats.data_ptr(), part.data_ptr()
+                st.partial_bytes, st.ldx, st.act = part.numel() * 4, sm.x2d.stride(0), act
+                sites.append(st)
+            n = C.c_int(0)
+            check(lib().ssc_conv_forward_bnbwd2(C.byref(d), ptr(ws), ws.numel() * 4, C.byref(sites[0]), C.byref(sites[1]), C0,
+                                                C.byref(n), stream_ptr()), 'ssc_conv_forward_bnbwd2')
+            for sm in (s0, s1):
+                sm.sources += 1
+                if n.value > 0:
+                    sm.rows += n.value
+                else:
+                    sm.missed += 1
+        elif bnbwd is not None:
             sums, act = bnbwd
             C2 = 2 * sums.x2d.shape[1]
             # the epilogue indexes the normed tensor and its tables with the conv's own column count and pixel rows
@@ -458,8 +503,28 @@ def _run_conv(d, bn=None, bnbwd=None):
                     (d.NB * d.PH * d.PW * d.nphase, d.Nn, d.TH * d.TW * d.k_real), nbytes))
 
 
-def _run_wgrad(d, side=False):
+def _run_wgrad(d, side=False, host=None):
+    """host: a pending norm-backward apply pass (bn_act_backward(..., defer=True)) that this launch carries as its side job."""
     global _wgrad_pending
+    if host is not None:
+        assert not host.done
+        host.done = True
+        ws = workspace()
+        call_w = lambda: check(lib().ssc_conv_wgrad_hosting(C.byref(d), ptr(ws), ws.numel() * 4, C.byref(host.c), stream_ptr()),
+                               'ssc_conv_wgrad_hosting')
+        if PROFILE is None:
+            call_w()
+            return
+        flops = 2.0 * d.NB * d.PH * d.PW * d.TH * d.TW * d.Cg_real * d.Nn
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call_w()
+        e1.record()
+        nbytes = 4.0 * (d.NB * d.g.H * d.g.W * (d.g.C0 + d.g.C1) + d.NB * d.PH * d.PW * (d.d.C0 + d.d.C1) +
+                        d.TH * d.TW * d.Cg_real * d.Nn * (2 if d.accumulate else 1))
+        PROFILE.append((_kernel_name('ssc_conv_wgrad_kernel_name', d), flops, e0, e1,
+                        (d.TH * d.TW * d.Cg_real, d.Nn, d.NB * d.PH * d.PW), nbytes))
+        return
     if side and WGRAD_STREAM is not None and PROFILE is None and \
             (WGRAD_SIDE_MAX_PIXELS is None or d.NB * d.PH * d.PW <= WGRAD_SIDE_MAX_PIXELS):
         WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
@@ -631,8 +696,9 @@ def deconv_dgrad(dy, f, out, n_off=0, nn=None, accumulate=False, bnbwd=None):
     _run_conv(d, bnbwd=bnbwd)
 
 
-def conv_wgrad(x, dy, w_grad, stride, pad, accumulate=False):
-    """dW[kh,kw,ci,co] = sum_pix x[pix@tap][ci] * dy[pix][co]  (w_grad in the conv's TF layout)."""
+def conv_wgrad(x, dy, w_grad, stride, pad, accumulate=False, host=None):
+    """dW[kh,kw,ci,co] = sum_pix x[pix@tap][ci] * dy[pix][co]  (w_grad in the conv's TF layout).
+    host: a deferred norm-backward apply pass (ApplyJob) carried inside this launch."""
     KH, KW, ci, co = w_grad.shape
     d = WgradDesc()
     d.g, d.d = x.c(), dy.c()
@@ -641,10 +707,10 @@ def conv_wgrad(x, dy, w_grad, stride, pad, accumulate=False):
     d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = KH, KW, stride, -pad, -pad
     d.Cg_real, d.Nn, d.ldc, d.accumulate = ci, co, co, int(accumulate)
     assert ci <= x.C and co <= dy.C
-    _run_wgrad(d, side=True)
+    _run_wgrad(d, side=True, host=host)
 
 
-def deconv_wgrad(x, dy, f_grad, accumulate=False):
+def deconv_wgrad(x, dy, f_grad, accumulate=False, host=None):
     """dF[kh,kw,co,ci] = sum_pix dy[pix@tap][co] * x[pix][ci]  (f_grad in the transposed-conv TF layout)."""
     KH, KW, co, ci = f_grad.shape
     d = WgradDesc()
@@ -654,7 +720,7 @@ def deconv_wgrad(x, dy, f_grad, accumulate=False):
     d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = 4, 4, 2, -1, -1
     d.Cg_real, d.Nn, d.ldc, d.accumulate = co, ci, ci, int(accumulate)
     assert co <= dy.C and ci <= x.C      # ci < x.C: 3-channel tensors padded to 4 (BG region branch)
-    _run_wgrad(d, side=True)
+    _run_wgrad(d, side=True, host=host)
 
 
 def _mat_view(a, ab=None, act=ACT_NONE):
@@ -850,16 +916,51 @@ def bn_stats(x2d, scale, offset, ab, stats, eps=1e-5):
                              ptr(ws), ws.numel() * 4, stream_ptr()), 'bn_stats')
 
 
-def bn_act_backward(x2d, ab, stats, g1, act1, dx, g2=None, act2=ACT_NONE, dscale=None, doffset=None, pre=None, rowb=None):
+SIDE_APPLY = os.environ.get('SSC_SIDE_APPLY', '0') == '1'    # norm-backward apply passes ride inside filter-gradient launches (off: no gain in the step)
+
+
+class ApplyJob(object):
+    """A norm backward whose sums are taken (coef written) and whose streaming apply pass is still to run: hand it to the
+    filter-gradient launch of the layer above (conv_wgrad / deconv_wgrad(..., host=job)) or run it with ``apply_now``."""
+
+    def __init__(self, c, keep):
+        self.c, self.keep, self.done = c, keep, False
+
+
+def apply_now(job):
+    """The apply pass of a deferred norm backward as a launch of its own (nothing could host it)."""
+    if job is not None and not job.done:
+        job.done = True
+        check(lib().ssc_bn_bwd_apply(C.byref(job.c), stream_ptr()), 'ssc_bn_bwd_apply')
+
+
+def bn_act_backward(x2d, ab, stats, g1, act1, dx, g2=None, act2=ACT_NONE, dscale=None, doffset=None, pre=None, rowb=None,
+                    defer=False, coef=None):
     """Backward through act(a*x+b) (has_bn when ab is given) for one or two consumers.  pre: BnBwdSums whose rows replace
     the pass that takes the two per-channel sums (only when every gradient source delivered its rows).
-    rowb = (v [N, C], scale, P): g1[r] += v[r // P] * scale while it is read (a per-image gradient broadcast over P pixels)."""
+    rowb = (v [N, C], scale, P): g1[r] += v[r // P] * scale while it is read (a per-image gradient broadcast over P pixels).
+    defer=True (needs ``coef`` [2C] when ab is given): only the sums are taken now; returns the ApplyJob of the streaming pass."""
     M, Cc = x2d.shape
     ws = workspace()
     has_bn = ab is not None
     rows, nrows = None, 0
     if pre is not None and has_bn and pre.missed == 0 and pre.sources == (1 if g2 is None else 2) and pre.rows > 0:
         rows, nrows = pre.buf, pre.rows
+    if defer:
+        j = BnApplyJob()
+        j.x, j.M, j.C, j.ldx = x2d.data_ptr(), M, Cc, x2d.stride(0)
+        j.ab, j.stats = (ab.data_ptr(), stats.data_ptr()) if has_bn else (None, None)
+        j.g1, j.ldg1, j.act1 = g1.data_ptr(), g1.stride(0), act1
+        j.g2, j.ldg2, j.act2 = (g2.data_ptr(), g2.stride(0), act2) if g2 is not None else (None, 0, act2)
+        j.has_bn = int(has_bn)
+        j.rowb, j.rowb_scale, j.rowb_P = (rowb[0].data_ptr(), float(rowb[1]), int(rowb[2])) if rowb else (None, 0.0, 0)
+        j.lddx, j.dx = dx.stride(0), dx.data_ptr()
+        if has_bn:
+            assert coef is not None and coef.numel() == 2 * Cc and coef.is_contiguous()
+            j.coef = coef.data_ptr()
+            check(lib().ssc_bn_bwd_sums(C.byref(j), ptr(rows), nrows, ptr(coef), ptr(dscale), ptr(doffset), ptr(ws),
+                                        ws.numel() * 4, stream_ptr()), 'ssc_bn_bwd_sums')
+        return ApplyJob(j, (x2d, ab, stats, g1, g2, dx, coef, rowb))
     check(lib().ssc_bn_act_backward_pre(ptr(x2d), M, Cc, x2d.stride(0), ptr(ab), ptr(stats),
                                         ptr(g1), g1.stride(0), act1, ptr(g2), (g2.stride(0) if g2 is not None else 0),
                                         act2, int(has_bn), ptr(dx), dx.stride(0), ptr(dscale), ptr(doffset),

@@ -22,6 +22,8 @@ def _rows(t):
 
 
 _MERGE_DDGRAD = os.environ.get('SSC_MERGE_DDGRAD', '1') == '1'
+_HOLD_FROM = int(os.environ.get('SSC_HOLD_FROM', '4'))       # decoder filter gradients from this layer on wait for the caption BPTT
+_BNBWD2 = os.environ.get('SSC_BNBWD2', '1') == '1'      # norm-backward sums of both halves out of the merged launch's epilogue (A/B)
 
 
 class Pix2PixGenerator(object):
@@ -157,45 +159,68 @@ class Pix2PixGenerator(object):
         sums_e = [None] * 6
         g_feat = g_noise = None
         hold = side_stream is not None and self.lstm_hybrid
+        # With a side stream the filter gradients of decoder_{_HOLD_FROM}.. are held back for the caption branch's BPTT (below);
+        # the others are launched in line, each HOSTING the streaming pass of the norm backward that follows its layer's data
+        # gradient (hip.ApplyJob): the pass needs the folded sums of that data gradient, the filter gradient needs neither.
+        inline_order = self.bn_stream is None and hip.SIDE_APPLY
         for k in (1, 2, 3, 4, 5):
             f = s['generator/decoder_%d/deconv/filter' % k]
             v = views[k]
             dyv = View(gcur)
-            wg = (lambda v=v, dyv=dyv, k=k:
-                  hip.deconv_wgrad(v, dyv, s.grad('generator/decoder_%d/deconv/filter' % k)))
-            if hold:
+            wg = (lambda v=v, dyv=dyv, k=k, host=None:
+                  hip.deconv_wgrad(v, dyv, s.grad('generator/decoder_%d/deconv/filter' % k), host=host))
+            held_k = hold and (k >= _HOLD_FROM or not inline_order)
+            if held_k:
                 held.append(wg)
             g0 = B.get(tag + '/gb/d%d_in0' % k, (N, v.H, v.W, v.C0))
             g1 = B.get(tag + '/gb/d%d_in1' % k, (N, v.H, v.W, v.C1))
-            # the chain continues from g0 (through the norm backward); the filter gradient and the skip half g1 are read
-            # much later, so they run on the helper stream NEXT TO the three small launches of the norm backward, and the
-            # chain waits for them before its next full-size launch (one implicit-GEMM launch at a time, as in line)
             # the two per-channel sums of each norm's backward are taken by the epilogues of the data-gradient launches
             # that produce its incoming gradients (hip.BnBwdSums): decoder_{k+1}'s norm from g0, encoder_k's from g1 + gin
             merged = _MERGE_DDGRAD and 2 <= k <= 4
-            sums_d = self._sums(tag, 'd%d' % (k + 1), d[k + 1], abd[k + 1], std[k + 1]) if (k < 5 and not merged) else None
+            sums_d = self._sums(tag, 'd%d' % (k + 1), d[k + 1], abd[k + 1], std[k + 1]) if k < 5 else None
             if 2 <= k <= 4:
                 sums_e[k] = self._sums(tag, 'e%d' % k, e[k], ab[k], st[k], sources=2)
             if merged:
                 # decoder_k reads concat[decoder_{k+1}, encoder_k]: the gradients of the two halves are the SAME gather of dy
                 # against two column ranges of the filter.  One launch over both ranges (twice the tiles: 288 instead of
                 # 2 x 144 for decoder_4 -- half-empty launches otherwise) into one buffer, the halves read back through
-                # strided row views; 17.77 -> 17.65 ms per step.  The norm-backward sums of these two sites then come from
-                # the separate pass (one launch cannot serve two normed tensors).
+                # strided row views; 17.77 -> 17.65 ms per step.  The norm-backward sums of BOTH sites come out of its
+                # epilogue: a column tile lies in one half, so each workgroup takes the tables of its own tensor.
                 g01 = B.get(tag + '/gb/d%d_in01' % k, (N, v.H, v.W, v.C0 + v.C1))
-                hip.deconv_dgrad(dyv, f, g01, n_off=0, nn=v.C0 + v.C1)
+                if _BNBWD2:
+                    hip.deconv_dgrad(dyv, f, g01, n_off=0, nn=v.C0 + v.C1,
+                                     bnbwd=[sums_d.take(ACT_RELU), sums_e[k].take(ACT_RELU)])
+                else:
+                    hip.deconv_dgrad(dyv, f, g01, n_off=0, nn=v.C0 + v.C1)
+                    for sm in (sums_d, sums_e[k]):
+                        sm.sources += 1
+                        sm.missed += 1
                 r01 = g01.view(-1, v.C0 + v.C1)
                 g0, g1 = r01[:, :v.C0], r01[:, v.C0:]
-                sums_e[k].sources += 1
-                sums_e[k].missed += 1
             else:
                 hip.deconv_dgrad(dyv, f, g0, n_off=0, nn=v.C0, bnbwd=(sums_d.take(ACT_RELU) if sums_d else None))
 
-            def rest(wg=wg, dyv=dyv, f=f, g1=g1, v=v, k=k, merged=merged):
-                if not hold:
-                    wg()
+            def rest(wg=wg, dyv=dyv, f=f, g1=g1, v=v, k=k, merged=merged, host=None, held_k=held_k):
                 if not merged:
                     hip.deconv_dgrad(dyv, f, g1, n_off=v.C0, nn=v.C1, bnbwd=(sums_e[k].take(ACT_RELU) if sums_e[k] else None))
+                if not held_k:
+                    wg(host=host)
+            job = None
+            if inline_order:
+                if k < 5:
+                    g_skip[k] = g1
+                    src = d[k + 1]
+                    dx = B.get(tag + '/gb/dd%d' % (k + 1), src.shape)
+                    job = hip.bn_act_backward(_rows(src), abd[k + 1], std[k + 1], _rows(g0), ACT_RELU, _rows(dx),
+                                              dscale=s.grad('generator/decoder_%d/scale' % (k + 1)),
+                                              doffset=s.grad('generator/decoder_%d/offset' % (k + 1)), pre=sums_d, defer=True,
+                                              coef=B.get(tag + '/gb/coef_d%d' % (k + 1), (2 * src.shape[-1],)))
+                    gcur = dx
+                else:
+                    g_feat, g_noise = g0, g1
+                rest(host=(None if held_k else job))
+                hip.apply_now(job)      # its host was held back (or has no hosting kernel): a launch of its own
+                continue
             forked = self._fork(rest)
             if k < 5:
                 g_skip[k] = g1          # through relu to encoder_k's output
@@ -264,21 +289,29 @@ class Pix2PixGenerator(object):
             xin = View(e[k - 1], None, ab[k - 1], ACT_LRELU)
             dyv = View(gcur)
             gin = B.get(tag + '/gb/e%d_in' % k, e[k - 1].shape)
-            # (a sums object that already missed a source -- the merged decoder launches -- falls back to the separate pass
-            # anyway: do not make this epilogue re-read e[k-1] for rows nobody will use)
+            # (a sums object that already missed a source falls back to the separate pass anyway: do not make this epilogue
+            # re-read e[k-1] for rows nobody will use)
             live = sums_e[k - 1] is not None and not sums_e[k - 1].missed
             hip.conv_dgrad(dyv, w, 2, 1, gin, bnbwd=(sums_e[k - 1].take(ACT_LRELU) if live else None))
-            forked = self._fork(lambda xin=xin, dyv=dyv, k=k:
-                                hip.conv_wgrad(xin, dyv, s.grad('generator/encoder_%d/conv/filter' % k), 2, 1))
             dx = B.get(tag + '/gb/de%d' % (k - 1), e[k - 1].shape)
+            inline_order = self.bn_stream is None and hip.SIDE_APPLY
+            forked = False
+            if not inline_order:
+                forked = self._fork(lambda xin=xin, dyv=dyv, k=k:
+                                    hip.conv_wgrad(xin, dyv, s.grad('generator/encoder_%d/conv/filter' % k), 2, 1))
             if k - 1 >= 2:
-                hip.bn_act_backward(_rows(e[k - 1]), ab[k - 1], st[k - 1], _rows(gin), ACT_LRELU, _rows(dx),
-                                    g2=_rows(g_skip[k - 1]), act2=ACT_RELU,
-                                    dscale=s.grad('generator/encoder_%d/scale' % (k - 1)),
-                                    doffset=s.grad('generator/encoder_%d/offset' % (k - 1)), pre=sums_e[k - 1])
+                job = hip.bn_act_backward(_rows(e[k - 1]), ab[k - 1], st[k - 1], _rows(gin), ACT_LRELU, _rows(dx),
+                                          g2=_rows(g_skip[k - 1]), act2=ACT_RELU,
+                                          dscale=s.grad('generator/encoder_%d/scale' % (k - 1)),
+                                          doffset=s.grad('generator/encoder_%d/offset' % (k - 1)), pre=sums_e[k - 1],
+                                          defer=inline_order,
+                                          coef=(B.get(tag + '/gb/coef_e%d' % (k - 1), (2 * e[k - 1].shape[-1],)) if inline_order else None))
             else:
-                hip.bn_act_backward(_rows(e[1]), None, None, _rows(gin), ACT_LRELU, _rows(dx),
-                                    g2=_rows(g_skip[1]), act2=ACT_RELU)
+                job = hip.bn_act_backward(_rows(e[1]), None, None, _rows(gin), ACT_LRELU, _rows(dx),
+                                          g2=_rows(g_skip[1]), act2=ACT_RELU, defer=inline_order)
+            if inline_order:
+                # the filter gradient of encoder_k carries the streaming pass of encoder_{k-1}'s norm backward
+                hip.conv_wgrad(xin, dyv, s.grad('generator/encoder_%d/conv/filter' % k), 2, 1, host=job)
             if forked:
                 self._join()
             gcur = dx
@@ -369,7 +402,7 @@ class Pix2PixDiscriminator(object):
         s, B = self.s, self.b
         tag, N, l, ab, st = ctx['tag'], ctx['N'], ctx['l'], ctx['ab'], ctx['st']
         gname = lambda k, what: s.grad('discriminator/layer_%d/%s' % (k, what))
-        if resume is not None:
+        if resume is not None:      # resume['gcur']: gradient w.r.t. the raw output of the first remaining layer (already applied)
             return self._backward_layers(ctx, resume['layers'], resume['gcur'], resume['sums'], None, None, need_params,
                                          need_input, accumulate, after_layer, None)
         # layer 5 (Cout = 1)
@@ -396,42 +429,63 @@ class Pix2PixDiscriminator(object):
         return self._backward_layers(ctx, (4, 3, 2, 1), None, None, dy5, rowb, need_params, need_input, accumulate, after_layer,
                                      stop_after)
 
-    def _backward_layers(self, ctx, layers, gcur, sums, dy5, rowb, need_params, need_input, accumulate, after_layer, stop_after):
-        """Layers ``layers`` of the backward pass.  gcur: gradient w.r.t. the activated output of layers[0] (None for layer 4:
-        layer 5's data gradient, taken here); sums: the norm-backward sums that came with it."""
+    def _norm_backward(self, ctx, k, gcur, sums, need_params, accumulate, rowb=None):
+        """The norm + lrelu backward of layer k's output (k = 1: lrelu only): the sums now, the streaming pass as a deferred job
+        (hip.ApplyJob) for the filter-gradient launch of layer k+1 to host -- see _backward_layers.  Returns (dx buffer, job)."""
+        s, B = self.s, self.b
+        tag, l, ab, st = ctx['tag'], ctx['l'], ctx['ab'], ctx['st']
+        gname = lambda kk, what: s.grad('discriminator/layer_%d/%s' % (kk, what))
+        dx = B.get(tag + '/gb/dl%d' % k, l[k].shape)
+        if k == 1:
+            return dx, hip.bn_act_backward(_rows(l[1]), None, None, _rows(gcur), ACT_LRELU, _rows(dx), defer=True)
+        ds = do = None
+        if need_params and accumulate:
+            tmp_s = B.get(tag + '/gb/tmp_scale%d' % k, (2, self.chans[k]))
+            ds, do = tmp_s[0], tmp_s[1]
+        elif need_params:
+            ds, do = gname(k, 'scale'), gname(k, 'offset')
+        coef = B.get(tag + '/gb/coef%d' % k, (2 * self.chans[k],))
+        job = hip.bn_act_backward(_rows(l[k]), ab[k], st[k], _rows(gcur), ACT_LRELU, _rows(dx), dscale=ds, doffset=do,
+                                  pre=sums, rowb=rowb, defer=True, coef=coef)
+        if need_params and accumulate:
+            hip.call('ssc_axpy', gname(k, 'scale'), ds, 1.0, self.chans[k])
+            hip.call('ssc_axpy', gname(k, 'offset'), do, 1.0, self.chans[k])
+        return dx, job
+
+    def _backward_layers(self, ctx, layers, dx, sums, dy5, rowb, need_params, need_input, accumulate, after_layer, stop_after):
+        """Layers ``layers`` of the backward pass.  dx: gradient w.r.t. the RAW output of layers[0], or None for layer 4 (layer 5's
+        data gradient and layer 4's norm backward are taken here).
+        Order per layer k: data gradient into layer k-1 (its epilogue takes the sums of layer k-1's norm backward) -> those sums
+        folded (one small launch) -> filter gradient of layer k, which HOSTS the streaming pass of layer k-1's norm backward
+        (hip.ApplyJob: HBM traffic beside the matrix work of a launch that needs neither its input nor its output)."""
         s, B = self.s, self.b
         tag, N, l, ab, st = ctx['tag'], ctx['N'], ctx['l'], ctx['ab'], ctx['st']
         gname = lambda k, what: s.grad('discriminator/layer_%d/%s' % (k, what))
         dgen = None
+        if dx is None:
+            assert layers[0] == 4
+            dx = B.get(tag + '/gb/dl4', l[4].shape)
+            ds = do = None
+            if need_params and accumulate:
+                tmp_s = B.get(tag + '/gb/tmp_scale4', (2, self.chans[4]))
+                ds, do = tmp_s[0], tmp_s[1]
+            elif need_params:
+                ds, do = gname(4, 'scale'), gname(4, 'offset')
+            # d loss / d act(norm(l4)) = layer 5's data gradient + the class head's term.  SSC_HEAD1_FUSED=1 recomputes
+            # it inside the two passes of the norm backward instead of storing it: 44 vs 55 us alone, but 0.1 ms
+            # SLOWER per iteration in the replayed step (its vector-ALU work competes with the matrix kernels of the
+            # chains running beside it; the separate launches are memory traffic those leave idle) -- off by default
+            fused = _HEAD1_FUSED and hip.head1_dgrad_bn_backward(dy5, s['discriminator/layer_5/conv/filter'], 1, l[4], ab[4], st[4],
+                                                                 ACT_LRELU, dx, dscale=ds, doffset=do,
+                                                                 rowb=(rowb[:2] if rowb else None))
+            if not fused:
+                g4 = B.get(tag + '/gb/g4', l[4].shape)
+                hip.conv_dgrad(dy5, s['discriminator/layer_5/conv/filter'], 1, 1, g4, k_real=1)
+                hip.bn_act_backward(_rows(l[4]), ab[4], st[4], _rows(g4), ACT_LRELU, _rows(dx), dscale=ds, doffset=do, rowb=rowb)
+            if need_params and accumulate:
+                hip.call('ssc_axpy', gname(4, 'scale'), ds, 1.0, self.chans[4])
+                hip.call('ssc_axpy', gname(4, 'offset'), do, 1.0, self.chans[4])
         for k in layers:
-            dx = B.get(tag + '/gb/dl%d' % k, l[k].shape)
-            if k >= 2:
-                ds = do = None
-                if need_params and accumulate:
-                    tmp_s = B.get(tag + '/gb/tmp_scale%d' % k, (2, self.chans[k]))
-                    ds, do = tmp_s[0], tmp_s[1]
-                elif need_params:
-                    ds, do = gname(k, 'scale'), gname(k, 'offset')
-                fused = False
-                if k == 4:
-                    # d loss / d act(norm(l4)) = layer 5's data gradient + the class head's term.  SSC_HEAD1_FUSED=1 recomputes
-                    # it inside the two passes of the norm backward instead of storing it: 44 vs 55 us alone, but 0.1 ms
-                    # SLOWER per iteration in the replayed step (its vector-ALU work competes with the matrix kernels of the
-                    # chains running beside it; the separate launches are memory traffic those leave idle) -- off by default
-                    fused = _HEAD1_FUSED and hip.head1_dgrad_bn_backward(dy5, s['discriminator/layer_5/conv/filter'], 1, l[4], ab[4], st[4],
-                                                        ACT_LRELU, dx, dscale=ds, doffset=do,
-                                                        rowb=(rowb[:2] if rowb else None))
-                    if not fused:
-                        gcur = B.get(tag + '/gb/g4', l[4].shape)
-                        hip.conv_dgrad(dy5, s['discriminator/layer_5/conv/filter'], 1, 1, gcur, k_real=1)
-                if not fused:
-                    hip.bn_act_backward(_rows(l[k]), ab[k], st[k], _rows(gcur), ACT_LRELU, _rows(dx), dscale=ds, doffset=do,
-                                        pre=sums, rowb=(rowb if k == 4 else None))
-                if need_params and accumulate:
-                    hip.call('ssc_axpy', gname(k, 'scale'), ds, 1.0, self.chans[k])
-                    hip.call('ssc_axpy', gname(k, 'offset'), do, 1.0, self.chans[k])
-            else:
-                hip.bn_act_backward(_rows(l[1]), None, None, _rows(gcur), ACT_LRELU, _rows(dx))
             if k == 1:
                 xin = View(l[0])
             elif k == 2:
@@ -440,10 +494,7 @@ class Pix2PixDiscriminator(object):
                 xin = View(l[k - 1], None, ab[k - 1], ACT_LRELU)
             dyv = View(dx)
             w = s['discriminator/layer_%d/conv/filter' % k]
-            if need_params:
-                hip.conv_wgrad(xin, dyv, gname(k, 'conv/filter'), self.strides[k], 1, accumulate=accumulate)
-                if after_layer is not None:
-                    after_layer(k)
+            job, dx_next = None, None
             if k > 1:
                 gin = B.get(tag + '/gb/g%d' % (k - 1), l[k - 1].shape)
                 sums = None
@@ -453,12 +504,19 @@ class Pix2PixDiscriminator(object):
                                          B.get(tag + '/gb/bnsums%d' % (k - 1),
                                                (hip.BnBwdSums.rows_needed(x2d.shape[0]), 2 * x2d.shape[1])))
                 hip.conv_dgrad(dyv, w, self.strides[k], 1, gin, bnbwd=(sums.take(ACT_LRELU) if sums else None))
-                gcur = gin
-                if stop_after == k:
-                    return {'layers': tuple(j for j in layers if j < k), 'gcur': gcur, 'sums': sums}
+                dx_next, job = self._norm_backward(ctx, k - 1, gin, sums, need_params, accumulate)
             elif need_input:
                 dgen = B.get(tag + '/gb/dgen', (N, l[0].shape[1], l[0].shape[2], 4))
                 hip.conv_dgrad(dyv, w, 2, 1, dgen, n_off=3, nn=3, nstore=4)
+            if need_params:
+                hip.conv_wgrad(xin, dyv, gname(k, 'conv/filter'), self.strides[k], 1, accumulate=accumulate,
+                               host=(job if hip.SIDE_APPLY else None))
+                if after_layer is not None:
+                    after_layer(k)
+            hip.apply_now(job)      # not hosted (no filter gradient in this pass, or hosting switched off)
+            dx = dx_next
+            if stop_after == k and k > 1:
+                return {'layers': tuple(j for j in layers if j < k), 'gcur': dx, 'sums': None}
         return dgen
 
     def finish_sn_backward(self, sn, accumulate=False):

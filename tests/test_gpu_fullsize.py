@@ -279,3 +279,107 @@ def test_cli_test_and_val_192_match_oracle(mode, tmp_path, monkeypatch):
             stem = os.path.join(run, 'validation_results', 'with_text', '%s_%04d' % (mp.CATEGORIES[int(cls[i])], i))
             check(stem + '_output.png', ref, i)
             assert np.array_equal(np.array(Image.open(stem + '_target.png')), mp._postprocess(b['images'])[i])
+
+
+# --------------------------------------------------------------------------- config 2 for the other block types ("MRU second")
+def _captions(n, g):
+    text = torch.zeros(n, 15, dtype=torch.int32)
+    for i in range(n):
+        k = 3 + (i % 9)
+        text[i, 15 - k:] = torch.randint(1, 58, (k,), generator=g, dtype=torch.int32)
+    return text
+
+
+def test_fg_generate_mru_batch16_192_oracle(host_threads):
+    """Config 2 with the reference's default --block_type: generate_mru (models_collection.py:251-377) at batch 16, 192x192,
+    through GanTrainer.generate (hipGraph replay), every sample against the oracle.  Float64 is the arbiter (the cond-norm
+    stack amplifies fp32 rounding on both sides): <= 1e-3, or no worse than 1.5x the fp32 CPU path's own distance."""
+    from oracle import mru as M
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    n, img = 16, 192
+    g = torch.Generator().manual_seed(31)
+    p = M.init_params(7, img=img)
+    z = torch.rand(n, 3, img, img, generator=g) * 2 - 1
+    text, labels, nv = _captions(n, g), torch.randint(0, 25, (n,), generator=g, dtype=torch.int32), torch.randn(n, 256, generator=g)
+    ref = M.generate_mru(p, z, text, labels, nv)
+    ref64 = M.generate_mru({k: v.double() for k, v in p.items()}, z.double(), text, labels, nv.double())
+    tr = GanTrainer(img=img, seed=1, block_type='MRU')
+    tr.store.load_dict(p)
+    outs = [tr.generate(z.cuda(), text.numpy(), nv.cuda(), labels=labels.cuda()) for _ in range(3)]    # eager, captured, replayed
+    assert any(k[0] == 'infer' for k in tr._graphs)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    err = (outs[2].cpu().double() - ref64).abs().amax(dim=(1, 2, 3))
+    cpu = (ref.double() - ref64).abs().amax(dim=(1, 2, 3))
+    assert float(err.max()) <= max(TOL, 1.5 * float(cpu.max())), (err.tolist(), cpu.tolist())
+
+
+def test_fg_generate_residual_batch16_192_oracle(host_threads):
+    """Config 2 for --block_type Residual: generate_residual (models_collection.py:541-672) at batch 16, 192x192."""
+    from oracle import residual as R
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    n, img = 16, 192
+    g = torch.Generator().manual_seed(32)
+    p = R.init_params('fg', seed=4, img=img)
+    z = torch.rand(n, 3, img, img, generator=g) * 2 - 1
+    text, nv = _captions(n, g), torch.randn(n, 256, generator=g)
+    ref = R.generate_residual(p, z, text, nv)
+    ref64 = R.generate_residual({k: v.double() for k, v in p.items()}, z.double(), text, nv.double())
+    tr = GanTrainer(img=img, seed=1, block_type='Residual')
+    tr.store.load_dict(p)
+    outs = [tr.generate(z.cuda(), text.numpy(), nv.cuda()) for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    err = (outs[2].cpu().double() - ref64).abs().amax(dim=(1, 2, 3))
+    cpu = (ref.double() - ref64).abs().amax(dim=(1, 2, 3))
+    assert float(err.max()) <= max(TOL, 1.5 * float(cpu.max())), (err.tolist(), cpu.tolist())
+
+
+def test_mru_discriminator_192_oracle(host_threads):
+    """discriminate_mru (models_collection.py:676-786) at the full 192x192 (the forward parity test of test_gpu_mru.py runs
+    64x64): patch logits, class logits and every spectral-norm u' of the power iteration."""
+    from oracle import mru as M
+    from oracle import pix2pix as O
+    from sketchyscenecolorization_amd import hip
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    n, img = 2, 192
+    p = M.init_params(5, img=img, with_discriminator=True)
+    tr = GanTrainer(img=img, seed=6, block_type='MRU')
+    tr.store.load_dict(p)
+    b = O.synthetic_batch(n, seed=989, img=img)
+    disc, logits, us = M.discriminate_mru(p, b['sketches'], b['images_d'], return_u=True)
+    xd = torch.zeros(n, img, img, 8, device='cuda')
+    hip.nchw_to_nhwc(b['sketches'].cuda(), xd, 0)
+    hip.nchw_to_nhwc(b['images_d'].cuda(), xd, 3)
+    sn = tr.D.prepare_sn()
+    c = tr.D.forward(xd, sn, 'dr')
+    assert c['disc'].shape[:3] == (n, 12, 12)
+    assert float((c['disc'][..., 0].cpu() - disc[:, 0]).abs().max()) < 1e-3 * max(1.0, float(disc.abs().max()))
+    assert float((c['logits'].cpu() - logits).abs().max()) < 1e-3 * max(1.0, float(logits.abs().max()))
+    for k, u in us.items():
+        a, r = sn[k[:-2]]['u_new'].detach().cpu().double().flatten(), u.double().flatten()
+        assert float((a - r).norm() / r.norm()) < 1e-4, k
+
+
+@pytest.mark.parametrize('block_type', ['MRU', 'Residual'])
+def test_full_size_train_step_overlapped_equals_inline_bitwise(block_type):
+    """The train steps bench.py times for the other block types (batch 32, 192x192), exercised at the size they are timed at:
+    trainer A launches every kernel in line on one stream, trainer B is the default (hipGraph replay, side streams, generator
+    forward run ahead inside the D-step).  Fixed summation orders everywhere, so only a missing dependency could make them
+    differ: weights bitwise equal after three iterations, losses equal to double rounding.  (Pix2Pix: test_gpu_pix2pix.py.)"""
+    from sketchyscenecolorization_amd.synthetic import synthetic_batch
+    from sketchyscenecolorization_amd.trainer import GanTrainer
+    a = GanTrainer(img=192, seed=3, max_iter_step=1000, use_graphs=False, overlap_real=False, block_type=block_type)
+    b = GanTrainer(img=192, seed=3, max_iter_step=1000, use_graphs=True, block_type=block_type)
+    ds = [synthetic_batch(32, 300 + k, 192) for k in range(2)]
+    gs = [synthetic_batch(32, 400 + k, 192) for k in range(2)]
+    for it in range(3):
+        bd, bg = ds[it % 2], gs[it % 2]
+        la = (float(a.d_step(bd, it)), float(a.g_step(bg, it)))
+        lg, ld = b.train_iteration(bd, bg, it)
+        assert la[0] == la[0] and la[1] == la[1]
+        assert abs(la[0] - float(ld)) < 1e-9 * max(1.0, abs(la[0])) and abs(la[1] - float(lg)) < 1e-9 * max(1.0, abs(la[1])), \
+            (it, la, float(ld), float(lg))
+    assert b._graphs, 'the steps were not captured'
+    for n in a.store.names():
+        assert torch.equal(a.store[n], b.store[n]), n
