@@ -119,6 +119,9 @@ typedef struct ssc_conv_desc {
     int64_t fin_M;        /* elements per channel */
     float fin_eps;
     int32_t fin_gs;       /* rows per group */
+    int32_t stat_mode;    /* set by ssc_conv_forward_minmax (callers leave 0): 1 = the rows of stat_partial hold the per-column
+                             MINIMUM and MAXIMUM of the tile's (activated) outputs instead of sum and sum of squares */
+    int32_t _pad1;
 } ssc_conv_desc;
 #define SSC_FIN_CNT_WORDS 8192   /* counters of the in-launch statistics fold: words [SSC_SK_FLAG_WORDS, + SSC_FIN_CNT_WORDS) of sk_flags */
 #define SSC_SK_FLAG_WORDS 8192   /* >= resident workgroups of the largest grid; the last word reports a hand-off timeout:
@@ -249,6 +252,13 @@ int ssc_mean_pool2(const float* x, int ldx, float* out, int ldo, int N, int H, i
  * [n_labels, C]; abn[n] = [a(C); b(C)] with a = scale[label_n]*rstd, b = offset[label_n] - mean*a */
 int ssc_cbn_fold(const float* stats, const float* scale_m, const float* offset_m, const int32_t* labels, int N, int C,
                  float* abn, void* stream);
+/* the fold of per-split rows [N][nsplit][2][C] (min row, max row) to mnmx [N][2][C] */
+int ssc_minmax_finalize(const float* part, int nsplit, int N, int C, float* mnmx, void* stream);
+/* ssc_conv_forward + ssc_minmax_hw of its output (the MRU gates: conv + bias + lrelu, then reduce_min / reduce_max over the
+ * positions of every sample and channel, mru.py:407-415): when the launch qualifies (uniform-tap kernel, whole tiles finished
+ * in one workgroup, a sample's positions a multiple of the tile's rows) the per-tile minima / maxima come out of the conv
+ * epilogue and only the fold remains; otherwise the output is read back once. */
+int ssc_conv_forward_minmax(const ssc_conv_desc* d, float* ws, int64_t ws_bytes, float* mnmx, void* stream);
 /* mnmx[n] = [min(C); max(C)] over the P = H*W rows of sample n (tf.reduce_min/max(axis=[2,3]), mru.py:414-415) */
 int ssc_minmax_hw(const float* x, int ld, int N, int P, int C, float* mnmx, float* workspace, int64_t workspace_bytes,
                   void* stream);
@@ -382,6 +392,17 @@ int ssc_bn_bwd_sums(const ssc_bn_apply_job* job, const float* pre, int nrows, fl
                     float* ws, int64_t ws_bytes, void* stream);
 int ssc_bn_bwd_apply(const ssc_bn_apply_job* job, void* stream);
 int ssc_conv_wgrad_hosting(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, const ssc_bn_apply_job* job, void* stream);
+/*
+ * Backward through the output of a bottleneck block, out = act(norm_A(xa) + shortcut) (residual_util.py:103-109, 138-146,
+ * 165-167): dz = g * act'(out) and, with that one dz, the backward of block_3's norm (site A: dxa, scale / offset gradients)
+ * and -- en / de blocks, xb != NULL -- of the projection shortcut's norm (site B).  Three launches for what is an activation
+ * pass + two ssc_bn_act_backward otherwise.  dz_out != NULL: dz is also written (the identity shortcut of a pu block needs
+ * it).  All tensors dense [M][C]; coef: [3][C] scratch of the caller.
+ */
+int ssc_block_out_backward(const float* out, const float* g, int64_t M, int C, int act, const float* xa, const float* aba,
+                           const float* sta, const float* xb, const float* abb, const float* stb, float* dz_out, float* dxa,
+                           float* dxb, float* dscale_a, float* doffset_a, float* dscale_b, float* doffset_b, float* coef,
+                           float* ws, int64_t ws_bytes, void* stream);
 /*
  * ssc_conv_forward for a launch whose output g is the gradient w.r.t. act(a*x+b) of a batch-statistics-normed
  * tensor x ([rows][ldx], addressed like the output): when the launch qualifies (uniform-tap kernel, no split-K

@@ -3,6 +3,7 @@
 // wavefront's 64 lanes cover 1 KiB per load instruction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "sketchycolor_hip.h"
 #include "bn_bwd.h"
 
@@ -371,22 +372,53 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// one wavefront per channel: lanes stride over the row-block partials, reduce in double
+// Per-channel fold of the row-block partials in double.  wpc = wavefronts per channel: 1 (four channels per block) for a few
+// hundred rows; 4 (a block per channel, its waves combined through LDS in wave order) when the epilogues of the big launches
+// delivered thousands of rows -- a lane then walks 1/256 of them (the fold of encoder_2's 2304 rows took 21 us on one wave,
+// longer than the streaming pass that follows it).  Returns whether this thread holds the channel's sums.
+__device__ __forceinline__ bool fold_rows(const float* __restrict__ partial, int nblk, int C, int wpc, int& c, double& s, double& q) {
+    __shared__ double sh[2][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    c = (wpc == 4) ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const int sub = (wpc == 4) ? wave : 0;
+    s = 0.0;
+    q = 0.0;
+    if (c < C) {
+        for (int b = sub * 64 + lane; b < nblk; b += 64 * wpc) {
+            s += (double)partial[(long)b * 2 * C + c];
+            q += (double)partial[(long)b * 2 * C + C + c];
+        }
+        s = wave_sum_d(s);
+        q = wave_sum_d(q);
+    }
+    if (wpc == 4) {     // block-uniform
+        if (lane == 0) { sh[0][wave] = s; sh[1][wave] = q; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3];
+            q = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
+        }
+        return threadIdx.x == 0 && c < C;
+    }
+    return lane == 0 && c < C;
+}
+static inline int fold_wpc(int nblk) {
+    static int force1 = -1;     // SSC_FOLD_WPC=1: always one wave per channel (A/B)
+    if (force1 < 0) {
+        const char* e = getenv("SSC_FOLD_WPC");
+        force1 = (e != nullptr && e[0] == '1') ? 1 : 0;
+    }
+    return (nblk >= 512 && !force1) ? 4 : 1;
+}
+static inline unsigned fold_grid(int C, int wpc) { return wpc == 4 ? (unsigned)C : (unsigned)((C + 3) / 4); }
+
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                                  long M, const float* __restrict__ scale,
                                                                  const float* __restrict__ offset, float eps,
-                                                                 float* __restrict__ ab, float* __restrict__ stats) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        s += (double)partial[(long)b * 2 * C + c];
-        q += (double)partial[(long)b * 2 * C + C + c];
-    }
-    s = wave_sum_d(s);
-    q = wave_sum_d(q);
-    if (lane != 0) return;
+                                                                 float* __restrict__ ab, float* __restrict__ stats, int wpc) {
+    int c;
+    double s, q;
+    if (!fold_rows(partial, nblk, C, wpc, c, s, q)) return;
     const double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -406,15 +438,15 @@ extern "C" int ssc_bn_stats(const float* x, int64_t M, int C, int ldx, const flo
     if ((int64_t)nbr * 2 * C * (int64_t)sizeof(float) > ws_bytes) return -2;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, x, (long)M, C, ldx, tcg, ws);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, ws, nbr, C, (long)M, scale,
-                       offset, eps, ab, stats);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(fold_grid(C, fold_wpc(nbr))), dim3(256), 0, st, ws, nbr, C, (long)M, scale,
+                       offset, eps, ab, stats, fold_wpc(nbr));
     return CHECK_LAUNCH();
 }
 
 extern "C" int ssc_bn_finalize(const float* partial, int nblk, int C, int64_t M, const float* scale, const float* offset,
                                float eps, float* ab, float* stats, void* stream) {
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
-                       (long)M, scale, offset, eps, ab, stats);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(fold_grid(C, fold_wpc(nblk))), dim3(256), 0, (hipStream_t)stream, partial,
+                       nblk, C, (long)M, scale, offset, eps, ab, stats, fold_wpc(nblk));
     return CHECK_LAUNCH();
 }
 
@@ -570,18 +602,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(BnBwdArgs a, int tc
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                                long M, float* __restrict__ coef,
                                                                float* __restrict__ dscale,
-                                                               float* __restrict__ doffset) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        s += (double)partial[(long)b * 2 * C + c];
-        q += (double)partial[(long)b * 2 * C + C + c];
-    }
-    s = wave_sum_d(s);
-    q = wave_sum_d(q);
-    if (lane != 0) return;
+                                                               float* __restrict__ doffset, int wpc) {
+    int c;
+    double s, q;
+    if (!fold_rows(partial, nblk, C, wpc, c, s, q)) return;
     coef[c] = (float)(s / (double)M);
     coef[C + c] = (float)(q / (double)M);
     if (dscale != nullptr) dscale[c] = (float)q;
@@ -614,8 +638,8 @@ extern "C" int ssc_bn_bwd_sums(const ssc_bn_apply_job* job, const float* pre, in
         if ((int64_t)nbr * 2 * j.C * (int64_t)sizeof(float) > ws_bytes) return -2;
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, a, tcg, ws);
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((j.C + 3) / 4), dim3(256), 0, st, partial, nbr, j.C, (long)j.M, coef, dscale,
-                       doffset);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(fold_grid(j.C, fold_wpc(nbr))), dim3(256), 0, st, partial, nbr, j.C, (long)j.M,
+                       coef, dscale, doffset, fold_wpc(nbr));
     return CHECK_LAUNCH();
 }
 
@@ -660,8 +684,8 @@ extern "C" int ssc_bn_act_backward_pre(const float* x, int64_t M, int C, int ldx
 // scale / offset gradients (head1.hip takes the sums inside its fused data-gradient pass)
 extern "C" int ssc_bn_bwd_finalize(const float* partial, int nblk, int C, int64_t M, float* coef, float* dscale, float* doffset,
                                    void* stream) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, (long)M,
-                       coef, dscale, doffset);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(fold_grid(C, fold_wpc(nblk))), dim3(256), 0, (hipStream_t)stream, partial, nblk,
+                       C, (long)M, coef, dscale, doffset, fold_wpc(nblk));
     return CHECK_LAUNCH();
 }
 
@@ -672,6 +696,175 @@ extern "C" int ssc_bn_act_backward(const float* x, int64_t M, int C, int ldx, co
     (void)scale;
     return ssc_bn_act_backward_pre(x, M, C, ldx, ab, stats, g1, ldg1, act1, g2, ldg2, act2, has_bn, dx, lddx, dscale, doffset,
                                    nullptr, 0, nullptr, 0.f, 0, ws, ws_bytes, stream);
+}
+
+// ------------------------------------------------------------------ block-output backward of a bottleneck (residual_util.py:83-171)
+// out = act(norm_A(xa) + shortcut): the gradient w.r.t. the block output g goes through act' (the sign of `out`) and then, with
+// the SAME dz, through the norm of block_3 (site A) and -- en / de blocks -- through the norm of the projection shortcut
+// (site B).  One partial-sum launch, one fold, one streaming launch for the whole of it instead of an activation pass + two
+// norm backwards (7 launches; 4 without site B): dz is only written when the caller needs it (identity shortcut).
+struct DualBwdArgs {
+    const float* out; const float* g; long M; int C; int act;
+    const float* xa; const float* aba; const float* sta;
+    const float* xb; const float* abb; const float* stb;      // xb == NULL: no site B
+};
+
+__device__ __forceinline__ float4 dual_dz(const DualBwdArgs& a, long i) {
+    const float4 o = *reinterpret_cast<const float4*>(a.out + i), g = *reinterpret_cast<const float4*>(a.g + i);
+    const float sl = a.act == SSC_ACT_RELU ? 0.f : (a.act == SSC_ACT_LRELU ? 0.2f : 1.f);
+    // act'(z) from the sign of the block output (relu / lrelu keep the sign; out == 0 <=> z <= 0 for relu)
+    return make_float4(g.x * (o.x > 0.f ? 1.f : sl), g.y * (o.y > 0.f ? 1.f : sl), g.z * (o.z > 0.f ? 1.f : sl),
+                       g.w * (o.w > 0.f ? 1.f : sl));
+}
+
+// rows of [sum dz | sum dz*xhat_A | sum dz*xhat_B] (3 x C, the third only with site B); grid (row blocks, column blocks)
+__global__ __launch_bounds__(256) void dual_bwd_partial_kernel(DualBwdArgs a, int tcg, float* __restrict__ partial) {
+    __shared__ float4 sh[3][256];
+    const int rl = 256 / tcg;
+    const int cgi = blockIdx.y * tcg + (threadIdx.x % tcg);
+    const int rlane = threadIdx.x / tcg;
+    const int c = cgi * 4;
+    const bool two = a.xb != nullptr;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), qa = s, qb = s;
+    if (c < a.C) {
+        const float4 mua = *reinterpret_cast<const float4*>(a.sta + c), rsa = *reinterpret_cast<const float4*>(a.sta + a.C + c);
+        float4 mub = s, rsb = s;
+        if (two) {
+            mub = *reinterpret_cast<const float4*>(a.stb + c);
+            rsb = *reinterpret_cast<const float4*>(a.stb + a.C + c);
+        }
+        const long step = (long)gridDim.x * rl;
+        for (long r = (long)blockIdx.x * rl + rlane; r < a.M; r += step) {
+            const long i = r * a.C + c;
+            const float4 dz = dual_dz(a, i);
+            const float4 xa = *reinterpret_cast<const float4*>(a.xa + i);
+            s.x += dz.x; s.y += dz.y; s.z += dz.z; s.w += dz.w;
+            qa.x += dz.x * (xa.x - mua.x) * rsa.x; qa.y += dz.y * (xa.y - mua.y) * rsa.y;
+            qa.z += dz.z * (xa.z - mua.z) * rsa.z; qa.w += dz.w * (xa.w - mua.w) * rsa.w;
+            if (two) {
+                const float4 xb = *reinterpret_cast<const float4*>(a.xb + i);
+                qb.x += dz.x * (xb.x - mub.x) * rsb.x; qb.y += dz.y * (xb.y - mub.y) * rsb.y;
+                qb.z += dz.z * (xb.z - mub.z) * rsb.z; qb.w += dz.w * (xb.w - mub.w) * rsb.w;
+            }
+        }
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = qa;
+    sh[2][threadIdx.x] = qb;
+    __syncthreads();
+    if (rlane == 0 && c < a.C) {
+        for (int k = 1; k < rl; ++k) {
+            const float4 u = sh[0][k * tcg + threadIdx.x], v = sh[1][k * tcg + threadIdx.x], w = sh[2][k * tcg + threadIdx.x];
+            s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+            qa.x += v.x; qa.y += v.y; qa.z += v.z; qa.w += v.w;
+            qb.x += w.x; qb.y += w.y; qb.z += w.z; qb.w += w.w;
+        }
+        float* p = partial + (long)blockIdx.x * 3 * a.C;
+        *reinterpret_cast<float4*>(p + c) = s;
+        *reinterpret_cast<float4*>(p + a.C + c) = qa;
+        *reinterpret_cast<float4*>(p + 2 * a.C + c) = qb;
+    }
+}
+
+// coef [3][C] = mean dz, mean dz*xhat_A, mean dz*xhat_B; the scale / offset gradients of both norms
+__global__ __launch_bounds__(256) void dual_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
+                                                                 float* __restrict__ coef, float* __restrict__ dsa,
+                                                                 float* __restrict__ doa, float* __restrict__ dsb,
+                                                                 float* __restrict__ dob) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0, qa = 0.0, qb = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        s += (double)partial[(long)b * 3 * C + c];
+        qa += (double)partial[(long)b * 3 * C + C + c];
+        qb += (double)partial[(long)b * 3 * C + 2 * C + c];
+    }
+    s = wave_sum_d(s);
+    qa = wave_sum_d(qa);
+    qb = wave_sum_d(qb);
+    if (lane != 0) return;
+    coef[c] = (float)(s / (double)M);
+    coef[C + c] = (float)(qa / (double)M);
+    coef[2 * C + c] = (float)(qb / (double)M);
+    if (dsa != nullptr) dsa[c] = (float)qa;
+    if (doa != nullptr) doa[c] = (float)s;
+    if (dsb != nullptr) dsb[c] = (float)qb;
+    if (dob != nullptr) dob[c] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void dual_bwd_apply_kernel(DualBwdArgs a, const float* __restrict__ coef, float* __restrict__ dz_out,
+                                                              float* __restrict__ dxa, float* __restrict__ dxb) {
+    const int cg = a.C / 4;
+    const bool two = a.xb != nullptr;
+    const int i0 = blockIdx.x * 256 + threadIdx.x;
+    const bool fast = (256 % cg) == 0;      // a thread keeps one column group: constants loaded once
+    const long tot = a.M * cg, stride = (long)gridDim.x * 256;
+    int c = (i0 % cg) * 4;
+    float4 aa, mua, rsa, c1, c2a, ab_, mub, rsb, c2b;
+    auto load_consts = [&](int cc) {
+        aa = *reinterpret_cast<const float4*>(a.aba + cc);
+        mua = *reinterpret_cast<const float4*>(a.sta + cc);
+        rsa = *reinterpret_cast<const float4*>(a.sta + a.C + cc);
+        c1 = *reinterpret_cast<const float4*>(coef + cc);
+        c2a = *reinterpret_cast<const float4*>(coef + a.C + cc);
+        if (two) {
+            ab_ = *reinterpret_cast<const float4*>(a.abb + cc);
+            mub = *reinterpret_cast<const float4*>(a.stb + cc);
+            rsb = *reinterpret_cast<const float4*>(a.stb + a.C + cc);
+            c2b = *reinterpret_cast<const float4*>(coef + 2 * a.C + cc);
+        }
+    };
+    if (fast) load_consts(c);
+    for (long i = i0; i < tot; i += stride) {
+        if (!fast) {
+            c = (int)(i % cg) * 4;
+            load_consts(c);
+        }
+        const long e = i * 4;       // element offset: rows are dense (ld == C)
+        const float4 dz = dual_dz(a, e);
+        const float4 xa = *reinterpret_cast<const float4*>(a.xa + e);
+        float4 o;
+        o.x = aa.x * (dz.x - c1.x - (xa.x - mua.x) * rsa.x * c2a.x);
+        o.y = aa.y * (dz.y - c1.y - (xa.y - mua.y) * rsa.y * c2a.y);
+        o.z = aa.z * (dz.z - c1.z - (xa.z - mua.z) * rsa.z * c2a.z);
+        o.w = aa.w * (dz.w - c1.w - (xa.w - mua.w) * rsa.w * c2a.w);
+        *reinterpret_cast<float4*>(dxa + e) = o;
+        if (two) {
+            const float4 xb = *reinterpret_cast<const float4*>(a.xb + e);
+            o.x = ab_.x * (dz.x - c1.x - (xb.x - mub.x) * rsb.x * c2b.x);
+            o.y = ab_.y * (dz.y - c1.y - (xb.y - mub.y) * rsb.y * c2b.y);
+            o.z = ab_.z * (dz.z - c1.z - (xb.z - mub.z) * rsb.z * c2b.z);
+            o.w = ab_.w * (dz.w - c1.w - (xb.w - mub.w) * rsb.w * c2b.w);
+            *reinterpret_cast<float4*>(dxb + e) = o;
+        }
+        if (dz_out != nullptr) *reinterpret_cast<float4*>(dz_out + e) = dz;
+    }
+}
+
+// every tensor dense [M][C]; coef: caller's [3][C]; dz_out / site B / the four parameter gradients may be NULL
+extern "C" int ssc_block_out_backward(const float* out, const float* g, int64_t M, int C, int act, const float* xa, const float* aba,
+                                      const float* sta, const float* xb, const float* abb, const float* stb, float* dz_out,
+                                      float* dxa, float* dxb, float* dscale_a, float* doffset_a, float* dscale_b, float* doffset_b,
+                                      float* coef, float* ws, int64_t ws_bytes, void* stream) {
+    if ((C & 3) || out == nullptr || g == nullptr || xa == nullptr || aba == nullptr || sta == nullptr || dxa == nullptr ||
+        coef == nullptr || (xb != nullptr && (abb == nullptr || stb == nullptr || dxb == nullptr)))
+        return -1;
+    hipStream_t st = (hipStream_t)stream;
+    DualBwdArgs a;
+    a.out = out; a.g = g; a.M = (long)M; a.C = C; a.act = act; a.xa = xa; a.aba = aba; a.sta = sta;
+    a.xb = xb; a.abb = abb; a.stb = stb;
+    int tcg, rl, nbr, nbc;
+    col_grid(M, C, tcg, rl, nbr, nbc);
+    if ((int64_t)nbr * 3 * C * (int64_t)sizeof(float) > ws_bytes) return -2;
+    hipLaunchKernelGGL(dual_bwd_partial_kernel, dim3(nbr, nbc), dim3(256), 0, st, a, tcg, ws);
+    hipLaunchKernelGGL(dual_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, ws, nbr, C, (long)M, coef, dscale_a,
+                       doffset_a, dscale_b, doffset_b);
+    long blocks = ((long)M * (C / 4) + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(dual_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, coef, dz_out, dxa, dxb);
+    return CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------ materialising helpers

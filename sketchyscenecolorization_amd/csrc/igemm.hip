@@ -912,7 +912,12 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
         // tile, taken here from the values on their way out instead of by a second pass over the tensor; one row of
         // partials per row tile, folded per channel by bn_stats_finalize (ssc_conv_forward_bn)
         float* const stat = final_pass ? d.stat_partial : nullptr;
+        const bool mmode = d.stat_mode == 1;        // rows of per-column minimum / maximum instead of sum / sum of squares
         float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
+        if (mmode) {
+            ssum = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+            ssq = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
         // ... or, when the output is the gradient w.r.t. the activated norm of a tensor x (sb_x: same layout as the output),
         // the two sums of that norm's backward: sum dz and sum dz * xhat with dz = out * act'(a x + b) (ssc_conv_forward_bnbwd);
         // the column group of a thread is the same in every pass of the loop below (256 % (BN / 4) == 0)
@@ -953,7 +958,12 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                     v.x += col + 0 < Nn ? bias[col + 0] : 0.f; v.y += col + 1 < Nn ? bias[col + 1] : 0.f;
                     v.z += col + 2 < Nn ? bias[col + 2] : 0.f; v.w += col + 3 < Nn ? bias[col + 3] : 0.f;
                 }
-                if (sbx == nullptr) {
+                if (mmode) {        // of the ACTIVATED output (lrelu is monotone: applied to the extrema's candidates here)
+                    const float tx = epi == 2 ? fmaxf(v.x, 0.2f * v.x) : v.x, ty = epi == 2 ? fmaxf(v.y, 0.2f * v.y) : v.y;
+                    const float tz = epi == 2 ? fmaxf(v.z, 0.2f * v.z) : v.z, tw = epi == 2 ? fmaxf(v.w, 0.2f * v.w) : v.w;
+                    ssum.x = fminf(ssum.x, tx); ssum.y = fminf(ssum.y, ty); ssum.z = fminf(ssum.z, tz); ssum.w = fminf(ssum.w, tw);
+                    ssq.x = fmaxf(ssq.x, tx); ssq.y = fmaxf(ssq.y, ty); ssq.z = fmaxf(ssq.z, tz); ssq.w = fmaxf(ssq.w, tw);
+                } else if (sbx == nullptr) {
                     ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
                     ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
                 } else {
@@ -985,8 +995,12 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             // thread t holds columns 4*(t % (BN/4)).. of the rows t / (BN/4) + k*1024/BN: fold the 1024/BN row groups in a
             // fixed order through LDS (behind the C tile), one writer per column group
             constexpr int CG = BN / 4, RG = 256 / CG;
-            static_assert(BM * C_LD + 2 * 256 * 4 <= 2 * (A_SZ + B_SZ) || BM * BN >= 128 * 128, "reduction scratch behind the C tile");
-            float4* red = reinterpret_cast<float4*>(smem + BM * C_LD);
+            // (the 128 x 128 tile's C image leaves no room behind it: there the scratch takes the image's place, once every
+            // thread has read its part of it)
+            constexpr bool RED_IN_C = BM * C_LD + 2 * 256 * 4 > 2 * (A_SZ + B_SZ);
+            static_assert(!RED_IN_C || BM * BN >= 128 * 128, "reduction scratch behind the C tile");
+            if (RED_IN_C) __syncthreads();
+            float4* red = reinterpret_cast<float4*>(RED_IN_C ? smem : smem + BM * C_LD);
             red[tid] = ssum;
             red[256 + tid] = ssq;
             __syncthreads();
@@ -995,8 +1009,13 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
 #pragma unroll
                 for (int g = 1; g < RG; ++g) {
                     const float4 a = red[g * CG + tid], c = red[256 + g * CG + tid];
-                    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-                    q.x += c.x; q.y += c.y; q.z += c.z; q.w += c.w;
+                    if (mmode) {
+                        s.x = fminf(s.x, a.x); s.y = fminf(s.y, a.y); s.z = fminf(s.z, a.z); s.w = fminf(s.w, a.w);
+                        q.x = fmaxf(q.x, c.x); q.y = fmaxf(q.y, c.y); q.z = fmaxf(q.z, c.z); q.w = fmaxf(q.w, c.w);
+                    } else {
+                        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+                        q.x += c.x; q.y += c.y; q.z += c.z; q.w += c.w;
+                    }
                 }
                 const int col = n0 + tid * 4;
                 if (col < Nst) {
@@ -1173,8 +1192,81 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(const float4* __restr
     out[i] = v;
 }
 
+// The slab sum of a conv whose output feeds a batch-statistics norm: the sum touches every output element once, so it takes
+// the per-column sum and sum of squares on the way (rows of partials per block, folded by bn_stats_finalize) instead of a
+// statistics pass of its own over the tensor.  A thread keeps one group of 4 columns (256 % (ldc / 4) == 0) and walks rows;
+// the additions over the slabs keep slab_reduce4_kernel's order (same output bits).
+__global__ __launch_bounds__(256) void slab_reduce4_stats_kernel(const float4* __restrict__ slabs, long slab_stride4, int splitk,
+                                                                  float4* __restrict__ out, long rows, int cg,
+                                                                  float* __restrict__ stat) {
+    __shared__ float4 sh[2][256];
+    const int R = 256 / cg;
+    const int c = threadIdx.x % cg, rl = threadIdx.x / cg;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    for (long r = (long)blockIdx.x * R + rl; r < rows; r += (long)gridDim.x * R) {
+        const long i = r * cg + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* p = slabs + i;
+        int k = 0;
+        for (; k + 4 <= splitk; k += 4) {
+            const float4 a = ntload4(p), b = ntload4(p + slab_stride4), c2 = ntload4(p + 2 * slab_stride4),
+                         e = ntload4(p + 3 * slab_stride4);
+            p += 4 * slab_stride4;
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            v.x += c2.x; v.y += c2.y; v.z += c2.z; v.w += c2.w;
+            v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+        }
+        for (; k < splitk; ++k, p += slab_stride4) {
+            const float4 a = ntload4(p);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        out[i] = v;
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < R; ++k) {
+            const float4 a = sh[0][k * cg + c], b = sh[1][k * cg + c];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+        }
+        float* sp = stat + (long)blockIdx.x * 2 * (4 * cg);
+        *reinterpret_cast<float4*>(sp + 4 * c) = s;
+        *reinterpret_cast<float4*>(sp + 4 * cg + 4 * c) = q;
+    }
+}
+
+static bool slab_stats_ok(const ssc_conv_desc& d) {
+    static int off = -1;        // SSC_SLAB_STATS=0: statistics by a pass of their own after the slab sum (A/B)
+    if (off < 0) {
+        const char* e = getenv("SSC_SLAB_STATS");
+        off = (e != nullptr && e[0] == '0') ? 1 : 0;
+    }
+    const int cg = d.ldc / 4;
+    return !off && (d.ldc & 3) == 0 && cg >= 1 && cg <= 256 && (256 % cg) == 0 && d.Nn == d.ldc && d.Nstore == d.ldc &&
+           d.bias == nullptr && d.epi == 0 && !d.accumulate && ((uintptr_t)d.out & 15) == 0;
+}
+// rows of partial sums the statistics form of the slab sum writes (one per block)
+static int slab_stats_blocks(long rows, int ldc) {
+    const int R = 256 / (ldc / 4);
+    long b = ((rows + R - 1) / R + 3) / 4;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
 static void launch_slab_reduce(const float* ws, long out_count, int splitk, const ssc_conv_desc& d, hipStream_t st) {
     const int thr = 256;
+    if (d.stat_partial != nullptr && slab_stats_ok(d) && ((uintptr_t)ws & 15) == 0 && (out_count % 4) == 0) {
+        const long rows = out_count / d.ldc;
+        hipLaunchKernelGGL(slab_reduce4_stats_kernel, dim3((unsigned)slab_stats_blocks(rows, d.ldc)), dim3(256), 0, st,
+                           (const float4*)ws, out_count / 4, splitk, (float4*)d.out, rows, d.ldc / 4, d.stat_partial);
+        return;
+    }
     const bool v4 = (out_count % 4) == 0 && (d.ldc % 4) == 0 && (d.Nn % 4) == 0 && (d.Nstore % 4) == 0 &&
                     (((uintptr_t)ws | (uintptr_t)d.out | (uintptr_t)d.bias) & 15) == 0;
     if (v4) {
@@ -1921,6 +2013,7 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
     d.sb_x = nullptr;
     d.sb2_x = nullptr;
     d.fin_cnt = nullptr;
+    d.stat_mode = 0;
     const long M = (long)d.NB * d.PH * d.PW;
     const long Mall = M * d.nphase;
     static int off = -1;        // SSC_FUSE_STATS=0: always the separate pass (A/B)
@@ -1934,22 +2027,25 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
         !d.accumulate && d.Nstore == d.ldc && ((d.Nstore & 3) == 0) && ((reinterpret_cast<unsigned long>(d.out) & 15) == 0) &&
         (fwd_is_ut(d) || fwd_is_utg(d) || (d.bmode == 0 && fwd_is_rowtap(d)))) {
         const Plan p = plan_fwd(d, ws_bytes, true);
-        if (p.cfg > 0 && p.splitk == 1) {
+        if (p.cfg >= 0 && p.splitk == 1) {
             const long mt = (M + FWD_CFGS[p.cfg].BM - 1) / FWD_CFGS[p.cfg].BM;
             const int64_t need = (int64_t)mt * d.nphase * 2 * d.Nstore * 4;
             // the fold itself inside the launch too (ssc_conv_desc.fin_*): group rows behind the partial rows, counters behind
             // the stream's hand-off flags
-            static int fin_on = -1;     // SSC_FIN_INLAUNCH=0: the fold as a launch of its own (A/B)
+            // OFF: measured slower everywhere -- Pix2Pix step 17.94 vs 17.85 ms (23 launches fewer), Residual 45.0 vs 44.0 ms
+            // (165 fewer), Background 27.1 vs 26.1 ms (84 fewer): the tickets, the two barriers and the write-through rows
+            // cost every workgroup more than the 5 us launch they replace (profiles/NOTEBOOK_r04.md)
+            static int fin_on = -1;     // SSC_FIN_INLAUNCH=1: the fold inside the launch (A/B)
             if (fin_on < 0) {
                 const char* e = getenv("SSC_FIN_INLAUNCH");
-                fin_on = (e != nullptr && e[0] == '0') ? 0 : 1;
+                fin_on = (e != nullptr && e[0] == '1') ? 1 : 0;
             }
             const long nrows = mt * d.nphase;
             const int gs = nrows <= 1024 ? 32 : 64;
             const long ngr = (nrows + gs - 1) / gs;
             const long ntile = (d.Nstore + FWD_CFGS[p.cfg].BN - 1) / FWD_CFGS[p.cfg].BN;
             const int64_t grp_bytes = (int64_t)ngr * 2 * d.Nstore * 8;
-            const bool fin = fin_on && d.sk_flags != nullptr && (ngr + 1) * ntile <= SSC_FIN_CNT_WORDS && nrows >= 2;
+            const bool fin = fin_on && p.cfg > 0 && d.sk_flags != nullptr && (ngr + 1) * ntile <= SSC_FIN_CNT_WORDS && nrows >= 2;
             const int64_t reserve = ((need + 255) & ~(int64_t)255) + (fin ? grp_bytes + 256 : 0);
             if (reserve * 4 <= ws_bytes) {     // the partial rows sit at the end of the workspace, the conv keeps the rest
                 ws_conv = (ws_bytes - reserve) & ~(int64_t)255;
@@ -1971,7 +2067,39 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
             }
         }
     }
+    // split-K launches (few rows, long K: the bottlenecks' 3x3 / 4x4 convs at the low resolutions, encoder_5): the statistics ride
+    // in the slab sum (slab_reduce4_stats_kernel) -- slab sum + fold instead of slab sum + statistics pass + fold
+    if (!off && ws != nullptr && !ssc_conv_narrow_supported(dp) && !ssc_conv_fewchan_supported(dp) && slab_stats_ok(d) &&
+        !(ssc_head1_forward_supported(dp) || ssc_head1_dgrad_supported(dp))) {
+        const Plan p = plan_fwd(d, ws_bytes, true);
+        if (p.cfg >= 0 && p.splitk > 1 && p.ts_s <= 1) {
+            const int nblk = slab_stats_blocks(Mall, d.ldc);
+            const int64_t reserve = (((int64_t)nblk * 2 * d.Nstore * 4) + 255) & ~(int64_t)255;
+            ws_conv = (ws_bytes - reserve) & ~(int64_t)255;
+            const Plan p2 = plan_fwd(d, ws_conv, true);
+            if (ws_conv > 0 && p2.cfg == p.cfg && p2.splitk == p.splitk && p2.ts_s <= 1) {
+                d.stat_partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_conv);
+                const int rc = ssc_conv_forward(&d, ws, ws_conv, stream);
+                if (rc != 0) return rc;
+                return ssc_bn_finalize(d.stat_partial, nblk, d.Nstore, Mall, scale, offset, eps, ab, stats, stream);
+            }
+            d.stat_partial = nullptr;
+        }
+    }
     (void)fused;
+    {
+        static int dbg = -1;        // SSC_DEBUG_BNPATH=1: why a conv + norm call took the separate statistics pass (stderr)
+        if (dbg < 0) {
+            const char* e = getenv("SSC_DEBUG_BNPATH");
+            dbg = (e != nullptr && e[0] == '1') ? 1 : 0;
+        }
+        if (dbg) {
+            const Plan p = plan_fwd(d, ws_bytes, ws != nullptr);
+            fprintf(stderr, "bnpath separate: M=%ld N=%d K=%d ut=%d utg=%d narrow=%d fewchan=%d cfg=%d splitk=%d epi=%d acc=%d\n", M * d.nphase,
+                    d.Nstore, d.TH * d.TW * (d.x.C0 + d.x.C1), (int)fwd_is_ut(d), (int)fwd_is_utg(d), ssc_conv_narrow_supported(dp),
+                    ssc_conv_fewchan_supported(dp), p.cfg, p.splitk, d.epi, d.accumulate);
+        }
+    }
     const int rc = ssc_conv_forward(&d, ws, ws_bytes, stream);
     if (rc != 0) return rc;
     return ssc_bn_stats(d.out, Mall, d.Nstore, d.ldc, scale, offset, eps, ab, stats, ws, ws_bytes, stream);
@@ -1989,6 +2117,7 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
     d.sb_x = nullptr;
     d.sb2_x = nullptr;
     d.fin_cnt = nullptr;
+    d.stat_mode = 0;
     *nrows = 0;
     const long M = (long)d.NB * d.PH * d.PW;
     static int off = -1;        // SSC_FUSE_BNBWD=0: always the separate pass (A/B)
@@ -2003,7 +2132,7 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
         ((reinterpret_cast<unsigned long>(x) & 15) == 0) &&
         (fwd_is_ut(d) || fwd_is_utg(d) || (d.bmode == 0 && fwd_is_rowtap(d)))) {
         const Plan p = plan_fwd(d, ws_bytes, true);
-        if (p.cfg > 0 && p.splitk == 1) {
+        if (p.cfg >= 0 && p.splitk == 1) {
             const long mt = (M + FWD_CFGS[p.cfg].BM - 1) / FWD_CFGS[p.cfg].BM;
             if ((int64_t)mt * d.nphase * 2 * d.Nstore * 4 <= partial_bytes) {
                 d.stat_partial = partial;
@@ -2015,6 +2144,52 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
     return ssc_conv_forward(&d, ws, ws_bytes, stream);
 }
 
+// mru_ops.hip
+extern "C" int ssc_minmax_hw(const float* x, int ld, int N, int P, int C, float* mnmx, float* workspace, int64_t workspace_bytes,
+                             void* stream);
+extern "C" int ssc_minmax_finalize(const float* part, int nsplit, int N, int C, float* mnmx, void* stream);
+
+// conv (+ bias + lrelu) whose output's per-sample, per-channel extrema are wanted (the MRU gates): the per-tile minima / maxima
+// out of the epilogue when the launch qualifies as for ssc_conv_forward_bn and no tile straddles two samples
+extern "C" int ssc_conv_forward_minmax(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, float* mnmx, void* stream) {
+    ssc_conv_desc d = *dp;
+    d.stat_partial = nullptr;
+    d.sb_x = nullptr;
+    d.sb2_x = nullptr;
+    d.fin_cnt = nullptr;
+    d.stat_mode = 0;
+    const long P = (long)d.PH * d.PW;
+    const long M = (long)d.NB * P;
+    static int off = -1;        // SSC_FUSE_MINMAX=0: always the separate pass (A/B)
+    if (off < 0) {
+        const char* e = getenv("SSC_FUSE_MINMAX");
+        off = (e != nullptr && e[0] == '0') ? 1 : 0;
+    }
+    if (!off && ws != nullptr && d.nphase == 1 && !ssc_conv_narrow_supported(dp) && !ssc_conv_fewchan_supported(dp) &&
+        (d.epi == 0 || d.epi == 2) && !d.accumulate && d.Nstore == d.ldc && d.Nn == d.Nstore && ((d.Nstore & 3) == 0) &&
+        ((reinterpret_cast<unsigned long>(d.out) & 15) == 0) && (fwd_is_ut(d) || fwd_is_utg(d))) {
+        const Plan p = plan_fwd(d, ws_bytes, true);
+        if (p.cfg >= 0 && p.splitk == 1 && (P % FWD_CFGS[p.cfg].BM) == 0) {
+            const long mt = M / FWD_CFGS[p.cfg].BM;
+            const int64_t need = (int64_t)mt * 2 * d.Nstore * 4;
+            if (need * 4 <= ws_bytes) {
+                const int64_t ws_conv = (ws_bytes - need) & ~(int64_t)255;
+                const Plan p2 = plan_fwd(d, ws_conv, true);
+                if (p2.cfg == p.cfg && p2.splitk == 1) {
+                    d.stat_partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_conv);
+                    d.stat_mode = 1;
+                    const int rc = ssc_conv_forward(&d, ws, ws_conv, stream);
+                    if (rc != 0) return rc;
+                    return ssc_minmax_finalize(d.stat_partial, (int)(P / FWD_CFGS[p.cfg].BM), d.NB, d.Nstore, mnmx, stream);
+                }
+            }
+        }
+    }
+    const int rc = ssc_conv_forward(&d, ws, ws_bytes, stream);
+    if (rc != 0) return rc;
+    return ssc_minmax_hw(d.out, d.ldc, d.NB, (int)P, d.Nstore, mnmx, ws, ws_bytes, stream);
+}
+
 extern "C" int ssc_conv_forward_bnbwd2(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, const ssc_bnbwd_site* s0,
                                        const ssc_bnbwd_site* s1, int C0, int* nrows, void* stream) {
     ssc_conv_desc d = *dp;
@@ -2022,6 +2197,7 @@ extern "C" int ssc_conv_forward_bnbwd2(const ssc_conv_desc* dp, float* ws, int64
     d.sb_x = nullptr;
     d.sb2_x = nullptr;
     d.fin_cnt = nullptr;
+    d.stat_mode = 0;
     *nrows = 0;
     const long M = (long)d.NB * d.PH * d.PW;
     static int off = -1;        // SSC_FUSE_BNBWD=0: always the separate pass (A/B)
@@ -2038,7 +2214,7 @@ extern "C" int ssc_conv_forward_bnbwd2(const ssc_conv_desc* dp, float* ws, int64
           reinterpret_cast<unsigned long>(s1->x)) & 15) == 0 &&
         (fwd_is_ut(d) || fwd_is_utg(d))) {
         const Plan p = plan_fwd(d, ws_bytes, true);
-        if (p.cfg > 0 && p.splitk == 1 && FWD_CFGS[p.cfg].BN <= 128) {
+        if (p.cfg >= 0 && p.splitk == 1 && FWD_CFGS[p.cfg].BN <= 128) {
             const long mt = (M + FWD_CFGS[p.cfg].BM - 1) / FWD_CFGS[p.cfg].BM;
             if ((int64_t)mt * d.nphase * 2 * C0 * 4 <= s0->partial_bytes && (int64_t)mt * d.nphase * 2 * C1 * 4 <= s1->partial_bytes) {
                 d.stat_partial = s0->partial;

@@ -257,6 +257,11 @@ __global__ void minmax_final_kernel(const float* __restrict__ part, int nsplit, 
     mnmx[(long)n * 2 * C + C + c] = mx;
 }
 
+extern "C" int ssc_minmax_finalize(const float* part, int nsplit, int N, int C, float* mnmx, void* stream) {
+    hipLaunchKernelGGL(minmax_final_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nsplit, N, C, mnmx);
+    return CHECK_LAUNCH();
+}
+
 extern "C" int ssc_minmax_hw(const float* x, int ld, int N, int P, int C, float* mnmx, float* workspace,
                              int64_t workspace_bytes, void* stream) {
     int nsplit = (P + 255) / 256;

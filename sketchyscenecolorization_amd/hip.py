@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
                 ('sb2_ldx', C.c_int32), ('sb2_act', C.c_int32),
                 ('fin_cnt', C.c_void_p), ('fin_grp', C.c_void_p), ('fin_scale', C.c_void_p), ('fin_offset', C.c_void_p),
                 ('fin_ab', C.c_void_p), ('fin_stats', C.c_void_p), ('fin_M', C.c_int64), ('fin_eps', C.c_float),
-                ('fin_gs', C.c_int32)]
+                ('fin_gs', C.c_int32), ('stat_mode', C.c_int32), ('_pad1', C.c_int32)]
 
 
 class BnApplyJob(C.Structure):
@@ -118,6 +118,8 @@ SIGNATURES = {
     'ssc_conv_forward_bn': [C.POINTER(ConvDesc), _P, _L, _P, _P, _F, _P, _P, _P],
     'ssc_bn_finalize': [_P, _I, _I, _L, _P, _P, _F, _P, _P, _P],
     'ssc_conv_forward_bnbwd': [C.POINTER(ConvDesc), _P, _L, _P, _I, _P, _P, _I, _P, _L, C.POINTER(C.c_int), _P],
+    'ssc_conv_forward_minmax': [C.POINTER(ConvDesc), _P, _L, _P, _P],
+    'ssc_minmax_finalize': [_P, _I, _I, _I, _P, _P],
     'ssc_conv_forward_bnbwd2': [C.POINTER(ConvDesc), _P, _L, C.POINTER(BnBwdSite), C.POINTER(BnBwdSite), _I,
                                 C.POINTER(C.c_int), _P],
     'ssc_bn_act_backward_pre': [_P, _L, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _F, _I, _P,
@@ -130,6 +132,7 @@ SIGNATURES = {
     'ssc_head1_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
     'ssc_head1_dgrad_bn_backward': [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _F, _P, _P, _P, _P, _L, _P],
     'ssc_bn_bwd_finalize': [_P, _I, _I, _L, _P, _P, _P, _P],
+    'ssc_block_out_backward': [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     'ssc_bn_bwd_sums': [C.POINTER(BnApplyJob), _P, _I, _P, _P, _P, _P, _L, _P],
     'ssc_bn_bwd_apply': [C.POINTER(BnApplyJob), _P],
     'ssc_conv_wgrad_hosting': [C.POINTER(WgradDesc), _P, _L, C.POINTER(BnApplyJob), _P],
@@ -431,7 +434,7 @@ class BnBwdSums(object):
         return (self, act)
 
 
-def _run_conv(d, bn=None, bnbwd=None):
+def _run_conv(d, bn=None, bnbwd=None, minmax=None):
     """bn = (scale, offset, ab, stats[, eps]): also fold the batch-statistics norm of the conv's output (the whole
     [rows, ldc] output must be the normed tensor).  bnbwd = BnBwdSums.take(act): the output is a gradient w.r.t. that
     activated norm; its backward sums come out of the epilogue when the launch qualifies."""
@@ -481,6 +484,10 @@ def _run_conv(d, bn=None, bnbwd=None):
                 sums.rows += n.value
             else:
                 sums.missed += 1
+        elif minmax is not None:        # mnmx [N,2,C] <- per-sample extrema of the (activated) output, out of the epilogue
+            assert minmax.shape == (d.NB, 2, d.Nstore) and minmax.is_contiguous(), (minmax.shape, d.NB, d.Nstore)
+            check(lib().ssc_conv_forward_minmax(C.byref(d), ptr(ws), ws.numel() * 4, ptr(minmax), stream_ptr()),
+                  'ssc_conv_forward_minmax')
         elif bn is None:
             check(lib().ssc_conv_forward(C.byref(d), ptr(ws), ws.numel() * 4, stream_ptr()), 'ssc_conv_forward')
         else:
@@ -560,7 +567,7 @@ def same_pad_before(size, k, stride):
 
 
 def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, accumulate=False, same=False, bn=None,
-                 w_nk=None):
+                 w_nk=None, minmax=None):
     """tf.pad + tf.nn.conv2d(VALID): x View, w [KH,KW,Cin_real,Cout] -> out[..., coff:coff+Cout].
     same=True: tf.nn.conv2d(padding='SAME') -- output ceil(in/stride), asymmetric pad (mru.py:125, conv_ex).
     w_nk: the same filter as [KH,KW,Cout,Cin] (a transposed copy, e.g. ``transpose_filter``): the launch then reads the [n][k]
@@ -587,7 +594,8 @@ def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, 
     d.n_off, d.Nn, d.Nstore = 0, co, (nstore if nstore is not None else co)
     d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 1, 0, 0
     d.epi, d.accumulate = epi, int(accumulate)
-    _run_conv(d, _bn_arg(bn, d, coff, out))
+    assert minmax is None or (bn is None and coff == 0)
+    _run_conv(d, _bn_arg(bn, d, coff, out), minmax=minmax)
 
 
 def transpose_filter(w, out):

@@ -26,6 +26,8 @@ from .text_fusion import TextFusion
 
 import os as _os
 _SPLIT_DGRAD = _os.environ.get('SSC_MRU_SPLIT_DGRAD', '1') == '1'
+_FUSE_MINMAX = _os.environ.get('SSC_MRU_FUSE_MINMAX', '1') == '1'           # gate extrema out of the conv epilogue (A/B)
+_FUSE_CBN_STATS = _os.environ.get('SSC_MRU_FUSE_STATS', '1') == '1'      # conditional-norm statistics out of the conv epilogue (A/B)
 
 ENC_UNITS = [(1, 8, 64), (2, 64, 128), (3, 128, 256), (4, 256, 512)]                 # (unit, C_h, D); inp = 3 ch
 DEC_UNITS = [(0, 512, 384), (2, 384, 256), (4, 256, 128), (6, 128, 128), (8, 128, 64)]      # (unit_num, C_h, D)
@@ -52,6 +54,7 @@ class _MRUBlocks(object):
     def _init(self, store, bufs):
         self.s, self.b = store, bufs
         self._gdone = {}
+        self._pre_stats = {}        # conv outputs whose batch statistics the conv's epilogue has already taken (-> scope)
         self.loss_acc = None        # device double scalar the regularisation terms are added to (set by the trainer)
         self._sn = None
 
@@ -97,7 +100,8 @@ class _MRUBlocks(object):
         N, C = raw.shape[0], raw.shape[-1]
         ab = B.get(tag + '/' + scope + '/ab0', (2 * C,))
         st = B.get(tag + '/' + scope + '/st', (2 * C,))
-        hip.bn_stats(_rows(raw), self._const(C, 1.0), self._const(C, 0.0), ab, st)
+        if self._pre_stats.pop(raw.data_ptr(), None) != scope:
+            hip.bn_stats(_rows(raw), self._const(C, 1.0), self._const(C, 0.0), ab, st)
         abn = B.get(tag + '/' + scope + '/abn', (N, 2 * C))
         hip.call('ssc_cbn_fold', st, s[scope + '/scale'], s[scope + '/offset'], labels, N, C, abn)
         hip.concat_parts(out, [dict(x=raw, ab=abn, act=ACT_MIU)])
@@ -117,7 +121,8 @@ class _MRUBlocks(object):
         N, C = raw.shape[0], raw.shape[-1]
         ab = B.get(tag + '/' + scope + '/ab0', (2 * C,))
         st = B.get(tag + '/' + scope + '/st', (2 * C,))
-        hip.bn_stats(_rows(raw), self._const(C, 1.0), self._const(C, 0.0), ab, st)
+        if self._pre_stats.pop(raw.data_ptr(), None) != scope:
+            hip.bn_stats(_rows(raw), self._const(C, 1.0), self._const(C, 0.0), ab, st)
         abn = B.get(tag + '/' + scope + '/abn', (N, 2 * C))
         hip.call('ssc_cbn_fold', st, s[scope + '/scale'], s[scope + '/offset'], labels, N, C, abn)
         return abn, st
@@ -140,15 +145,29 @@ class _MRUBlocks(object):
                  dx, dx.shape[-1], int(acc_dx), ds, do, int(acc_params), ws, ws.numel() * 4)
 
     # ------------------------------------------------------------------ conv with bias, its gradients
-    def _conv(self, tag, pre, xv, cout, name, stride=1, epi=0, accumulate_into=None, nstore=None):
+    def _conv(self, tag, pre, xv, cout, name, stride=1, epi=0, accumulate_into=None, nstore=None, stats=False, minmax=None):
+        """stats=True (generator): the conv's output goes to the conditional norm of the same scope -- its batch statistics are
+        taken by the conv's epilogue (hip.conv_forward(bn=...)) instead of a pass of their own over the tensor; ``_cbn`` /
+        ``_na_fwd`` find them under the scope's buffer names."""
         s = self.s
         if accumulate_into is not None:
             out = accumulate_into
         else:
             co = cout if nstore is None else nstore
             out = self.b.get(tag + '/' + pre + '/' + name, (xv.N, -(-xv.H // stride), -(-xv.W // stride), co))
+        bn = None
+        if stats and _FUSE_CBN_STATS and self.cond_norm and accumulate_into is None and nstore is None and epi == 0:
+            ab = self.b.get(tag + '/' + pre + '/ab0', (2 * cout,))
+            st = self.b.get(tag + '/' + pre + '/st', (2 * cout,))
+            bn = (self._const(cout, 1.0), self._const(cout, 0.0), ab, st)
+            self._pre_stats[out.data_ptr()] = pre
+        if minmax is not None and (accumulate_into is not None or nstore is not None or not _FUSE_MINMAX):
+            hip.conv_forward(xv, self._w(pre), stride, 0, out, bias=s[pre + '/biases'], epi=epi, same=True,
+                             accumulate=accumulate_into is not None, nstore=nstore)
+            hip.minmax_hw(out, minmax)
+            return out
         hip.conv_forward(xv, self._w(pre), stride, 0, out, bias=s[pre + '/biases'], epi=epi, same=True,
-                         accumulate=accumulate_into is not None, nstore=nstore)
+                         accumulate=accumulate_into is not None, nstore=nstore, bn=bn, minmax=minmax)
         return out
 
     def _conv_param_grads(self, pre, xv, dy, stride, need_params, acc, reg):
@@ -199,14 +218,13 @@ class _MRUBlocks(object):
         na, rec['aux_in'] = self._na_part(tag, pre + '/norm_activation_in', ht, labels)
         full = B.get(tag + '/' + pre + '/full', (N, h, w, ch + 4), zero_on_alloc=True)
         hip.concat_parts(full, [na, dict(x=xin, C=3)])
-        rg = self._conv(tag, pre + '/update_gate', View(full), ch, 'rg', epi=2)
         mm = B.get(tag + '/' + pre + '/rg_mm', (N, 2, ch))
-        hip.minmax_hw(rg, mm)
+        rg = self._conv(tag, pre + '/update_gate', View(full), ch, 'rg', epi=2, minmax=mm)
         img = self._conv(tag, pre + '/Conv', View(xin), ch, 'img')
         htp = B.get(tag + '/' + pre + '/ht_plus', ht.shape)
         hip.call('ssc_mru_gate_merge', ht, rg, mm, img, htp, N, h * w, ch)
         hin, rec['aux_m'] = self._na_fwd(tag, pre + '/norm_activation_merge_1', htp, labels)
-        h1 = self._conv(tag, pre + '/Conv_1', View(hin), d, 'raw')
+        h1 = self._conv(tag, pre + '/Conv_1', View(hin), d, 'raw', stats=True)
         h1a, rec['aux_1'] = self._na_fwd(tag, pre + '/Conv_1', h1, labels)
         out = self._conv(tag, pre + '/Conv_2', View(h1a), d, 'raw')
         if ch != d:
@@ -295,22 +313,20 @@ class MRUGenerator(_MRUBlocks):
         ct = ch + 3 + cs
         full = B.get(tag + '/' + pre + '/full', (N, H, W, _pad4(ct)), zero_on_alloc=True)
         hip.concat_parts(full, [dict(x=ht, upsample=True)] + inp)
-        rg = self._conv(tag, pre + '/Conv', View(full), ch, 'raw', epi=2)
         mm_r = B.get(tag + '/' + pre + '/rg_mm', (N, 2, ch))
-        hip.minmax_hw(rg, mm_r)
-        zg = self._conv(tag, pre + '/Conv_1', View(full), d, 'raw', epi=2)
+        rg = self._conv(tag, pre + '/Conv', View(full), ch, 'raw', epi=2, minmax=mm_r)
         mm_z = B.get(tag + '/' + pre + '/zg_mm', (N, 2, d))
-        hip.minmax_hw(zg, mm_z)
+        zg = self._conv(tag, pre + '/Conv_1', View(full), d, 'raw', epi=2, minmax=mm_z)
         in2 = B.get(tag + '/' + pre + '/in2', (N, H, W, _pad4(ct)), zero_on_alloc=True)
         hip.concat_parts(in2, [dict(x=ht, upsample=True, gate=(rg, mm_r))] + inp)
-        h1 = self._conv(tag, pre + '/Conv_2', View(in2), d, 'raw')
+        h1 = self._conv(tag, pre + '/Conv_2', View(in2), d, 'raw', stats=True)
         h1a, aux1 = self._na_fwd(tag, pre + '/Conv_2', h1, labels)
-        h2 = self._conv(tag, pre + '/Conv_3', View(h1a), d, 'raw')
+        h2 = self._conv(tag, pre + '/Conv_3', View(h1a), d, 'raw', stats=True)
         aux2 = self._cbn(tag, pre + '/Conv_3', h2, labels)
         out = B.get(tag + '/' + pre + '/out', (N, H, W, d))
         pj = auxp = None
         if ch != d:
-            pj = self._conv(tag, pre + '/Conv_4', View(ht), d, 'raw')        # at low resolution (see module doc)
+            pj = self._conv(tag, pre + '/Conv_4', View(ht), d, 'raw', stats=True)        # at low resolution (see module doc)
             auxp = self._cbn(tag, pre + '/Conv_4', pj, labels)
             hip.call('ssc_mru_blend', pj, auxp[0], 1, h2, aux2[0], zg, mm_z, out, N, H, W, d)
         else:

@@ -36,6 +36,10 @@ class Pix2PixGenerator(object):
         # (Backward only when no gradient section ends a graph segment in between: the fork must be joined inside it.)
         self.text_stream = None
         self.text_stream_bwd = None
+        # many towers (graph segments): the word half of the caption backward is started after the decoders' section has been
+        # handed over and joined after encoder_{text_join_after}'s backward, where its section goes out with encoder_5's
+        self.text_defer_stream = None
+        self.text_join_after = int(os.environ.get('SSC_TEXT_JOIN_AFTER', '4'))
         self.text = TextFusion(store, bufs)
 
     def forward(self, sketches, text, noise_vec, tag='g', out=None, out_coff=0):
@@ -255,13 +259,18 @@ class Pix2PixGenerator(object):
         text_pending = False
         if self.lstm_hybrid:
             tstream = self.text_stream_bwd if hip.PROFILE is None else None
-            dy5 = self.text.backward(ctx['tctx'], g_feat, side_stream=tstream)
+            dstream = self.text_defer_stream if (hip.PROFILE is None and tstream is None and on_section is not None) else None
+            dy5 = self.text.backward(ctx['tctx'], g_feat, side_stream=tstream, defer_words=dstream is not None)
             hip.mark(tag + '/bwd caption branch: last (main stream)')
             if held:
                 main.wait_stream(side_stream)
                 hip.mark(tag + '/bwd held decoder wgrads joined')
                 done('decoders')
-            if tstream is None:
+            deferred = False
+            if dstream is not None:
+                # (the decoders' section is on its way: a new graph segment has begun, the fork lives inside it)
+                deferred = self.text.run_deferred_words(dstream)
+            if tstream is None and not deferred:
                 done('text')
             else:
                 text_pending = True     # its word-branch gradients are still being computed next to the encoder backward
@@ -317,6 +326,13 @@ class Pix2PixGenerator(object):
             gcur = dx
             if k == 5 and not text_pending:
                 done('encoder_5')       # its filter, scale and offset gradients are final (trainer._sections)
+            if text_pending and self.text_defer_stream is not None and self.text._bwd_stream is self.text_defer_stream and \
+                    k == max(2, min(5, self.text_join_after)):
+                # deferred word half: joined here, inside the segment that began after the decoders' hand-over; its section
+                # and encoder_5's (adjacent in the flat buffer) travel as one exchange beside the rest of the encoder backward
+                self.text.join_backward()
+                done('text+encoder_5')
+                text_pending = False
         hip.conv_wgrad(View(ctx['xs']), View(gcur), s.grad('generator/encoder_1/conv/filter'), 2, 1)
         hip.mark(tag + '/bwd encoders: last')
         if text_pending:

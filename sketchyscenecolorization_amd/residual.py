@@ -26,6 +26,11 @@ from .params import RESIDUAL_UNITS
 from .text_fusion import TextFusion
 
 
+import os as _os
+
+_BLOCK_OUT_FUSED = _os.environ.get('SSC_BLOCK_OUT_FUSED', '1') == '1'     # ssc_block_out_backward (A/B switch)
+
+
 def _rows(t):
     return t.view(-1, t.shape[-1])
 
@@ -182,6 +187,40 @@ class _Bottlenecks(object):
                 s.grad(pre + '/offset').copy_(do[:cr])
         return dx
 
+    def _block_out_backward(self, rec, g_out, dz, need_params, accumulate):
+        """Gradient w.r.t. the raw outputs of block_3 and (en / de blocks) of the projection shortcut from the gradient w.r.t. the
+        block output; the scale / offset gradients of both norms."""
+        s, B = self.s, self.b
+        tag, pre, kind = rec['tag'], rec['pre'], rec['kind']
+        r3 = rec['r3']
+        M, C = _rows(r3).shape
+        two = kind != 'pu'
+        dxa = B.get(tag + '/gb/' + pre + '/block_3/batchnorm/dx', r3.shape)
+        dxb = B.get(tag + '/gb/' + pre + '/block_add/batchnorm/dx', r3.shape) if two else None
+        sites = [pre + '/block_3/batchnorm'] + ([pre + '/block_add/batchnorm'] if two else [])
+        direct = need_params and not accumulate
+        grads = []
+        for site in sites:
+            if direct:
+                grads.append((s.grad(site + '/scale'), s.grad(site + '/offset')))
+            elif need_params:
+                tmp = B.get(tag + '/gb/' + site + '/dso', (2, C))
+                grads.append((tmp[0], tmp[1]))
+            else:
+                grads.append((None, None))
+        if not two:
+            grads.append((None, None))
+        coef = B.get(tag + '/gb/' + pre + '/block_out/coef', (3 * C,))
+        ws = hip.workspace()
+        hip.call('ssc_block_out_backward', rec['out'], g_out, M, C, rec['act'], r3, rec['ab3'], rec['st3'],
+                 rec['sc'] if two else None, rec['absc'] if two else None, rec['stsc'] if two else None, dz, dxa, dxb,
+                 grads[0][0], grads[0][1], grads[1][0], grads[1][1], coef, ws, ws.numel() * 4)
+        if need_params and accumulate:
+            for site, (ds, do) in zip(sites, grads):
+                hip.call('ssc_axpy', s.grad(site + '/scale'), ds, 1.0, C)
+                hip.call('ssc_axpy', s.grad(site + '/offset'), do, 1.0, C)
+        return dxa, dxb
+
     def _block_backward(self, rec, g_out, need_params=True, accumulate=False, need_input=True, input_slice=None):
         """g_out: gradient w.r.t. the block output.  Adds the gradients of the block's input sources to their
         slots (``_gslot``).  input_slice=(n_off, nn, out, nstore): instead write the gradient of that channel range
@@ -190,11 +229,18 @@ class _Bottlenecks(object):
         tag, pre, act, kind = rec['tag'], rec['pre'], rec['act'], rec['kind']
         out = rec['out']
         dz = B.get(tag + '/gb/' + pre + '/dz', out.shape)
-        hip.bn_act_backward(_rows(out), None, None, _rows(g_out), act, _rows(dz))      # act'(z) from the sign of out
         acc = accumulate
-        # block_3 (1x1), block_2 (3x3 SAME)
-        dr3 = self._bn_bwd(tag, pre + '/block_3/batchnorm', rec['r3'], rec['ab3'], rec['st3'], dz, ACT_NONE,
-                           need_params, acc)
+        if _BLOCK_OUT_FUSED:
+            # dz = g_out * act'(out) and, with that one dz, the norm backward of block_3 and (en / de) of the projection
+            # shortcut: one partial-sum launch, one fold, one streaming launch (ssc_block_out_backward); dz itself is only
+            # written for the identity shortcut of a pu block
+            dr3, dsc = self._block_out_backward(rec, g_out, dz if kind == 'pu' else None, need_params, acc)
+        else:
+            hip.bn_act_backward(_rows(out), None, None, _rows(g_out), act, _rows(dz))      # act'(z) from the sign of out
+            # block_3 (1x1), block_2 (3x3 SAME)
+            dr3 = self._bn_bwd(tag, pre + '/block_3/batchnorm', rec['r3'], rec['ab3'], rec['st3'], dz, ACT_NONE,
+                               need_params, acc)
+            dsc = None
         x3 = View(rec['r2'], None, rec['ab2'], act)
         if need_params:
             hip.conv_wgrad(x3, View(dr3), s.grad(pre + '/block_3/conv_ex/filter'), 1, 0, accumulate=acc)
@@ -214,8 +260,9 @@ class _Bottlenecks(object):
         xv = rec['xv']
         branches = [(dr1, 'block_1')]
         if kind != 'pu':
-            dsc = self._bn_bwd(tag, pre + '/block_add/batchnorm', rec['sc'], rec['absc'], rec['stsc'], dz, ACT_NONE,
-                               need_params, acc)
+            if dsc is None:
+                dsc = self._bn_bwd(tag, pre + '/block_add/batchnorm', rec['sc'], rec['absc'], rec['stsc'], dz, ACT_NONE,
+                                   need_params, acc)
             branches.append((dsc, 'block_add'))
         op = {'en': 'conv', 'de': 'deconv', 'pu': 'conv_ex'}[kind]
         for dy, blk in branches:

@@ -1,0 +1,212 @@
+"""Round-4 kernels and entry points against torch restatements (through the C ABI):
+  ssc_conv_forward_bnbwd2   norm-backward sums of BOTH halves of a merged decoder data gradient (models_collection.py:512-531)
+  ssc_bn_bwd_sums / _apply / ssc_conv_wgrad_hosting   the norm backward in two steps, the streaming pass hosted by a filter gradient
+  slab_reduce4_stats_kernel batch statistics taken by the split-K slab sum
+  ssc_block_out_backward    the backward through a bottleneck's output (residual_util.py:103-109, 138-146, 165-167)
+  ssc_conv_forward_minmax   the MRU gates' per-sample extrema out of the conv epilogue (mru.py:407-415)"""
+import pytest
+import torch
+
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from sketchyscenecolorization_amd import hip
+    return hip
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, tol=2e-4):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max()) / scale
+    assert err < tol, err
+
+
+def rnd(*shape, seed=0, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * std
+
+
+def test_merged_decoder_dgrad_delivers_both_sites_sums():
+    """decoder_k reads relu(concat[norm(d), norm(e)]): one data-gradient launch over both column ranges, the sums of both norms'
+    backward out of its epilogue -- against autograd on the oracle ops and against the separate passes."""
+    hip = _hip()
+    n, h, c0, c1, co = 16, 24, 128, 128, 64
+    xd_ = (rnd(n, c0, h, h, seed=1) * 1.3 + 0.2).requires_grad_(True)
+    xe_ = (rnd(n, c1, h, h, seed=2) * 0.7 - 0.1).requires_grad_(True)
+    sd, od = (1.0 + 0.1 * rnd(c0, seed=3)).requires_grad_(True), (0.1 * rnd(c0, seed=4)).requires_grad_(True)
+    se, oe = (1.0 + 0.1 * rnd(c1, seed=5)).requires_grad_(True), (0.1 * rnd(c1, seed=6)).requires_grad_(True)
+    f = rnd(4, 4, co, c0 + c1, seed=7, std=0.05)
+    y = torch.relu(torch.cat([T.batchnorm(xd_, sd, od), T.batchnorm(xe_, se, oe)], 1))
+    o = T.conv2d_transpose_same_s2(y, f)
+    dy = rnd(*o.shape, seed=8)
+    (o * dy).sum().backward()
+    xs = [nhwc(xd_.detach()).cuda(), nhwc(xe_.detach()).cuda()]
+    tabs = []
+    for x, sc, of in ((xs[0], sd, od), (xs[1], se, oe)):
+        c = x.shape[-1]
+        ab, st = torch.empty(2 * c, device='cuda'), torch.empty(2 * c, device='cuda')
+        hip.bn_stats(x.view(-1, c), sc.detach().cuda(), of.detach().cuda(), ab, st)
+        tabs.append((ab, st))
+    sums = [hip.BnBwdSums(x.view(-1, x.shape[-1]), ab, st,
+                          torch.zeros(hip.BnBwdSums.rows_needed(n * h * h), 2 * x.shape[-1], device='cuda'))
+            for x, (ab, st) in zip(xs, tabs)]
+    g01 = torch.full((n, h, h, c0 + c1), float('nan'), device='cuda')
+    hip.deconv_dgrad(hip.View(nhwc(dy).cuda()), f.cuda(), g01, n_off=0, nn=c0 + c1, bnbwd=[sums[0].take(1), sums[1].take(1)])
+    assert all(sm.sources == 1 and sm.missed == 0 and sm.rows > 0 for sm in sums)       # both came out of the epilogue
+    r01 = g01.view(-1, c0 + c1)
+    for k, (x, ref_x, ref_s, ref_o) in enumerate(((xs[0], xd_, sd, od), (xs[1], xe_, se, oe))):
+        c = x.shape[-1]
+        g = r01[:, :c0] if k == 0 else r01[:, c0:]
+        outs = []
+        for pre in (sums[k], None):
+            dx = torch.full((n * h * h, c), float('nan'), device='cuda')
+            ds, do = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+            hip.bn_act_backward(x.view(-1, c), tabs[k][0], tabs[k][1], g, 1, dx, dscale=ds, doffset=do, pre=pre)
+            outs.append((dx, ds, do))
+            close(nchw(dx.view(n, h, h, c)), ref_x.grad, tol=5e-4)
+            close(ds, ref_s.grad, tol=5e-4)
+            close(do, ref_o.grad, tol=5e-4)
+        for a, b in zip(*outs):
+            close(a, b, tol=1e-4)
+
+
+@pytest.mark.parametrize('c,two', [(128, True), (64, False)])
+def test_norm_backward_in_two_steps_and_hosted(c, two):
+    """ssc_bn_bwd_sums + ssc_bn_bwd_apply == ssc_bn_act_backward (same bits), and the pass hosted by a filter-gradient launch
+    (ssc_conv_wgrad_hosting) gives the same dx and the same filter gradient, bit for bit."""
+    hip = _hip()
+    n, h, co = 4, 48, 2 * c
+    dev = 'cuda'
+    x = (rnd(n, h, h, c, seed=11) * 1.2 + 0.1).to(dev)
+    g1, g2 = rnd(n, h, h, c, seed=12).to(dev), rnd(n, h, h, c, seed=13).to(dev)
+    scale, offset = (1.0 + 0.1 * rnd(c, seed=14)).to(dev), (0.1 * rnd(c, seed=15)).to(dev)
+    ab, st = torch.empty(2 * c, device=dev), torch.empty(2 * c, device=dev)
+    x2d = x.view(-1, c)
+    hip.bn_stats(x2d, scale, offset, ab, st)
+    g2r = g2.view(-1, c) if two else None
+    ref_dx = torch.full_like(x2d, float('nan'))
+    ds0, do0 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    hip.bn_act_backward(x2d, ab, st, g1.view(-1, c), 2, ref_dx, g2=g2r, act2=1, dscale=ds0, doffset=do0)
+    # torch restatement
+    z = ab[:c] * x2d + ab[c:]
+    dz = g1.view(-1, c) * torch.where(z > 0, 1.0, 0.2) + (g2r * (z > 0).float() if two else 0.0)
+    xh = (x2d - st[:c]) * st[c:]
+    want = ab[:c] * (dz - dz.mean(0) - xh * (dz * xh).mean(0))
+    close(ref_dx, want, tol=2e-5)
+    # two steps, then hosted
+    xin = hip.View(x, None, ab, 2)
+    dy = rnd(n, h // 2, h // 2, co, seed=16).to(dev)
+    dw_plain = torch.full((4, 4, c, co), float('nan'), device=dev)
+    hip.conv_wgrad(xin, hip.View(dy), dw_plain, 2, 1)
+    for hosted in (False, True):
+        dx = torch.full_like(x2d, float('nan'))
+        coef = torch.zeros(2 * c, device=dev)
+        ds, do = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        job = hip.bn_act_backward(x2d, ab, st, g1.view(-1, c), 2, dx, g2=g2r, act2=1, dscale=ds, doffset=do, defer=True, coef=coef)
+        dw = torch.full((4, 4, c, co), float('nan'), device=dev)
+        if hosted:
+            hip.conv_wgrad(xin, hip.View(dy), dw, 2, 1, host=job)
+        else:
+            hip.apply_now(job)
+            hip.conv_wgrad(xin, hip.View(dy), dw, 2, 1)
+        assert job.done
+        assert torch.equal(dx, ref_dx) and torch.equal(ds, ds0) and torch.equal(do, do0), hosted
+        assert torch.equal(dw, dw_plain), hosted
+
+
+def test_batch_statistics_from_the_slab_sum():
+    """A conv with few rows and a long K is cut into split-K slabs; its batch statistics then come out of the slab sum
+    (slab_reduce4_stats_kernel) instead of a pass of their own: output bits unchanged, (a, b) and (mean, 1/std) as torch's."""
+    hip = _hip()
+    n, h, ci, co = 2, 12, 512, 512
+    x = rnd(n, ci, h, h, seed=21)
+    w = rnd(4, 4, ci, co, seed=22, std=0.02)
+    scale, offset = 1.0 + 0.1 * rnd(co, seed=23), 0.1 * rnd(co, seed=24)
+    xv = hip.View(nhwc(x).cuda(), None, None, 2)
+    plain = torch.full((n, 6, 6, co), float('nan'), device='cuda')
+    hip.conv_forward(xv, w.cuda(), 2, 1, plain)
+    out = torch.full((n, 6, 6, co), float('nan'), device='cuda')
+    ab, st = torch.empty(2 * co, device='cuda'), torch.empty(2 * co, device='cuda')
+    hip.conv_forward(xv, w.cuda(), 2, 1, out, bn=(scale.cuda(), offset.cuda(), ab, st))
+    assert torch.equal(out, plain)
+    o2 = plain.view(-1, co).double()
+    mean, var = o2.mean(0), o2.var(0, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    close(st[:co], mean, tol=1e-5)
+    close(st[co:], rstd, tol=1e-5)
+    close(ab[:co], rstd * scale.cuda().double(), tol=1e-5)
+    close(ab[co:], offset.cuda().double() - mean * rstd * scale.cuda().double(), tol=1e-5)
+
+
+@pytest.mark.parametrize('two,act', [(True, 2), (True, 1), (False, 1)])
+def test_block_output_backward(two, act):
+    """out = act(norm(r3) + shortcut): ssc_block_out_backward against autograd through the same expression."""
+    hip = _hip()
+    m, c = 3 * 24 * 24, 128
+    dev = 'cuda'
+    r3 = (rnd(m, c, seed=31) * 1.1 + 0.2).to(dev).requires_grad_(True)
+    sc = (rnd(m, c, seed=32) * 0.9 - 0.3).to(dev).requires_grad_(True)
+    s3, o3 = (1.0 + 0.1 * rnd(c, seed=33)).to(dev).requires_grad_(True), (0.1 * rnd(c, seed=34)).to(dev).requires_grad_(True)
+    ss, os_ = (1.0 + 0.1 * rnd(c, seed=35)).to(dev).requires_grad_(True), (0.1 * rnd(c, seed=36)).to(dev).requires_grad_(True)
+
+    def bn(x, s, o):
+        mu, var = x.mean(0), x.var(0, unbiased=False)
+        return (x - mu) / torch.sqrt(var + 1e-5) * s + o
+
+    pre = bn(r3, s3, o3) + (bn(sc, ss, os_) if two else sc)
+    out = torch.relu(pre) if act == 1 else torch.maximum(pre, 0.2 * pre)
+    g = rnd(m, c, seed=37).to(dev)
+    (out * g).sum().backward()
+    tabs = []
+    for x, s, o in ((r3, s3, o3), (sc, ss, os_)):
+        ab, st = torch.empty(2 * c, device=dev), torch.empty(2 * c, device=dev)
+        hip.bn_stats(x.detach(), s.detach(), o.detach(), ab, st)
+        tabs.append((ab, st))
+    dz = torch.full((m, c), float('nan'), device=dev)
+    dxa = torch.full((m, c), float('nan'), device=dev)
+    dxb = torch.full((m, c), float('nan'), device=dev) if two else None
+    gs = [torch.empty(c, device=dev) for _ in range(4)]
+    coef = torch.zeros(3 * c, device=dev)
+    ws = hip.workspace()
+    hip.call('ssc_block_out_backward', out.detach().contiguous(), g, m, c, act, r3.detach(), tabs[0][0], tabs[0][1],
+             sc.detach() if two else None, tabs[1][0] if two else None, tabs[1][1] if two else None, dz, dxa, dxb,
+             gs[0], gs[1], gs[2] if two else None, gs[3] if two else None, coef, ws, ws.numel() * 4)
+    close(dxa, r3.grad, tol=5e-5)
+    close(gs[0], s3.grad, tol=5e-5)
+    close(gs[1], o3.grad, tol=5e-5)
+    if two:
+        close(dxb, sc.grad, tol=5e-5)
+        close(gs[2], ss.grad, tol=5e-5)
+        close(gs[3], os_.grad, tol=5e-5)
+    else:
+        close(dz, sc.grad, tol=5e-5)       # identity shortcut: its gradient is dz itself
+
+
+@pytest.mark.parametrize('n,h,ci,co', [(3, 48, 128, 128), (2, 96, 64, 64), (2, 12, 64, 128)])
+def test_gate_extrema_from_the_conv_epilogue(n, h, ci, co):
+    """conv 3x3 SAME + bias + lrelu, then reduce_min / reduce_max over the positions of every sample and channel (mru.py:
+    407-415): ssc_conv_forward_minmax (extrema out of the epilogue where a sample's positions are whole tiles; the 12 x 12 case
+    takes the separate pass) against torch, and the conv output against the plain launch bit for bit."""
+    hip = _hip()
+    x = rnd(n, h, h, ci, seed=41).cuda()
+    w = rnd(3, 3, ci, co, seed=42, std=0.05).cuda()
+    b = (0.1 * rnd(co, seed=43)).cuda()
+    plain = torch.full((n, h, h, co), float('nan'), device='cuda')
+    hip.conv_forward(hip.View(x), w, 1, 0, plain, bias=b, epi=2, same=True)
+    out = torch.full((n, h, h, co), float('nan'), device='cuda')
+    mm = torch.full((n, 2, co), float('nan'), device='cuda')
+    hip.conv_forward(hip.View(x), w, 1, 0, out, bias=b, epi=2, same=True, minmax=mm)
+    assert torch.equal(out, plain)
+    flat = plain.view(n, h * h, co)
+    assert torch.equal(mm[:, 0], flat.amin(1)) and torch.equal(mm[:, 1], flat.amax(1))
