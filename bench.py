@@ -355,6 +355,7 @@ def main():
                     help='skip the secondary workloads (fg_infer, bg768, MRU / Residual train steps, BG train step) that the '
                          'default single-GPU run times after the headline and reports under "secondary"')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--no-gen-fb', action='store_true', help='skip the generator forward + backward graph (kernel-trace runs)')
     ap.add_argument('--no-graphs', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
     ap.add_argument('--preheat-seconds', type=float, default=2.0,
                     help='extra UNTIMED steps after the warmup until this much wall time has passed: the first GPU '
@@ -472,7 +473,7 @@ def main():
     launches_per_step = None if args.no_graphs else _graph_launches(list(tr._graphs.values()))
     hip.check_sk('bench.py timed region')       # a conv launch that stored a partial sum (hand-off timeout) fails the run
     gen_fb = None
-    if args.block_type == 'Pix2Pix' and not args.no_graphs and world == 1:
+    if args.block_type == 'Pix2Pix' and not args.no_graphs and world == 1 and not args.no_gen_fb:
         gen_fb = generator_fwd_bwd(tr, bg, args)
         if args.batch == 32 and not args.no_secondary:
             # the same graph at larger batches: BASELINE.json's 70 % target names the generator forward + backward at 192x192
@@ -532,7 +533,7 @@ def main():
             exec_flops_step = sum(v[0] for v in agg.values()) / prof_steps
             out['step_tflops_executed'] = exec_flops_step / (ms * 1e-3) / 1e12
             out['step_frac_of_fp32_peak'] = out['step_tflops_executed'] / PEAK_FP32_MFMA_TFLOPS
-            traffic = mfma_busy = valu_busy = traffic_note = None
+            traffic = mfma_busy = valu_busy = traffic_note = in_step = None
             tree = _csrc_hash()
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc.json') and f[0] == 'r')
             tpath = os.path.join(ROOT, 'profiles', cands[-1] if cands else 'r03_pmc.json')      # the latest round's passes
@@ -544,6 +545,12 @@ def main():
                     if tk:
                         traffic = tk.get('hbm_bytes_per_launch')
                         mfma_busy, valu_busy = tk.get('mfma_busy_frac'), tk.get('valu_busy_frac')
+                        if tk.get('in_step_tflops'):
+                            # the same kernel inside the replayed step (kernel trace of the graph-replayed bench, same binary):
+                            # there its launches share the chip with the step's other chains
+                            in_step = {'tflops': tk['in_step_tflops'], 'frac': tk['in_step_tflops'] / PEAK_FP32_MFMA_TFLOPS,
+                                       'ms_per_step': tk['in_step_ms_per_step'],
+                                       'source': os.path.basename(tpath) + ' (rocprofv3 --kernel-trace of the replayed bench)'}
                 else:
                     traffic_note = ('%s was collected on kernel tree %s, this run is %s: not attached'
                                     % (os.path.basename(tpath), pm.get('csrc_hash'), tree))
@@ -555,6 +562,8 @@ def main():
                                'algorithmic_bytes_per_launch': nb / cnt,
                                'traffic_ratio': (traffic / (nb / cnt)) if traffic else None,
                                'mfma_busy_frac_pmc': mfma_busy, 'valu_busy_frac_pmc': valu_busy,
+                               'achieved_is': 'the dominant kernel alone on the chip (eager launches bracketed by HIP events)',
+                               'in_step': in_step,
                                'flop_per_launch': fl / cnt,
                                'launches': cnt, 'avg_launch_ms': sec / cnt * 1e3,
                                'igemm_ms_per_step': tot_sec / prof_steps * 1e3,

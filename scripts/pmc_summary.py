@@ -29,6 +29,27 @@ def demangled_short(name):
     return 'narrow_fwd<%s>' % ('transposed' if int(args[0]) == 1 else 'conv')
 
 
+def mangled_short(name):
+    """The same report names from the MANGLED symbol (the kernel_symbol table of a kernel trace keeps `_Z14conv_ut_kernelILi2E...`)."""
+    m = re.match(r'_Z\d+(conv_fwd_kernel|conv_ut_kernel|conv_wgrad_kernel|narrow_fwd_kernel|narrow_sc_kernel|conv_wgrad128_kernel|'
+                 r'lstm_step_fwd_kernel|lstm_step_fwd_k2_kernel)(?:I((?:L[ib]\d+E)+)E)?', name)
+    if not m:
+        return None
+    k = m.group(1)
+    args = [int(a) for a in re.findall(r'L[ib](\d+)E', m.group(2) or '')]
+    if k.startswith('lstm_step_fwd'):
+        return 'lstm_step_fwd<64x64>'
+    if k == 'conv_wgrad128_kernel':
+        return 'conv_wgrad128<128x128>'
+    if k in ('conv_fwd_kernel', 'conv_ut_kernel'):
+        wm, wn, sm, sn, bm = args[:5]
+        return 'conv_fwd<%dx%d,%s>' % (wm * sm * 32, wn * sn * 32, 'NK' if bm else 'KN')
+    if k == 'conv_wgrad_kernel':
+        wm, wn, sm, sn = args[:4]
+        return 'conv_wgrad<%dx%d>' % (wm * sm * 32, wn * sn * 32)
+    return 'narrow_fwd<%s>' % ('transposed' if args[0] == 1 else 'conv')
+
+
 def collect(db):
     c = sqlite3.connect(db)
     out = defaultdict(lambda: defaultdict(list))
@@ -44,7 +65,7 @@ def main(base, dst, bench_json=None):
     import sys as _sys
     _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
     import bench as _bench
-    alg = {}
+    alg, pk = {}, {}
     if bench_json and _os.path.exists(bench_json):
         lines = [l for l in open(bench_json).read().splitlines() if l.startswith('{')]
         if lines:
@@ -79,6 +100,29 @@ def main(base, dst, bench_json=None):
                      mfma_instructions=tot('SQ_VALU_MFMA_BUSY_CYCLES') / 64.0, valu_instructions=tot('SQ_INSTS_VALU'),
                      kernel_cycles=gui, launches_profiled_sq=len(sq[k]['GRBM_GUI_ACTIVE']))
         res['kernels'][k] = e
+    # the same kernels INSIDE the replayed step: a kernel trace of the graph-replayed bench (every iteration launches the same
+    # kernels: iterations = calls / launches per step of the bench line) -> time per iteration and the rate on the bench line's
+    # FLOPs.  A launch shares the chip with the other chains of the step there: this is the figure that bounds the step.
+    tdb = os.path.join(base, 'trace_replay', 'p_results.db')
+    if os.path.exists(tdb) and pk:
+        c = sqlite3.connect(tdb)
+        tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
+        ks = [t for t in tabs if 'kernel_symbol' in t][0]
+        kd = [t for t in tabs if 'kernel_dispatch' in t][0]
+        agg = defaultdict(lambda: [0.0, 0])
+        for name, s0, e0 in c.execute('select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id = s.id' % (kd, ks)):
+            sh = demangled_short(name) or mangled_short(name)
+            if sh:
+                agg[sh][0] += (e0 - s0) / 1e3
+                agg[sh][1] += 1
+        for k, (us, calls) in agg.items():
+            L = pk.get(k, {}).get('launches_per_step')
+            if not L or k not in res['kernels']:
+                continue
+            iters = calls / L
+            ms = us / iters / 1e3
+            res['kernels'][k].update(in_step_ms_per_step=ms, in_step_launches_traced=calls,
+                                     in_step_tflops=pk[k]['flop_per_launch'] * L / (ms * 1e-3) / 1e12)
     json.dump(res, open(dst, 'w'), indent=1)
     for k, e in res['kernels'].items():
         print('%-26s hbm/launch %8.1f MB  mfma_busy %s  valu_busy %s' % (

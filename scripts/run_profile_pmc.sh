@@ -14,5 +14,11 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES G
   echo "$tag rc=$?"
   mkdir -p /tmp/pmcflat/pmc_final_$tag; cp $(find /tmp/pmc_final_$tag -name '*.db' | head -1) /tmp/pmcflat/pmc_final_$tag/p_results.db
 done
+# kernel trace of the graph-REPLAYED step (no counters): per-kernel time inside the step
+rm -rf /tmp/trace_replay
+timeout 400 rocprofv3 --kernel-trace -d /tmp/trace_replay -o p -- python $R/bench.py --steps 30 --warmup 5 --preheat-seconds 0 --no-kernel-events --no-cpu-baseline --no-secondary --no-gen-fb > /dev/null 2>&1
+echo "trace_replay rc=$?"
+mkdir -p /tmp/pmcflat/trace_replay; cp $(find /tmp/trace_replay -name '*.db' | head -1) /tmp/pmcflat/trace_replay/p_results.db
+python $R/scripts/rocpd_stats.py /tmp/pmcflat/trace_replay/p_results.db > $R/gpurun_out/${TAG}_bench_n1_kernel_stats.txt 2>&1
 cd $R
 python scripts/pmc_summary.py /tmp/pmcflat gpurun_out/${TAG}_pmc.json gpurun_out/bench_for_pmc.json | tail -16
