@@ -805,12 +805,35 @@ class GanTrainer(object):
         lg = self.g_step(batch_g, counter, use_ahead=True, next_d=next_batch_d)
         return lg, ld
 
-    def _infer(self, kind, sketches, text, noise_vec, labels, thicken):
+    def _infer_inputs(self, kind, sketches, noise_vec, labels):
+        """The static device tensors a replayed inference pass of this input shape reads."""
+        ikey = ('infer_in', kind, tuple(sketches.shape), tuple(noise_vec.shape))
+        st = self._static.get(ikey)
+        if st is None:
+            st = {'sk': torch.empty_like(sketches), 'nv': torch.empty_like(noise_vec),
+                  'lb': None if labels is None else torch.empty_like(labels)}
+            self._static[ikey] = st
+        return st
+
+    def infer_buffers(self, sketches, noise_vec, labels=None, kind='f32'):
+        """(sketches, noise_vec, labels) as the tensors the replayed inference graphs read, allocated after the given ones and
+        filled with them.  A serving loop that writes its next request into them and passes THEM to ``generate`` /
+        ``generate_u8`` (kind 'u8') saves the per-call device copies (graphs replay fixed addresses)."""
+        labels = None if (self.block_type != 'MRU' or labels is None) else labels.to(device='cuda', dtype=torch.int32).contiguous()
+        st = self._infer_inputs(kind, sketches.contiguous(), noise_vec.contiguous(), labels)
+        st['sk'].copy_(sketches)
+        st['nv'].copy_(noise_vec)
+        if labels is not None:
+            st['lb'].copy_(labels)
+        return st['sk'], st['nv'], st['lb']
+
+    def _infer(self, kind, sketches, text, noise_vec, labels, thicken, clone=True):
         """The generator forward of ``generate`` ('f32': NCHW float in / out) and ``generate_u8`` ('u8': uint8 NHWC in /
         out, pre- and post-processing kernels included).  Like the training steps it runs eagerly the first time a
         shape is seen, is captured into a hipGraph the second time and replayed afterwards (a batch-16 forward is ~150
         launches of 5-100 us: launch-bound when issued one by one); inputs are copied into the graph's static tensors
-        and the result is returned as a fresh tensor."""
+        (unless they ARE those tensors: ``infer_buffers``) and the result is returned as a fresh tensor (clone=False: the
+        graph's own output tensor, valid until the next call)."""
         if self.block_type == 'MRU' and labels is None:
             raise ValueError('the MRU generator is class-conditional: pass the class ids (image_data_class_id)')
         labels = None if self.block_type != 'MRU' else labels.to(device='cuda', dtype=torch.int32).contiguous()
@@ -826,15 +849,10 @@ class GanTrainer(object):
         prep = text if isinstance(text, dict) or not self.G.lstm_hybrid else self.G.text.prepare(text, 'gi')
         S = prep['S'] if isinstance(prep, dict) else -1
         key = ('infer', kind, bool(thicken), bool(self.G.lstm_hybrid), tuple(sketches.shape), S)
-        st = self._static.get(key)
-        if st is None:
-            st = {'sk': torch.empty_like(sketches), 'nv': torch.empty_like(noise_vec),
-                  'lb': None if labels is None else torch.empty_like(labels)}
-            self._static[key] = st
-        st['sk'].copy_(sketches)
-        st['nv'].copy_(noise_vec)
-        if labels is not None:
-            st['lb'].copy_(labels)
+        st = self._infer_inputs(kind, sketches, noise_vec, labels)
+        for name, src in (('sk', sketches), ('nv', noise_vec), ('lb', labels)):
+            if src is not None and src.data_ptr() != st[name].data_ptr():
+                st[name].copy_(src)
         g = self._graphs.get(key)
         if g is None:
             if key not in self._seen:
@@ -843,7 +861,7 @@ class GanTrainer(object):
             try:
                 g = hip.new_graph()
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                    st['out'] = body(st['sk'], prep, st['nv'], st['lb'])
+                    self._static[key] = body(st['sk'], prep, st['nv'], st['lb'])
             except Exception as e:      # never lose a request to graph capture
                 print('hipGraph capture of the inference pass failed (%r): continuing with eager launches' % (e,))
                 self.use_graphs_infer = False
@@ -851,17 +869,18 @@ class GanTrainer(object):
                 return body(sketches, text, noise_vec, labels)
             self._graphs[key] = g
         g.replay()
-        return st['out'].clone()
+        return self._static[key].clone() if clone else self._static[key]
 
-    def generate_u8(self, sketch_u8, text, noise_vec, labels=None, thicken=False):
+    def generate_u8(self, sketch_u8, text, noise_vec, labels=None, thicken=False, clone=True):
         """Serving path without host arithmetic: uint8 sketches [N,H,W,3] on the device -> uint8 images [N,H,W,3].
         Pre-processing (x/255*2-1, optional thicken_drawings) and post-processing ((x+1)/2*255, truncating cast) of
         main_procedure.py:361-621 run as kernels; the network reads / writes NHWC directly."""
-        return self._infer('u8', sketch_u8, text, noise_vec, labels, thicken)
+        return self._infer('u8', sketch_u8, text, noise_vec, labels, thicken, clone)
 
-    def generate(self, sketches, text, noise_vec, labels=None):
-        """Inference path of build_single_graph (training=False): NCHW in, NCHW out."""
-        return self._infer('f32', sketches, text, noise_vec, labels, False)
+    def generate(self, sketches, text, noise_vec, labels=None, clone=True):
+        """Inference path of build_single_graph (training=False): NCHW in, NCHW out.  clone=False: the replayed graph's own
+        output tensor (overwritten by the next call); inputs from ``infer_buffers`` are read in place."""
+        return self._infer('f32', sketches, text, noise_vec, labels, False, clone)
 
 
 Pix2PixTrainer = GanTrainer     # the name the first round used
