@@ -200,6 +200,8 @@ int ssc_conv_narrow_forward(const ssc_conv_desc* d, void* stream);
 /* 1 when ssc_conv_forward runs the launch on the few-input-channel kernel (fewchan.hip): 4x4 stride-2 pad-1 conv over a
  * single 4- or 8-channel raw source to 33..64 outputs, output lattice a multiple of 4 x 32 -- generator encoder_1
  * (models_collection.py:454-458), discriminator layer_1 (:798-801), the data gradient of decoder_1 (:529-534) */
+/* the 1x1 expansion conv of the bottleneck blocks (K = 16 .. 128 input channels, N = 4 K outputs): streaming kernel (pw1x1.hip) */
+int ssc_conv_pw1x1_supported(const ssc_conv_desc* d);
 int ssc_conv_fewchan_supported(const ssc_conv_desc* d);
 /* name of the tile configuration the launcher picks for a descriptor (host only; for profiling) */
 int ssc_conv_forward_kernel_name(const ssc_conv_desc* d, char* buf, int len);

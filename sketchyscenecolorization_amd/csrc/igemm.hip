@@ -30,6 +30,10 @@ int ssc_conv_wgrad128_job(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes,
 int ssc_conv_narrow_forward_ws(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, void* stream, int* csplit_out);
 // fewchan.hip
 int ssc_conv_fewchan_forward(const ssc_conv_desc* dp, int num_cu, void* stream);
+// pw1x1.hip
+extern "C" int ssc_conv_pw1x1_supported(const ssc_conv_desc* dp);
+int ssc_conv_pw1x1_walkers(const ssc_conv_desc* dp);
+int ssc_conv_pw1x1_forward(const ssc_conv_desc* dp, float* stat, void* stream);
 
 #define BK 32
 // 8-byte write-through (agent-scope relaxed atomic) stores: data another workgroup of the same launch will read
@@ -1989,6 +1993,10 @@ extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, 
         copy_name(dp->x.C0 == 8 ? "conv_fewchan<8>" : "conv_fewchan<4>", buf, len);
         return 0;
     }
+    if (ssc_conv_pw1x1_supported(dp)) {
+        copy_name("conv_pw1x1", buf, len);
+        return 0;
+    }
     static const char* names[2][5] = {
         {"conv_fwd<128x128,KN>", "conv_fwd<64x128,KN>", "conv_fwd<128x64,KN>", "conv_fwd<128x32,KN>", "conv_fwd<64x64,KN>"},
         {"conv_fwd<128x128,NK>", "conv_fwd<64x128,NK>", "conv_fwd<128x64,NK>", "conv_fwd<128x32,NK>", "conv_fwd<64x64,NK>"}};
@@ -2023,6 +2031,17 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
     }
     bool fused = false;
     int64_t ws_conv = ws_bytes;
+    if (!off && ws != nullptr && d.Nstore == d.ldc && ssc_conv_pw1x1_supported(&d)) {
+        // the streaming 1x1 kernel takes the statistics as per-lane sums over the tiles a workgroup walks: one row per walker
+        const int nblk = ssc_conv_pw1x1_walkers(&d);
+        const int64_t need = (int64_t)nblk * 2 * d.Nstore * 4;
+        if (need <= ws_bytes) {
+            d.stat_partial = ws;
+            const int rc = ssc_conv_forward(&d, ws, ws_bytes, stream);
+            if (rc != 0) return rc;
+            return ssc_bn_finalize(d.stat_partial, nblk, d.Nstore, Mall, scale, offset, eps, ab, stats, stream);
+        }
+    }
     if (!off && ws != nullptr && !ssc_conv_narrow_supported(dp) && !ssc_conv_fewchan_supported(dp) && d.epi == 0 &&
         !d.accumulate && d.Nstore == d.ldc && ((d.Nstore & 3) == 0) && ((reinterpret_cast<unsigned long>(d.out) & 15) == 0) &&
         (fwd_is_ut(d) || fwd_is_utg(d) || (d.bmode == 0 && fwd_is_rowtap(d)))) {
@@ -2268,6 +2287,8 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
     }
     if (ssc_conv_fewchan_supported(dp))         // 4x4 stride-2 over 4 or 8 input channels
         return ssc_conv_fewchan_forward(dp, num_cu(), stream);
+    if (ssc_conv_pw1x1_supported(dp))           // 1x1 expansion of a bottleneck: K <= 128, streaming kernel
+        return ssc_conv_pw1x1_forward(dp, d.stat_partial, stream);
     const Plan p = plan_fwd(d, ws_bytes, ws != nullptr);
     if (p.cfg < 0) return -4;
     g_launch_res = FWD_CFGS[p.cfg].res;

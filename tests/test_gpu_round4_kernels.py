@@ -210,3 +210,45 @@ def test_gate_extrema_from_the_conv_epilogue(n, h, ci, co):
     assert torch.equal(out, plain)
     flat = plain.view(n, h * h, co)
     assert torch.equal(mm[:, 0], flat.amin(1)) and torch.equal(mm[:, 1], flat.amax(1))
+
+
+@pytest.mark.parametrize('m_hw,k,act,with_bn', [((3, 40, 48), 32, 2, True), ((4, 24, 24), 128, 1, True), ((5, 37, 21), 16, 0, False),
+                                                 ((2, 48, 48), 64, 2, True)])
+def test_bottleneck_expansion_conv_streaming_kernel(m_hw, k, act, with_bn):
+    """The 1x1 expansion conv of the bottleneck blocks (C/4 -> C, residual_util.py:97-101) on the streaming kernel of pw1x1.hip
+    (filter in registers, persistent workgroups, norm + activation on load, batch statistics as per-lane sums): against
+    torch in float64, a ragged last tile included."""
+    hip = _hip()
+    n, h, w_ = m_hw
+    co = 4 * k
+    dev = 'cuda'
+    x = rnd(n, h, w_, k, seed=51).to(dev)
+    wt = rnd(1, 1, k, co, seed=52, std=0.1).to(dev)
+    ab = torch.cat([1.0 + 0.2 * rnd(k, seed=53), 0.3 * rnd(k, seed=54)]).to(dev)
+    d = hip.ConvDesc()      # the launch must be the streaming kernel's
+    xv = hip.View(x, None, ab, act)
+    out = torch.full((n, h, w_, co), float('nan'), device=dev)
+    scale, offset = (1.0 + 0.1 * rnd(co, seed=55)).to(dev), (0.1 * rnd(co, seed=56)).to(dev)
+    a2, s2 = torch.empty(2 * co, device=dev), torch.empty(2 * co, device=dev)
+    hip.conv_forward(xv, wt, 1, 0, out, bn=(scale, offset, a2, s2) if with_bn else None)
+    z = (ab[:k] * x + ab[k:]).double()
+    z = torch.relu(z) if act == 1 else (torch.maximum(z, 0.2 * z) if act == 2 else z)
+    ref = z.view(-1, k) @ wt.view(k, co).double()
+    close(out.view(-1, co), ref, tol=2e-5)
+    if with_bn:
+        o2 = out.view(-1, co).double()
+        mean, var = o2.mean(0), o2.var(0, unbiased=False)
+        rstd = 1.0 / torch.sqrt(var + 1e-5)
+        close(s2[:co], mean, tol=1e-5)
+        close(s2[co:], rstd, tol=1e-5)
+        close(a2[:co], rstd * scale.double(), tol=1e-5)
+        close(a2[co:], offset.double() - mean * rstd * scale.double(), tol=1e-5)
+    # the dispatcher really took the streaming kernel for this shape
+    import ctypes as C
+    KH, KW, ci, coo = wt.shape
+    d.x = xv.c()
+    d.w, d.out = wt.data_ptr(), out.data_ptr()
+    d.NB, d.PH, d.PW, d.TH, d.TW, d.in_stride, d.nphase = n, h, w_, 1, 1, 1, 1
+    d.kstep, d.KH, d.KW, d.wC0, d.wC1, d.k_real = 1, 1, 1, k, co, k
+    d.Nn, d.Nstore, d.OH, d.OW, d.ldc, d.out_stride = co, co, h, w_, co, 1
+    assert hip.lib().ssc_conv_pw1x1_supported(C.byref(d)) == 1
