@@ -202,6 +202,9 @@ int ssc_conv_narrow_forward(const ssc_conv_desc* d, void* stream);
  * (models_collection.py:454-458), discriminator layer_1 (:798-801), the data gradient of decoder_1 (:529-534) */
 /* the 1x1 expansion conv of the bottleneck blocks (K = 16 .. 128 input channels, N = 4 K outputs): streaming kernel (pw1x1.hip) */
 int ssc_conv_pw1x1_supported(const ssc_conv_desc* d);
+/* the 3x3 stride-1 conv of the bottleneck blocks at 16 / 32 channels and its data gradient (residual_util.py:92-96): streaming
+   kernel (c3x3.hip); the batch statistics (ssc_conv_forward_bn) / norm-backward sums (ssc_conv_forward_bnbwd) ride as per-lane sums */
+int ssc_conv_c3x3_supported(const ssc_conv_desc* d);
 int ssc_conv_fewchan_supported(const ssc_conv_desc* d);
 /* name of the tile configuration the launcher picks for a descriptor (host only; for profiling) */
 int ssc_conv_forward_kernel_name(const ssc_conv_desc* d, char* buf, int len);

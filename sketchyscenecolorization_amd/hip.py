@@ -140,6 +140,7 @@ SIGNATURES = {
     'ssc_conv_narrow_forward': [C.POINTER(ConvDesc), _P],
     'ssc_conv_fewchan_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_pw1x1_supported': [C.POINTER(ConvDesc)],
+    'ssc_conv_c3x3_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_forward_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, _I],
     'ssc_conv_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, _I],
     'ssc_conv_forward_plan': [C.POINTER(ConvDesc), _L, C.POINTER(C.c_int)],

@@ -252,3 +252,69 @@ def test_bottleneck_expansion_conv_streaming_kernel(m_hw, k, act, with_bn):
     d.kstep, d.KH, d.KW, d.wC0, d.wC1, d.k_real = 1, 1, 1, k, co, k
     d.Nn, d.Nstore, d.OH, d.OW, d.ldc, d.out_stride = co, co, h, w_, co, 1
     assert hip.lib().ssc_conv_pw1x1_supported(C.byref(d)) == 1
+
+
+@pytest.mark.parametrize('shape,c,act', [((2, 96, 96), 16, 1), ((3, 48, 64), 32, 2), ((1, 131, 137), 16, 0), ((5, 61, 70), 32, 1),
+                                             ((8, 48, 48), 32, 1), ((2, 90, 125), 16, 2), ((2, 90, 125), 32, 2)])
+def test_bottleneck_3x3_conv_streaming_kernel(shape, c, act):
+    """The 3x3 conv of the bottleneck blocks at 16 / 32 channels (residual_util.py:92-96) on the streaming kernel of c3x3.hip:
+    forward (norm + activation on load, zero padding of the ACTIVATED tensor, batch statistics of the output as per-lane sums)
+    against torch in float64, and its data gradient (flipped NK filter) with the norm-backward sums out of the epilogue
+    against the separate pass.  Both tile shapes (4 x 32; 8 x 16 where it wastes fewer pixels), ragged tiles included."""
+    import ctypes as C
+    import torch.nn.functional as F
+    hip = _hip()
+    n, h, w_ = shape
+    dev = 'cuda'
+    x = rnd(n, h, w_, c, seed=61).to(dev)
+    wt = rnd(3, 3, c, c, seed=62, std=0.1).to(dev)
+    ab = torch.cat([1.0 + 0.2 * rnd(c, seed=63), 0.3 * rnd(c, seed=64)]).to(dev)
+    xv = hip.View(x, None, ab, act)
+    out = torch.full((n, h, w_, c), float('nan'), device=dev)
+    scale, offset = (1.0 + 0.1 * rnd(c, seed=65)).to(dev), (0.1 * rnd(c, seed=66)).to(dev)
+    a2, s2 = torch.empty(2 * c, device=dev), torch.empty(2 * c, device=dev)
+    hip.conv_forward(xv, wt, 1, 0, out, same=True, bn=(scale, offset, a2, s2))
+    z = (ab[:c] * x + ab[c:]).double()
+    z = torch.relu(z) if act == 1 else (torch.maximum(z, 0.2 * z) if act == 2 else z)
+    ref = nhwc(F.conv2d(nchw(z), wt.double().permute(3, 2, 0, 1), padding=1))
+    close(out, ref, tol=2e-5)
+    plain = torch.full_like(out, float('nan'))
+    hip.conv_forward(xv, wt, 1, 0, plain, same=True)
+    assert torch.equal(plain, out)
+    o2 = out.view(-1, c).double()
+    mean, var = o2.mean(0), o2.var(0, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    close(s2[:c], mean, tol=1e-5)
+    close(s2[c:], rstd, tol=1e-5)
+    close(a2[:c], rstd * scale.double(), tol=1e-5)
+    close(a2[c:], offset.double() - mean * rstd * scale.double(), tol=1e-5)
+    # data gradient of the same conv: dx = conv(dy, flipped filter); the sums of the backward of the norm of x from the epilogue
+    dy = rnd(n, h, w_, c, seed=67).to(dev)
+    st = torch.empty(2 * c, device=dev)
+    abx = torch.empty(2 * c, device=dev)
+    x2d = x.view(-1, c)
+    hip.bn_stats(x2d, scale, offset, abx, st)
+    sums = hip.BnBwdSums(x2d, abx, st, torch.zeros(hip.BnBwdSums.rows_needed(n * h * w_), 2 * c, device=dev))
+    g = torch.full((n, h, w_, c), float('nan'), device=dev)
+    hip.conv_dgrad(hip.View(dy), wt, 1, 1, g, bnbwd=sums.take(max(act, 1)))
+    want_g = nhwc(F.conv_transpose2d(nchw(dy).double(), wt.double().permute(3, 2, 0, 1), padding=1))
+    close(g, want_g, tol=2e-5)
+    if n * h * w_ >= 16384:
+        assert sums.sources == 1 and sums.missed == 0 and 0 < sums.rows <= 3 * 256
+    outs = []
+    for pre in (sums, None):
+        dx = torch.full((n * h * w_, c), float('nan'), device=dev)
+        ds, do = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        hip.bn_act_backward(x2d, abx, st, g.view(-1, c), max(act, 1), dx, dscale=ds, doffset=do, pre=pre)
+        outs.append((dx, ds, do))
+    for a, b in zip(*outs):
+        close(a, b, tol=1e-4)
+    # the dispatcher really took the streaming kernel for the forward shape
+    d = hip.ConvDesc()
+    d.x = xv.c()
+    d.w, d.out = wt.data_ptr(), out.data_ptr()
+    d.NB, d.PH, d.PW, d.TH, d.TW, d.in_stride, d.nphase = n, h, w_, 3, 3, 1, 1
+    d.ioff_y = d.ioff_x = -1
+    d.kstep, d.KH, d.KW, d.wC0, d.wC1, d.k_real = 1, 3, 3, c, c, c
+    d.Nn, d.Nstore, d.OH, d.OW, d.ldc, d.out_stride = c, c, h, w_, c, 1
+    assert hip.lib().ssc_conv_c3x3_supported(C.byref(d)) == (1 if n * h * w_ >= 16384 else 0)
