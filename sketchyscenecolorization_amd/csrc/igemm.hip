@@ -34,6 +34,9 @@ int ssc_conv_fewchan_forward(const ssc_conv_desc* dp, int num_cu, void* stream);
 extern "C" int ssc_conv_pw1x1_supported(const ssc_conv_desc* dp);
 int ssc_conv_pw1x1_walkers(const ssc_conv_desc* dp);
 int ssc_conv_pw1x1_forward(const ssc_conv_desc* dp, float* stat, void* stream);
+// tr4mfma.hip
+extern "C" int ssc_conv_tr4_mfma_supported(const ssc_conv_desc* dp);
+int ssc_conv_tr4_mfma_forward(const ssc_conv_desc* dp, void* stream);
 // c3x3.hip
 extern "C" int ssc_conv_c3x3_supported(const ssc_conv_desc* dp);
 int ssc_conv_c3x3_walkers(const ssc_conv_desc* dp);
@@ -1989,6 +1992,10 @@ extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, 
         copy_name(ssc_head1_dgrad_supported(dp) ? "head1_dgrad" : "head1_fwd", buf, len);
         return 0;
     }
+    if (ssc_conv_tr4_mfma_supported(dp)) {
+        copy_name("deconv_tr4_mfma", buf, len);
+        return 0;
+    }
     if (ssc_conv_narrow_supported(dp)) {
         copy_name(dp->nphase == 4 ? "narrow_fwd<transposed>" : "narrow_fwd<conv>", buf, len);
         return 0;
@@ -2296,6 +2303,8 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
     if (ws != nullptr && ssc_head1_forward_supported(dp) && (int64_t)d.NB * d.x.H * d.x.W * 16 * 4 <= ws_bytes)
         return ssc_head1_forward(dp, ws, ws_bytes, stream);
     if (ssc_head1_dgrad_supported(dp)) return ssc_head1_dgrad(dp, stream);
+    if (ssc_conv_tr4_mfma_supported(dp))        // 128 -> <= 4 channels, k = 4 stride-2 transposed: 4x4x1 MFMA blocks, K split 16 ways
+        return ssc_conv_tr4_mfma_forward(dp, stream);
     if (ssc_conv_narrow_supported(dp)) {        // <= 4 output channels
         int csplit = 1;
         const int rc = ssc_conv_narrow_forward_ws(dp, ws, ws_bytes, stream, &csplit);

@@ -343,42 +343,55 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_k2_kernel(const float* __re
         const float* ap0 = h_in + (long)min(m0 + a_r, rows - 1) * C + a_c;
         const float* ap1 = h_in + (long)min(m0 + a_r + 32, rows - 1) * C + a_c;
         const float* bp = Kh + (long)b_k * ldk + b_g * C + u0 + b_u;
-        float4 ra0, ra1, rb0;
-        auto load = [&](int kt) {
-            ra0 = *reinterpret_cast<const float4*>(ap0 + kt * BK);
-            ra1 = *reinterpret_cast<const float4*>(ap1 + kt * BK);
-            rb0 = *reinterpret_cast<const float4*>(bp + (long)kt * BK * ldk);
-        };
-        auto store = [&](int buf) {
-            float* A = As + buf * BM * A_LD;
-            float* B = Bs + buf * BK * B_LD;
-            *reinterpret_cast<float4*>(A + a_r * A_LD + a_c) = ra0;
-            *reinterpret_cast<float4*>(A + (a_r + 32) * A_LD + a_c) = ra1;
-            *reinterpret_cast<float4*>(B + b_k * B_LD + (tid & 7) * 4) = rb0;
-        };
-        const int nkt = C / BK;
-        load(0);
-        store(0);
+        // K = C is 16 tiles of 32 at C = 512 and a tile is 8 MFMAs per wave (0.2 us) against > 1 us of load latency: the loads
+        // run PF tiles ahead in registers (3 float4 per tile and thread), LDS stays double-buffered
+        float4 ra0_0, ra1_0, rb0_0, ra0_1, ra1_1, rb0_1, ra0_2, ra1_2, rb0_2, ra0_3, ra1_3, rb0_3;      // 4 register sets (named: no scratch)
+        const int nkt = C / BK;         // host: a multiple of 4
+#define K2_LOAD(S, kt)                                                          \
+    {                                                                           \
+        ra0_##S = *reinterpret_cast<const float4*>(ap0 + (kt) * BK);            \
+        ra1_##S = *reinterpret_cast<const float4*>(ap1 + (kt) * BK);            \
+        rb0_##S = *reinterpret_cast<const float4*>(bp + (long)(kt) * BK * ldk); \
+    }
+#define K2_STORE(buf, S)                                                                  \
+    {                                                                                     \
+        float* A_ = As + (buf) * BM * A_LD;                                               \
+        float* B_ = Bs + (buf) * BK * B_LD;                                               \
+        *reinterpret_cast<float4*>(A_ + a_r * A_LD + a_c) = ra0_##S;                      \
+        *reinterpret_cast<float4*>(A_ + (a_r + 32) * A_LD + a_c) = ra1_##S;               \
+        *reinterpret_cast<float4*>(B_ + b_k * B_LD + (tid & 7) * 4) = rb0_##S;            \
+    }
+        // tile kt (set S, LDS buffer S & 1): the load of tile kt + 4 goes to set S (tile kt went to LDS in the previous
+        // sub-step), the MFMAs of tile kt, then tile kt + 1 (set SN) to the other LDS buffer
+#define K2_STEP(S, SN)                                                                                                  \
+    {                                                                                                                   \
+        const int kt = kt0 + S;                                                                                         \
+        constexpr int cur = S & 1;                                                                                      \
+        K2_LOAD(S, min(kt + 4, nkt - 1)) /* branch-free (the tail re-reads the last tile): the wait counts stay exact */  \
+        /* K index of MFMA step kk on lane half lhi: 16 * lhi + kk; this wave pair takes kk in [8 * kh, 8 * kh + 8) */ \
+        const float* A = As + cur * BM * A_LD + (wm * 32 + l31) * A_LD + lhi * 16 + kh * 8;                             \
+        const float* B = Bs + cur * BK * B_LD + (lhi * 16 + kh * 8) * B_LD + l31;                                       \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                 \
+            const float4 av = *reinterpret_cast<const float4*>(A + g * 4);                                              \
+            const float b0 = B[(g * 4 + 0) * B_LD], b1 = B[(g * 4 + 1) * B_LD], b2 = B[(g * 4 + 2) * B_LD],             \
+                        b3 = B[(g * 4 + 3) * B_LD];                                                                     \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);                                         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);                                         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);                                         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);                                         \
+        }                                                                                                               \
+        K2_STORE(cur ^ 1, SN)                                                                                           \
+        __syncthreads();                                                                                                \
+    }
+        K2_LOAD(0, 0) K2_LOAD(1, 1) K2_LOAD(2, 2) K2_LOAD(3, 3)
+        K2_STORE(0, 0)
         __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nkt) load(kt + 1);
-            // K index of MFMA step kk on lane half lhi: 16 * lhi + kk; this wave pair takes kk in [8 * kh, 8 * kh + 8)
-            const float* A = As + cur * BM * A_LD + (wm * 32 + l31) * A_LD + lhi * 16 + kh * 8;
-            const float* B = Bs + cur * BK * B_LD + (lhi * 16 + kh * 8) * B_LD + l31;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const float4 av = *reinterpret_cast<const float4*>(A + g * 4);
-                const float b0 = B[(g * 4 + 0) * B_LD], b1 = B[(g * 4 + 1) * B_LD], b2 = B[(g * 4 + 2) * B_LD],
-                            b3 = B[(g * 4 + 3) * B_LD];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
-            }
-            if (kt + 1 < nkt) store(cur ^ 1);
-            __syncthreads();
+        for (int kt0 = 0; kt0 < nkt; kt0 += 4) {
+            K2_STEP(0, 1) K2_STEP(1, 2) K2_STEP(2, 3) K2_STEP(3, 0)
         }
+#undef K2_LOAD
+#undef K2_STORE
+#undef K2_STEP
     }
     // accumulators -> LDS [K half][row][gate * 8 + unit]
     float* Cs = smem + kh * BM * C_LD;
@@ -430,7 +443,7 @@ extern "C" int ssc_lstm_step_fwd(const float* h_in, const float* Kh, int ldk, co
         k2 = (e == nullptr) ? -1 : atoi(e);
     }
     const long wgs = ((rows + 63) / 64) * (C / 16);
-    const bool use_k2 = with_gemm && (k2 == 1 || (k2 == -1 && wgs < 1200));
+    const bool use_k2 = with_gemm && (C % 128) == 0 && (k2 == 1 || (k2 == -1 && wgs < 1200));     // its loads run 4 K tiles ahead
     if (use_k2)
         hipLaunchKernelGGL(lstm_step_fwd_k2_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(C / 8)), dim3(256), 0,
                            (hipStream_t)stream, h_in, Kh, ldk, g1, g2, div2 > 0 ? div2 : 1, mask, mdiv > 0 ? mdiv : 1, c_in,

@@ -141,6 +141,7 @@ SIGNATURES = {
     'ssc_conv_fewchan_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_pw1x1_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_c3x3_supported': [C.POINTER(ConvDesc)],
+    'ssc_conv_tr4_mfma_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_forward_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, _I],
     'ssc_conv_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, _I],
     'ssc_conv_forward_plan': [C.POINTER(ConvDesc), _L, C.POINTER(C.c_int)],
@@ -618,7 +619,7 @@ def _bn_arg(bn, d, coff, out):
     return bn
 
 
-def deconv_forward(x, f, out, coff=0, nstore=None, epi=0, bn=None):
+def deconv_forward(x, f, out, coff=0, nstore=None, epi=0, bn=None, _desc_only=False):
     """tf.nn.conv2d_transpose(k=4, s=2, SAME): x View [N,H,W,Cin], f [4,4,Cout,Cin] -> out [N,2H,2W,*]."""
     KH, KW, co, ci = f.shape
     assert KH == 4 and KW == 4 and ci <= x.C        # ci < x.C: 3-channel tensors padded to 4 (BG region branch)
@@ -634,6 +635,8 @@ def deconv_forward(x, f, out, coff=0, nstore=None, epi=0, bn=None):
     d.n_off, d.Nn, d.Nstore = 0, co, (nstore if nstore is not None else co)
     d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 2, 0, 0
     d.epi, d.accumulate = epi, 0
+    if _desc_only:
+        return d
     _run_conv(d, _bn_arg(bn, d, coff, out))
 
 

@@ -318,3 +318,39 @@ def test_bottleneck_3x3_conv_streaming_kernel(shape, c, act):
     d.kstep, d.KH, d.KW, d.wC0, d.wC1, d.k_real = 1, 3, 3, c, c, c
     d.Nn, d.Nstore, d.OH, d.OW, d.ldc, d.out_stride = c, c, h, w_, c, 1
     assert hip.lib().ssc_conv_c3x3_supported(C.byref(d)) == (1 if n * h * w_ >= 16384 else 0)
+
+
+@pytest.mark.parametrize('shape,c0,nstore,act', [((12, 32, 48), 64, 4, 1), ((8, 30, 50), 128, 3, 2), ((24, 24, 32), 32, 4, 0)])
+def test_last_transposed_conv_on_4x4_mfma_blocks(shape, c0, nstore, act, monkeypatch):
+    """(Experiment kept in the tree, off by default: SSC_TR4_MFMA=1.)  The generators' last layer (k = 4, stride-2 transposed conv 128 -> 3, tanh; models_collection.py:529-534) on
+    v_mfma_f32_4x4x1 blocks with K split 16 ways (tr4mfma.hip): two sources with their own folded norms, ragged tiles, 3 or 4 stored
+    channels, against torch in float64."""
+    import ctypes as C
+    import torch.nn.functional as F
+    hip = _hip()
+    monkeypatch.setenv('SSC_TR4_MFMA', '1')
+    n, h, w_ = shape
+    dev = 'cuda'
+    c1 = 128 - c0
+    x0 = rnd(n, h, w_, c0, seed=71).to(dev)
+    x1 = rnd(n, h, w_, c1, seed=72).to(dev) if c1 else None
+    ab0 = torch.cat([1.0 + 0.2 * rnd(c0, seed=73), 0.3 * rnd(c0, seed=74)]).to(dev)
+    ab1 = torch.cat([1.0 + 0.2 * rnd(c1, seed=75), 0.3 * rnd(c1, seed=76)]).to(dev) if c1 else None
+    f = rnd(4, 4, 3, 128, seed=77, std=0.05).to(dev)
+    xv = hip.View(x0, x1, ab0, act, ab1) if c1 else hip.View(x0, None, ab0, act)
+    out = torch.full((n, 2 * h, 2 * w_, 4), float('nan'), device=dev)
+    hip.deconv_forward(xv, f, out, nstore=nstore, epi=1)
+    z0 = (ab0[:c0] * x0 + ab0[c0:]).double()
+    zs = [z0] + ([(ab1[:c1] * x1 + ab1[c1:]).double()] if c1 else [])
+    z = torch.cat(zs, -1)
+    z = torch.relu(z) if act == 1 else (torch.maximum(z, 0.2 * z) if act == 2 else z)
+    # conv2d_transpose(k=4, s=2, SAME) with f [4,4,Cout,Cin]: torch weight [Cin, Cout, kh, kw]
+    ref = F.conv_transpose2d(nchw(z), f.double().permute(3, 2, 0, 1), stride=2, padding=1)
+    ref = nhwc(torch.tanh(ref))
+    close(out[..., :3], ref, tol=2e-5)
+    if nstore == 4:
+        assert torch.all(out[..., 3] == 0)
+    else:
+        assert torch.isnan(out[..., 3]).all()
+    d = hip.deconv_forward(xv, f, out, nstore=nstore, epi=1, _desc_only=True)
+    assert hip.lib().ssc_conv_tr4_mfma_supported(C.byref(d)) == 1
