@@ -103,6 +103,12 @@ class GanTrainer(object):
         # (66 KB LDS per workgroup), so co-scheduling them only adds contention.
         if overlap_wgrad is None:
             overlap_wgrad = os.environ.get('SSC_OVERLAP_WGRAD', '0') == '1'
+        if overlap_wgrad and self.use_graphs:
+            # round 4: with several filter gradients queued on the side stream the CAPTURED step is not bit-identical to the eager
+            # one (a hazard that stream order hides in eager mode; profiles/NOTEBOOK_r04.md section 8): eager steps only
+            import warnings as _w
+            _w.warn('SSC_OVERLAP_WGRAD=1 is ignored when steps are captured into hipGraphs')
+            overlap_wgrad = False
         self._wgrad_stream = torch.cuda.Stream() if (overlap_wgrad and block_type == 'Pix2Pix') else None
         self._aux_stream = torch.cuda.Stream() if overlap_real else None
         # discriminator backward of the real and of the fake pair side by side (Pix2Pix / Residual discriminators: their
