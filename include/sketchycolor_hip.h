@@ -205,6 +205,9 @@ int ssc_conv_pw1x1_supported(const ssc_conv_desc* d);
 /* the 3x3 stride-1 conv of the bottleneck blocks at 16 / 32 channels and its data gradient (residual_util.py:92-96): streaming
    kernel (c3x3.hip); the batch statistics (ssc_conv_forward_bn) / norm-backward sums (ssc_conv_forward_bnbwd) ride as per-lane sums */
 int ssc_conv_c3x3_supported(const ssc_conv_desc* d);
+/* the 4x4 stride-2 conv 64 -> <= 16 channels (block_1 of the first encoder bottleneck, residual_util.py:87-91) on the 16-column
+   MFMA with K split over the four wavefronts (s2n16.hip) */
+int ssc_conv_s2n16_supported(const ssc_conv_desc* d);
 /* the generators' last layer, the k = 4 stride-2 transposed conv 128 -> <= 4 channels (models_collection.py:529-534), on
    v_mfma_f32_4x4x1 blocks with K split 16 ways (tr4mfma.hip) */
 int ssc_conv_tr4_mfma_supported(const ssc_conv_desc* d);

@@ -37,6 +37,10 @@ int ssc_conv_pw1x1_forward(const ssc_conv_desc* dp, float* stat, void* stream);
 // tr4mfma.hip
 extern "C" int ssc_conv_tr4_mfma_supported(const ssc_conv_desc* dp);
 int ssc_conv_tr4_mfma_forward(const ssc_conv_desc* dp, void* stream);
+// s2n16.hip
+extern "C" int ssc_conv_s2n16_supported(const ssc_conv_desc* dp);
+int ssc_conv_s2n16_walkers(const ssc_conv_desc* dp);
+int ssc_conv_s2n16_forward(const ssc_conv_desc* dp, float* stat, void* stream);
 // c3x3.hip
 extern "C" int ssc_conv_c3x3_supported(const ssc_conv_desc* dp);
 int ssc_conv_c3x3_walkers(const ssc_conv_desc* dp);
@@ -2012,6 +2016,10 @@ extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, 
         copy_name(dp->bmode ? "conv_c3x3<NK>" : "conv_c3x3<KN>", buf, len);
         return 0;
     }
+    if (ssc_conv_s2n16_supported(dp)) {
+        copy_name("conv_s2n16", buf, len);
+        return 0;
+    }
     static const char* names[2][5] = {
         {"conv_fwd<128x128,KN>", "conv_fwd<64x128,KN>", "conv_fwd<128x64,KN>", "conv_fwd<128x32,KN>", "conv_fwd<64x64,KN>"},
         {"conv_fwd<128x128,NK>", "conv_fwd<64x128,NK>", "conv_fwd<128x64,NK>", "conv_fwd<128x32,NK>", "conv_fwd<64x64,NK>"}};
@@ -2046,9 +2054,11 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
     }
     bool fused = false;
     int64_t ws_conv = ws_bytes;
-    if (!off && ws != nullptr && d.Nstore == d.ldc && (ssc_conv_pw1x1_supported(&d) || ssc_conv_c3x3_supported(&d))) {
+    if (!off && ws != nullptr && d.Nstore == d.ldc &&
+        (ssc_conv_pw1x1_supported(&d) || ssc_conv_c3x3_supported(&d) || ssc_conv_s2n16_supported(&d))) {
         // the streaming kernels take the statistics as per-lane sums over the tiles a workgroup walks: one row per walker
-        const int nblk = ssc_conv_pw1x1_supported(&d) ? ssc_conv_pw1x1_walkers(&d) : ssc_conv_c3x3_walkers(&d);
+        const int nblk = ssc_conv_pw1x1_supported(&d) ? ssc_conv_pw1x1_walkers(&d)
+                         : (ssc_conv_c3x3_supported(&d) ? ssc_conv_c3x3_walkers(&d) : ssc_conv_s2n16_walkers(&d));
         const int64_t need = (int64_t)nblk * 2 * d.Nstore * 4;
         if (need <= ws_bytes) {
             d.stat_partial = ws;
@@ -2057,7 +2067,7 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
             return ssc_bn_finalize(d.stat_partial, nblk, d.Nstore, Mall, scale, offset, eps, ab, stats, stream);
         }
     }
-    const bool streaming = ssc_conv_pw1x1_supported(&d) || ssc_conv_c3x3_supported(&d);     // rows per walker, not per tile
+    const bool streaming = ssc_conv_pw1x1_supported(&d) || ssc_conv_c3x3_supported(&d) || ssc_conv_s2n16_supported(&d);     // rows per walker, not per tile
     if (!off && !streaming && ws != nullptr && !ssc_conv_narrow_supported(dp) && !ssc_conv_fewchan_supported(dp) && d.epi == 0 &&
         !d.accumulate && d.Nstore == d.ldc && ((d.Nstore & 3) == 0) && ((reinterpret_cast<unsigned long>(d.out) & 15) == 0) &&
         (fwd_is_ut(d) || fwd_is_utg(d) || (d.bmode == 0 && fwd_is_rowtap(d)))) {
@@ -2161,9 +2171,9 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
     if (!off && partial != nullptr && x != nullptr && ab != nullptr && stats != nullptr && d.Nstore == d.ldc &&
-        ssc_conv_c3x3_supported(&d)) {
-        // streaming 3x3 kernel: the two sums as per-lane sums, one row per walker
-        const int nblk = ssc_conv_c3x3_walkers(&d);
+        (ssc_conv_c3x3_supported(&d) || ssc_conv_s2n16_supported(&d))) {
+        // streaming kernels: the two sums as per-lane sums, one row per walker
+        const int nblk = ssc_conv_c3x3_supported(&d) ? ssc_conv_c3x3_walkers(&d) : ssc_conv_s2n16_walkers(&d);
         if ((int64_t)nblk * 2 * d.Nstore * 4 <= partial_bytes) {
             d.stat_partial = partial;
             d.sb_x = x; d.sb_ldx = ldx; d.sb_ab = ab; d.sb_stats = stats; d.sb_act = act;
@@ -2172,7 +2182,7 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
         }
     }
     if (!off && ws != nullptr && partial != nullptr && x != nullptr && ab != nullptr && stats != nullptr &&
-        !ssc_conv_c3x3_supported(&d) && !ssc_conv_narrow_supported(dp) && !ssc_conv_fewchan_supported(dp) && d.epi == 0 && !d.accumulate &&
+        !ssc_conv_c3x3_supported(&d) && !ssc_conv_s2n16_supported(&d) && !ssc_conv_narrow_supported(dp) && !ssc_conv_fewchan_supported(dp) && d.epi == 0 && !d.accumulate &&
         d.bias == nullptr && d.Nstore == d.ldc &&
         d.Nn == d.Nstore && ((d.Nstore & 3) == 0) && ((ldx & 3) == 0) && ((reinterpret_cast<unsigned long>(d.out) & 15) == 0) &&
         ((reinterpret_cast<unsigned long>(x) & 15) == 0) &&
@@ -2320,6 +2330,8 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
         return ssc_conv_pw1x1_forward(dp, d.stat_partial, stream);
     if (ssc_conv_c3x3_supported(dp))            // 3x3 of a bottleneck at 16 / 32 channels (either filter orientation)
         return ssc_conv_c3x3_forward(dp, d.stat_partial, stream);
+    if (ssc_conv_s2n16_supported(dp))           // 4x4 stride-2 conv 64 -> <= 16 channels: 16-column MFMA, K split over the waves
+        return ssc_conv_s2n16_forward(dp, d.stat_partial, stream);
     const Plan p = plan_fwd(d, ws_bytes, ws != nullptr);
     if (p.cfg < 0) return -4;
     g_launch_res = FWD_CFGS[p.cfg].res;

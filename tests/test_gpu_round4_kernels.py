@@ -354,3 +354,81 @@ def test_last_transposed_conv_on_4x4_mfma_blocks(shape, c0, nstore, act, monkeyp
         assert torch.isnan(out[..., 3]).all()
     d = hip.deconv_forward(xv, f, out, nstore=nstore, epi=1, _desc_only=True)
     assert hip.lib().ssc_conv_tr4_mfma_supported(C.byref(d)) == 1
+
+
+@pytest.mark.parametrize('shape,co,act,stride', [((8, 128, 128), 16, 2, 2), ((9, 126, 132), 16, 1, 2), ((8, 128, 128), 8, 0, 2),
+                                                  ((4, 96, 96), 16, 1, 1), ((4, 101, 107), 16, 2, 1)])
+def test_4x4_conv_to_16_channels_on_the_16_column_mfma(shape, co, act, stride):
+    """The 4x4 conv 64 -> 16 (stride 1: block_1 of the plain bottlenecks at the highest resolution, conv_ex SAME,
+    residual_util.py:147-151; stride 2) on v_mfma_f32_16x16x4_f32 with K split over the four wavefronts (s2n16.hip): norm +
+    activation on load, zero padding of the activated tensor (1 before, 2 after at stride 1), batch statistics as per-thread
+    sums, ragged tiles; against torch in float64 and bit for bit against the launch without statistics."""
+    import ctypes as C
+    import torch.nn.functional as F
+    hip = _hip()
+    n, h, w_ = shape
+    dev = 'cuda'
+    c = 64
+    oh, ow = h // stride, w_ // stride
+    x = rnd(n, h, w_, c, seed=81).to(dev)
+    wt = rnd(4, 4, c, co, seed=82, std=0.05).to(dev)
+    ab = torch.cat([1.0 + 0.2 * rnd(c, seed=83), 0.3 * rnd(c, seed=84)]).to(dev)
+    xv = hip.View(x, None, ab, act)
+    out = torch.full((n, oh, ow, co), float('nan'), device=dev)
+    scale, offset = (1.0 + 0.1 * rnd(co, seed=85)).to(dev), (0.1 * rnd(co, seed=86)).to(dev)
+    a2, s2 = torch.empty(2 * co, device=dev), torch.empty(2 * co, device=dev)
+    hip.conv_forward(xv, wt, stride, 0, out, same=True, bn=(scale, offset, a2, s2))
+    z = (ab[:c] * x + ab[c:]).double()
+    z = torch.relu(z) if act == 1 else (torch.maximum(z, 0.2 * z) if act == 2 else z)
+    zp = F.pad(nchw(z), (1, 2, 1, 2)) if stride == 1 else F.pad(nchw(z), (1, 1, 1, 1))
+    ref = nhwc(F.conv2d(zp, wt.double().permute(3, 2, 0, 1), stride=stride))
+    close(out, ref, tol=2e-5)
+    plain = torch.full_like(out, float('nan'))
+    hip.conv_forward(xv, wt, stride, 0, plain, same=True)
+    assert torch.equal(plain, out)
+    o2 = out.view(-1, co).double()
+    mean, var = o2.mean(0), o2.var(0, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    close(s2[:co], mean, tol=1e-5)
+    close(s2[co:], rstd, tol=1e-5)
+    close(a2[:co], rstd * scale.double(), tol=1e-5)
+    close(a2[co:], offset.double() - mean * rstd * scale.double(), tol=1e-5)
+    d = hip.ConvDesc()
+    d.x = xv.c()
+    d.w, d.out = wt.data_ptr(), out.data_ptr()
+    d.NB, d.PH, d.PW, d.TH, d.TW, d.in_stride, d.nphase = n, oh, ow, 4, 4, stride, 1
+    d.ioff_y = d.ioff_x = -1
+    d.kstep, d.KH, d.KW, d.wC0, d.wC1, d.k_real = 1, 4, 4, c, co, c
+    d.Nn, d.Nstore, d.OH, d.OW, d.ldc, d.out_stride = co, co, oh, ow, co, 1
+    assert hip.lib().ssc_conv_s2n16_supported(C.byref(d)) == 1
+
+
+def test_transposed_conv_data_gradient_on_the_16_column_mfma():
+    """The data gradient of the k = 4 stride-2 transposed conv 16 -> 64 (the last decoder bottleneck) has the geometry of the 4x4
+    stride-2 conv 64 -> 16 and runs on s2n16.hip; the two sums of the backward of the norm its output is the gradient of come out
+    of its epilogue (ssc_conv_forward_bnbwd): against torch and against the separate pass."""
+    import torch.nn.functional as F
+    hip = _hip()
+    n, h, w_, ci, co = 8, 64, 72, 16, 64
+    dev = 'cuda'
+    dy = rnd(n, 2 * h, 2 * w_, co, seed=91).to(dev)
+    f = rnd(4, 4, co, ci, seed=92, std=0.05).to(dev)
+    x = rnd(n, h, w_, ci, seed=93).to(dev)
+    scale, offset = (1.0 + 0.1 * rnd(ci, seed=94)).to(dev), (0.1 * rnd(ci, seed=95)).to(dev)
+    abx, st = torch.empty(2 * ci, device=dev), torch.empty(2 * ci, device=dev)
+    x2d = x.view(-1, ci)
+    hip.bn_stats(x2d, scale, offset, abx, st)
+    sums = hip.BnBwdSums(x2d, abx, st, torch.zeros(hip.BnBwdSums.rows_needed(n * h * w_), 2 * ci, device=dev))
+    g = torch.full((n, h, w_, ci), float('nan'), device=dev)
+    hip.deconv_dgrad(hip.View(dy), f, g, bnbwd=sums.take(1))
+    want = nhwc(F.conv2d(nchw(dy).double(), f.double().permute(3, 2, 0, 1), stride=2, padding=1))
+    close(g, want, tol=2e-5)
+    assert sums.sources == 1 and sums.missed == 0 and 0 < sums.rows <= 512
+    outs = []
+    for pre in (sums, None):
+        dx = torch.full((n * h * w_, ci), float('nan'), device=dev)
+        ds, do = torch.empty(ci, device=dev), torch.empty(ci, device=dev)
+        hip.bn_act_backward(x2d, abx, st, g.view(-1, ci), 1, dx, dscale=ds, doffset=do, pre=pre)
+        outs.append((dx, ds, do))
+    for a, b in zip(*outs):
+        close(a, b, tol=1e-4)
