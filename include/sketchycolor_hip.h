@@ -208,6 +208,9 @@ int ssc_conv_c3x3_supported(const ssc_conv_desc* d);
 /* the 4x4 stride-2 conv 64 -> <= 16 channels (block_1 of the first encoder bottleneck, residual_util.py:87-91) on the 16-column
    MFMA with K split over the four wavefronts (s2n16.hip) */
 int ssc_conv_s2n16_supported(const ssc_conv_desc* d);
+/* the k = 4 stride-2 transposed convs of the Background generator's region branch (<= 4 channels in and out,
+   bg_colorization_main.py:392-397): a thread per lattice pixel (tr4tiny.hip) */
+int ssc_conv_tr4_tiny_supported(const ssc_conv_desc* d);
 /* the generators' last layer, the k = 4 stride-2 transposed conv 128 -> <= 4 channels (models_collection.py:529-534), on
    v_mfma_f32_4x4x1 blocks with K split 16 ways (tr4mfma.hip) */
 int ssc_conv_tr4_mfma_supported(const ssc_conv_desc* d);

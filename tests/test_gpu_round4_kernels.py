@@ -432,3 +432,35 @@ def test_transposed_conv_data_gradient_on_the_16_column_mfma():
         outs.append((dx, ds, do))
     for a, b in zip(*outs):
         close(a, b, tol=1e-4)
+
+
+@pytest.mark.parametrize('shape,act', [((2, 96, 96), 1), ((3, 37, 53), 0)])
+def test_region_branch_transposed_conv_thread_per_pixel(shape, act):
+    """The region branch's k = 4 stride-2 transposed conv 3 -> 3 over a 4-channel padded tensor (bg_colorization_main.py:392-397) on
+    tr4tiny.hip: folded norm + activation on load, the padding column written as 0, batch statistics as per-thread sums; against
+    torch in float64."""
+    import ctypes as C
+    import torch.nn.functional as F
+    hip = _hip()
+    n, h, w_ = shape
+    dev = 'cuda'
+    x = rnd(n, h, w_, 4, seed=101).to(dev)
+    x[..., 3] = 7.0         # the padding channel of the input must not be read
+    f = rnd(4, 4, 3, 3, seed=102, std=0.3).to(dev)
+    ab = torch.cat([1.0 + 0.2 * rnd(4, seed=103), 0.3 * rnd(4, seed=104)]).to(dev)
+    xv = hip.View(x, None, ab, act)
+    out = torch.full((n, 2 * h, 2 * w_, 4), float('nan'), device=dev)
+    scale, offset = torch.ones(4, device=dev), torch.zeros(4, device=dev)
+    a2, s2 = torch.empty(8, device=dev), torch.empty(8, device=dev)
+    hip.deconv_forward(xv, f, out, nstore=4, bn=(scale, offset, a2, s2))
+    z = (ab[:4] * x + ab[4:]).double()[..., :3]
+    z = torch.relu(z) if act == 1 else z
+    ref = nhwc(F.conv_transpose2d(nchw(z), f.double().permute(3, 2, 0, 1), stride=2, padding=1))
+    close(out[..., :3], ref, tol=2e-5)
+    assert torch.all(out[..., 3] == 0)
+    o2 = out.view(-1, 4).double()
+    mean, var = o2.mean(0), o2.var(0, unbiased=False)
+    close(s2[:4], mean, tol=1e-5)
+    close(s2[4:], 1.0 / torch.sqrt(var + 1e-5), tol=1e-5)
+    d = hip.deconv_forward(xv, f, out, nstore=4, _desc_only=True)
+    assert hip.lib().ssc_conv_tr4_tiny_supported(C.byref(d)) == 1
