@@ -464,3 +464,38 @@ def test_region_branch_transposed_conv_thread_per_pixel(shape, act):
     close(s2[4:], 1.0 / torch.sqrt(var + 1e-5), tol=1e-5)
     d = hip.deconv_forward(xv, f, out, nstore=4, _desc_only=True)
     assert hip.lib().ssc_conv_tr4_tiny_supported(C.byref(d)) == 1
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 192), (1, 384, 384)])
+def test_first_7x7_conv_over_the_image_channels(shape):
+    """encoder_1 of the Residual / Background generators: 7x7 stride-2 SAME conv over the 3 image channels (padded to 4) -> 64 + batch
+    statistics (fewchan7.hip); against torch in float64 (SAME = 2 before, 3 after)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    hip = _hip()
+    n, h, w_ = shape
+    dev = 'cuda'
+    x = rnd(n, h, w_, 4, seed=111).to(dev)
+    x[..., 3] = 5.0         # the padding channel must not be read
+    wt = rnd(7, 7, 3, 64, seed=112, std=0.1).to(dev)
+    out = torch.full((n, h // 2, w_ // 2, 64), float('nan'), device=dev)
+    scale, offset = (1.0 + 0.1 * rnd(64, seed=113)).to(dev), (0.1 * rnd(64, seed=114)).to(dev)
+    a2, s2 = torch.empty(128, device=dev), torch.empty(128, device=dev)
+    hip.conv_forward(hip.View(x), wt, 2, 0, out, same=True, bn=(scale, offset, a2, s2))
+    z = nchw(x[..., :3].double())
+    ref = nhwc(F.conv2d(F.pad(z, (2, 3, 2, 3)), wt.double().permute(3, 2, 0, 1), stride=2))
+    close(out, ref, tol=2e-5)
+    o2 = out.view(-1, 64).double()
+    mean, var = o2.mean(0), o2.var(0, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    close(s2[:64], mean, tol=1e-5)
+    close(s2[64:], rstd, tol=1e-5)
+    close(a2[:64], rstd * scale.double(), tol=1e-5)
+    d = hip.ConvDesc()
+    d.x = hip.View(x).c()
+    d.w, d.out = wt.data_ptr(), out.data_ptr()
+    d.NB, d.PH, d.PW, d.TH, d.TW, d.in_stride, d.nphase = n, h // 2, w_ // 2, 7, 7, 2, 1
+    d.ioff_y = d.ioff_x = -2
+    d.kstep, d.KH, d.KW, d.wC0, d.wC1, d.k_real = 1, 7, 7, 3, 64, 3
+    d.Nn, d.Nstore, d.OH, d.OW, d.ldc, d.out_stride = 64, 64, h // 2, w_ // 2, 64, 1
+    assert hip.lib().ssc_conv_fewchan7_supported(C.byref(d)) == 1
