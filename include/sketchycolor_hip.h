@@ -208,6 +208,9 @@ int ssc_conv_c3x3_supported(const ssc_conv_desc* d);
 /* the 4x4 stride-2 conv 64 -> <= 16 channels (block_1 of the first encoder bottleneck, residual_util.py:87-91) on the 16-column
    MFMA with K split over the four wavefronts (s2n16.hip) */
 int ssc_conv_s2n16_supported(const ssc_conv_desc* d);
+/* the k = 4 stride-2 transposed conv 256 -> <= 16 channels (block_1 of the last decoder bottleneck) on the 16-column MFMA, one
+   sub-pixel phase per workgroup (tr4n16.hip) */
+int ssc_conv_tr4n16_supported(const ssc_conv_desc* d);
 /* the Residual / Background generators' first conv, 7x7 stride 2 over the padded image channels -> 64 (fewchan7.hip) */
 int ssc_conv_fewchan7_supported(const ssc_conv_desc* d);
 /* the k = 4 stride-2 transposed convs of the Background generator's region branch (<= 4 channels in and out,

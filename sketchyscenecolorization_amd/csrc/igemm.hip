@@ -37,6 +37,10 @@ int ssc_conv_pw1x1_forward(const ssc_conv_desc* dp, float* stat, void* stream);
 // tr4mfma.hip
 extern "C" int ssc_conv_tr4_mfma_supported(const ssc_conv_desc* dp);
 int ssc_conv_tr4_mfma_forward(const ssc_conv_desc* dp, void* stream);
+// tr4n16.hip
+extern "C" int ssc_conv_tr4n16_supported(const ssc_conv_desc* dp);
+int ssc_conv_tr4n16_rows(const ssc_conv_desc* dp);
+int ssc_conv_tr4n16_forward(const ssc_conv_desc* dp, float* stat, void* stream);
 // fewchan7.hip
 extern "C" int ssc_conv_fewchan7_supported(const ssc_conv_desc* dp);
 int ssc_conv_fewchan7_walkers(const ssc_conv_desc* dp);
@@ -2036,6 +2040,10 @@ extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, 
         copy_name("conv_fewchan7", buf, len);
         return 0;
     }
+    if (ssc_conv_tr4n16_supported(dp)) {
+        copy_name("deconv_tr4n16", buf, len);
+        return 0;
+    }
     static const char* names[2][5] = {
         {"conv_fwd<128x128,KN>", "conv_fwd<64x128,KN>", "conv_fwd<128x64,KN>", "conv_fwd<128x32,KN>", "conv_fwd<64x64,KN>"},
         {"conv_fwd<128x128,NK>", "conv_fwd<64x128,NK>", "conv_fwd<128x64,NK>", "conv_fwd<128x32,NK>", "conv_fwd<64x64,NK>"}};
@@ -2072,12 +2080,13 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
     int64_t ws_conv = ws_bytes;
     if (!off && ws != nullptr && d.Nstore == d.ldc &&
         (ssc_conv_pw1x1_supported(&d) || ssc_conv_c3x3_supported(&d) || ssc_conv_s2n16_supported(&d) ||
-         ssc_conv_tr4_tiny_supported(&d) || ssc_conv_fewchan7_supported(&d))) {
+         ssc_conv_tr4_tiny_supported(&d) || ssc_conv_fewchan7_supported(&d) || ssc_conv_tr4n16_supported(&d))) {
         // the streaming kernels take the statistics as per-lane sums over the tiles a workgroup walks: one row per walker
         const int nblk = ssc_conv_pw1x1_supported(&d) ? ssc_conv_pw1x1_walkers(&d)
                          : (ssc_conv_c3x3_supported(&d) ? ssc_conv_c3x3_walkers(&d)
                             : (ssc_conv_s2n16_supported(&d) ? ssc_conv_s2n16_walkers(&d)
-                               : (ssc_conv_tr4_tiny_supported(&d) ? ssc_conv_tr4_tiny_blocks(&d) : ssc_conv_fewchan7_walkers(&d))));
+                               : (ssc_conv_tr4_tiny_supported(&d) ? ssc_conv_tr4_tiny_blocks(&d)
+                                  : (ssc_conv_fewchan7_supported(&d) ? ssc_conv_fewchan7_walkers(&d) : ssc_conv_tr4n16_rows(&d)))));
         const int64_t need = (int64_t)nblk * 2 * d.Nstore * 4;
         if (need <= ws_bytes) {
             d.stat_partial = ws;
@@ -2087,7 +2096,8 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
         }
     }
     const bool streaming = ssc_conv_pw1x1_supported(&d) || ssc_conv_c3x3_supported(&d) || ssc_conv_s2n16_supported(&d) ||
-                           ssc_conv_tr4_tiny_supported(&d) || ssc_conv_fewchan7_supported(&d);     // rows per walker, not per tile
+                           ssc_conv_tr4_tiny_supported(&d) || ssc_conv_fewchan7_supported(&d) ||
+                           ssc_conv_tr4n16_supported(&d);     // rows per walker, not per tile
     if (!off && !streaming && ws != nullptr && !ssc_conv_narrow_supported(dp) && !ssc_conv_fewchan_supported(dp) && d.epi == 0 &&
         !d.accumulate && d.Nstore == d.ldc && ((d.Nstore & 3) == 0) && ((reinterpret_cast<unsigned long>(d.out) & 15) == 0) &&
         (fwd_is_ut(d) || fwd_is_utg(d) || (d.bmode == 0 && fwd_is_rowtap(d)))) {
@@ -2356,6 +2366,8 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
         return ssc_conv_tr4_tiny_forward(dp, d.stat_partial, stream);
     if (ssc_conv_fewchan7_supported(dp))        // 7x7 stride-2 conv over the (padded) image channels
         return ssc_conv_fewchan7_forward(dp, d.stat_partial, stream);
+    if (ssc_conv_tr4n16_supported(dp))          // k = 4 stride-2 transposed conv 256 -> <= 16 channels: 16-column MFMA, a phase per workgroup
+        return ssc_conv_tr4n16_forward(dp, d.stat_partial, stream);
     const Plan p = plan_fwd(d, ws_bytes, ws != nullptr);
     if (p.cfg < 0) return -4;
     g_launch_res = FWD_CFGS[p.cfg].res;

@@ -142,6 +142,7 @@ SIGNATURES = {
     'ssc_conv_pw1x1_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_c3x3_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_s2n16_supported': [C.POINTER(ConvDesc)],
+    'ssc_conv_tr4n16_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_fewchan7_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_tr4_tiny_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_tr4_mfma_supported': [C.POINTER(ConvDesc)],

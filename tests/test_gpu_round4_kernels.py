@@ -499,3 +499,42 @@ def test_first_7x7_conv_over_the_image_channels(shape):
     d.kstep, d.KH, d.KW, d.wC0, d.wC1, d.k_real = 1, 7, 7, 3, 64, 3
     d.Nn, d.Nstore, d.OH, d.OW, d.ldc, d.out_stride = 64, 64, h // 2, w_ // 2, 64, 1
     assert hip.lib().ssc_conv_fewchan7_supported(C.byref(d)) == 1
+
+
+@pytest.mark.parametrize('shape,c0,act', [((8, 48, 48), 128, 1), ((5, 50, 70), 256, 2), ((8, 48, 48), 64, 0)])
+def test_transposed_conv_to_16_channels_on_the_16_column_mfma(shape, c0, act):
+    """block_1 of the last decoder bottleneck: k = 4 stride-2 transposed conv over concat[128, 128] -> 16 + batch statistics on
+    tr4n16.hip (16-column MFMA, one sub-pixel phase per workgroup, K split by tap over the waves): two sources with their own
+    folded norms, ragged tiles; against torch in float64 and bit for bit against the launch without statistics."""
+    import ctypes as C
+    import torch.nn.functional as F
+    hip = _hip()
+    n, h, w_ = shape
+    dev = 'cuda'
+    c1 = 256 - c0
+    x0 = rnd(n, h, w_, c0, seed=121).to(dev)
+    x1 = rnd(n, h, w_, c1, seed=122).to(dev) if c1 else None
+    ab0 = torch.cat([1.0 + 0.2 * rnd(c0, seed=123), 0.3 * rnd(c0, seed=124)]).to(dev)
+    ab1 = torch.cat([1.0 + 0.2 * rnd(c1, seed=125), 0.3 * rnd(c1, seed=126)]).to(dev) if c1 else None
+    f = rnd(4, 4, 16, 256, seed=127, std=0.05).to(dev)
+    xv = hip.View(x0, x1, ab0, act, ab1) if c1 else hip.View(x0, None, ab0, act)
+    out = torch.full((n, 2 * h, 2 * w_, 16), float('nan'), device=dev)
+    scale, offset = (1.0 + 0.1 * rnd(16, seed=128)).to(dev), (0.1 * rnd(16, seed=129)).to(dev)
+    a2, s2 = torch.empty(32, device=dev), torch.empty(32, device=dev)
+    hip.deconv_forward(xv, f, out, bn=(scale, offset, a2, s2))
+    zs = [(ab0[:c0] * x0 + ab0[c0:]).double()] + ([(ab1[:c1] * x1 + ab1[c1:]).double()] if c1 else [])
+    z = torch.cat(zs, -1)
+    z = torch.relu(z) if act == 1 else (torch.maximum(z, 0.2 * z) if act == 2 else z)
+    ref = nhwc(F.conv_transpose2d(nchw(z), f.double().permute(3, 2, 0, 1), stride=2, padding=1))
+    close(out, ref, tol=2e-5)
+    plain = torch.full_like(out, float('nan'))
+    hip.deconv_forward(xv, f, plain)
+    assert torch.equal(plain, out)
+    o2 = out.view(-1, 16).double()
+    mean, var = o2.mean(0), o2.var(0, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    close(s2[:16], mean, tol=1e-5)
+    close(s2[16:], rstd, tol=1e-5)
+    close(a2[:16], rstd * scale.double(), tol=1e-5)
+    d = hip.deconv_forward(xv, f, out, _desc_only=True)
+    assert hip.lib().ssc_conv_tr4n16_supported(C.byref(d)) == 1
