@@ -167,6 +167,9 @@ int ssc_conv_wgrad(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void* s
  * padding on the gathered side, >= 128 real dense channels, every tensor below 2 GiB */
 int ssc_conv_wgrad128_supported(const ssc_wgrad_desc* d);
 int ssc_conv_wgrad128(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, void* stream);
+/* filter gradients with 16 dense channels of the 3x3 conv over 16 and the 4x4 stride-1 conv over 64 gathered channels
+ * (residual_util.py:92-96, 147-151) on the 16-column MFMA (wgn16.hip); ssc_conv_wgrad dispatches to it when _supported */
+int ssc_conv_wgn16_supported(const ssc_wgrad_desc* d);
 /* conv + the batch-statistics norm of its output [M*nphase rows, Nstore == ldc columns] folded to ab = [a; b] (y = a*x + b)
  * and stats = [mean; rstd] (models_collection.py:36-46 after :389 / :402): the column sums come out of the conv epilogue
  * when the launch allows it, else ssc_bn_stats reads the output back */

@@ -26,6 +26,9 @@
 extern "C" int ssc_conv_wgrad128_supported(const ssc_wgrad_desc* dp);
 extern "C" int ssc_conv_wgrad128(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream);
 int ssc_conv_wgrad128_job(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, const ssc_bn_apply_job* job, void* stream);
+// wgn16.hip
+extern "C" int ssc_conv_wgn16_supported(const ssc_wgrad_desc* dp);
+int ssc_conv_wgn16(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream);
 // narrow.hip
 int ssc_conv_narrow_forward_ws(const ssc_conv_desc* dp, float* ws, int64_t ws_bytes, void* stream, int* csplit_out);
 // fewchan.hip
@@ -2501,6 +2504,10 @@ extern "C" int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* dp, char* buf, i
         copy_name("conv_wgrad128<128x128>", buf, len);
         return 0;
     }
+    if (ssc_conv_wgn16_supported(dp)) {
+        copy_name(dp->TH == 3 ? "conv_wgn16<3x3>" : "conv_wgn16<4x4>", buf, len);
+        return 0;
+    }
     const Plan p = plan_wgrad(*dp, (int64_t)1 << 40, true);
     copy_name(names[p.cfg < 0 ? 0 : p.cfg], buf, len);
     return 0;
@@ -2537,6 +2544,10 @@ extern "C" int ssc_conv_wgrad(const ssc_wgrad_desc* dp, float* ws, int64_t ws_by
     if (ws != nullptr && ws_bytes >= (int64_t)16 * 512 * 4 && ssc_head1_wgrad_supported(dp))     // the one-output patch head
         return ssc_head1_wgrad(dp, ws, ws_bytes, stream);
     if (ssc_conv_wgrad128_supported(dp)) return ssc_conv_wgrad128(dp, ws, ws_bytes, stream);     // the large layers
+    if (ws != nullptr && ssc_conv_wgn16_supported(dp)) {      // 16 output channels, 3x3 x 16 or 4x4 x 64 gathered: 16-column MFMA
+        const int rc = ssc_conv_wgn16(dp, ws, ws_bytes, stream);
+        if (rc != -2) return rc;        // -2: the workspace cannot hold a slab
+    }
     const Plan p = plan_wgrad(d, ws_bytes, ws != nullptr);
     switch (p.cfg) {
         case 0: return launch_wgrad<2, 2, 2, 2>(d, p.splitk, ws, st);

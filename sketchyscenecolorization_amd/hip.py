@@ -114,6 +114,7 @@ SIGNATURES = {
     'ssc_conv_forward': [C.POINTER(ConvDesc), _P, _L, _P],
     'ssc_conv_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
     'ssc_conv_wgrad128_supported': [C.POINTER(WgradDesc)],
+    'ssc_conv_wgn16_supported': [C.POINTER(WgradDesc)],
     'ssc_conv_wgrad128': [C.POINTER(WgradDesc), _P, _L, _P],
     'ssc_conv_forward_bn': [C.POINTER(ConvDesc), _P, _L, _P, _P, _F, _P, _P, _P],
     'ssc_bn_finalize': [_P, _I, _I, _L, _P, _P, _F, _P, _P, _P],

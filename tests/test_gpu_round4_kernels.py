@@ -538,3 +538,39 @@ def test_transposed_conv_to_16_channels_on_the_16_column_mfma(shape, c0, act):
     close(a2[:16], rstd * scale.double(), tol=1e-5)
     d = hip.deconv_forward(xv, f, out, _desc_only=True)
     assert hip.lib().ssc_conv_tr4n16_supported(C.byref(d)) == 1
+
+
+@pytest.mark.parametrize('k,ci,shape,act,acc', [(3, 16, (4, 96, 96), 1, False), (3, 16, (3, 101, 119), 2, True),
+                                                (4, 64, (4, 96, 96), 1, False), (4, 64, (3, 101, 119), 0, True)])
+def test_filter_gradients_with_16_output_channels(k, ci, shape, act, acc):
+    """dW of the bottlenecks' 3x3 conv 16 -> 16 and 4x4 stride-1 conv 64 -> 16 (residual_util.py:92-96, 147-151) on the 16-column MFMA
+    (wgn16.hip): folded norm + activation of the gathered tensor on load, SAME padding (1 before), ragged tiles, the accumulate of a
+    second pass; against torch autograd in float64."""
+    import ctypes as C
+    import torch.nn.functional as F
+    hip = _hip()
+    n, h, w_ = shape
+    dev = 'cuda'
+    co = 16
+    x = rnd(n, h, w_, ci, seed=131).to(dev)
+    dy = rnd(n, h, w_, co, seed=132).to(dev)
+    ab = torch.cat([1.0 + 0.2 * rnd(ci, seed=133), 0.3 * rnd(ci, seed=134)]).to(dev)
+    xv = hip.View(x, None, ab, act)
+    base = rnd(k, k, ci, co, seed=135).to(dev)
+    dw = base.clone() if acc else torch.full((k, k, ci, co), float('nan'), device=dev)
+    hip.conv_wgrad(xv, hip.View(dy), dw, 1, 1, accumulate=acc)
+    z = (ab[:ci] * x + ab[ci:]).double()
+    z = torch.relu(z) if act == 1 else (torch.maximum(z, 0.2 * z) if act == 2 else z)
+    zp = F.pad(nchw(z), (1, k - 2, 1, k - 2))
+    wt = torch.zeros(co, ci, k, k, dtype=torch.float64, device=dev, requires_grad=True)
+    (F.conv2d(zp, wt) * nchw(dy).double()).sum().backward()
+    want = wt.grad.permute(2, 3, 1, 0) + (base.double() if acc else 0.0)
+    scale = float(want.abs().max())
+    assert float((dw.double() - want).abs().max()) < 2e-5 * scale
+    d = hip.WgradDesc()
+    d.g, d.d = xv.c(), hip.View(dy).c()
+    d.out = dw.data_ptr()
+    d.NB, d.PH, d.PW = n, h, w_
+    d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = k, k, 1, -1, -1
+    d.Cg_real, d.Nn, d.ldc, d.accumulate = ci, co, co, int(acc)
+    assert hip.lib().ssc_conv_wgn16_supported(C.byref(d)) == 1
