@@ -23,24 +23,34 @@ __device__ __forceinline__ float mru_act(float v, int act) {
 // ---- 16-byte forms: thread layout and row decode
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte access at 4-byte alignment (concat slices)
 struct PwMap {
-    int txl, _pad;              // log2 of the threads that walk the channel groups of a row
+    int txl, cg;                // log2 of the threads that walk the channel groups of a row (fallback layout); groups per row
     unsigned long mP, oneP;     // row / P by multiply-high (exact for 32-bit rows)
     unsigned mW, oneW;          // pix / W (pix < P, P * W < 2^32)
+    unsigned long mG, oneG;     // flat index / cg
 };
 static inline PwMap pw_map(int cg, long P, int W) {
     PwMap m;
     m.txl = 0;
     while ((1 << m.txl) < cg && m.txl < 8) ++m.txl;
-    m._pad = 0;
+    m.cg = cg;
     m.mP = P <= 1 ? 0UL : (unsigned long)((((unsigned __int128)1) << 64) / (unsigned long)P) + 1UL;
     m.oneP = P <= 1 ? ~0UL : 0UL;
     m.mW = W <= 1 ? 0u : (unsigned)(0x100000000ULL / (unsigned)W) + 1u;
     m.oneW = W <= 1 ? ~0u : 0u;
+    m.mG = cg <= 1 ? 0UL : (unsigned long)((((unsigned __int128)1) << 64) / (unsigned long)cg) + 1UL;
+    m.oneG = cg <= 1 ? ~0UL : 0UL;
     return m;
 }
+// the flat layout (below) covers rows * groups < 2^32
+static inline bool pw_flat(long M, const PwMap& m) { return M * (long)m.cg < 0xffffffffL; }
 static inline unsigned pw_blocks(long M, const PwMap& m) {
-    const long ty = 256 >> m.txl;
-    long b = (M + ty - 1) / ty;
+    long b;
+    if (pw_flat(M, m)) {
+        b = (M * m.cg + 255) / 256;
+    } else {
+        const long ty = 256 >> m.txl;
+        b = (M + ty - 1) / ty;
+    }
     if (b > 8192) b = 8192;
     if (b < 1) b = 1;
     return (unsigned)b;
@@ -51,9 +61,19 @@ __device__ __forceinline__ int pw_sample(long row, const PwMap& m) {
 __device__ __forceinline__ int pw_div_w(int pix, const PwMap& m) {
     return (int)(__umulhi((unsigned)pix, m.mW) + ((unsigned)pix & m.oneW));
 }
-// f(row, c): every (row < M, c = 4 * group < 4 * cg)
+// f(row, c): every (row < M, c = 4 * group < 4 * cg).  Flat layout: consecutive threads take consecutive 16-byte groups ACROSS rows, so
+// no lane idles when the groups per row are not a power of two (33 of 64 lanes worked on the 128 + 4-channel concats); rows *
+// groups >= 2^32 keeps the row-per-thread-group layout
 template <class F>
 __device__ __forceinline__ void pw_rows(long M, int cg, const PwMap& m, F f) {
+    const long total = M * (long)cg;
+    if (total < 0xffffffffL) {
+        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+            const long row = (long)(__umul64hi((unsigned long)idx, m.mG) + ((unsigned long)idx & m.oneG));
+            f(row, (int)(idx - row * cg) * 4);
+        }
+        return;
+    }
     const int TX = 1 << m.txl, TY = 256 >> m.txl;
     const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> m.txl;
     for (long row = (long)blockIdx.x * TY + ty; row < M; row += (long)gridDim.x * TY)
