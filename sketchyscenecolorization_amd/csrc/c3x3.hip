@@ -221,6 +221,188 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 16 channels on the 16-column MFMA (v_mfma_f32_16x16x4_f32): the 32-column instruction above multiplies padding in half of its
+// columns when the conv has 16 outputs.  Same structure (4 x 32-pixel tiles, a wavefront per row, two LDS images, persistent
+// workgroups, per-lane sums); a lane's share of the filter is 36 registers, a row is two MFMA row groups of 16 pixels, pixel stride
+// 20 floats in LDS (the 16 pixels x 4 k of an operand read hit 64 distinct banks).
+typedef float c3f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void c3x3n16_kernel(const ssc_conv_desc d, int tiles, int tiles_x, int tiles_y, float* __restrict__ stat) {
+    constexpr int C = 16, K = 144, KS = 36, TR = 4, TC = 32, PR = TR + 2, PC = TC + 2, CP = 20;
+    constexpr int PSZ = PR * PC * CP;
+    constexpr int NQ = (PR * PC * 4 + 255) / 256;       // 4
+    __shared__ __attribute__((aligned(16))) float simg[2 * PSZ];       // 32.6 KB
+    __shared__ float red[2][4][16];
+    float* const img0 = simg;
+    float* const img1 = simg + PSZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const bool colv = l15 < d.Nn;
+    const int H = d.x.H, W = d.x.W;
+
+    // ---- filter fragments through LDS once: F[k][n] (k = (tap, c)), bf[s] = F[4 s + kq][l15] ----
+    float bf[KS];
+    {
+        constexpr int FLD = 17;
+        float* const F = simg;                      // [144][17] <= 2 * PSZ floats
+        const int Nn = d.Nn;
+        constexpr int NF = K * C / 256;             // 9
+        float fv[NF];
+        int fo[NF];
+        const int kn = K * Nn;
+#pragma unroll
+        for (int q = 0; q < NF; ++q) {
+            const int idx = tid + 256 * q;
+            int tap, c, n;
+            if (d.bmode == 0) {                     // KN: w[ky][kx][c][n_off + n], n contiguous
+                const int k = idx / Nn;
+                n = idx - k * Nn;
+                tap = k / C;
+                c = k - tap * C;
+            } else {                                // NK: w[ky][kx][n_off + n][c], c contiguous
+                c = idx % C;
+                const int r = idx / C;
+                tap = r / Nn;
+                n = r - tap * Nn;
+            }
+            const int ky = d.ky0 + (tap / 3) * d.kstep, kx = d.kx0 + (tap % 3) * d.kstep;
+            const long g = d.bmode == 0 ? ((long)(ky * 3 + kx) * d.wC0 + c) * d.wC1 + d.n_off + n
+                                        : ((long)(ky * 3 + kx) * d.wC0 + d.n_off + n) * d.wC1 + c;
+            fo[q] = idx < kn ? (tap * C + c) * FLD + n : -1;
+            fv[q] = idx < kn ? d.w[g] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NF; ++q)
+            if (fo[q] >= 0) F[fo[q]] = fv[q];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bf[s] = colv ? F[(4 * s + kq) * FLD + l15] : 0.f;
+        __syncthreads();
+    }
+
+    // ---- patch staging: thread -> (pixel (tid + 256 q) / 4, chunk tid % 4) ----
+    const int ch = tid & 3;
+    float4 ta = make_float4(1.f, 1.f, 1.f, 1.f), tb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.x.ab0 != nullptr) {
+        ta = *reinterpret_cast<const float4*>(d.x.ab0 + 4 * ch);
+        tb = *reinterpret_cast<const float4*>(d.x.ab0 + C + 4 * ch);
+    }
+    const float slope = d.x.act == SSC_ACT_RELU ? 0.f : (d.x.act == SSC_ACT_LRELU ? 0.2f : 1.f);
+    float4 rv[NQ];
+    auto load_patch = [&](int tile) {
+        const int tx = tile % tiles_x;
+        const int r = tile / tiles_x;
+        const int ty = r % tiles_y, n = r / tiles_y;
+        const int iy0 = TR * ty - 1, ix0 = TC * tx - 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int pix = (tid >> 2) + 64 * q;
+            const int pr = pix / PC, pc = pix - pr * PC;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            const bool ok = (pix < PR * PC) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+            const float4 v = *reinterpret_cast<const float4*>(d.x.s0 + (ok ? (((long)n * H + iy) * W + ix) * C + 4 * ch : 0));
+            float4 t;
+            t.x = fmaf(ta.x, v.x, tb.x); t.y = fmaf(ta.y, v.y, tb.y); t.z = fmaf(ta.z, v.z, tb.z); t.w = fmaf(ta.w, v.w, tb.w);
+            t.x = fmaxf(t.x, slope * t.x); t.y = fmaxf(t.y, slope * t.y); t.z = fmaxf(t.z, slope * t.z); t.w = fmaxf(t.w, slope * t.w);
+            rv[q] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);       // zero padding of the ACTIVATED tensor
+        }
+    };
+    auto store_patch = [&](float* P) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int pix = (tid >> 2) + 64 * q;
+            if (pix < PR * PC) *reinterpret_cast<float4*>(P + pix * CP + 4 * ch) = rv[q];
+        }
+    };
+
+    const bool bwd = stat != nullptr && d.sb_x != nullptr;
+    float sa = 1.f, sb = 0.f, smu = 0.f, srs = 1.f, sneg = 1.f;
+    if (bwd && colv) {
+        sa = d.sb_ab[l15]; sb = d.sb_ab[d.Nstore + l15];
+        smu = d.sb_stats[l15]; srs = d.sb_stats[d.Nstore + l15];
+        sneg = d.sb_act == SSC_ACT_RELU ? 0.f : (d.sb_act == SSC_ACT_LRELU ? 0.2f : 1.f);
+    }
+    float ssum = 0.f, ssq = 0.f;
+
+    const int G = gridDim.x;
+    int tile = blockIdx.x;
+    if (tile < tiles) {
+        load_patch(tile);
+        store_patch(img0);
+    }
+    __syncthreads();
+    int buf = 0;
+    const int abase = (wave * PC + l15) * CP + kq;       // pixel (row `wave`, column l15 of a half) of the patch, + k within a step
+    for (; tile < tiles; tile += G) {
+        const int next = tile + G;
+        if (next < tiles) load_patch(next);
+        const float* P = (buf ? img1 : img0) + abase;
+        c3f4 acc[2];
+        acc[0] = (c3f4){0.f, 0.f, 0.f, 0.f};
+        acc[1] = (c3f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int tap = s >> 2;
+            const int off = ((tap / 3) * PC + (tap % 3)) * CP + 4 * (s & 3);        // compile-time after unrolling
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[off], bf[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[off + 16 * CP], bf[s], acc[1], 0, 0, 0);
+        }
+        // ---- epilogue: acc[h][r] is pixel 16 h + 4 kq + r of the wave's row, column l15 ----
+        {
+            const int tx = tile % tiles_x;
+            const int rr = tile / tiles_x;
+            const int ty = rr % tiles_y, n = rr / tiles_y;
+            const int oy = TR * ty + wave;
+            if (colv & (oy < H)) {
+                const long prow = ((long)n * H + oy) * W + TC * tx + 4 * kq;
+                const int wleft = W - (TC * tx + 4 * kq);
+                const float* xp = d.sb_x + prow * d.sb_ldx + l15;
+                float* o = d.out + prow * d.ldc + l15;
+                float xv[8];
+                if (bwd) {          // the loads of the normed tensor issued ahead of the stores
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int x = 16 * (q >> 2) + (q & 3);
+                        xv[q] = x < wleft ? xp[(long)x * d.sb_ldx] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int x = 16 * (q >> 2) + (q & 3);
+                    if (x < wleft) {
+                        const float v = acc[q >> 2][q & 3];
+                        o[(long)x * d.ldc] = v;
+                        if (bwd) {
+                            const float dz = v * (fmaf(sa, xv[q], sb) > 0.f ? 1.f : sneg);
+                            ssum += dz;
+                            ssq += dz * (xv[q] - smu) * srs;
+                        } else {
+                            ssum += v;
+                            ssq += v * v;
+                        }
+                    }
+                }
+            }
+        }
+        if (next < tiles) store_patch(buf ? img0 : img1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (stat != nullptr) {      // one row of the two sums per workgroup: the four k-quarters of a wave, then the four waves, in order
+        ssum += __shfl_xor(ssum, 16, 64);
+        ssq += __shfl_xor(ssq, 16, 64);
+        ssum += __shfl_xor(ssum, 32, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (kq == 0) { red[0][wave][l15] = ssum; red[1][wave][l15] = ssq; }
+        __syncthreads();
+        if (wave == 0 && kq == 0 && colv) {
+            float* sp = stat + (long)blockIdx.x * 2 * d.Nstore;
+            sp[l15] = ((red[0][0][l15] + red[0][1][l15]) + red[0][2][l15]) + red[0][3][l15];
+            sp[d.Nstore + l15] = ((red[1][0][l15] + red[1][1][l15]) + red[1][2][l15]) + red[1][3][l15];
+        }
+    }
+}
+
 static bool c3_on() {
     static int on = -1;         // SSC_C3X3=0: the tile kernel (A/B)
     if (on < 0) {
@@ -276,7 +458,14 @@ int ssc_conv_c3x3_forward(const ssc_conv_desc* dp, float* stat, void* stream) {
     const int G = ssc_conv_c3x3_walkers(dp);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)2 * (tr + 2) * (tcw + 2) * (d.x.C0 + 1) * sizeof(float);
-    if (d.x.C0 == 16) {
+    static int n16 = -1;        // SSC_C3X3_N16=0: the 32-column instruction also at 16 outputs (A/B)
+    if (n16 < 0) {
+        const char* e = getenv("SSC_C3X3_N16");
+        n16 = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    if (d.x.C0 == 16 && d.Nn <= 16 && tcw == 32 && n16) {
+        hipLaunchKernelGGL(c3x3n16_kernel, dim3(G), dim3(256), 0, st, d, tiles, tiles_x, tiles_y, stat);
+    } else if (d.x.C0 == 16) {
         if (tcw == 32)
             hipLaunchKernelGGL((c3x3_kernel<16, 32>), dim3(G), dim3(256), lds, st, d, tiles, tiles_x, tiles_y, stat);
         else

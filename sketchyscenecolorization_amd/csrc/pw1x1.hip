@@ -24,7 +24,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define PW_TR 64         // rows per tile
 #define PW_BN 128        // columns per workgroup
 
-template <int K>
+// NARROW (at most 64 outputs: the expansion 16 -> 64): the four wavefronts are 2 row blocks x 2 column blocks of the 64-row tile instead of
+// 4 column blocks of which two would be empty
+template <int K, bool NARROW>
 __global__ __launch_bounds__(256) void pw1x1_kernel(const ssc_conv_desc d, long M, int tiles, float* __restrict__ stat) {
     constexpr int KS = K / 2;                   // MFMA steps (2 k per v_mfma_f32_32x32x2_f32)
     constexpr int LD = K + 1;                   // floats per staged row (odd: the 32 lanes of an operand read hit 32 banks)
@@ -36,7 +38,8 @@ __global__ __launch_bounds__(256) void pw1x1_kernel(const ssc_conv_desc d, long 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int n0 = blockIdx.y * PW_BN + wave * 32;          // this wave's 32 columns
+    const int n0 = NARROW ? (wave & 1) * 32 : blockIdx.y * PW_BN + wave * 32;          // this wave's 32 columns
+    const int wr = NARROW ? (wave >> 1) : 0;                // NARROW: this wave's row block
     const int col = n0 + l31;
     const bool colv = col < d.Nn;
 
@@ -95,20 +98,23 @@ __global__ __launch_bounds__(256) void pw1x1_kernel(const ssc_conv_desc d, long 
         const int next = tile + G;
         if (next < tiles) load_tile(next);          // in flight across the MFMAs below
         const float* P = buf ? img1 : img0;
-        const float* a0p = P + l31 * LD + lhi;
+        const float* a0p = P + (l31 + 32 * wr) * LD + lhi;
         const float* a1p = a0p + 32 * LD;
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const float a0 = a0p[2 * s], a1 = a1p[2 * s];
+            const float a0 = a0p[2 * s];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[s], acc1, 0, 0, 0);
+            if (!NARROW) {
+                const float a1 = a1p[2 * s];
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[s], acc1, 0, 0, 0);
+            }
         }
         // ---- epilogue: acc[r] is row (r & 3) + 8 * (r >> 2) + 4 * lhi of its 32-row block, column l31 ----
         if (colv) {
-            const long m0 = (long)tile * PW_TR;
+            const long m0 = (long)tile * PW_TR + 32 * wr;
             float* o = d.out + (m0 + 4 * lhi) * d.ldc + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256) void pw1x1_kernel(const ssc_conv_desc d, long 
                     ssum += acc0[r];
                     ssq += acc0[r] * acc0[r];
                 }
-                if (m0 + 32 + 4 * lhi + x < M) {
+                if (!NARROW && m0 + 32 + 4 * lhi + x < M) {
                     o[(long)(32 + x) * d.ldc] = acc1[r];
                     ssum += acc1[r];
                     ssq += acc1[r] * acc1[r];
@@ -129,7 +135,18 @@ __global__ __launch_bounds__(256) void pw1x1_kernel(const ssc_conv_desc d, long 
         __syncthreads();        // one barrier per tile: the image written above was last read before the previous barrier
         buf ^= 1;
     }
-    if (stat != nullptr) {      // one row [sum | sum of squares] per workgroup of a column group: rows blockIdx.x, width Nstore
+    if (stat != nullptr && NARROW) {       // the two row blocks of a column fold through LDS (row block 0 first)
+        __shared__ float nred[2][2][32];
+        ssum += __shfl_xor(ssum, 32, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (wr == 1 && lhi == 0) { nred[0][wave & 1][l31] = ssum; nred[1][wave & 1][l31] = ssq; }
+        __syncthreads();
+        if (wr == 0 && lhi == 0 && colv) {
+            float* sp = stat + (long)blockIdx.x * 2 * d.Nstore;
+            sp[col] = ssum + nred[0][wave & 1][l31];
+            sp[d.Nstore + col] = ssq + nred[1][wave & 1][l31];
+        }
+    } else if (stat != nullptr) {      // one row [sum | sum of squares] per workgroup of a column group: rows blockIdx.x, width Nstore
         ssum += __shfl_xor(ssum, 32, 64);
         ssq += __shfl_xor(ssq, 32, 64);
         if (lhi == 0 && colv) {
@@ -191,13 +208,21 @@ int ssc_conv_pw1x1_forward(const ssc_conv_desc* dp, float* stat, void* stream) {
     const int tiles = (int)((M + PW_TR - 1) / PW_TR);
     const dim3 grid((unsigned)ssc_conv_pw1x1_walkers(dp), (unsigned)((d.Nn + PW_BN - 1) / PW_BN));
     hipStream_t st = (hipStream_t)stream;
+    const bool narrow = d.Nn <= 64;
     const size_t lds = (size_t)2 * PW_TR * (d.x.C0 + 1) * sizeof(float);
 #define PW_LAUNCH(KK)                                                                                              \
     {                                                                                                              \
         static unsigned long long attr_done = 0;                                                                   \
-        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&pw1x1_kernel<KK>), (int)lds, &attr_done);   \
-        if (arc != 0) return arc;                                                                                  \
-        hipLaunchKernelGGL(pw1x1_kernel<KK>, grid, dim3(256), lds, st, d, M, tiles, stat);                         \
+        if (narrow) {                                                                                              \
+            const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&pw1x1_kernel<KK, true>), (int)lds, &attr_done);   \
+            if (arc != 0) return arc;                                                                              \
+            hipLaunchKernelGGL((pw1x1_kernel<KK, true>), grid, dim3(256), lds, st, d, M, tiles, stat);             \
+        } else {                                                                                                   \
+            static unsigned long long attr_done2 = 0;                                                              \
+            const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&pw1x1_kernel<KK, false>), (int)lds, &attr_done2); \
+            if (arc != 0) return arc;                                                                              \
+            hipLaunchKernelGGL((pw1x1_kernel<KK, false>), grid, dim3(256), lds, st, d, M, tiles, stat);            \
+        }                                                                                                          \
     }
     switch (d.x.C0) {
         case 16: PW_LAUNCH(16) break;

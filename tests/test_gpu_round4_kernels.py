@@ -213,7 +213,7 @@ def test_gate_extrema_from_the_conv_epilogue(n, h, ci, co):
 
 
 @pytest.mark.parametrize('m_hw,k,act,with_bn', [((3, 40, 48), 32, 2, True), ((4, 24, 24), 128, 1, True), ((5, 37, 21), 16, 0, False),
-                                                 ((2, 48, 48), 64, 2, True)])
+                                                 ((2, 48, 48), 64, 2, True), ((6, 40, 40), 16, 1, True)])
 def test_bottleneck_expansion_conv_streaming_kernel(m_hw, k, act, with_bn):
     """The 1x1 expansion conv of the bottleneck blocks (C/4 -> C, residual_util.py:97-101) on the streaming kernel of pw1x1.hip
     (filter in registers, persistent workgroups, norm + activation on load, batch statistics as per-lane sums): against
