@@ -23,6 +23,8 @@ def _rows(t):
 
 _MERGE_DDGRAD = os.environ.get('SSC_MERGE_DDGRAD', '1') == '1'
 _HOLD_FROM = int(os.environ.get('SSC_HOLD_FROM', '4'))       # decoder filter gradients from this layer on wait for the caption BPTT
+_DBWD_WGRAD_FIRST = os.environ.get('SSC_DBWD_WGRAD_FIRST', '1') == '1'   # discriminator backward: filter gradient of layer k in front of its data gradient (round-3 order; the round-4 order -- behind the data gradient and the sums' fold -- measured 0.3 ms slower per iteration on one box, profiles/r05_ab_envsets.txt)
+_DBWD_DEFER = os.environ.get('SSC_DBWD_DEFER', '0') == '1'     # discriminator norm backward as sums + a deferred apply job (1) or one call (0: 0.1 ms faster per iteration)
 _BNBWD2 = os.environ.get('SSC_BNBWD2', '1') == '1'      # norm-backward sums of both halves out of the merged launch's epilogue (A/B)
 
 
@@ -453,7 +455,7 @@ class Pix2PixDiscriminator(object):
         gname = lambda kk, what: s.grad('discriminator/layer_%d/%s' % (kk, what))
         dx = B.get(tag + '/gb/dl%d' % k, l[k].shape)
         if k == 1:
-            return dx, hip.bn_act_backward(_rows(l[1]), None, None, _rows(gcur), ACT_LRELU, _rows(dx), defer=True)
+            return dx, hip.bn_act_backward(_rows(l[1]), None, None, _rows(gcur), ACT_LRELU, _rows(dx), defer=_DBWD_DEFER)
         ds = do = None
         if need_params and accumulate:
             tmp_s = B.get(tag + '/gb/tmp_scale%d' % k, (2, self.chans[k]))
@@ -462,7 +464,7 @@ class Pix2PixDiscriminator(object):
             ds, do = gname(k, 'scale'), gname(k, 'offset')
         coef = B.get(tag + '/gb/coef%d' % k, (2 * self.chans[k],))
         job = hip.bn_act_backward(_rows(l[k]), ab[k], st[k], _rows(gcur), ACT_LRELU, _rows(dx), dscale=ds, doffset=do,
-                                  pre=sums, rowb=rowb, defer=True, coef=coef)
+                                  pre=sums, rowb=rowb, defer=_DBWD_DEFER, coef=coef)
         if need_params and accumulate:
             hip.call('ssc_axpy', gname(k, 'scale'), ds, 1.0, self.chans[k])
             hip.call('ssc_axpy', gname(k, 'offset'), do, 1.0, self.chans[k])
@@ -511,6 +513,12 @@ class Pix2PixDiscriminator(object):
             dyv = View(dx)
             w = s['discriminator/layer_%d/conv/filter' % k]
             job, dx_next = None, None
+            if need_params and _DBWD_WGRAD_FIRST:
+                # round-3 order: the filter gradient of layer k in front of its data gradient (the chain's next full-size launch
+                # then follows the small launches of the norm backward directly)
+                hip.conv_wgrad(xin, dyv, gname(k, 'conv/filter'), self.strides[k], 1, accumulate=accumulate)
+                if after_layer is not None:
+                    after_layer(k)
             if k > 1:
                 gin = B.get(tag + '/gb/g%d' % (k - 1), l[k - 1].shape)
                 sums = None
@@ -524,7 +532,7 @@ class Pix2PixDiscriminator(object):
             elif need_input:
                 dgen = B.get(tag + '/gb/dgen', (N, l[0].shape[1], l[0].shape[2], 4))
                 hip.conv_dgrad(dyv, w, 2, 1, dgen, n_off=3, nn=3, nstore=4)
-            if need_params:
+            if need_params and not _DBWD_WGRAD_FIRST:
                 hip.conv_wgrad(xin, dyv, gname(k, 'conv/filter'), self.strides[k], 1, accumulate=accumulate,
                                host=(job if hip.SIDE_APPLY else None))
                 if after_layer is not None:
