@@ -122,6 +122,13 @@ typedef struct ssc_conv_desc {
     int32_t stat_mode;    /* set by ssc_conv_forward_minmax (callers leave 0): 1 = the rows of stat_partial hold the per-column
                              MINIMUM and MAXIMUM of the tile's (activated) outputs instead of sum and sum of squares */
     int32_t _pad1;
+    /* Filter pre-split into three bf16 planes (ssc_filter_split; orientation = bmode), or NULL.  When set and the launch
+       qualifies (every 32-wide K-tile inside one tap and one source, n_off a multiple of 32, more than 32 stored columns) the
+       contraction runs on the bf16 matrix pipe as six bf16 products per fp32 product with fp32 accumulation (igemm_bf16.hip:
+       fp32-grade results at 6/16 of the fp32 MFMA's cycles); `w` must still point at the fp32 filter.  ws_kc / ws_nbp: the
+       planes' chunk and block counts as ssc_filter_split_geom reports them. */
+    const void* wsplit;
+    int32_t ws_kc, ws_nbp;
 } ssc_conv_desc;
 #define SSC_FIN_CNT_WORDS 8192   /* counters of the in-launch statistics fold: words [SSC_SK_FLAG_WORDS, + SSC_FIN_CNT_WORDS) of sk_flags */
 #define SSC_SK_FLAG_WORDS 8192   /* >= resident workgroups of the largest grid; the last word reports a hand-off timeout:
@@ -129,6 +136,25 @@ typedef struct ssc_conv_desc {
                                     waiting for a K slice.  The output of that launch is WRONG (a partial sum): callers must
                                     read the word wherever they read results back (losses, snapshots) and fail; the flags
                                     are to be zeroed before the array is used again. */
+/*
+ * 3-way bf16 split of a filter W[taps][c0][c1] (fp32, c1 contiguous) for the bf16 form of ssc_conv_forward: x = h + m + l
+ * exactly, each part a bf16, stored as the B operands of v_mfma_f32_32x32x16_bf16 (fragment-major, zero padded).
+ * orient 0: GEMM k = c0, n = c1 (ssc_conv_desc.bmode 0);  orient 1: k = c1, n = c0 (bmode 1).
+ * The planes must be refreshed whenever the fp32 filter changes (once per optimizer step).
+ */
+typedef struct ssc_split_job {
+    const float* w;
+    void* dst;              /* ssc_filter_split_bytes bytes, 16-byte aligned */
+    int32_t taps, c0, c1, orient;
+    int64_t first_thread;   /* batch form: running sum of the preceding jobs' `threads` (ssc_filter_split_geom) */
+} ssc_split_job;
+/* kc, nbp: the planes' chunk / block counts (ssc_conv_desc.ws_kc, ws_nbp); bytes: size of the planes buffer; threads: the
+   job's share of a batch launch (whole blocks of 256) */
+int ssc_filter_split_geom(int taps, int c0, int c1, int orient, int* kc, int* nbp, int64_t* bytes, int64_t* threads);
+int ssc_filter_split(const float* w, int taps, int c0, int c1, int orient, void* dst, void* stream);
+/* jobs_dev: DEVICE array; total_threads = sum of the jobs' `threads` */
+int ssc_filter_split_batch(const ssc_split_job* jobs_dev, int njobs, int64_t total_threads, void* stream);
+
 /* hand-off wait bound in milliseconds (default 20000: only a deadlock guard -- the owner waits for workgroups that were
  * dispatched before it) and a test hook that makes the producers withhold their flags so that the bound is reached */
 int ssc_sk_configure(int timeout_ms, int test_withhold);

@@ -328,7 +328,8 @@ int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4096;
     std::vector<float> hA((size_t)M * K), hB((size_t)K * N), hC((size_t)M * N);
     srand(1);
-    for (auto& v : hA) v = (float)rand() / RAND_MAX * 2.f - 1.f;
+    const int relu = argc > 4 ? atoi(argv[4]) : 0;
+    for (auto& v : hA) { v = (float)rand() / RAND_MAX * 2.f - 1.f; if (relu) v = v < 0.f ? 0.f : 3.f * v; }
     for (auto& v : hB) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.05f;
     float *dA, *dB, *dC;
     unsigned short *ph, *pm, *pl;

@@ -160,6 +160,7 @@ class BGTrainer(object):
         for i, sc in enumerate((self.store.discriminator, self.store.generator)):
             hip.call('ssc_adam_tf', sc.flat, sc.grad, sc.adam_m, sc.adam_v, sc.numel, 0.0, self.lr_dev[i:i + 1],
                      self.beta1, self.beta2, self.eps, 1.0)
+            hip.refresh_splits(sc.flat)     # the bf16 planes of this scope's filters follow the weights
 
     def apply_gradients(self):
         self._adam_prepare()

@@ -10,7 +10,7 @@ LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libsketchycolor_hip.so')
 EXTRA_FLAGS = {'igemm.hip': ['-Xclang', '-target-feature', '-Xclang', '-load-store-opt']} if os.environ.get('SSC_NO_LSOPT') == '1' else {}     # per-source compiler flags
 LAST_BUILD = None       # 'rebuilt' | 'reused' after build_library()
-SOURCES = ['igemm.hip', 'wgrad128.hip', 'wgn16.hip', 'narrow.hip', 'head1.hip', 'fewchan.hip', 'fewchan7.hip', 'pw1x1.hip', 'c3x3.hip', 's2n16.hip', 'tr4tiny.hip', 'tr4n16.hip', 'tr4mfma.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip', 'mru_ops.hip']
+SOURCES = ['igemm.hip', 'igemm_bf16.hip', 'wgrad128.hip', 'wgn16.hip', 'narrow.hip', 'head1.hip', 'fewchan.hip', 'fewchan7.hip', 'pw1x1.hip', 'c3x3.hip', 's2n16.hip', 'tr4tiny.hip', 'tr4n16.hip', 'tr4mfma.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip', 'mru_ops.hip']
 
 
 def _hipcc():

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include "sketchycolor_hip.h"
 #include "igemm_util.h"
+#include "igemm_epilogue.h"
 #include "host_util.h"
 
 // wgrad128.hip
@@ -61,17 +62,12 @@ extern "C" int ssc_conv_c3x3_supported(const ssc_conv_desc* dp);
 int ssc_conv_c3x3_walkers(const ssc_conv_desc* dp);
 int ssc_conv_c3x3_forward(const ssc_conv_desc* dp, float* stat, void* stream);
 
+// igemm_bf16.hip
+int ssc_launch_conv_bf(int cfg, bool plain, const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s,
+                       int64_t ws_bytes, int xcd);
+int ssc_sk_configure_bf(const unsigned* cfg4);
+
 #define BK 32
-// 8-byte write-through (agent-scope relaxed atomic) stores: data another workgroup of the same launch will read
-__device__ __forceinline__ void st_agent2(float* p, float a, float b) {
-    union { float f[2]; unsigned long long u; } cv;
-    cv.f[0] = a; cv.f[1] = b;
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), cv.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent_d(double* p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
 // in-launch K-slice hand-off (conv_ut_kernel): {wait bound in ticks of the 100 MHz wall clock (lo, hi), test hook: producers
 // withhold their flags, -}.  ssc_sk_configure writes it.
 __device__ unsigned g_sk_cfg[4] = {2000000000u, 0u, 0u, 0u};
@@ -89,25 +85,6 @@ __device__ unsigned g_sk_cfg[4] = {2000000000u, 0u, 0u, 0u};
 // ---------------------------------------------------------------------------------------------
 // forward form
 // ---------------------------------------------------------------------------------------------
-struct FwdPhase {
-    int ioff_y, ioff_x, ky0, kx0, ooff_y, ooff_x;
-};
-
-__device__ __forceinline__ FwdPhase fwd_phase(const ssc_conv_desc& d, int phase) {
-    FwdPhase p;
-    if (d.nphase == 4) {   // stride-2 transposed conv, k=4, pad 1: output parity (ry,rx)
-        const int ry = phase >> 1, rx = phase & 1;
-        p.ioff_y = ry - 1; p.ioff_x = rx - 1;
-        p.ky0 = 3 - ry;    p.kx0 = 3 - rx;
-        p.ooff_y = ry;     p.ooff_x = rx;
-    } else {
-        p.ioff_y = d.ioff_y; p.ioff_x = d.ioff_x;
-        p.ky0 = d.ky0;       p.kx0 = d.kx0;
-        p.ooff_y = d.ooff_y; p.ooff_x = d.ooff_x;
-    }
-    return p;
-}
-
 // General form: any channel counts (K-tiles may straddle taps and sources: per-thread tap decode), scalar or float4
 // filter loads.  Phases per wave: issue the next K-tile's loads | MFMAs of the current one | transform + LDS write |
 // barrier.  The layers whose K-tiles lie inside one tap and one source take conv_ut_kernel below instead.
@@ -848,315 +825,8 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
     }
 
     // ---- epilogue ----
-    if (part != nullptr) {      // tail split
-        if (ks != sk - 1) {
-            // producer: raw partial tile as [pair of accumulator entries][thread], 8-byte write-through (sc1) stores
-#pragma unroll
-            for (int i = 0; i < SM; ++i)
-#pragma unroll
-                for (int j = 0; j < SN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const int e2 = ((i * SN + j) * 16 + r) >> 1;
-                        union { float f[2]; unsigned long long u; } cv;
-                        cv.f[0] = acc[i][j][r]; cv.f[1] = acc[i][j][r + 1];
-                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + ((long)e2 * 256 + tid) * 2), cv.u,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores
-            __syncthreads();
-            if (tid == 0 && g_sk_cfg[2] == 0u) __hip_atomic_store(flags + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        // owner: the other slices of this tile are workgroups slot-(sk-1) .. slot-1.  The wait is bounded (a deadlock guard:
-        // everything waited for was dispatched earlier); an owner that gives up REPORTS it -- the timeout word gets
-        // 0x80000000 | sk_tag, which the host must read wherever it reads results (hip.check_sk) -- because what it then
-        // stores is a partial sum.  A flag that was never seen set is not cleared (its late producer would otherwise leave
-        // a 1 behind for the next launch to trust); the host zeroes the array after a reported timeout.
-        if (tid == 0) {
-            const unsigned long long t0 = wall_clock64();
-            const unsigned long long bound = ((unsigned long long)g_sk_cfg[1] << 32) | g_sk_cfg[0];
-            bool gave_up = false;
-            for (int q = sk - 1; q >= 1; --q) {
-                bool seen = true;
-                while (__hip_atomic_load(flags + slot - q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (gave_up || wall_clock64() - t0 > bound) {
-                        gave_up = true;
-                        seen = false;
-                        break;
-                    }
-                }
-                if (seen) __hip_atomic_store(flags + slot - q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // leave them zero
-            }
-            if (gave_up)
-                __hip_atomic_store(flags + (SSC_SK_FLAG_WORDS - 1), 0x80000000u | (unsigned)d.sk_tag, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // one L1 invalidate after the last flag
-        }
-        __syncthreads();
-#pragma nounroll
-        for (int q = sk - 1; q >= 1; --q) {
-            const float* pp = part - (long)q * (BM * BN);
-#pragma unroll
-            for (int i = 0; i < SM; ++i)
-#pragma unroll
-                for (int j = 0; j < SN; ++j) {
-                    float2 pv[8];       // one accumulator's worth of loads in flight
-#pragma unroll
-                    for (int r2 = 0; r2 < 8; ++r2)
-                        pv[r2] = *reinterpret_cast<const float2*>(pp + ((long)((i * SN + j) * 8 + r2) * 256 + tid) * 2);
-#pragma unroll
-                    for (int r2 = 0; r2 < 8; ++r2) {
-                        acc[i][j][2 * r2] += pv[r2].x;
-                        acc[i][j][2 * r2 + 1] += pv[r2].y;
-                    }
-                }
-        }
-    }
-    float* outp = (ts_s == 0 && splitk > 1) ? (slab_base + (long)ks * slab_stride) : d.out;
-    const bool final_pass = (ts_s > 0) || (splitk == 1);
-    // Vector epilogue: the accumulators go through LDS (the tile buffers are free after the loop's last barrier) and leave
-    // as one 16-byte store per thread and 4 columns -- 8 stores per thread instead of 32 with a 64-bit address, a row test
-    // and a column test each.  Every workgroup of a round reaches its epilogue at about the same time, so the epilogue's
-    // length is matrix-pipe idle time.  Needs 16-byte aligned rows (the scalar form below covers the rest).
-    constexpr int C_LD = BN + 4;
-    static_assert(BM * C_LD <= 2 * (A_SZ + B_SZ), "the C tile fits the operand buffers");
-    if ((((d.Nstore | d.ldc) & 3) == 0) & ((reinterpret_cast<unsigned long>(outp) & 15) == 0)) {
-        float* Cs = smem;
-#pragma unroll
-        for (int i = 0; i < SM; ++i)
-#pragma unroll
-            for (int j = 0; j < SN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * SM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    Cs[row * C_LD + wn * SN * 32 + j * 32 + l31] = acc[i][j][r];
-                }
-        __syncthreads();
-        const float* const bias = final_pass ? d.bias : nullptr;
-        const int epi = final_pass ? d.epi : 0;
-        const bool accum = final_pass && d.accumulate != 0;
-        const int Nn = d.Nn, Nst = d.Nstore, ldc = d.ldc;
-        // batch-statistics norm of this layer's output (models_collection.py:36-46): per-column sum and sum of squares of the
-        // tile, taken here from the values on their way out instead of by a second pass over the tensor; one row of
-        // partials per row tile, folded per channel by bn_stats_finalize (ssc_conv_forward_bn)
-        float* const stat = final_pass ? d.stat_partial : nullptr;
-        const bool mmode = d.stat_mode == 1;        // rows of per-column minimum / maximum instead of sum / sum of squares
-        float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
-        if (mmode) {
-            ssum = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-            ssq = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        }
-        // ... or, when the output is the gradient w.r.t. the activated norm of a tensor x (sb_x: same layout as the output),
-        // the two sums of that norm's backward: sum dz and sum dz * xhat with dz = out * act'(a x + b) (ssc_conv_forward_bnbwd);
-        // the column group of a thread is the same in every pass of the loop below (256 % (BN / 4) == 0)
-        // two normed tensors side by side (ssc_conv_forward_bnbwd2): this workgroup's column tile lies in one of them; cb = its
-        // first column, sbC = its channel count (the width of its tables and of its rows of sums)
-        const bool sb_two = (stat != nullptr) && d.sb2_x != nullptr;
-        const bool sb_second = sb_two && n0 >= d.sb2_col0;
-        const int cb = sb_second ? d.sb2_col0 : 0;
-        const int sbC = sb_two ? (sb_second ? Nst - d.sb2_col0 : d.sb2_col0) : Nst;
-        float* const statw = sb_second ? d.stat_partial2 : stat;
-        const float* const sbx = (stat != nullptr) ? (sb_second ? d.sb2_x : d.sb_x) : nullptr;
-        const int sb_ldx = sb_second ? d.sb2_ldx : d.sb_ldx;
-        float4 sb_a = make_float4(1.f, 1.f, 1.f, 1.f), sb_b = make_float4(0.f, 0.f, 0.f, 0.f), sb_mu = sb_b, sb_rs = sb_a;
-        float sb_neg = 1.f;         // act'(z) for z <= 0
-        if (sbx != nullptr) {
-            const int c = n0 + (tid % (BN / 4)) * 4;
-            if (c < Nst) {
-                const float* const tab = sb_second ? d.sb2_ab : d.sb_ab;
-                const float* const tst = sb_second ? d.sb2_stats : d.sb_stats;
-                sb_a = *reinterpret_cast<const float4*>(tab + (c - cb));
-                sb_b = *reinterpret_cast<const float4*>(tab + sbC + (c - cb));
-                sb_mu = *reinterpret_cast<const float4*>(tst + (c - cb));
-                sb_rs = *reinterpret_cast<const float4*>(tst + sbC + (c - cb));
-            }
-            const int sact = sb_second ? d.sb2_act : d.sb_act;
-            sb_neg = sact == SSC_ACT_RELU ? 0.f : (sact == SSC_ACT_LRELU ? 0.2f : 1.f);
-        }
-#pragma unroll
-        for (int p = 0; p < BM * BN / 1024; ++p) {
-            const int e = p * 256 + tid;
-            const int row = e / (BN / 4), col = n0 + (e % (BN / 4)) * 4;
-            if ((m0 + row < M) & (col < Nst)) {
-                float4 v = *reinterpret_cast<const float4*>(Cs + row * C_LD + (col - n0));
-                // the filter loads of columns >= Nn were not masked
-                v.x = col + 0 < Nn ? v.x : 0.f; v.y = col + 1 < Nn ? v.y : 0.f;
-                v.z = col + 2 < Nn ? v.z : 0.f; v.w = col + 3 < Nn ? v.w : 0.f;
-                if (bias != nullptr) {
-                    v.x += col + 0 < Nn ? bias[col + 0] : 0.f; v.y += col + 1 < Nn ? bias[col + 1] : 0.f;
-                    v.z += col + 2 < Nn ? bias[col + 2] : 0.f; v.w += col + 3 < Nn ? bias[col + 3] : 0.f;
-                }
-                if (mmode) {        // of the ACTIVATED output (lrelu is monotone: applied to the extrema's candidates here)
-                    const float tx = epi == 2 ? fmaxf(v.x, 0.2f * v.x) : v.x, ty = epi == 2 ? fmaxf(v.y, 0.2f * v.y) : v.y;
-                    const float tz = epi == 2 ? fmaxf(v.z, 0.2f * v.z) : v.z, tw = epi == 2 ? fmaxf(v.w, 0.2f * v.w) : v.w;
-                    ssum.x = fminf(ssum.x, tx); ssum.y = fminf(ssum.y, ty); ssum.z = fminf(ssum.z, tz); ssum.w = fminf(ssum.w, tw);
-                    ssq.x = fmaxf(ssq.x, tx); ssq.y = fmaxf(ssq.y, ty); ssq.z = fmaxf(ssq.z, tz); ssq.w = fmaxf(ssq.w, tw);
-                } else if (sbx == nullptr) {
-                    ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
-                    ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
-                } else {
-                    const float4 xv = *reinterpret_cast<const float4*>(sbx + rowpix[row] * sb_ldx + (col - cb));
-                    float4 dz;
-                    dz.x = v.x * (fmaf(sb_a.x, xv.x, sb_b.x) > 0.f ? 1.f : sb_neg);
-                    dz.y = v.y * (fmaf(sb_a.y, xv.y, sb_b.y) > 0.f ? 1.f : sb_neg);
-                    dz.z = v.z * (fmaf(sb_a.z, xv.z, sb_b.z) > 0.f ? 1.f : sb_neg);
-                    dz.w = v.w * (fmaf(sb_a.w, xv.w, sb_b.w) > 0.f ? 1.f : sb_neg);
-                    ssum.x += dz.x; ssum.y += dz.y; ssum.z += dz.z; ssum.w += dz.w;
-                    ssq.x += dz.x * (xv.x - sb_mu.x) * sb_rs.x; ssq.y += dz.y * (xv.y - sb_mu.y) * sb_rs.y;
-                    ssq.z += dz.z * (xv.z - sb_mu.z) * sb_rs.z; ssq.w += dz.w * (xv.w - sb_mu.w) * sb_rs.w;
-                }
-                if (epi == 1) {
-                    v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
-                } else if (epi == 2) {
-                    v.x = fmaxf(v.x, 0.2f * v.x); v.y = fmaxf(v.y, 0.2f * v.y);
-                    v.z = fmaxf(v.z, 0.2f * v.z); v.w = fmaxf(v.w, 0.2f * v.w);
-                }
-                float4* o = reinterpret_cast<float4*>(outp + rowpix[row] * ldc + col);
-                if (accum) {
-                    const float4 t = *o;
-                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-                }
-                *o = v;
-            }
-        }
-        if (stat != nullptr) {
-            // thread t holds columns 4*(t % (BN/4)).. of the rows t / (BN/4) + k*1024/BN: fold the 1024/BN row groups in a
-            // fixed order through LDS (behind the C tile), one writer per column group
-            constexpr int CG = BN / 4, RG = 256 / CG;
-            // (the 128 x 128 tile's C image leaves no room behind it: there the scratch takes the image's place, once every
-            // thread has read its part of it)
-            constexpr bool RED_IN_C = BM * C_LD + 2 * 256 * 4 > 2 * (A_SZ + B_SZ);
-            static_assert(!RED_IN_C || BM * BN >= 128 * 128, "reduction scratch behind the C tile");
-            if (RED_IN_C) __syncthreads();
-            float4* red = reinterpret_cast<float4*>(RED_IN_C ? smem : smem + BM * C_LD);
-            red[tid] = ssum;
-            red[256 + tid] = ssq;
-            __syncthreads();
-            if (tid < CG) {
-                float4 s = red[tid], q = red[256 + tid];
-#pragma unroll
-                for (int g = 1; g < RG; ++g) {
-                    const float4 a = red[g * CG + tid], c = red[256 + g * CG + tid];
-                    if (mmode) {
-                        s.x = fminf(s.x, a.x); s.y = fminf(s.y, a.y); s.z = fminf(s.z, a.z); s.w = fminf(s.w, a.w);
-                        q.x = fmaxf(q.x, c.x); q.y = fmaxf(q.y, c.y); q.z = fmaxf(q.z, c.z); q.w = fmaxf(q.w, c.w);
-                    } else {
-                        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-                        q.x += c.x; q.y += c.y; q.z += c.z; q.w += c.w;
-                    }
-                }
-                const int col = n0 + tid * 4;
-                if (col < Nst) {
-                    const long blk = (long)phase * ((M + BM - 1) / BM) + m0 / BM;
-                    float* sp = statw + blk * 2 * sbC;
-                    if (d.fin_cnt != nullptr) {     // other workgroups will read this row: 8-byte write-through stores
-                        st_agent2(sp + (col - cb), s.x, s.y);
-                        st_agent2(sp + (col - cb) + 2, s.z, s.w);
-                        st_agent2(sp + sbC + (col - cb), q.x, q.y);
-                        st_agent2(sp + sbC + (col - cb) + 2, q.z, q.w);
-                    } else {
-                        *reinterpret_cast<float4*>(sp + (col - cb)) = s;
-                        *reinterpret_cast<float4*>(sp + sbC + (col - cb)) = q;
-                    }
-                }
-            }
-            // In-launch fold of the batch statistics (ssc_conv_desc.fin_*): two levels of "the last one to arrive sums".  Rows
-            // travel write-through (above); a ticket is taken only after the row's stores have completed; the reader takes one
-            // agent-scope acquire after it saw the last ticket, then plain loads (MI355X guide, inter-workgroup visibility).
-            if (d.fin_cnt != nullptr && sbx == nullptr) {
-                int* const fl = reinterpret_cast<int*>(smem + BM * C_LD + 2 * 256 * 4);
-                const int mtiles = (int)((M + BM - 1) / BM);
-                const int nrows = mtiles * d.nphase;
-                const int gs = d.fin_gs, ngr = (nrows + gs - 1) / gs;
-                const int ctile = n0 / BN, ntile = (Nst + BN - 1) / BN;
-                const int blk = phase * mtiles + (int)(m0 / BM);
-                const int grp = blk / gs;
-                const int want = min(gs, nrows - grp * gs);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    const unsigned t = __hip_atomic_fetch_add(d.fin_cnt + grp * ntile + ctile, 1u, __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_AGENT);
-                    const int last = t == (unsigned)(want - 1);
-                    if (last) {
-                        __hip_atomic_store(d.fin_cnt + grp * ntile + ctile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    }
-                    fl[0] = last;
-                    fl[1] = 0;
-                }
-                __syncthreads();
-                if (fl[0]) {        // this workgroup saw the last row of its group: sum the group, column by column, in row order
-                    const int col = n0 + tid;
-                    if (tid < BN && col < Nst) {
-                        double ss = 0.0, qq = 0.0;
-                        const float* rp = stat + (long)grp * gs * 2 * Nst + col;
-                        for (int r = 0; r < want; ++r) {
-                            ss += (double)rp[(long)r * 2 * Nst];
-                            qq += (double)rp[(long)r * 2 * Nst + Nst];
-                        }
-                        st_agent_d(d.fin_grp + ((long)grp * 2 + 0) * Nst + col, ss);
-                        st_agent_d(d.fin_grp + ((long)grp * 2 + 1) * Nst + col, qq);
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (tid == 0) {
-                        const unsigned t2 = __hip_atomic_fetch_add(d.fin_cnt + ngr * ntile + ctile, 1u, __ATOMIC_RELAXED,
-                                                                   __HIP_MEMORY_SCOPE_AGENT);
-                        const int last2 = t2 == (unsigned)(ngr - 1);
-                        if (last2) {
-                            __hip_atomic_store(d.fin_cnt + ngr * ntile + ctile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        }
-                        fl[1] = last2;
-                    }
-                    __syncthreads();
-                    if (fl[1] && tid < BN && col < Nst) {      // the last group: sum the groups in order, fold (bn_stats_finalize_kernel)
-                        double ss = 0.0, qq = 0.0;
-                        for (int g = 0; g < ngr; ++g) {
-                            ss += d.fin_grp[((long)g * 2 + 0) * Nst + col];
-                            qq += d.fin_grp[((long)g * 2 + 1) * Nst + col];
-                        }
-                        const double mean = ss / (double)d.fin_M;
-                        double var = qq / (double)d.fin_M - mean * mean;
-                        if (var < 0.0) var = 0.0;
-                        const float rstd = (float)(1.0 / sqrt(var + (double)d.fin_eps));
-                        const float a = rstd * d.fin_scale[col];
-                        d.fin_ab[col] = a;
-                        d.fin_ab[Nst + col] = d.fin_offset[col] - (float)mean * a;
-                        d.fin_stats[col] = (float)mean;
-                        d.fin_stats[Nst + col] = rstd;
-                    }
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < SM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * SM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (m0 + row >= M) continue;
-            const long opix = rowpix[row];
-#pragma unroll
-            for (int j = 0; j < SN; ++j) {
-                const int col = n0 + wn * SN * 32 + j * 32 + l31;
-                if (col >= d.Nstore) continue;
-                float v = col < d.Nn ? acc[i][j][r] : 0.f;    // the filter loads of columns >= Nn were not masked
-                float* o = outp + opix * d.ldc + col;
-                if (final_pass) {
-                    if (d.bias != nullptr && col < d.Nn) v += d.bias[col];
-                    if (d.epi == 1) v = tanhf(v);
-                    else if (d.epi == 2) v = fmaxf(v, 0.2f * v);
-                    if (d.accumulate) v += *o;
-                }
-                *o = v;
-            }
-        }
-    }
+    ut_epilogue<BM, BN, WM, WN, SM, SN, 2 * (A_SZ + B_SZ)>(acc, d, smem, rowpix, part, ks, sk, slot, flags, ts_s, splitk, slab_base,
+                                                          slab_stride, m0, n0, phase, M, g_sk_cfg);
 }
 
 
@@ -1308,6 +978,11 @@ static void launch_slab_reduce(const float* ws, long out_count, int splitk, cons
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_count + thr - 1) / thr)), dim3(thr), 0, st, ws,
                            out_count, splitk, d.out, out_count, d.ldc, d.Nn, d.Nstore, d.bias, d.epi, d.accumulate);
     }
+}
+
+// igemm_bf16.hip sums its split-K slabs with the same kernels
+void ssc_launch_slab_reduce(const float* ws, long out_count, int splitk, const ssc_conv_desc& d, hipStream_t st) {
+    launch_slab_reduce(ws, out_count, splitk, d, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1696,6 +1371,9 @@ struct TileCfg { int id, BM, BN, res; double penalty; };
 // filter float4, 4 cycles each, against 64 cycles per MFMA: (MFMA + VALU) / MFMA, normalised to 128x128
 static const TileCfg FWD_CFGS[5] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.03}, {2, 128, 64, 3, 1.11}, {3, 128, 32, 3, 1.33},
                                     {4, 64, 64, 4, 1.30}};    // 64x64: small-M GEMMs (LSTM steps) that leave CUs under-filled
+// the bf16-split form (igemm_bf16.hip): larger LDS images (fewer resident workgroups), the same ids; 128x32 is not built
+static const TileCfg BF_CFGS[5] = {{0, 128, 128, 1, 1.05}, {1, 64, 128, 2, 1.00}, {2, 128, 64, 2, 1.12}, {3, 128, 32, 1, 9.9},
+                                   {4, 64, 64, 3, 1.40}};     // measured on the batch-32 layers: 64x128 ahead of 128x128 / 128x64 by ~9 %, 64x64 behind by ~15 %
 static const TileCfg WG_CFGS[5] = {{0, 128, 128, 2, 1.00}, {1, 64, 128, 3, 1.00}, {2, 128, 64, 3, 1.10}, {3, 64, 64, 4, 1.2},
                                    {4, 128, 32, 4, 1.3}};
 
@@ -1740,7 +1418,7 @@ static bool inlaunch_splitk() {
 }
 
 static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long M, long N, long nphase, long nkt,
-                        long out_elems, int64_t ws_bytes, bool have_ws, bool can_ts = false) {
+                        long out_elems, int64_t ws_bytes, bool have_ws, bool can_ts = false, double cyc_scale = 1.0) {
     const int ncu = num_cu();
     Plan best = {-1, 1, 1e300, 0, 1};
     static int force = -2;      // SSC_FWD_CFG=n: tuning aid, restricts the search to tile configuration n where allowed
@@ -1754,7 +1432,7 @@ static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long
         const TileCfg& t = cfgs[c];
         const long mt = (M + t.BM - 1) / t.BM, nt = (N + t.BN - 1) / t.BN;
         const long blocks = mt * nt * nphase;
-        const double wfull = (double)nkt * 16.0 * (t.BM / 32) * (t.BN / 32) / 4.0 * 64.0 * t.penalty;  // cycles
+        const double wfull = (double)nkt * 16.0 * (t.BM / 32) * (t.BN / 32) / 4.0 * 64.0 * t.penalty * cyc_scale;  // cycles
         for (int sk = 1; sk <= 16; ++sk) {
             if (sk > 1 && (!have_ws || nkt / sk < 4 || (int64_t)sk * out_elems * 4 > ws_bytes)) break;
             const long per = (nkt + sk - 1) / sk;
@@ -1984,6 +1662,17 @@ static int launch_fwd(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t
                : launch_fwd_v<WM, WN, SM, SN, BMODE, false>(d, splitk, ws, st);
 }
 
+// bf16-split form (igemm_bf16.hip): the caller supplied the filter's planes, every K-tile lies inside one tap and one source,
+// the column range starts at a 32-column block.  SSC_ARITH=fp32 keeps everything on the exact-fp32 MFMA.
+static bool fwd_is_bf(const ssc_conv_desc& d) {
+    static int off = -1;
+    if (off < 0) {
+        const char* e = getenv("SSC_ARITH");
+        off = (e != nullptr && (e[0] == 'f' || e[0] == 'F')) ? 1 : 0;
+    }
+    return !off && d.wsplit != nullptr && d.ws_kc > 0 && d.ws_nbp > 0 && fwd_is_ut(d) && (d.n_off & 31) == 0 && d.Nstore > 32;
+}
+
 static Plan plan_fwd(const ssc_conv_desc& d, int64_t ws_bytes, bool have_ws) {
     const long M = (long)d.NB * d.PH * d.PW;
     const int C = d.x.C0 + d.x.C1;
@@ -1996,6 +1685,12 @@ static Plan plan_fwd(const ssc_conv_desc& d, int64_t ws_bytes, bool have_ws) {
     const bool allowed[5] = {d.Nstore > 64, d.Nstore > 64, d.Nstore > 32, d.Nstore <= 32, d.Nstore > 32};
     const bool can_ts = d.sk_flags != nullptr && tail_split_mode() != 0 &&
                         (fwd_is_ut(d) || fwd_is_utg(d) || (d.bmode == 0 && fwd_is_rowtap(d)));
+    if (fwd_is_bf(d)) {
+        const bool allowed_bf[5] = {d.Nstore > 64, d.Nstore > 64, true, false, true};
+        // six bf16 passes = 6/16 of the fp32 MFMA's cycles; the staging beside them and the shorter K steps make it ~0.45
+        return plan_launch(BF_CFGS, 5, allowed_bf, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,
+                           have_ws, can_ts, plan_const("SSC_PLAN_BF_SCALE", 0.45));
+    }
     return plan_launch(FWD_CFGS, 5, allowed, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,
                        have_ws, can_ts);
 }
@@ -2051,6 +1746,12 @@ extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, 
         {"conv_fwd<128x128,KN>", "conv_fwd<64x128,KN>", "conv_fwd<128x64,KN>", "conv_fwd<128x32,KN>", "conv_fwd<64x64,KN>"},
         {"conv_fwd<128x128,NK>", "conv_fwd<64x128,NK>", "conv_fwd<128x64,NK>", "conv_fwd<128x32,NK>", "conv_fwd<64x64,NK>"}};
     const Plan p = plan_fwd(*dp, (int64_t)1 << 40, true);
+    if (fwd_is_bf(*dp)) {
+        static const char* bfn[5] = {"conv_bf16x6<128x128>", "conv_bf16x6<64x128>", "conv_bf16x6<128x64>", "conv_bf16x6<128x32>",
+                                     "conv_bf16x6<64x64>"};
+        copy_name(bfn[p.cfg < 0 ? 0 : p.cfg], buf, len);
+        return 0;
+    }
     copy_name(names[dp->bmode ? 1 : 0][p.cfg < 0 ? 0 : p.cfg], buf, len);
     return 0;
 }
@@ -2320,6 +2021,8 @@ extern "C" int ssc_conv_forward_bnbwd2(const ssc_conv_desc* dp, float* ws, int64
 extern "C" int ssc_sk_configure(int timeout_ms, int test_withhold) {
     const unsigned long long ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 20000) * 100000ull;     // 100 MHz
     const unsigned cfg[4] = {(unsigned)(ticks & 0xffffffffu), (unsigned)(ticks >> 32), test_withhold ? 1u : 0u, 0u};
+    const int rc = ssc_sk_configure_bf(cfg);
+    if (rc != 0) return rc;
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sk_cfg), cfg, sizeof(cfg), 0, hipMemcpyHostToDevice);
 }
 
@@ -2373,6 +2076,11 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
         return ssc_conv_tr4n16_forward(dp, d.stat_partial, stream);
     const Plan p = plan_fwd(d, ws_bytes, ws != nullptr);
     if (p.cfg < 0) return -4;
+    if (fwd_is_bf(d)) {
+        const bool plain0 = d.x.ab0 == nullptr && d.x.act == SSC_ACT_NONE;
+        const bool plain1 = d.x.C1 == 0 || (d.x.ab1 == nullptr && (d.x.act1 >= 0 ? d.x.act1 : d.x.act) == SSC_ACT_NONE);
+        return ssc_launch_conv_bf(p.cfg, plain0 && plain1, d, p.splitk, ws, st, p.ts_full, p.ts_s, ws_bytes, xcd_order());
+    }
     g_launch_res = FWD_CFGS[p.cfg].res;
     g_launch_ws_bytes = ws_bytes;
     g_launch_ts_full = p.ts_full;

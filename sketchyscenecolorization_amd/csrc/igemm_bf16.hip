@@ -1,0 +1,578 @@
+// igemm_bf16.hip -- the uniform-tap implicit GEMM of igemm.hip on the bf16 matrix pipe with fp32-grade arithmetic.
+//
+// gfx950 runs the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) at the vector-ALU rate (157 TFLOP/s) and it does not co-issue with
+// vector-ALU work; the bf16 MFMA (v_mfma_f32_32x32x16_bf16) runs at 16x that rate beside the vector ALU.  Every fp32 value is
+// the EXACT sum of three bf16 values (x = h + m + l: 8 + 8 + 8 significant bits, round-to-nearest at each step, residuals are
+// exact in fp32), so
+//     a * b = (ah + am + al) * (bh + bm + bl) = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh) + [am*bl + al*bm + al*bl]
+// and the six products outside the brackets, each exact in the MFMA's fp32 accumulator, reproduce a * b to 2^-23 relative
+// (|am| <= 2^-8 |a|, |bl| <= 2^-16 |b|: the three dropped products are together below one fp32 rounding of the product).  Six
+// bf16 MFMA passes cost 6/16 of the fp32 MFMA's cycles.  Accumulation is fp32 in both forms.
+//   * The FILTER operand is split ahead of time (ssc_filter_split: once per optimizer step) into three bf16 planes stored
+//     fragment-major -- the 64 x 16-byte image of one MFMA B operand (32 columns x 16 k) is one contiguous KiB -- so a K-tile's
+//     filter data goes global memory -> LDS by LDS-DMA and is read back as operands with lane-linear ds_read_b128.
+//   * The GATHERED operand is split inside the staging that already transforms it (folded norm + activation + padding mask):
+//     v_cvt_pk_bf16_f32 + shifts + subtractions beside the MFMAs, three ds_write_b64 per float4.
+//   * Prologue (tile order, tail split, XCD-aware mapping, pixel decode) and epilogue are conv_ut_kernel's (igemm_epilogue.h).
+// Replaces tf.nn.conv2d / conv2d_transpose and their data gradients (models_collection.py:380-405) on the layers whose channel
+// counts are multiples of 32; everything else stays on the exact-fp32 kernels of igemm.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "sketchycolor_hip.h"
+#include "igemm_util.h"
+#include "igemm_epilogue.h"
+#include "host_util.h"
+
+#define BK 32
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// this translation unit's copy of the hand-off configuration (ssc_sk_configure sets both)
+__device__ unsigned g_sk_cfg_bf[4] = {2000000000u, 0u, 0u, 0u};
+
+int ssc_sk_configure_bf(const unsigned* cfg4) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sk_cfg_bf), cfg4, 4 * sizeof(unsigned), 0, hipMemcpyHostToDevice);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the 3-way split
+// ---------------------------------------------------------------------------------------------
+// two values at a time: v_cvt_pk_bf16_f32 rounds to nearest even and packs; {lo, hi} halves back to fp32 are a shift and a mask
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter planes
+// ---------------------------------------------------------------------------------------------
+// A filter W[tap][c0][c1] (fp32, c1 contiguous: tf conv [kh,kw,Cin,Cout] and conv2d_transpose [kh,kw,Cout,Cin] alike) as a GEMM
+// operand B[k][n] per tap, orient 0: k = c0, n = c1 ("KN");  orient 1: k = c1, n = c0 ("NK").  Layout of the planes buffer:
+//   fragment(tap, kc, plane, nb) at byte (((tap * KC + kc) * 3 + plane) * NBP + nb) * 1024, KC = 2 * ceil(K / 32) chunks of 16 k,
+//   NBP = ceil(N / 32) + 3 blocks of 32 columns (three zero blocks: a 128-column tile may start at any block);
+//   inside a fragment lane L holds the 8 bf16 B[kc * 16 + (L >> 5) * 8 + e][nb * 32 + (L & 31)], e = 0..7 -- the B operand of
+//   v_mfma_f32_32x32x16_bf16.  k >= K and n >= N hold zeros.
+struct SplitGeom { int K, N, KC, NBP; };
+static inline SplitGeom split_geom(int c0, int c1, int orient) {
+    SplitGeom g;
+    g.K = orient ? c1 : c0;
+    g.N = orient ? c0 : c1;
+    g.KC = 2 * ((g.K + 31) / 32);
+    g.NBP = (g.N + 31) / 32 + 3;
+    return g;
+}
+
+static int64_t ssc_filter_split_bytes(int taps, int c0, int c1, int orient) {
+    const SplitGeom g = split_geom(c0, c1, orient);
+    return (int64_t)taps * g.KC * 3 * g.NBP * 1024;
+}
+
+// round-to-nearest-even to bf16 on the integer pipe (this kernel is not on a hot path); finite inputs
+__device__ __forceinline__ unsigned rne_bf16_bits(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+}
+
+// one thread per (fragment, lane): 8 values read, 3 x 16 bytes written
+__device__ __forceinline__ void filter_split_body(const ssc_split_job& jb, long lt) {
+    const int K = jb.orient ? jb.c1 : jb.c0, N = jb.orient ? jb.c0 : jb.c1;
+    const int KC = 2 * ((K + 31) / 32), NBP = (N + 31) / 32 + 3;
+    const long nfrag = (long)jb.taps * KC * NBP;
+    if (lt >= nfrag * 64) return;
+    const int lane = (int)(lt & 63);
+    const long f = lt >> 6;
+    const int nb = (int)(f % NBP);
+    const long r = f / NBP;
+    const int kc = (int)(r % KC), tap = (int)(r / KC);
+    const int n = nb * 32 + (lane & 31), k0 = kc * 16 + (lane >> 5) * 8;
+    unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        float x = 0.f;
+        if (k < K && n < N)
+            x = jb.orient ? jb.w[((long)tap * jb.c0 + n) * jb.c1 + k] : jb.w[((long)tap * jb.c0 + k) * jb.c1 + n];
+        const unsigned h = rne_bf16_bits(x);
+        const float r1 = x - __uint_as_float(h);
+        const unsigned m = rne_bf16_bits(r1);
+        const float r2 = r1 - __uint_as_float(m);
+        hb[e] = h; mb[e] = m; lb[e] = rne_bf16_bits(r2);
+    }
+    uint4 vh, vm, vl;
+    vh.x = (hb[0] >> 16) | hb[1]; vh.y = (hb[2] >> 16) | hb[3]; vh.z = (hb[4] >> 16) | hb[5]; vh.w = (hb[6] >> 16) | hb[7];
+    vm.x = (mb[0] >> 16) | mb[1]; vm.y = (mb[2] >> 16) | mb[3]; vm.z = (mb[4] >> 16) | mb[5]; vm.w = (mb[6] >> 16) | mb[7];
+    vl.x = (lb[0] >> 16) | lb[1]; vl.y = (lb[2] >> 16) | lb[3]; vl.z = (lb[4] >> 16) | lb[5]; vl.w = (lb[6] >> 16) | lb[7];
+    char* base = reinterpret_cast<char*>(jb.dst) + ((((long)tap * KC + kc) * 3) * NBP + nb) * 1024 + lane * 16;
+    *reinterpret_cast<uint4*>(base) = vh;
+    *reinterpret_cast<uint4*>(base + (long)NBP * 1024) = vm;
+    *reinterpret_cast<uint4*>(base + (long)2 * NBP * 1024) = vl;
+}
+
+// many filters in one launch: jobs in device memory, first_thread ascending
+__global__ __launch_bounds__(256) void filter_split_kernel(const ssc_split_job* __restrict__ jobs, int njobs) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    int j = 0;
+    while (j + 1 < njobs && t >= jobs[j + 1].first_thread) ++j;
+    const ssc_split_job jb = jobs[j];
+    filter_split_body(jb, t - jb.first_thread);
+}
+__global__ __launch_bounds__(256) void filter_split_one_kernel(const ssc_split_job jb) {
+    filter_split_body(jb, (long)blockIdx.x * 256 + threadIdx.x);
+}
+
+static int64_t ssc_filter_split_threads(int taps, int c0, int c1, int orient) {
+    const SplitGeom g = split_geom(c0, c1, orient);
+    return (((int64_t)taps * g.KC * g.NBP * 64 + 255) / 256) * 256;     // whole blocks per job
+}
+
+extern "C" int ssc_filter_split_geom(int taps, int c0, int c1, int orient, int* kc, int* nbp, int64_t* bytes, int64_t* threads) {
+    if (taps <= 0 || c0 <= 0 || c1 <= 0) return -1;
+    const SplitGeom g = split_geom(c0, c1, orient);
+    if (kc) *kc = g.KC;
+    if (nbp) *nbp = g.NBP;
+    if (bytes) *bytes = ssc_filter_split_bytes(taps, c0, c1, orient);
+    if (threads) *threads = ssc_filter_split_threads(taps, c0, c1, orient);
+    return 0;
+}
+
+// jobs: DEVICE array of njobs entries, first_thread ascending from 0 in steps of the jobs' thread counts; total_threads = their sum
+extern "C" int ssc_filter_split_batch(const ssc_split_job* jobs_dev, int njobs, int64_t total_threads, void* stream) {
+    if (njobs <= 0 || total_threads <= 0) return 0;
+    if (total_threads / 256 > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(filter_split_kernel, dim3((unsigned)(total_threads / 256)), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+// LDS images of one K-tile (32 k):
+//   A [BM rows][208 bytes]: three planes of 64 bytes (32 bf16: the 16-byte chunk (kc, lhi) holds k = kc*16 + lhi*8 .. +7) + 16 bytes
+//     of padding -- a row stride of 13 x 16 bytes keeps the ds_read_b128 of a wave's 32 rows conflict-free;
+//   B [kc 2][plane 3][BN/32 blocks][1 KiB fragment]: the DMA's image, read with lane-linear addresses.
+#define BF_A_RS 208
+// s_waitcnt vmcnt(0) lgkmcnt(0) through the builtin (simm16: vmcnt [3:0] and [15:14], expcnt [6:4] = 7 = no wait, lgkmcnt [11:8]): the
+// compiler's own wait insertion then knows that every load it issued has landed and adds no vmcnt wait of its own in front of the
+// first use of the staged registers -- which, counted without the LDS-DMA instructions it cannot see, would wait for those too.
+// The inline-asm statement keeps the DMA's LDS writes (which the compiler does not know about) ordered before the barrier.
+#define BF_WAIT_ALL() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0070); } while (0)
+template <int BM, int BN> struct BfLds {
+    static constexpr int A_BYTES = BM * BF_A_RS;
+    static constexpr int B_BYTES = 6 * (BN / 32) * 1024;
+    static constexpr int OPER_BYTES = 2 * (A_BYTES + B_BYTES);
+    static constexpr int TOTAL = OPER_BYTES + BM * 8;
+};
+
+template <int WM, int WN, int SM, int SN, bool PLAIN>
+__global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, const Magics mg, float* __restrict__ slab_base,
+                                                       long slab_stride, int splitk, int ts_full, int ts_s,
+                                                       unsigned* __restrict__ flags) {
+    constexpr int BM = WM * SM * 32;
+    constexpr int BN = WN * SN * 32;
+    constexpr int NBT = BN / 32;
+    constexpr int A_BYTES = BfLds<BM, BN>::A_BYTES, B_BYTES = BfLds<BM, BN>::B_BYTES;
+    constexpr int LDS_FLOATS = BfLds<BM, BN>::OPER_BYTES / 4;
+    constexpr int A_ROWS = BM / 32;
+    constexpr int B_IPW = 6 * NBT / 4;          // DMA instructions per wave and K-tile
+    static_assert(WM * WN == 4 && (6 * NBT) % 4 == 0, "4 waves share the fragments of a K-tile evenly");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const sm_b = reinterpret_cast<char*>(smem);
+    long* rowpix = reinterpret_cast<long*>(smem + LDS_FLOATS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const float* const xs0 = d.x.s0;
+    const float* const xs1 = d.x.s1;
+    const float* const xab0 = d.x.ab0;
+    const float* const xab1 = d.x.ab1;
+    const int xC0 = d.x.C0, xC1 = d.x.C1, xH = d.x.H, xW = d.x.W;
+    const int TWv = d.TW, kstep = d.kstep, KWv = d.KW;
+    const float slope0 = act_slope(d.x.act), slope1 = act_slope(d.x.act1 >= 0 ? d.x.act1 : d.x.act);
+
+    const int nch0 = xC0 / BK, nch1 = xC1 / BK;
+    const int tpt = nch0 + nch1;
+    const long M = (long)d.NB * d.PH * d.PW;
+    const int PHW = d.PH * d.PW;
+    // workgroup -> (tile, K range): conv_ut_kernel's layouts (igemm.hip)
+    int phase, ks, sk, n0, slot = 0;
+    long m0;
+    float* part = nullptr;
+    if (ts_s > 0) {
+        const int bid = blockIdx.x;
+        int tile;
+        if (bid < ts_full) {
+            tile = bid; ks = 0; sk = 1;
+        } else {
+            const int r = bid - ts_full;
+            const int q = r / (ts_s & 0xffff);
+            tile = ts_full + q; ks = r - q * (ts_s & 0xffff); sk = ts_s & 0xffff;
+            part = slab_base + (long)r * (BM * BN);
+            slot = r;
+        }
+        const int mt = (int)((M + BM - 1) / BM), nt = (d.Nstore + BN - 1) / BN;
+        if (ts_s & 0x10000) {
+            if (bid < ts_full) tile = (bid & 7) * (ts_full >> 3) + (bid >> 3);
+            const int r2 = tile / nt;
+            n0 = (tile - r2 * nt) * BN;
+            if (ts_s & 0x20000) {
+                phase = r2 & 3;
+                m0 = (long)(r2 >> 2) * BM;
+            } else {
+                phase = r2 / mt;
+                m0 = (long)(r2 - phase * mt) * BM;
+            }
+            ts_s &= 0xffff;
+            sk = bid < ts_full ? 1 : ts_s;
+        } else {
+            const int rest = tile / mt;
+            m0 = (long)(tile - rest * mt) * BM;
+            phase = rest / nt;
+            n0 = (rest - phase * nt) * BN;
+        }
+    } else {
+        phase = blockIdx.z / splitk;
+        ks = blockIdx.z % splitk;
+        sk = splitk;
+        m0 = (long)blockIdx.x * BM;
+        n0 = blockIdx.y * BN;
+    }
+    const FwdPhase ph = fwd_phase(d, phase);
+
+    // gathered side: thread t stages the float4 (4 k) at chunk t & 7 of the rows arow + 32 i.  arow: the 8 rows of a wave with
+    // bits 0 and 1 of the row swapped, so that the two rows a 16-lane group of a ds_write_b64 covers lie two rows (416 bytes =
+    // 40 banks) apart instead of one (208 bytes = 52 banks: the second row's 16 banks wrapped onto 4 of the first's)
+    const int a_col4 = tid & 7;
+    const int arow = ((tid >> 3) & ~3) | (((tid >> 3) & 1) << 1) | (((tid >> 3) >> 1) & 1);
+    int a_iyb[A_ROWS], a_ixb[A_ROWS], a_off0[A_ROWS], a_off1[A_ROWS];
+    bool a_mv[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        const int row = arow + 32 * i;
+        const long m = m0 + row;
+        a_mv[i] = m < M;
+        const long mm = a_mv[i] ? m : 0;
+        int n, rem, py;
+        if (mg.use32) {
+            n = (int)__umulhi((unsigned)mm, mg.mPHPW32) + (int)((unsigned)mm & (unsigned)mg.onePHPW);
+            rem = (int)mm - n * PHW;
+            py = (int)__umulhi((unsigned)rem, mg.mPW32) + (int)((unsigned)rem & (unsigned)mg.onePW);
+        } else {
+            n = (int)div64(mm, mg.mPHPW, mg.onePHPW);
+            rem = (int)(mm - (long)n * PHW);
+            py = (int)div64(rem, mg.mPW, mg.onePW);
+        }
+        const int px = rem - py * d.PW;
+        a_iyb[i] = py * d.in_stride + ph.ioff_y;
+        a_ixb[i] = px * d.in_stride + ph.ioff_x;
+        const int pix0 = (n * xH + a_iyb[i]) * xW + a_ixb[i];
+        a_off0[i] = (pix0 * xC0 + a_col4 * 4) * 4;
+        a_off1[i] = (pix0 * xC1 + a_col4 * 4) * 4;
+        if (a_col4 == 0)
+            rowpix[row] = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
+    }
+
+    // filter side: fragment q of this wave = f = wave * B_IPW + q of the K-tile's [kc][plane][block] image
+    const int NBP = d.ws_nbp, KC = d.ws_kc;
+    const int nb0 = (d.n_off + n0) >> 5;
+    unsigned bd_off[B_IPW];
+#pragma unroll
+    for (int q = 0; q < B_IPW; ++q) {
+        const int f = wave * B_IPW + q;
+        const int kc = f / (3 * NBT), pl = (f / NBT) % 3, nbl = f % NBT;
+        bd_off[q] = (unsigned)((((kc * 3 + pl) * NBP) + nb0 + nbl) * 1024 + lane * 16);
+    }
+    const char* const wsp = reinterpret_cast<const char*>(d.wsplit);
+    const long ktile_bytes = (long)6 * NBP * 1024;      // 2 chunks x 3 planes x NBP blocks
+
+    const int nkt = d.TH * d.TW * tpt;
+    const int per = (nkt + sk - 1) / sk;
+    const int kt_begin = ks * per;
+    const int kt_end = min(nkt, kt_begin + per);
+
+    // Two accumulators per 32x32 block: the hh products (the sum's magnitude) in one, the five correction products (2^-8 of it and
+    // below) in the other, added once behind the K loop.  The matrix pipe aligns the 16 products of an instruction and the
+    // accumulator to the largest exponent among them, so every pass into a LARGE accumulator costs a rounding of the large value:
+    // six passes per K step into one accumulator measured 3.8e-7 rms at K = 512 against 1.4e-7 for this form and 4.5e-7 for the
+    // fp32 fmaf chain (scripts/mfma_bf16_acc_probe.hip) -- the split form is then MORE exact than the exact-fp32 MFMA's chain.
+    f32x16 acc[SM][SN], accc[SM][SN];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = accc[i][j][r] = 0.f;
+
+    // K-tile index -> (tap row, tap column, chunk), advanced by one K-tile at a time on the scalar unit (K-tiles run chunk fastest,
+    // then tap column, then tap row) instead of decoded by division every step
+    struct KTile { int ty, tx, chunk; };
+    auto kt_decode = [&](int kt) {
+        KTile t;
+        const int tap = div32(kt, mg.mC, mg.oneC);      // mC: magic of tpt
+        t.chunk = kt - tap * tpt;
+        t.ty = div32(tap, mg.mTW, mg.oneTW);
+        t.tx = tap - t.ty * TWv;
+        return t;
+    };
+    auto kt_next = [&](KTile t, bool adv) {      // adv false: stay (the clamp at the last K-tile), arithmetic selects, no branch
+        t.chunk += adv ? 1 : 0;
+        const bool wc = t.chunk == tpt;
+        t.chunk = wc ? 0 : t.chunk;
+        t.tx += wc ? 1 : 0;
+        const bool wx = t.tx == TWv;
+        t.tx = wx ? 0 : t.tx;
+        t.ty += wx ? 1 : 0;
+        return t;
+    };
+
+    // a staged K-tile of the gathered side in registers: raw rows, their 1.0 / 0.0 validity, the source's norm table and slope
+    struct ASet { float4 r[A_ROWS]; float v[A_ROWS]; float4 aa, ab; float slope; };
+
+    auto issue_loads = [&](const KTile& t, ASet& S) {
+        const bool first = t.chunk < nch0;
+        const int cs = first ? xC0 : xC1;
+        const int cc = (first ? t.chunk : t.chunk - nch0) * BK;
+        const char* sbase = reinterpret_cast<const char*>((first ? xs0 : xs1) + cc);
+        const int tapshift = (t.ty * xW + t.tx) * cs * 4;
+        const int fmask = first ? -1 : 0;
+        if (!PLAIN) {
+            const float* abp = first ? xab0 : xab1;
+            const bool has = abp != nullptr;
+            const float* pa = has ? abp + cc + a_col4 * 4 : xs0;
+            const float* pb = has ? abp + cs + cc + a_col4 * 4 : xs0;
+            const float4 va = *reinterpret_cast<const float4*>(pa);
+            const float4 vb = *reinterpret_cast<const float4*>(pb);
+            S.aa = has ? va : make_float4(1.f, 1.f, 1.f, 1.f);
+            S.ab = has ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
+            S.slope = first ? slope0 : slope1;
+        }
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const int iy = a_iyb[i] + t.ty, ix = a_ixb[i] + t.tx;
+            const bool v = a_mv[i] & ((unsigned)iy < (unsigned)xH) & ((unsigned)ix < (unsigned)xW);
+            const int osel = (a_off0[i] & fmask) | (a_off1[i] & ~fmask);
+            const unsigned off = v ? (unsigned)(osel + tapshift) : (unsigned)(a_col4 * 16);
+            S.v[i] = v ? 1.f : 0.f;
+            S.r[i] = *reinterpret_cast<const float4*>(sbase + off);
+        }
+    };
+
+    // filter K-tile `t` straight into LDS buffer `buf`: this wave's fragments [q0, q1)
+    auto dma_b = [&](const KTile& t, int buf, int q0, int q1) {
+        const int ky = ph.ky0 + t.ty * kstep, kx = ph.kx0 + t.tx * kstep;
+        const char* wtap = wsp + ((long)(ky * KWv + kx) * (KC >> 1) + t.chunk) * ktile_bytes;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(2 * A_BYTES + buf * B_BYTES + wave * B_IPW * 1024));
+        for (int q = q0; q < q1; ++q) glds16(wtap, bd_off[q], dst + q * 1024);
+    };
+
+    // row i of the staged K-tile: transform, split, three 8-byte stores
+    auto stage_row = [&](const ASet& S, int buf, int i) {
+        float4 v = S.r[i];
+        if (PLAIN) {
+            v.x *= S.v[i]; v.y *= S.v[i]; v.z *= S.v[i]; v.w *= S.v[i];
+        } else {
+            float t;
+            t = fmaf(S.aa.x, v.x, S.ab.x); v.x = fmaxf(t, t * S.slope) * S.v[i];
+            t = fmaf(S.aa.y, v.y, S.ab.y); v.y = fmaxf(t, t * S.slope) * S.v[i];
+            t = fmaf(S.aa.z, v.z, S.ab.z); v.z = fmaxf(t, t * S.slope) * S.v[i];
+            t = fmaf(S.aa.w, v.w, S.ab.w); v.w = fmaxf(t, t * S.slope) * S.v[i];
+        }
+        u32x2_t h, m, l;
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pair(v.x, v.y, h0, m0_, l0);
+        split3_pair(v.z, v.w, h1, m1, l1);
+        h.x = h0; h.y = h1; m.x = m0_; m.y = m1; l.x = l0; l.y = l1;
+        char* p = sm_b + buf * A_BYTES + (arow + 32 * i) * BF_A_RS + a_col4 * 8;
+        *reinterpret_cast<u32x2_t*>(p) = h;
+        *reinterpret_cast<u32x2_t*>(p + 64) = m;
+        *reinterpret_cast<u32x2_t*>(p + 128) = l;
+    };
+
+    if (kt_begin < kt_end) {
+        const int last = kt_end - 1;
+        ASet SA, SB;        // SA: the K-tile being staged; SB: the one in flight behind it
+        KTile tl = kt_decode(kt_begin);     // decode of the K-tile the next issue_loads takes
+        dma_b(tl, 0, 0, B_IPW);
+        issue_loads(tl, SA);
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) stage_row(SA, 0, i);
+        KTile td = tl;                      // decode of the K-tile the next dma_b takes
+        tl = kt_next(tl, kt_begin + 1 <= last);
+        td = tl;
+        issue_loads(tl, SA);
+        BF_WAIT_ALL();
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        constexpr int G = SM * SN;          // MFMAs per group (one product over the wave's blocks)
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const char* Ab = sm_b + cur * A_BYTES + (wm * SM * 32 + l31) * BF_A_RS + lhi * 16;
+            const char* Bb = sm_b + 2 * A_BYTES + cur * B_BYTES + (wn * SN) * 1024 + lane * 16;
+            bf16x8 av[2][SM][3], bv[2][SN][3];
+            auto fetch_a = [&](int kc) {
+#pragma unroll
+                for (int i = 0; i < SM; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        av[kc][i][p] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * BF_A_RS + p * 64 + kc * 32);
+            };
+            auto fetch_b = [&](int kc) {
+#pragma unroll
+                for (int j = 0; j < SN; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        bv[kc][j][p] = *reinterpret_cast<const bf16x8*>(Bb + ((kc * 3 + p) * NBT + j) * 1024);
+            };
+            // one product over the wave's blocks (consecutive MFMAs go to different accumulators); products smallest first
+            auto group = [&](int kc, int t) {
+                constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int i = 0; i < SM; ++i)
+#pragma unroll
+                    for (int j = 0; j < SN; ++j) {
+                        if (t == 5)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kc][i][0], bv[kc][j][0], acc[i][j], 0, 0, 0);
+                        else
+                            accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kc][i][pa[t]], bv[kc][j][pb[t]], accc[i][j], 0, 0, 0);
+                    }
+            };
+#define BF_SB __builtin_amdgcn_sched_barrier(0)
+            // The K step, hand-placed: twelve groups of G MFMAs with one piece of the step's other work behind each, full
+            // scheduling barriers in between (the compiler's own order put the six DMA instructions and their scalar code in one
+            // run without a single MFMA).  Right behind the barrier that freed buffer cur ^ 1: the filter tile of K-tile kt+1 by
+            // DMA into it and the gather loads of K-tile kt+2 into the second register set -- both have the whole step to land.
+            fetch_a(0);
+            fetch_b(0);
+            BF_SB;
+            group(0, 0); dma_b(td, cur ^ 1, 0, B_IPW / 2); BF_SB;
+            group(0, 1); dma_b(td, cur ^ 1, B_IPW / 2, B_IPW); BF_SB;
+            tl = kt_next(tl, kt + 2 <= last);
+            group(0, 2); issue_loads(tl, SB); BF_SB;
+            group(0, 3); fetch_a(1); BF_SB;
+            group(0, 4); fetch_b(1); BF_SB;
+            group(0, 5); BF_SB;
+            // K-tile kt+1: registers -> the LDS buffer nobody reads now
+            if (A_ROWS == 2) {
+                group(1, 0); stage_row(SA, cur ^ 1, 0); BF_SB;
+                group(1, 1); BF_SB;
+                group(1, 2); stage_row(SA, cur ^ 1, 1); BF_SB;
+                group(1, 3); BF_SB;
+            } else {
+                group(1, 0); stage_row(SA, cur ^ 1, 0); BF_SB;
+                group(1, 1); stage_row(SA, cur ^ 1, 1); BF_SB;
+                group(1, 2); stage_row(SA, cur ^ 1, 2); BF_SB;
+                group(1, 3); stage_row(SA, cur ^ 1, 3); BF_SB;
+            }
+            group(1, 4); BF_SB;
+            group(1, 5); BF_SB;
+#undef BF_SB
+            // everything issued in this step has landed: the DMA tile and this wave's ds_writes are in LDS (published by the
+            // barrier), the loads of K-tile kt+2 are in registers and become the staged set
+            BF_WAIT_ALL();
+            SA = SB;
+            td = tl;
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += accc[i][j][r];
+    ut_epilogue<BM, BN, WM, WN, SM, SN, LDS_FLOATS>(acc, d, smem, rowpix, part, ks, sk, slot, flags, ts_s, splitk, slab_base,
+                                                   slab_stride, m0, n0, phase, M, g_sk_cfg_bf);
+}
+
+#ifdef SSC_ISA_ONLY
+template __global__ void conv_bf_kernel<2, 2, 1, 2, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*);
+template __global__ void conv_bf_kernel<2, 2, 2, 2, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*);
+#else
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+void ssc_launch_slab_reduce(const float* ws, long out_count, int splitk, const ssc_conv_desc& d, hipStream_t st);     // igemm.hip
+
+template <int WM, int WN, int SM, int SN, bool PLAIN>
+static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s, int64_t ws_bytes,
+                       int xcd) {
+    constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
+    constexpr size_t lds = BfLds<BM, BN>::TOTAL;
+    const long M = (long)d.NB * d.PH * d.PW;
+    const int tpt = d.x.C0 / BK + d.x.C1 / BK;
+    const Magics mg = make_magics((unsigned)tpt, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW, (unsigned long)M);
+    const long mt = (M + BM - 1) / BM;
+    const int nt = (d.Nstore + BN - 1) / BN;
+    const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
+    static unsigned long long attr_done = 0;
+    {
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_bf_kernel<WM, WN, SM, SN, PLAIN>), (int)lds, &attr_done);
+        if (arc != 0) return arc;
+    }
+    const int xflag = 0x10000 | ((xcd >= 2 && d.nphase == 4) ? 0x20000 : 0);
+    if (splitk == 1 && ws != nullptr && d.sk_flags != nullptr && ts_s > 1) {        // whole tiles + K slices combined in the launch
+        const long tiles = mt * nt * d.nphase;
+        const long full = ts_full, tail = tiles - full, s = ts_s;
+        if (full >= 0 && tail > 0 && (int64_t)tail * s * BM * BN * 4 <= ws_bytes && tail * s < SSC_SK_FLAG_WORDS - 1 &&
+            full + tail * s < 0x7fffffffL) {
+            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg,
+                               ws, out_count, 1, (int)full, (int)s | ((xcd && (full & 7) == 0) ? xflag : 0), d.sk_flags);
+            return (int)hipGetLastError();
+        }
+    }
+    if (splitk == 1 && xcd) {       // whole tiles only, 1-D grid in the XCD-aware order
+        const long tiles = mt * nt * d.nphase;
+        const long full = tiles & ~7L;
+        if (tiles < 0x7fffffffL && full > 0) {
+            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws,
+                               out_count, 1, (int)full, 1 | xflag, (unsigned*)nullptr);
+            return (int)hipGetLastError();
+        }
+    }
+    dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
+    hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0,
+                       (unsigned*)nullptr);
+    if (splitk > 1) ssc_launch_slab_reduce(ws, out_count, splitk, d, st);
+    return (int)hipGetLastError();
+}
+
+// cfg: 0 = 128x128, 1 = 64x128, 2 = 128x64, 4 = 64x64 (the ids of igemm.hip's tile table)
+int ssc_launch_conv_bf(int cfg, bool plain, const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s,
+                       int64_t ws_bytes, int xcd) {
+#define BF_CASE(WM, WN, SM, SN)                                                                                   \
+    return plain ? launch_bf_t<WM, WN, SM, SN, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)             \
+                 : launch_bf_t<WM, WN, SM, SN, false>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)
+    switch (cfg) {
+        case 0: BF_CASE(2, 2, 2, 2);
+        case 1: BF_CASE(2, 2, 1, 2);
+        case 2: BF_CASE(2, 2, 2, 1);
+        case 4: BF_CASE(2, 2, 1, 1);
+        default: return -4;
+    }
+#undef BF_CASE
+}
+
+extern "C" int ssc_filter_split(const float* w, int taps, int c0, int c1, int orient, void* dst, void* stream) {
+    ssc_split_job jb;
+    jb.w = w; jb.dst = dst; jb.taps = taps; jb.c0 = c0; jb.c1 = c1; jb.orient = orient; jb.first_thread = 0;
+    const int64_t threads = ssc_filter_split_threads(taps, c0, c1, orient);
+    if (threads / 256 > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(filter_split_one_kernel, dim3((unsigned)(threads / 256)), dim3(256), 0, (hipStream_t)stream, jb);
+    return (int)hipGetLastError();
+}
+#endif

@@ -39,7 +39,13 @@ class ConvDesc(C.Structure):
                 ('sb2_ldx', C.c_int32), ('sb2_act', C.c_int32),
                 ('fin_cnt', C.c_void_p), ('fin_grp', C.c_void_p), ('fin_scale', C.c_void_p), ('fin_offset', C.c_void_p),
                 ('fin_ab', C.c_void_p), ('fin_stats', C.c_void_p), ('fin_M', C.c_int64), ('fin_eps', C.c_float),
-                ('fin_gs', C.c_int32), ('stat_mode', C.c_int32), ('_pad1', C.c_int32)]
+                ('fin_gs', C.c_int32), ('stat_mode', C.c_int32), ('_pad1', C.c_int32),
+                ('wsplit', C.c_void_p), ('ws_kc', C.c_int32), ('ws_nbp', C.c_int32)]
+
+
+class SplitJob(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('dst', C.c_void_p), ('taps', C.c_int32), ('c0', C.c_int32), ('c1', C.c_int32),
+                ('orient', C.c_int32), ('first_thread', C.c_int64)]
 
 
 class BnApplyJob(C.Structure):
@@ -112,6 +118,9 @@ SIGNATURES = {
     'ssc_build_hash': [C.c_char_p, _I],
     'ssc_device_info': [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, _I],
     'ssc_conv_forward': [C.POINTER(ConvDesc), _P, _L, _P],
+    'ssc_filter_split_geom': [_I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    'ssc_filter_split': [_P, _I, _I, _I, _I, _P, _P],
+    'ssc_filter_split_batch': [_P, _I, _L, _P],
     'ssc_conv_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
     'ssc_conv_wgrad128_supported': [C.POINTER(WgradDesc)],
     'ssc_conv_wgn16_supported': [C.POINTER(WgradDesc)],
@@ -423,6 +432,93 @@ def check_sk(where=''):
                                                                                  '; '.join(what)))
 
 
+# ---------------------------------------------------------------------------
+# bf16-split filters (igemm_bf16.hip)
+# ---------------------------------------------------------------------------
+# SSC_ARITH=fp32: every contraction on the exact-fp32 MFMA.  Default: the layers whose channel counts allow it run as six bf16
+# products per fp32 product with fp32 accumulation (fp32-grade results, 6/16 of the matrix cycles); their filters are split into
+# three bf16 planes ahead of the launches -- lazily at first use, again whenever torch modifies the tensor (its version counter),
+# and by refresh_splits() after every optimizer launch (which writes the weights behind torch's back).
+ARITH_BF16 = os.environ.get('SSC_ARITH', 'bf16x6').lower() not in ('fp32', 'f32', 'float32')
+_SPLITS = {}            # (data_ptr, taps, c0, c1, orient) -> _Split; the entry keeps the filter tensor alive (its address stays taken)
+_SPLIT_TABLES = {}      # tuple of keys -> (device job table, total threads)
+_SPLITS_MAX = 512
+
+
+class _Split(object):
+    __slots__ = ('key', 'w', 'buf', 'kc', 'nbp', 'threads', 'version', 'taps', 'c0', 'c1', 'orient')
+
+
+def _split_launch(e):
+    check(lib().ssc_filter_split(ptr(e.w), e.taps, e.c0, e.c1, e.orient, ptr(e.buf), stream_ptr()), 'ssc_filter_split')
+
+
+def filter_split(w, orient):
+    """The bf16 planes of filter w [KH,KW,c0,c1] in orientation ``orient`` (0: k = c0, n = c1; 1: k = c1, n = c0), split now if
+    they do not exist or torch has modified the tensor since."""
+    KH, KW, c0, c1 = w.shape
+    key = (w.data_ptr(), KH * KW, c0, c1, orient)
+    e = _SPLITS.get(key)
+    if e is None:
+        if len(_SPLITS) >= _SPLITS_MAX:
+            _SPLITS.clear()
+            _SPLIT_TABLES.clear()
+        kc, nbp, nbytes, threads = C.c_int(0), C.c_int(0), C.c_int64(0), C.c_int64(0)
+        check(lib().ssc_filter_split_geom(KH * KW, c0, c1, orient, C.byref(kc), C.byref(nbp), C.byref(nbytes), C.byref(threads)),
+              'ssc_filter_split_geom')
+        e = _Split()
+        e.key, e.w, e.kc, e.nbp, e.threads, e.version = key, w, kc.value, nbp.value, threads.value, None
+        e.taps, e.c0, e.c1, e.orient = KH * KW, c0, c1, orient
+        e.buf = torch.empty(nbytes.value, dtype=torch.uint8, device=w.device)
+        _SPLITS[key] = e
+    if e.version != w._version:
+        _split_launch(e)
+        e.version = w._version
+    return e
+
+
+def refresh_splits(flat=None):
+    """Split again every registered filter that lives inside the flat parameter buffer ``flat`` (all of them when None): one
+    batched launch.  Called behind every optimizer launch (the kernel writes the weights without torch noticing)."""
+    if not _SPLITS:
+        return
+    if flat is not None:
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        es = [e for e in _SPLITS.values() if lo <= e.key[0] < hi]
+    else:
+        es = list(_SPLITS.values())
+    if not es:
+        return
+    tk = tuple(e.key for e in es)
+    tab = _SPLIT_TABLES.get(tk)
+    if tab is None:
+        if torch.cuda.is_current_stream_capturing():     # no host-to-device copy inside a capture: one launch per filter
+            for e in es:
+                _split_launch(e)
+            return
+        jobs = (SplitJob * len(es))()
+        first = 0
+        for j, e in zip(jobs, es):
+            j.w, j.dst, j.taps, j.c0, j.c1, j.orient, j.first_thread = e.w.data_ptr(), e.buf.data_ptr(), e.taps, e.c0, e.c1, e.orient, first
+            first += e.threads
+        host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+        tab = (host.to(es[0].w.device), first)
+        _SPLIT_TABLES[tk] = tab
+    check(lib().ssc_filter_split_batch(ptr(tab[0]), len(es), tab[1], stream_ptr()), 'ssc_filter_split_batch')
+
+
+def _attach_split(d, w):
+    """Give the launch its filter's bf16 planes when it can run on the bf16 pipe (the library decides again: fwd_is_bf)."""
+    if not ARITH_BF16 or w is None:
+        return
+    if (d.x.C0 % 32) or (d.x.C1 % 32) or d.k_real != d.x.C0 + d.x.C1 or (d.n_off % 32) or d.Nstore <= 32:
+        return
+    if d.NB * d.PH * d.PW * d.nphase < 64:        # a handful of rows: nothing to win
+        return
+    e = filter_split(w, 1 if d.bmode else 0)
+    d.wsplit, d.ws_kc, d.ws_nbp = e.buf.data_ptr(), e.kc, e.nbp
+
+
 class BnBwdSums(object):
     """Partial sums of a norm backward gathered from the epilogues of the launches that produce its incoming gradients
     (ssc_conv_forward_bnbwd).  x2d [M, C]: the normed tensor (raw), ab / stats its folded norm.  ``take(act)`` gives the
@@ -603,6 +699,7 @@ def conv_forward(x, w, stride, pad, out, coff=0, nstore=None, bias=None, epi=0, 
     d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 1, 0, 0
     d.epi, d.accumulate = epi, int(accumulate)
     assert minmax is None or (bn is None and coff == 0)
+    _attach_split(d, w_nk if w_nk is not None else w)
     _run_conv(d, _bn_arg(bn, d, coff, out), minmax=minmax)
 
 
@@ -642,6 +739,7 @@ def deconv_forward(x, f, out, coff=0, nstore=None, epi=0, bn=None, _desc_only=Fa
     d.epi, d.accumulate = epi, 0
     if _desc_only:
         return d
+    _attach_split(d, f)
     _run_conv(d, _bn_arg(bn, d, coff, out))
 
 
@@ -674,6 +772,7 @@ def conv_dgrad(dy, w, stride, pad, out, n_off=0, nn=None, k_real=None, nstore=No
     d.epi, d.accumulate = 0, int(accumulate)
     if _desc_only:
         return d
+    _attach_split(d, w)
     _run_conv(d, bnbwd=bnbwd)
 
 
@@ -711,6 +810,7 @@ def deconv_dgrad(dy, f, out, n_off=0, nn=None, accumulate=False, bnbwd=None):
     d.n_off, d.Nn, d.Nstore = n_off, nn, nn
     d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = OH, OW, ldc, 1, 0, 0
     d.epi, d.accumulate = 0, int(accumulate)
+    _attach_split(d, f)
     _run_conv(d, bnbwd=bnbwd)
 
 
@@ -767,6 +867,7 @@ def matmul_nt(a, b, out, accumulate=False):
     d.ky0, d.kx0, d.kstep, d.KH, d.KW, d.wC0, d.wC1, d.bmode, d.k_real = 0, 0, 1, 1, 1, N, K, 1, K
     d.n_off, d.Nn, d.Nstore, d.OH, d.OW, d.ldc, d.out_stride, d.ooff_y, d.ooff_x = 0, N, N, 1, M, N, 1, 0, 0
     d.epi, d.accumulate = 0, int(accumulate)
+    _attach_split(d, b.view(1, 1, N, K))
     _run_conv(d)
 
 

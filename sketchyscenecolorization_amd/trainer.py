@@ -285,6 +285,7 @@ class GanTrainer(object):
         else:
             hip.call('ssc_optimizer_step', 3, scope.flat, scope.grad, scope.adam_v, scope.adam_m, scope.numel, lr_dev,
                      0.95, 0.0, 1e-8, gs)
+        hip.refresh_splits(scope.flat)      # the bf16 planes of this scope's filters follow the weights
 
     def _static_inputs(self, kind, batch):
         N, _, H, W = batch['sketches'].shape

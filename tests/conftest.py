@@ -20,3 +20,19 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def parity_log(test, config, max_abs_err, bound, **extra):
+    """Append one parity measurement to the JSON-lines file SSC_PARITY_LOG (default gpurun_out/parity.jsonl): every test that
+    asserts against the oracle records how far it actually was from it, so the margins are visible outside the GPU box
+    (the final tree's file is committed as profiles/r05_parity.jsonl)."""
+    import json
+    path = os.environ.get('SSC_PARITY_LOG', os.path.join(ROOT, 'gpurun_out', 'parity.jsonl'))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        rec = {'test': test, 'config': config, 'max_abs_err': float(max_abs_err), 'bound': float(bound)}
+        rec.update(extra)
+        with open(path, 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass

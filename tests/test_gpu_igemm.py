@@ -575,7 +575,7 @@ def test_handoff_timeout_is_reported_and_fatal():
         # right here; after a real timeout it is a partial sum, which is why the report must be fatal)
         with pytest.raises(hip.HandoffTimeout) as ei:
             hip.check_sk('unit test')
-        assert 'conv_fwd<' in str(ei.value) and 'M=18432 N=256 K=2048' in str(ei.value), str(ei.value)
+        assert ('conv_fwd<' in str(ei.value) or 'conv_bf16x6<' in str(ei.value)) and 'M=18432 N=256 K=2048' in str(ei.value), str(ei.value)
     finally:
         assert hip.lib().ssc_sk_configure(0, 0) == 0
     assert hip.sk_timeouts() == 0 and int(hip.sk_flags().abs().sum()) == 0     # zeroed by check_sk
