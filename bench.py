@@ -28,6 +28,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_bf16, dense: six bf16 products per fp32 product -> 416.7 fp32-equivalent
+
+
+def _dtype_label():
+    """What the contractions compute in: fp32 values, fp32 accumulation; by default the layers whose channel counts allow it run
+    as a 3-way bf16 split of both operands on the bf16 matrix pipe (six products per fp32 product, igemm_bf16.hip)."""
+    if os.environ.get('SSC_ARITH', 'bf16x6').lower() in ('fp32', 'f32', 'float32'):
+        return 'fp32'
+    return 'fp32 (bf16x6 split on the bf16 MFMA, fp32 accumulate; filter gradients and few-channel layers on the exact-fp32 MFMA)'
+
 F_G, F_D = 10.84e9, 3.55e9         # forward FLOPs per image as written in the reference (SURVEY.md 8a)
 
 
@@ -176,7 +186,7 @@ def run_forward_workload(args):
     ms = dt / args.steps * 1e3
     out = {'metric': 'generator forward images/sec', 'value': n * args.steps / dt, 'unit': 'images/sec', 'n_gpus': 1,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
-           'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+           'vs_baseline': None, 'dtype': _dtype_label(), 'data': 'synthetic',
            'config': {'workload': '%s, %dx%d, batch %d' % (name, img, img, n),
                       'launch': 'eager' if args.no_graphs else 'hipGraph replay'},
            'launches_per_step': launches,
@@ -265,6 +275,57 @@ def secondary_workloads(args):
         except Exception as e:     # noqa: BLE001 -- a secondary workload must never cost the headline line
             out[name] = {'error': repr(e)[:300]}
     return out
+
+
+def arithmetic_error_table():
+    """The bf16-split kernels beside the exact-fp32 kernels against float64, live on this GPU: three layer-sized contractions
+    (max-abs error; `scale` = max |float64 result|).  The split form keeps the hh products and the correction products in separate
+    fp32 accumulators and is the more exact of the two (profiles/NOTEBOOK_r05.md section 2)."""
+    import torch
+    import torch.nn.functional as F
+    from sketchyscenecolorization_amd import hip
+    g = torch.Generator(device='cuda').manual_seed(7)
+    r = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    cases = {}
+    a, b = r(1152, 2048), r(2048, 512) * 0.03
+    cases['matmul 1152x2048x512'] = (lambda out: hip.matmul(a, b, out), (1152, 512), a.double() @ b.double())
+    x, w = r(4, 48, 48, 128), r(4, 4, 128, 256) * 0.03
+    cols = F.unfold(F.pad(x.double().permute(0, 3, 1, 2), (1, 1, 1, 1)), 4, stride=2)           # [N, c*16, P], index c*16 + tap
+    ref = torch.einsum('nkp,kc->npc', cols, w.double().permute(2, 0, 1, 3).reshape(128 * 16, 256)).reshape(4, 24, 24, 256)
+    cases['conv 4x4 s2 128->256 @48^2, batch 4'] = (lambda out: hip.conv_forward(hip.View(x), w, 2, 1, out), (4, 24, 24, 256), ref)
+    a2, b2 = r(4608, 4096), r(4096, 512) * 0.02
+    cases['matmul 4608x4096x512 (encoder_4)'] = (lambda out: hip.matmul(a2, b2, out), (4608, 512), a2.double() @ b2.double())
+    table = {}
+    for name, (fn, shape, ref64) in cases.items():
+        row = {'scale': float(ref64.abs().max())}
+        for mode in ('bf16x6', 'exact_fp32'):
+            hip.ARITH_BF16 = mode == 'bf16x6'
+            try:
+                out = torch.empty(shape, device='cuda')
+                fn(out)
+                torch.cuda.synchronize()
+            finally:
+                hip.ARITH_BF16 = True
+            row[mode] = float((out.double() - ref64).abs().max())
+        table[name] = row
+    return table
+
+
+def exact_fp32_step(args):
+    """The same train step with SSC_ARITH=fp32 (every contraction on the exact-fp32 MFMA), in a process of its own."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--no-cpu-baseline', '--no-secondary', '--no-kernel-events', '--no-gen-fb',
+           '--steps', '10', '--warmup', '3', '--preheat-seconds', '1']
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, universal_newlines=True,
+                           env=dict(os.environ, SSC_ARITH='fp32'))
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if r.returncode != 0 or not line:
+            return {'error': 'rc %d: %s' % (r.returncode, r.stderr[-300:])}
+        j = json.loads(line[-1])
+        return {'ms_per_step': j['ms_per_step'], 'images_per_sec': j['value'], 'dtype': j['dtype'], 'steps': j['steps']}
+    except Exception as e:     # noqa: BLE001
+        return {'error': repr(e)[:300]}
 
 
 def _free_port():
@@ -507,7 +568,7 @@ def main():
                'ms_per_step': ms, 'launches_per_step': launches_per_step,
                'ms_per_step_median': step_ms[len(step_ms) // 2] if step_ms else None,
                'ms_per_step_min_max': [step_ms[0], step_ms[-1]] if step_ms else None,
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32',
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': _dtype_label(),
                'data': 'synthetic (the same two resident batches every step: loss_d collapses, throughput is unaffected)',
                'config': {'workload': 'Foreground_Instance_Colorization ' + args.block_type + ' GAN train step '
                                       '(D-step + G-step, TF-Adam), %dx%d, batch %d per GPU' % (args.img, args.img,
@@ -586,6 +647,15 @@ def main():
         # and only the names of other extra keys): the train step's and the generator forward + backward graph's fraction of
         # the fp32-MFMA peak on executed FLOPs at the configured batch, and one line per secondary workload.
         rl = out.setdefault('roofline', {'bound': 'mfma', 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s'})
+        rl['peak_is'] = ('the fp32-MFMA dense peak, as in rounds 1-4: FLOPs are fp32-equivalent (2 x MAC of the fp32 contraction).  The '
+                         'bf16x6 kernels run on the bf16 pipe (%.0f TFLOP/s dense = %.1f fp32-equivalent at six products), so a fraction '
+                         'above 1.0 of this peak would be legitimate for them' % (PEAK_BF16_MFMA_TFLOPS, PEAK_BF16_MFMA_TFLOPS / 6))
+        rl['arithmetic'] = out['dtype']
+        if world == 1 and not under_launcher:
+            try:
+                rl['arithmetic_error_vs_f64'] = arithmetic_error_table()
+            except Exception as e:     # noqa: BLE001 -- never cost the headline line
+                rl['arithmetic_error_vs_f64'] = {'error': repr(e)[:200]}
         tg = rl['targets'] = {'step_frac_of_fp32_peak_executed': out.get('step_frac_of_fp32_peak'),
                               'step_ms': ms, 'step_images_per_sec': value, 'batch_per_gpu': args.batch}
         if gen_fb is not None:
@@ -600,6 +670,8 @@ def main():
                 args.batch == 32 and args.img == 192 and not args.no_graphs):
             del tr
             torch.cuda.empty_cache()
+            if _dtype_label() != 'fp32':
+                tg['exact_fp32_step'] = exact_fp32_step(args)       # SSC_ARITH=fp32: the same step on the exact-fp32 MFMA
             out['secondary'] = secondary_workloads(args)
             rl['secondary'] = {k: ({'images_per_sec': v['images_per_sec'], 'ms': v['ms'], 'frac_executed': v['frac_executed'],
                                     'launches_per_step': v.get('launches_per_step')}

@@ -104,33 +104,17 @@ typedef struct ssc_conv_desc {
     float* stat_partial2;
     int32_t sb2_ldx;
     int32_t sb2_act;
-    /* set by ssc_conv_forward_bn (callers leave fin_cnt NULL): the fold of the batch statistics -- sum the rows of stat_partial
-       per channel, mean / variance -> (a, b) and (mean, 1/std) -- happens INSIDE the launch instead of in a launch of its own:
-       the rows are written through to memory, the last workgroup of every group of fin_gs rows (an agent-scope ticket per group
-       and column tile) sums its group in row order into fin_grp, the last group to finish sums the groups in order and writes
-       ab / stats.  Fixed groups, fixed orders: deterministic.  fin_cnt: (groups + 1) x column tiles counters, zero on entry,
-       left zero (the words behind the SSC_SK_FLAG_WORDS hand-off flags of the stream's flag array). */
-    uint32_t* fin_cnt;
-    double* fin_grp;      /* [groups][2][Nstore] */
-    const float* fin_scale;
-    const float* fin_offset;
-    float* fin_ab;        /* [2][Nstore] */
-    float* fin_stats;     /* [2][Nstore] */
-    int64_t fin_M;        /* elements per channel */
-    float fin_eps;
-    int32_t fin_gs;       /* rows per group */
     int32_t stat_mode;    /* set by ssc_conv_forward_minmax (callers leave 0): 1 = the rows of stat_partial hold the per-column
                              MINIMUM and MAXIMUM of the tile's (activated) outputs instead of sum and sum of squares */
-    int32_t _pad1;
+    int32_t ws_kc;
     /* Filter pre-split into three bf16 planes (ssc_filter_split; orientation = bmode), or NULL.  When set and the launch
        qualifies (every 32-wide K-tile inside one tap and one source, n_off a multiple of 32, more than 32 stored columns) the
        contraction runs on the bf16 matrix pipe as six bf16 products per fp32 product with fp32 accumulation (igemm_bf16.hip:
        fp32-grade results at 6/16 of the fp32 MFMA's cycles); `w` must still point at the fp32 filter.  ws_kc / ws_nbp: the
        planes' chunk and block counts as ssc_filter_split_geom reports them. */
     const void* wsplit;
-    int32_t ws_kc, ws_nbp;
+    int32_t ws_nbp, _pad1;
 } ssc_conv_desc;
-#define SSC_FIN_CNT_WORDS 8192   /* counters of the in-launch statistics fold: words [SSC_SK_FLAG_WORDS, + SSC_FIN_CNT_WORDS) of sk_flags */
 #define SSC_SK_FLAG_WORDS 8192   /* >= resident workgroups of the largest grid; the last word reports a hand-off timeout:
                                     0 = none, else 0x80000000 | sk_tag of the first launch whose owner workgroup gave up
                                     waiting for a K slice.  The output of that launch is WRONG (a partial sum): callers must
@@ -152,6 +136,9 @@ typedef struct ssc_split_job {
    job's share of a batch launch (whole blocks of 256) */
 int ssc_filter_split_geom(int taps, int c0, int c1, int orient, int* kc, int* nbp, int64_t* bytes, int64_t* threads);
 int ssc_filter_split(const float* w, int taps, int c0, int c1, int orient, void* dst, void* stream);
+/* allocates the bf16 form's per-device constants (a hipMalloc + a copy: call once OUTSIDE any stream capture, before the first
+   launch that carries `wsplit`; the launches call it too) */
+int ssc_bf16_prepare(void);
 /* jobs_dev: DEVICE array; total_threads = sum of the jobs' `threads` */
 int ssc_filter_split_batch(const ssc_split_job* jobs_dev, int njobs, int64_t total_threads, void* stream);
 
@@ -245,9 +232,6 @@ int ssc_conv_fewchan7_supported(const ssc_conv_desc* d);
 /* the k = 4 stride-2 transposed convs of the Background generator's region branch (<= 4 channels in and out,
    bg_colorization_main.py:392-397): a thread per lattice pixel (tr4tiny.hip) */
 int ssc_conv_tr4_tiny_supported(const ssc_conv_desc* d);
-/* the generators' last layer, the k = 4 stride-2 transposed conv 128 -> <= 4 channels (models_collection.py:529-534), on
-   v_mfma_f32_4x4x1 blocks with K split 16 ways (tr4mfma.hip) */
-int ssc_conv_tr4_mfma_supported(const ssc_conv_desc* d);
 int ssc_conv_fewchan_supported(const ssc_conv_desc* d);
 /* name of the tile configuration the launcher picks for a descriptor (host only; for profiling) */
 int ssc_conv_forward_kernel_name(const ssc_conv_desc* d, char* buf, int len);
@@ -407,17 +391,14 @@ int ssc_bn_act_backward_pre(const float* x, int64_t M, int C, int ldx, const flo
                             float* dx, int lddx, float* dscale, float* doffset, const float* pre, int nrows,
                             const float* rowb, float rowb_scale, int rowb_P, float* ws, int64_t ws_bytes, void* stream);
 /*
- * The norm backward in two steps, so that its streaming pass can ride inside another launch.  `job` describes the site exactly
+ * The norm backward in two steps (sums, streaming apply pass).  `job` describes the site exactly
  * as the arguments of ssc_bn_act_backward_pre do (host memory, read during the call).
  *   ssc_bn_bwd_sums     partial sums (from `pre` / nrows when given, else a pass over x, g1, g2) -> coef [2][C] = mean dz,
  *                       mean dz*xhat, and the scale / offset gradients.  coef is the caller's buffer: it must stay untouched
  *                       until the apply pass has run (the workspace is not a place for it).
  *   ssc_bn_bwd_apply    dx = a*(dz - coef0 - xhat*coef1) (has_bn) or dx = dz, as a launch of its own.
- *   ssc_conv_wgrad_hosting   ssc_conv_wgrad + that apply pass: the filter gradient of the layer ABOVE the site needs neither
- *                       dx nor anything the pass writes, so the pass runs as the first workgroups of the filter-gradient
- *                       launch (HBM traffic beside its MFMA work; conv_wgrad128_kernel and conv_wgrad_kernel host it).  Where
- *                       the launch cannot host (the one-output head's streaming kernel) the pass is launched in front of it:
- *                       same results either way, and the same bits as ssc_bn_act_backward_pre.
+ * Same bits as ssc_bn_act_backward_pre.  (Round 4's ssc_conv_wgrad_hosting, the apply pass inside the filter-gradient launch of
+ * the layer above, measured slower in the step and was removed in round 5.)
  */
 typedef struct ssc_bn_apply_job {
     const float* x;       /* the normed tensor (raw), [M][ldx] */
@@ -439,7 +420,6 @@ typedef struct ssc_bn_apply_job {
 int ssc_bn_bwd_sums(const ssc_bn_apply_job* job, const float* pre, int nrows, float* coef, float* dscale, float* doffset,
                     float* ws, int64_t ws_bytes, void* stream);
 int ssc_bn_bwd_apply(const ssc_bn_apply_job* job, void* stream);
-int ssc_conv_wgrad_hosting(const ssc_wgrad_desc* d, float* ws, int64_t ws_bytes, const ssc_bn_apply_job* job, void* stream);
 /*
  * Backward through the output of a bottleneck block, out = act(norm_A(xa) + shortcut) (residual_util.py:103-109, 138-146,
  * 165-167): dz = g * act'(out) and, with that one dz, the backward of block_3's norm (site A: dxa, scale / offset gradients)

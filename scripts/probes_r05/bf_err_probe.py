@@ -1,7 +1,7 @@
 """Where does the bf16-split kernel's distance from float64 come from?  Error statistics (max, rms) of the split and the exact
 kernel on one transposed-conv case, by variant: activation, sources, sub-pixel phase."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import tf_ops as T
 from sketchyscenecolorization_amd import hip

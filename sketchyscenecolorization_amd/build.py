@@ -9,8 +9,12 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libsketchycolor_hip.so')
 EXTRA_FLAGS = {'igemm.hip': ['-Xclang', '-target-feature', '-Xclang', '-load-store-opt']} if os.environ.get('SSC_NO_LSOPT') == '1' else {}     # per-source compiler flags
+# -fno-slp-vectorize: the compiler must not pack scalar fp32 math into v_pk_*_f32 instructions -- beside another wave's bf16
+# MFMAs they corrupt the results of a wave that issues fp32 MFMAs (csrc/igemm_util.h).  narrow.hip (no MFMA of its own) keeps
+# its explicit packed FMAs.
+NO_PACKED_FP32 = {'narrow.hip': []}
 LAST_BUILD = None       # 'rebuilt' | 'reused' after build_library()
-SOURCES = ['igemm.hip', 'igemm_bf16.hip', 'wgrad128.hip', 'wgn16.hip', 'narrow.hip', 'head1.hip', 'fewchan.hip', 'fewchan7.hip', 'pw1x1.hip', 'c3x3.hip', 's2n16.hip', 'tr4tiny.hip', 'tr4n16.hip', 'tr4mfma.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip', 'mru_ops.hip']
+SOURCES = ['igemm.hip', 'igemm_bf16.hip', 'wgrad128.hip', 'wgn16.hip', 'narrow.hip', 'head1.hip', 'fewchan.hip', 'fewchan7.hip', 'pw1x1.hip', 'c3x3.hip', 's2n16.hip', 'tr4tiny.hip', 'tr4n16.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip', 'mru_ops.hip']
 
 
 def _hipcc():
@@ -79,7 +83,8 @@ def build_library(force=False, verbose=True):
             continue
         obj = os.path.join(LIB_DIR, s.replace('.hip', '.o'))
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'),
-               '-Wno-unused-value', '-Wno-unused-function'] + os.environ.get('SSC_EXTRA_HIPCC_FLAGS', '').split() + \
+               '-Wno-unused-value', '-Wno-unused-function'] + NO_PACKED_FP32.get(s, ['-fno-slp-vectorize']) + \
+              os.environ.get('SSC_EXTRA_HIPCC_FLAGS', '').split() + \
               EXTRA_FLAGS.get(s, []) + (['-DSSC_CSRC_HASH="%s"' % th] if s == 'elementwise.hip' else []) + ['-c', src, '-o', obj]
         objs.append(obj)
         # an object is reused when its source, the shared headers and its command line are what it was compiled from

@@ -1,13 +1,11 @@
 // bn_bwd.h -- the pointwise half of the backward pass of  act(batch-statistics norm(x))  (models_collection.py:36-46 under
-// tf.gradients), shared by the stand-alone kernels of elementwise.hip and by the filter-gradient kernels that HOST it:
+// tf.gradients), used by the stand-alone kernels of elementwise.hip:
 //
 //   dx = a * (dz - mean(dz) - xhat * mean(dz * xhat)),   dz = g1 * act1'(z) [+ g2 * act2'(z)],   z = a x + b
 //
-// is one streaming pass over x, g1 (g2) -> dx once the two per-channel means are known (coef).  On its own it is a launch of
-// 5-55 us in the middle of a chain of matrix launches, with the matrix cores idle; the filter gradient of the layer above
-// needs neither its input nor its output, so conv_wgrad128_kernel / conv_wgrad_kernel can carry it as a SIDE JOB: the first
-// `side_blocks` workgroups of the launch run bn_bwd_apply_blocks() and leave, the others do the filter gradient -- HBM traffic
-// beside MFMA work inside one launch, no cross-stream dependency in the step's graph.
+// is one streaming pass over x, g1 (g2) -> dx once the two per-channel means are known (coef).  (Round 4 also let the filter-
+// gradient launch of the layer above carry it as a side job; measured slower in the step, removed in round 5 -- profiles/
+// NOTEBOOK_r04.md.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "sketchycolor_hip.h"
@@ -19,15 +17,6 @@ struct BnBwdArgs {
     const float* g2; int ldg2; int act2;
     int has_bn;
     const float* rowb; float rowb_scale; int rowb_P;    // g1[r][c] += rowb[r / rowb_P][c] * rowb_scale (NULL: nothing added)
-};
-
-// a hosted apply: the arguments of bn_bwd_apply_kernel
-struct BnApplySide {
-    BnBwdArgs a;
-    const float* coef;      // [2][C]: mean dz, mean dz * xhat (bn_bwd_finalize_kernel)
-    float* dx;
-    int lddx;
-    int blocks;             // workgroups of the host launch that run it (0: no side job)
 };
 
 static inline BnBwdArgs bn_args_of(const ssc_bn_apply_job& j) {
@@ -42,26 +31,6 @@ static inline bool bn_job_ok(const ssc_bn_apply_job& j) {
              (j.rowb != nullptr && j.rowb_P <= 0) || j.x == nullptr || j.g1 == nullptr || j.dx == nullptr ||
              (j.has_bn && (j.ab == nullptr || j.stats == nullptr || j.coef == nullptr)));
 }
-// workgroups of a host launch that carry the pass: one per CU (they are dispatched first and spread over the CUs), fewer for a
-// small tensor (at least ~16 groups of 16 bytes per thread), a multiple of 8 so that the host's XCD mapping keeps its phase
-static inline BnApplySide bn_side_of(const ssc_bn_apply_job& j, int num_cu) {
-    BnApplySide s;
-    s.a = bn_args_of(j);
-    s.coef = j.coef; s.dx = j.dx; s.lddx = j.lddx;
-    const long tot = (long)j.M * (j.C / 4);
-    long b = (tot + 256 * 16 - 1) / (256 * 16);
-    if (b > num_cu) b = num_cu;
-    b = (b + 7) & ~7L;
-    s.blocks = (int)b;
-    return s;
-}
-static inline BnApplySide bn_side_none() {
-    BnApplySide s;
-    s.a = BnBwdArgs();
-    s.coef = nullptr; s.dx = nullptr; s.lddx = 0; s.blocks = 0;
-    return s;
-}
-
 __device__ __forceinline__ float dact(float z, int act) {
     if (act == SSC_ACT_RELU) return z > 0.f ? 1.f : 0.f;
     if (act == SSC_ACT_LRELU) return z > 0.f ? 1.f : 0.2f;

@@ -429,7 +429,7 @@ extern "C" int ssc_conv_c3x3_supported(const ssc_conv_desc* dp) {
         return 0;
     const long M = (long)d.NB * d.PH * d.PW;
     if (M < 16384 || M >= 0x7fffffffL / 64) return 0;
-    if (d.fin_cnt != nullptr || d.stat_mode != 0 || d.sb2_x != nullptr) return 0;
+    if (d.stat_mode != 0 || d.sb2_x != nullptr) return 0;
     return 1;
 }
 

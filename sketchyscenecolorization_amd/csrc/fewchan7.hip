@@ -163,7 +163,7 @@ extern "C" int ssc_conv_fewchan7_supported(const ssc_conv_desc* dp) {
     if (2 * d.PH != d.x.H || 2 * d.PW != d.x.W) return 0;
     if ((reinterpret_cast<uintptr_t>(d.x.s0) & 15) != 0) return 0;
     if ((long)d.NB * (d.PH / F7_TR) * (d.PW / F7_TC) >= 0x7fffffffL) return 0;
-    if (d.sb_x != nullptr || d.sb2_x != nullptr || d.fin_cnt != nullptr || d.stat_mode != 0) return 0;
+    if (d.sb_x != nullptr || d.sb2_x != nullptr || d.stat_mode != 0) return 0;
     return 1;
 }
 

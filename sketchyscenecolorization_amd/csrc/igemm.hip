@@ -26,7 +26,6 @@
 // wgrad128.hip
 extern "C" int ssc_conv_wgrad128_supported(const ssc_wgrad_desc* dp);
 extern "C" int ssc_conv_wgrad128(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream);
-int ssc_conv_wgrad128_job(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, const ssc_bn_apply_job* job, void* stream);
 // wgn16.hip
 extern "C" int ssc_conv_wgn16_supported(const ssc_wgrad_desc* dp);
 int ssc_conv_wgn16(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream);
@@ -38,9 +37,6 @@ int ssc_conv_fewchan_forward(const ssc_conv_desc* dp, int num_cu, void* stream);
 extern "C" int ssc_conv_pw1x1_supported(const ssc_conv_desc* dp);
 int ssc_conv_pw1x1_walkers(const ssc_conv_desc* dp);
 int ssc_conv_pw1x1_forward(const ssc_conv_desc* dp, float* stat, void* stream);
-// tr4mfma.hip
-extern "C" int ssc_conv_tr4_mfma_supported(const ssc_conv_desc* dp);
-int ssc_conv_tr4_mfma_forward(const ssc_conv_desc* dp, void* stream);
 // tr4n16.hip
 extern "C" int ssc_conv_tr4n16_supported(const ssc_conv_desc* dp);
 int ssc_conv_tr4n16_rows(const ssc_conv_desc* dp);
@@ -762,28 +758,6 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
                         for (int j = 0; j < SN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][q][i], bv[g & 1][q][j], acc[i][j], 0, 0, 0);
             };
-#if SSC_UT_SGB == 2
-            // hand-placed: full scheduling barriers between the pieces (the compiler orders only inside one); MFMAs strictly
-            // round robin over the accumulators
-            fetch(0, 0);
-            fetch(1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(0);
-            stage(cur ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (BDMA && !ADMA) dma_b(min(kt + 1, last), cur ^ 1);
-            fetch(2, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(1);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_loads(min(kt + 2, last));
-            fetch(3, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(2);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(3);
-            __builtin_amdgcn_sched_barrier(0);
-#else
             fetch(0, 0);
             fetch(1, 1);
             mfmas(0);
@@ -798,7 +772,6 @@ __global__ __launch_bounds__(256) void conv_ut_kernel(const ssc_conv_desc d, con
             fetch(3, 1);
             mfmas(2);
             mfmas(3);
-#endif
 #if SSC_UT_SGB == 1
             // interleave hint: one MFMA, then a few of the independent staging instructions
 #pragma unroll
@@ -1408,15 +1381,6 @@ static double makespan(long blocks, double w, int res, int ncu) {
 
 struct Plan { int cfg; int splitk; double cost; long ts_full; int ts_s; };
 
-static bool inlaunch_splitk() {
-    static int on = -1;     // SSC_INLAUNCH_SPLITK=1: split-K of every tile combined in the launch (A/B; default: slabs + a reduce launch)
-    if (on < 0) {
-        const char* e = getenv("SSC_INLAUNCH_SPLITK");
-        on = (e != nullptr && e[0] == '1') ? 1 : 0;      // off: measured slower (17.79 vs 17.71 ms per Pix2Pix step, 7.05 vs
-    }                                                    // 6.90 ms generator forward + backward): few owners do the combining
-    return on != 0;                                      // while the reduce launch spreads it over the chip
-}
-
 static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long M, long N, long nphase, long nkt,
                         long out_elems, int64_t ws_bytes, bool have_ws, bool can_ts = false, double cyc_scale = 1.0) {
     const int ncu = num_cu();
@@ -1475,15 +1439,6 @@ static Plan plan_launch(const TileCfg* cfgs, int ncfg, const bool* allowed, long
             best.splitk = 1;
             best.ts_full = full;
             best.ts_s = (int)sl;
-        } else if (best.splitk > 1 && ff < 0 && inlaunch_splitk() && blocks * best.splitk < SSC_SK_FLAG_WORDS - 1 &&
-                   (int64_t)blocks * best.splitk * t.BM * t.BN * 4 <= ws_bytes) {
-            // Split-K of EVERY tile (few tiles, long K: the recurrent GEMMs, encoder_5): the slices are combined inside the
-            // launch by the same hand-off (no whole tiles, every tile cut into splitk slices) instead of through slabs and a
-            // reduce launch of its own -- one launch less on a dependent chain, and the owner's epilogue can take the
-            // batch statistics, which a slab pass cannot
-            best.ts_full = 0;
-            best.ts_s = best.splitk;
-            best.splitk = 1;
         }
     }
     return best;
@@ -1706,10 +1661,6 @@ extern "C" int ssc_conv_forward_kernel_name(const ssc_conv_desc* dp, char* buf, 
         copy_name(ssc_head1_dgrad_supported(dp) ? "head1_dgrad" : "head1_fwd", buf, len);
         return 0;
     }
-    if (ssc_conv_tr4_mfma_supported(dp)) {
-        copy_name("deconv_tr4_mfma", buf, len);
-        return 0;
-    }
     if (ssc_conv_narrow_supported(dp)) {
         copy_name(dp->nphase == 4 ? "narrow_fwd<transposed>" : "narrow_fwd<conv>", buf, len);
         return 0;
@@ -1771,7 +1722,6 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
     d.stat_partial = nullptr;
     d.sb_x = nullptr;
     d.sb2_x = nullptr;
-    d.fin_cnt = nullptr;
     d.stat_mode = 0;
     const long M = (long)d.NB * d.PH * d.PW;
     const long Mall = M * d.nphase;
@@ -1782,7 +1732,11 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
     }
     bool fused = false;
     int64_t ws_conv = ws_bytes;
-    if (!off && ws != nullptr && d.Nstore == d.ldc &&
+    // (the streaming kernels are dispatched BEHIND the one-output head, the few-output and the few-channel kernels in
+    // ssc_conv_forward: a descriptor those take must not be promised rows only a streaming kernel writes)
+    const bool earlier = ssc_head1_forward_supported(dp) || ssc_head1_dgrad_supported(dp) || ssc_conv_narrow_supported(dp) ||
+                         ssc_conv_fewchan_supported(dp);
+    if (!off && !earlier && ws != nullptr && d.Nstore == d.ldc &&
         (ssc_conv_pw1x1_supported(&d) || ssc_conv_c3x3_supported(&d) || ssc_conv_s2n16_supported(&d) ||
          ssc_conv_tr4_tiny_supported(&d) || ssc_conv_fewchan7_supported(&d) || ssc_conv_tr4n16_supported(&d))) {
         // the streaming kernels take the statistics as per-lane sums over the tiles a workgroup walks: one row per walker
@@ -1809,37 +1763,15 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
         if (p.cfg >= 0 && p.splitk == 1) {
             const long mt = (M + FWD_CFGS[p.cfg].BM - 1) / FWD_CFGS[p.cfg].BM;
             const int64_t need = (int64_t)mt * d.nphase * 2 * d.Nstore * 4;
-            // the fold itself inside the launch too (ssc_conv_desc.fin_*): group rows behind the partial rows, counters behind
-            // the stream's hand-off flags
-            // OFF: measured slower everywhere -- Pix2Pix step 17.94 vs 17.85 ms (23 launches fewer), Residual 45.0 vs 44.0 ms
-            // (165 fewer), Background 27.1 vs 26.1 ms (84 fewer): the tickets, the two barriers and the write-through rows
-            // cost every workgroup more than the 5 us launch they replace (profiles/NOTEBOOK_r04.md)
-            static int fin_on = -1;     // SSC_FIN_INLAUNCH=1: the fold inside the launch (A/B)
-            if (fin_on < 0) {
-                const char* e = getenv("SSC_FIN_INLAUNCH");
-                fin_on = (e != nullptr && e[0] == '1') ? 1 : 0;
-            }
-            const long nrows = mt * d.nphase;
-            const int gs = nrows <= 1024 ? 32 : 64;
-            const long ngr = (nrows + gs - 1) / gs;
-            const long ntile = (d.Nstore + FWD_CFGS[p.cfg].BN - 1) / FWD_CFGS[p.cfg].BN;
-            const int64_t grp_bytes = (int64_t)ngr * 2 * d.Nstore * 8;
-            const bool fin = fin_on && p.cfg > 0 && d.sk_flags != nullptr && (ngr + 1) * ntile <= SSC_FIN_CNT_WORDS && nrows >= 2;
-            const int64_t reserve = ((need + 255) & ~(int64_t)255) + (fin ? grp_bytes + 256 : 0);
+            const int64_t reserve = (need + 255) & ~(int64_t)255;
             if (reserve * 4 <= ws_bytes) {     // the partial rows sit at the end of the workspace, the conv keeps the rest
                 ws_conv = (ws_bytes - reserve) & ~(int64_t)255;
                 const Plan p2 = plan_fwd(d, ws_conv, true);
                 if (p2.cfg == p.cfg && p2.splitk == 1) {
                     d.stat_partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_conv);
                     fused = true;
-                    if (fin) {
-                        d.fin_cnt = d.sk_flags + SSC_SK_FLAG_WORDS;
-                        d.fin_grp = reinterpret_cast<double*>(reinterpret_cast<char*>(d.stat_partial) + ((need + 255) & ~(int64_t)255));
-                        d.fin_scale = scale; d.fin_offset = offset; d.fin_ab = ab; d.fin_stats = stats;
-                        d.fin_M = Mall; d.fin_eps = eps; d.fin_gs = gs;
-                    }
                     const int rc = ssc_conv_forward(&d, ws, ws_conv, stream);
-                    if (rc != 0 || fin) return rc;
+                    if (rc != 0) return rc;
                     return ssc_bn_finalize(d.stat_partial, (int)(mt * d.nphase), d.Nstore, Mall, scale, offset, eps, ab, stats,
                                            stream);
                 }
@@ -1895,7 +1827,6 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
     d.stat_partial = nullptr;
     d.sb_x = nullptr;
     d.sb2_x = nullptr;
-    d.fin_cnt = nullptr;
     d.stat_mode = 0;
     *nrows = 0;
     const long M = (long)d.NB * d.PH * d.PW;
@@ -1904,7 +1835,9 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
         const char* e = getenv("SSC_FUSE_BNBWD");
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
-    if (!off && partial != nullptr && x != nullptr && ab != nullptr && stats != nullptr && d.Nstore == d.ldc &&
+    const bool earlier = ssc_head1_forward_supported(dp) || ssc_head1_dgrad_supported(dp) || ssc_conv_narrow_supported(dp) ||
+                         ssc_conv_fewchan_supported(dp);        // dispatched in front of the streaming kernels
+    if (!off && !earlier && partial != nullptr && x != nullptr && ab != nullptr && stats != nullptr && d.Nstore == d.ldc &&
         (ssc_conv_c3x3_supported(&d) || ssc_conv_s2n16_supported(&d))) {
         // streaming kernels: the two sums as per-lane sums, one row per walker
         const int nblk = ssc_conv_c3x3_supported(&d) ? ssc_conv_c3x3_walkers(&d) : ssc_conv_s2n16_walkers(&d);
@@ -1946,7 +1879,6 @@ extern "C" int ssc_conv_forward_minmax(const ssc_conv_desc* dp, float* ws, int64
     d.stat_partial = nullptr;
     d.sb_x = nullptr;
     d.sb2_x = nullptr;
-    d.fin_cnt = nullptr;
     d.stat_mode = 0;
     const long P = (long)d.PH * d.PW;
     const long M = (long)d.NB * P;
@@ -1986,7 +1918,6 @@ extern "C" int ssc_conv_forward_bnbwd2(const ssc_conv_desc* dp, float* ws, int64
     d.stat_partial = nullptr;
     d.sb_x = nullptr;
     d.sb2_x = nullptr;
-    d.fin_cnt = nullptr;
     d.stat_mode = 0;
     *nrows = 0;
     const long M = (long)d.NB * d.PH * d.PW;
@@ -2049,8 +1980,6 @@ extern "C" int ssc_conv_forward(const ssc_conv_desc* dp, float* ws, int64_t ws_b
     if (ws != nullptr && ssc_head1_forward_supported(dp) && (int64_t)d.NB * d.x.H * d.x.W * 16 * 4 <= ws_bytes)
         return ssc_head1_forward(dp, ws, ws_bytes, stream);
     if (ssc_head1_dgrad_supported(dp)) return ssc_head1_dgrad(dp, stream);
-    if (ssc_conv_tr4_mfma_supported(dp))        // 128 -> <= 4 channels, k = 4 stride-2 transposed: 4x4x1 MFMA blocks, K split 16 ways
-        return ssc_conv_tr4_mfma_forward(dp, stream);
     if (ssc_conv_narrow_supported(dp)) {        // <= 4 output channels
         int csplit = 1;
         const int rc = ssc_conv_narrow_forward_ws(dp, ws, ws_bytes, stream, &csplit);
@@ -2219,26 +2148,6 @@ extern "C" int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* dp, char* buf, i
     const Plan p = plan_wgrad(*dp, (int64_t)1 << 40, true);
     copy_name(names[p.cfg < 0 ? 0 : p.cfg], buf, len);
     return 0;
-}
-
-// filter gradient + the apply pass of a norm backward (bn_bwd.h): inside the launch where the kernel hosts it, in front of it
-// otherwise
-extern "C" int ssc_conv_wgrad_hosting(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, const ssc_bn_apply_job* job,
-                                      void* stream) {
-    static int off = -1;        // SSC_SIDE_APPLY=0: always a launch of its own (A/B)
-    if (off < 0) {
-        const char* e = getenv("SSC_SIDE_APPLY");
-        off = (e != nullptr && e[0] == '0') ? 1 : 0;
-    }
-    if (job == nullptr) return ssc_conv_wgrad(dp, ws, ws_bytes, stream);
-    const ssc_wgrad_desc& d = *dp;
-    const bool head1 = ws != nullptr && ws_bytes >= (int64_t)16 * 512 * 4 && ssc_head1_wgrad_supported(dp);
-    if (!off && !head1 && !((d.g.C0 & 3) || (d.g.C1 & 3) || (d.d.C0 & 3) || (d.d.C1 & 3)) && d.d.H == d.PH && d.d.W == d.PW &&
-        d.ldc == d.Nn && ssc_conv_wgrad128_supported(dp))
-        return ssc_conv_wgrad128_job(dp, ws, ws_bytes, job, stream);
-    const int rc = ssc_bn_bwd_apply(job, stream);
-    if (rc != 0) return rc;
-    return ssc_conv_wgrad(dp, ws, ws_bytes, stream);
 }
 
 extern "C" int ssc_conv_wgrad(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream) {

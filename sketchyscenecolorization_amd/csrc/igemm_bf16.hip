@@ -26,6 +26,9 @@
 #include "host_util.h"
 
 #define BK 32
+#ifndef SSC_BF_DIAG_BUILD
+#define SSC_BF_DIAG_BUILD 0     // diagnostic builds: bit 0 no MFMAs, bit 1 no LDS-DMA, bit 2 no staging stores, bit 3 no gather loads
+#endif
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -35,6 +38,28 @@ __device__ unsigned g_sk_cfg_bf[4] = {2000000000u, 0u, 0u, 0u};
 
 int ssc_sk_configure_bf(const unsigned* cfg4) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sk_cfg_bf), cfg4, 4 * sizeof(unsigned), 0, hipMemcpyHostToDevice);
+}
+
+// N LDS-DMA instructions (16 bytes per lane from sbase + voff[q] to LDS at lds_addr + q * 1024 + 16 * lane) with ONE save / restore
+// of M0: the per-instruction form (glds16) spends four scalar instructions on M0 per DMA, and the scalar stream of this kernel
+// is as long as its vector stream
+template <int N>
+__device__ __forceinline__ void glds16_run(const char* sbase, const unsigned* voff, unsigned lds_addr) {
+    unsigned keep;
+    if (N == 1) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "s"(sbase), "s"(lds_addr) : "memory");
+    } else if (N == 2) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(sbase), "s"(lds_addr) : "memory", "scc");
+    } else {
+        static_assert(N >= 1 && N <= 3, "1..3 instructions per run");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(sbase), "s"(lds_addr) : "memory", "scc");
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -173,10 +198,13 @@ template <int BM, int BN> struct BfLds {
     static constexpr int TOTAL = OPER_BYTES + BM * 8;
 };
 
+// tab: the norm tables of the two sources as {a0, b0, a1, b1} ([C] each), never NULL: a source without a table gets the launcher's
+// identity rows (ones, zeros) -- no per-step "has a table" selects, and the pointers stay plain global pointers
+struct BfTabs { const float* a0; const float* b0; const float* a1; const float* b1; };
 template <int WM, int WN, int SM, int SN, bool PLAIN>
 __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, const Magics mg, float* __restrict__ slab_base,
                                                        long slab_stride, int splitk, int ts_full, int ts_s,
-                                                       unsigned* __restrict__ flags) {
+                                                       unsigned* __restrict__ flags, const BfTabs tab) {
     constexpr int BM = WM * SM * 32;
     constexpr int BN = WN * SN * 32;
     constexpr int NBT = BN / 32;
@@ -198,8 +226,6 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
 
     const float* const xs0 = d.x.s0;
     const float* const xs1 = d.x.s1;
-    const float* const xab0 = d.x.ab0;
-    const float* const xab1 = d.x.ab1;
     const int xC0 = d.x.C0, xC1 = d.x.C1, xH = d.x.H, xW = d.x.W;
     const int TWv = d.TW, kstep = d.kstep, KWv = d.KW;
     const float slope0 = act_slope(d.x.act), slope1 = act_slope(d.x.act1 >= 0 ? d.x.act1 : d.x.act);
@@ -319,16 +345,20 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
 
     // K-tile index -> (tap row, tap column, chunk), advanced by one K-tile at a time on the scalar unit (K-tiles run chunk fastest,
     // then tap column, then tap row) instead of decoded by division every step
-    struct KTile { int ty, tx, chunk; };
+    struct KTile { int ty, tx, chunk; long woff; };      // woff: byte offset of the K-tile's filter data inside the planes
+    const long KB = ktile_bytes;
+    const long SX = (long)kstep * (KC >> 1) * KB, SY = (long)kstep * KWv * (KC >> 1) * KB;     // one tap column / row further
+    const long DX = SX - (long)tpt * KB, DY = SY - (long)TWv * SX;
     auto kt_decode = [&](int kt) {
         KTile t;
         const int tap = div32(kt, mg.mC, mg.oneC);      // mC: magic of tpt
         t.chunk = kt - tap * tpt;
         t.ty = div32(tap, mg.mTW, mg.oneTW);
         t.tx = tap - t.ty * TWv;
+        t.woff = ((long)((ph.ky0 + t.ty * kstep) * KWv + ph.kx0 + t.tx * kstep) * (KC >> 1) + t.chunk) * KB;
         return t;
     };
-    auto kt_next = [&](KTile t, bool adv) {      // adv false: stay (the clamp at the last K-tile), arithmetic selects, no branch
+    auto kt_next = [&](KTile t, bool adv) {      // adv false: stay (the clamp at the last K-tile); arithmetic selects, no branch
         t.chunk += adv ? 1 : 0;
         const bool wc = t.chunk == tpt;
         t.chunk = wc ? 0 : t.chunk;
@@ -336,6 +366,7 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
         const bool wx = t.tx == TWv;
         t.tx = wx ? 0 : t.tx;
         t.ty += wx ? 1 : 0;
+        t.woff += (adv ? KB : 0) + (wc ? DX : 0) + (wx ? DY : 0);
         return t;
     };
 
@@ -350,14 +381,10 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
         const int tapshift = (t.ty * xW + t.tx) * cs * 4;
         const int fmask = first ? -1 : 0;
         if (!PLAIN) {
-            const float* abp = first ? xab0 : xab1;
-            const bool has = abp != nullptr;
-            const float* pa = has ? abp + cc + a_col4 * 4 : xs0;
-            const float* pb = has ? abp + cs + cc + a_col4 * 4 : xs0;
-            const float4 va = *reinterpret_cast<const float4*>(pa);
-            const float4 vb = *reinterpret_cast<const float4*>(pb);
-            S.aa = has ? va : make_float4(1.f, 1.f, 1.f, 1.f);
-            S.ab = has ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
+            const char* pa = reinterpret_cast<const char*>((first ? tab.a0 : tab.a1) + cc);
+            const char* pb = reinterpret_cast<const char*>((first ? tab.b0 : tab.b1) + cc);
+            S.aa = *reinterpret_cast<const float4*>(pa + a_col4 * 16);
+            S.ab = *reinterpret_cast<const float4*>(pb + a_col4 * 16);
             S.slope = first ? slope0 : slope1;
         }
 #pragma unroll
@@ -367,49 +394,63 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
             const int osel = (a_off0[i] & fmask) | (a_off1[i] & ~fmask);
             const unsigned off = v ? (unsigned)(osel + tapshift) : (unsigned)(a_col4 * 16);
             S.v[i] = v ? 1.f : 0.f;
+            if (SSC_BF_DIAG_BUILD & 8) { S.r[i] = make_float4(1.f, 2.f, 3.f, 4.f); continue; }
             S.r[i] = *reinterpret_cast<const float4*>(sbase + off);
         }
     };
 
-    // filter K-tile `t` straight into LDS buffer `buf`: this wave's fragments [q0, q1)
-    auto dma_b = [&](const KTile& t, int buf, int q0, int q1) {
-        const int ky = ph.ky0 + t.ty * kstep, kx = ph.kx0 + t.tx * kstep;
-        const char* wtap = wsp + ((long)(ky * KWv + kx) * (KC >> 1) + t.chunk) * ktile_bytes;
+    // filter K-tile `t` straight into LDS buffer `buf`: run `half` (0 / 1) of this wave's fragments
+    constexpr int RUN0 = (B_IPW + 1) / 2, RUN1 = B_IPW - RUN0;
+    auto dma_b = [&](const KTile& t, int buf, int half) {
+        if (SSC_BF_DIAG_BUILD & 2) return;
+        const char* wtap = wsp + t.woff;
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(2 * A_BYTES + buf * B_BYTES + wave * B_IPW * 1024));
-        for (int q = q0; q < q1; ++q) glds16(wtap, bd_off[q], dst + q * 1024);
+        if (half == 0) glds16_run<RUN0>(wtap, bd_off, dst);
+        else glds16_run<RUN1>(wtap, bd_off + RUN0, dst + RUN0 * 1024);
     };
 
-    // row i of the staged K-tile: transform, split, three 8-byte stores
-    auto stage_row = [&](const ASet& S, int buf, int i) {
-        float4 v = S.r[i];
-        if (PLAIN) {
-            v.x *= S.v[i]; v.y *= S.v[i]; v.z *= S.v[i]; v.w *= S.v[i];
-        } else {
-            float t;
-            t = fmaf(S.aa.x, v.x, S.ab.x); v.x = fmaxf(t, t * S.slope) * S.v[i];
-            t = fmaf(S.aa.y, v.y, S.ab.y); v.y = fmaxf(t, t * S.slope) * S.v[i];
-            t = fmaf(S.aa.z, v.z, S.ab.z); v.z = fmaxf(t, t * S.slope) * S.v[i];
-            t = fmaf(S.aa.w, v.w, S.ab.w); v.w = fmaxf(t, t * S.slope) * S.v[i];
-        }
-        u32x2_t h, m, l;
-        unsigned h0, m0_, l0, h1, m1, l1;
-        split3_pair(v.x, v.y, h0, m0_, l0);
-        split3_pair(v.z, v.w, h1, m1, l1);
-        h.x = h0; h.y = h1; m.x = m0_; m.y = m1; l.x = l0; l.y = l1;
-        char* p = sm_b + buf * A_BYTES + (arow + 32 * i) * BF_A_RS + a_col4 * 8;
-        *reinterpret_cast<u32x2_t*>(p) = h;
-        *reinterpret_cast<u32x2_t*>(p + 64) = m;
-        *reinterpret_cast<u32x2_t*>(p + 128) = l;
-    };
+    // row i of the staged K-tile in two pieces: transform + split of the first pair | split of the second pair + three 8-byte stores
+    // (plain scalars between the pieces: a struct handed from one lambda to the other went through scratch memory)
+#define BF_STAGE_A(S, i, Z, W, H0, M0, L0)                                                        \
+    do {                                                                                          \
+        float4 v_ = (S).r[i];                                                                     \
+        if (PLAIN) {                                                                              \
+            v_.x *= (S).v[i]; v_.y *= (S).v[i]; v_.z *= (S).v[i]; v_.w *= (S).v[i];               \
+        } else {                                                                                  \
+            float t_;                                                                             \
+            t_ = fmaf((S).aa.x, v_.x, (S).ab.x); v_.x = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
+            t_ = fmaf((S).aa.y, v_.y, (S).ab.y); v_.y = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
+            t_ = fmaf((S).aa.z, v_.z, (S).ab.z); v_.z = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
+            t_ = fmaf((S).aa.w, v_.w, (S).ab.w); v_.w = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
+        }                                                                                         \
+        split3_pair(v_.x, v_.y, H0, M0, L0);                                                      \
+        Z = v_.z; W = v_.w;                                                                       \
+    } while (0)
+#define BF_STAGE_B(buf, i, Z, W, H0, M0, L0)                                                      \
+    do {                                                                                          \
+        unsigned h1_, m1_, l1_;                                                                   \
+        split3_pair(Z, W, h1_, m1_, l1_);                                                         \
+        char* p_ = sm_b + (buf) * A_BYTES + (arow + 32 * (i)) * BF_A_RS + a_col4 * 8;             \
+        if (SSC_BF_DIAG_BUILD & 4) break;                                                         \
+        *reinterpret_cast<uint2*>(p_) = make_uint2(H0, h1_);                                      \
+        *reinterpret_cast<uint2*>(p_ + 64) = make_uint2(M0, m1_);                                 \
+        *reinterpret_cast<uint2*>(p_ + 128) = make_uint2(L0, l1_);                                \
+    } while (0)
 
     if (kt_begin < kt_end) {
         const int last = kt_end - 1;
         ASet SA, SB;        // SA: the K-tile being staged; SB: the one in flight behind it
         KTile tl = kt_decode(kt_begin);     // decode of the K-tile the next issue_loads takes
-        dma_b(tl, 0, 0, B_IPW);
+        dma_b(tl, 0, 0);
+        if (RUN1 > 0) dma_b(tl, 0, 1);
         issue_loads(tl, SA);
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) stage_row(SA, 0, i);
+        for (int i = 0; i < A_ROWS; ++i) {
+            float z, w;
+            unsigned h0, m0_, l0;
+            BF_STAGE_A(SA, i, z, w, h0, m0_, l0);
+            BF_STAGE_B(0, i, z, w, h0, m0_, l0);
+        }
         KTile td = tl;                      // decode of the K-tile the next dma_b takes
         tl = kt_next(tl, kt_begin + 1 <= last);
         td = tl;
@@ -438,6 +479,7 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
             };
             // one product over the wave's blocks (consecutive MFMAs go to different accumulators); products smallest first
             auto group = [&](int kc, int t) {
+                if (SSC_BF_DIAG_BUILD & 1) return;
                 constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
                 for (int i = 0; i < SM; ++i)
@@ -457,27 +499,32 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
             fetch_a(0);
             fetch_b(0);
             BF_SB;
-            group(0, 0); dma_b(td, cur ^ 1, 0, B_IPW / 2); BF_SB;
-            group(0, 1); dma_b(td, cur ^ 1, B_IPW / 2, B_IPW); BF_SB;
+            float z0, w0, z1, w1;
+            unsigned ha, ma, la, hb, mb, lb;
+            group(0, 0); dma_b(td, cur ^ 1, 0); BF_SB;
+            group(0, 1); if (RUN1 > 0) dma_b(td, cur ^ 1, 1); BF_SB;
             tl = kt_next(tl, kt + 2 <= last);
             group(0, 2); issue_loads(tl, SB); BF_SB;
             group(0, 3); fetch_a(1); BF_SB;
             group(0, 4); fetch_b(1); BF_SB;
-            group(0, 5); BF_SB;
             // K-tile kt+1: registers -> the LDS buffer nobody reads now
             if (A_ROWS == 2) {
-                group(1, 0); stage_row(SA, cur ^ 1, 0); BF_SB;
-                group(1, 1); BF_SB;
-                group(1, 2); stage_row(SA, cur ^ 1, 1); BF_SB;
+                group(0, 5); BF_STAGE_A(SA, 0, z0, w0, ha, ma, la); BF_SB;
+                group(1, 0); BF_STAGE_B(cur ^ 1, 0, z0, w0, ha, ma, la); BF_SB;
+                group(1, 1); BF_STAGE_A(SA, 1, z1, w1, hb, mb, lb); BF_SB;
+                group(1, 2); BF_STAGE_B(cur ^ 1, 1, z1, w1, hb, mb, lb); BF_SB;
                 group(1, 3); BF_SB;
+                group(1, 4); BF_SB;
+                group(1, 5); BF_SB;
             } else {
-                group(1, 0); stage_row(SA, cur ^ 1, 0); BF_SB;
-                group(1, 1); stage_row(SA, cur ^ 1, 1); BF_SB;
-                group(1, 2); stage_row(SA, cur ^ 1, 2); BF_SB;
-                group(1, 3); stage_row(SA, cur ^ 1, 3); BF_SB;
+                group(0, 5); BF_STAGE_A(SA, 0, z0, w0, ha, ma, la); BF_SB;
+                group(1, 0); BF_STAGE_B(cur ^ 1, 0, z0, w0, ha, ma, la); BF_STAGE_A(SA, 1, z1, w1, hb, mb, lb); BF_SB;
+                group(1, 1); BF_STAGE_B(cur ^ 1, 1, z1, w1, hb, mb, lb); BF_STAGE_A(SA, 2, z0, w0, ha, ma, la); BF_SB;
+                group(1, 2); BF_STAGE_B(cur ^ 1, 2, z0, w0, ha, ma, la); BF_STAGE_A(SA, 3, z1, w1, hb, mb, lb); BF_SB;
+                group(1, 3); BF_STAGE_B(cur ^ 1, 3, z1, w1, hb, mb, lb); BF_SB;
+                group(1, 4); BF_SB;
+                group(1, 5); BF_SB;
             }
-            group(1, 4); BF_SB;
-            group(1, 5); BF_SB;
 #undef BF_SB
             // everything issued in this step has landed: the DMA tile and this wave's ds_writes are in LDS (published by the
             // barrier), the loads of K-tile kt+2 are in registers and become the staged set
@@ -500,13 +547,43 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
 }
 
 #ifdef SSC_ISA_ONLY
-template __global__ void conv_bf_kernel<2, 2, 1, 2, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*);
-template __global__ void conv_bf_kernel<2, 2, 2, 2, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*);
+template __global__ void conv_bf_kernel<2, 2, 1, 2, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs);
+template __global__ void conv_bf_kernel<2, 2, 2, 2, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs);
 #else
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 void ssc_launch_slab_reduce(const float* ws, long out_count, int splitk, const ssc_conv_desc& d, hipStream_t st);     // igemm.hip
+
+// ones[4096] then zeros[4096] in device memory (per device): the norm "table" of a source that has none
+#define BF_IDENT_C 4096
+static const float* bf_identity_rows() {
+    static float* rows[16] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (rows[dev] == nullptr) {
+        float* p = nullptr;
+        if (hipMalloc(&p, 2 * BF_IDENT_C * sizeof(float)) != hipSuccess) return nullptr;
+        float* h = (float*)malloc(2 * BF_IDENT_C * sizeof(float));
+        for (int i = 0; i < BF_IDENT_C; ++i) { h[i] = 1.f; h[BF_IDENT_C + i] = 0.f; }
+        const hipError_t e = hipMemcpy(p, h, 2 * BF_IDENT_C * sizeof(float), hipMemcpyHostToDevice);
+        free(h);
+        if (e != hipSuccess) return nullptr;
+        rows[dev] = p;
+    }
+    return rows[dev];
+}
+extern "C" int ssc_bf16_prepare(void) { return bf_identity_rows() != nullptr ? 0 : -1; }
+
+static bool bf_tabs(const ssc_conv_desc& d, BfTabs& t) {
+    const float* id = bf_identity_rows();
+    if (id == nullptr || d.x.C0 > BF_IDENT_C || d.x.C1 > BF_IDENT_C) return false;
+    t.a0 = d.x.ab0 ? d.x.ab0 : id;
+    t.b0 = d.x.ab0 ? d.x.ab0 + d.x.C0 : id + BF_IDENT_C;
+    t.a1 = d.x.ab1 ? d.x.ab1 : id;
+    t.b1 = d.x.ab1 ? d.x.ab1 + d.x.C1 : id + BF_IDENT_C;
+    return true;
+}
 
 template <int WM, int WN, int SM, int SN, bool PLAIN>
 static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s, int64_t ws_bytes,
@@ -524,14 +601,22 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
         const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_bf_kernel<WM, WN, SM, SN, PLAIN>), (int)lds, &attr_done);
         if (arc != 0) return arc;
     }
+    BfTabs tab = {nullptr, nullptr, nullptr, nullptr};
+    if (!PLAIN && !bf_tabs(d, tab)) return -5;
     const int xflag = 0x10000 | ((xcd >= 2 && d.nphase == 4) ? 0x20000 : 0);
-    if (splitk == 1 && ws != nullptr && d.sk_flags != nullptr && ts_s > 1) {        // whole tiles + K slices combined in the launch
+    static int diag = -1;       // SSC_BF_DIAG bit 0: no in-launch K slices (plain tiles), bit 1: no XCD-aware order (diagnostics)
+    if (diag < 0) {
+        const char* e = getenv("SSC_BF_DIAG");
+        diag = e != nullptr ? atoi(e) : 0;
+    }
+    if (diag & 2) xcd = 0;
+    if (!(diag & 1) && splitk == 1 && ws != nullptr && d.sk_flags != nullptr && ts_s > 1) {        // whole tiles + K slices combined in the launch
         const long tiles = mt * nt * d.nphase;
         const long full = ts_full, tail = tiles - full, s = ts_s;
         if (full >= 0 && tail > 0 && (int64_t)tail * s * BM * BN * 4 <= ws_bytes && tail * s < SSC_SK_FLAG_WORDS - 1 &&
             full + tail * s < 0x7fffffffL) {
             hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg,
-                               ws, out_count, 1, (int)full, (int)s | ((xcd && (full & 7) == 0) ? xflag : 0), d.sk_flags);
+                               ws, out_count, 1, (int)full, (int)s | ((xcd && (full & 7) == 0) ? xflag : 0), d.sk_flags, tab);
             return (int)hipGetLastError();
         }
     }
@@ -540,13 +625,13 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
         const long full = tiles & ~7L;
         if (tiles < 0x7fffffffL && full > 0) {
             hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws,
-                               out_count, 1, (int)full, 1 | xflag, (unsigned*)nullptr);
+                               out_count, 1, (int)full, 1 | xflag, (unsigned*)nullptr, tab);
             return (int)hipGetLastError();
         }
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
     hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0,
-                       (unsigned*)nullptr);
+                       (unsigned*)nullptr, tab);
     if (splitk > 1) ssc_launch_slab_reduce(ws, out_count, splitk, d, st);
     return (int)hipGetLastError();
 }

@@ -262,84 +262,8 @@ __device__ __forceinline__ void ut_epilogue(f32x16 (&acc)[SM][SN], const ssc_con
                 if (col < Nst) {
                     const long blk = (long)phase * ((M + BM - 1) / BM) + m0 / BM;
                     float* sp = statw + blk * 2 * sbC;
-                    if (d.fin_cnt != nullptr) {     // other workgroups will read this row: 8-byte write-through stores
-                        st_agent2(sp + (col - cb), s.x, s.y);
-                        st_agent2(sp + (col - cb) + 2, s.z, s.w);
-                        st_agent2(sp + sbC + (col - cb), q.x, q.y);
-                        st_agent2(sp + sbC + (col - cb) + 2, q.z, q.w);
-                    } else {
-                        *reinterpret_cast<float4*>(sp + (col - cb)) = s;
-                        *reinterpret_cast<float4*>(sp + sbC + (col - cb)) = q;
-                    }
-                }
-            }
-            // In-launch fold of the batch statistics (ssc_conv_desc.fin_*): two levels of "the last one to arrive sums".  Rows
-            // travel write-through (above); a ticket is taken only after the row's stores have completed; the reader takes one
-            // agent-scope acquire after it saw the last ticket, then plain loads (MI355X guide, inter-workgroup visibility).
-            if (d.fin_cnt != nullptr && sbx == nullptr) {
-                int* const fl = reinterpret_cast<int*>(smem + BM * C_LD + 2 * 256 * 4);
-                const int mtiles = (int)((M + BM - 1) / BM);
-                const int nrows = mtiles * d.nphase;
-                const int gs = d.fin_gs, ngr = (nrows + gs - 1) / gs;
-                const int ctile = n0 / BN, ntile = (Nst + BN - 1) / BN;
-                const int blk = phase * mtiles + (int)(m0 / BM);
-                const int grp = blk / gs;
-                const int want = min(gs, nrows - grp * gs);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    const unsigned t = __hip_atomic_fetch_add(d.fin_cnt + grp * ntile + ctile, 1u, __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_AGENT);
-                    const int last = t == (unsigned)(want - 1);
-                    if (last) {
-                        __hip_atomic_store(d.fin_cnt + grp * ntile + ctile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    }
-                    fl[0] = last;
-                    fl[1] = 0;
-                }
-                __syncthreads();
-                if (fl[0]) {        // this workgroup saw the last row of its group: sum the group, column by column, in row order
-                    const int col = n0 + tid;
-                    if (tid < BN && col < Nst) {
-                        double ss = 0.0, qq = 0.0;
-                        const float* rp = stat + (long)grp * gs * 2 * Nst + col;
-                        for (int r = 0; r < want; ++r) {
-                            ss += (double)rp[(long)r * 2 * Nst];
-                            qq += (double)rp[(long)r * 2 * Nst + Nst];
-                        }
-                        st_agent_d(d.fin_grp + ((long)grp * 2 + 0) * Nst + col, ss);
-                        st_agent_d(d.fin_grp + ((long)grp * 2 + 1) * Nst + col, qq);
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (tid == 0) {
-                        const unsigned t2 = __hip_atomic_fetch_add(d.fin_cnt + ngr * ntile + ctile, 1u, __ATOMIC_RELAXED,
-                                                                   __HIP_MEMORY_SCOPE_AGENT);
-                        const int last2 = t2 == (unsigned)(ngr - 1);
-                        if (last2) {
-                            __hip_atomic_store(d.fin_cnt + ngr * ntile + ctile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        }
-                        fl[1] = last2;
-                    }
-                    __syncthreads();
-                    if (fl[1] && tid < BN && col < Nst) {      // the last group: sum the groups in order, fold (bn_stats_finalize_kernel)
-                        double ss = 0.0, qq = 0.0;
-                        for (int g = 0; g < ngr; ++g) {
-                            ss += d.fin_grp[((long)g * 2 + 0) * Nst + col];
-                            qq += d.fin_grp[((long)g * 2 + 1) * Nst + col];
-                        }
-                        const double mean = ss / (double)d.fin_M;
-                        double var = qq / (double)d.fin_M - mean * mean;
-                        if (var < 0.0) var = 0.0;
-                        const float rstd = (float)(1.0 / sqrt(var + (double)d.fin_eps));
-                        const float a = rstd * d.fin_scale[col];
-                        d.fin_ab[col] = a;
-                        d.fin_ab[Nst + col] = d.fin_offset[col] - (float)mean * a;
-                        d.fin_stats[col] = (float)mean;
-                        d.fin_stats[Nst + col] = rstd;
-                    }
+                    *reinterpret_cast<float4*>(sp + (col - cb)) = s;
+                    *reinterpret_cast<float4*>(sp + sbC + (col - cb)) = q;
                 }
             }
         }

@@ -68,22 +68,22 @@ __device__ __forceinline__ void gview_src(const ssc_gview& g, int c, const float
 __device__ __forceinline__ float act_slope(int act) {
     return act == SSC_ACT_RELU ? 0.f : (act == SSC_ACT_LRELU ? 0.2f : 1.f);
 }
-// Packed math: v_pk_fma_f32 / v_pk_mul_f32 do two lanes' worth per instruction, and every VALU cycle here is taken from
-// the matrix pipe, so the transform is written on float2 halves (10 instead of 16 vector instructions per float4).
+// NO packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in kernels that issue fp32 MFMAs: measured on MI355X
+// (scripts/mfma_mix_probe.py, round 5), a wave that mixes v_mfma_f32_32x32x2_f32 with packed-fp32 vector instructions computes
+// WRONG values (errors of whole product terms) while another wave on the same SIMD issues v_mfma_f32_32x32x16_bf16 -- i.e. as
+// soon as a bf16-split conv launch of another stream shares a CU with the filter-gradient kernel.  The transform is therefore
+// written on scalars, and the library is compiled with -fno-slp-vectorize (build.py) so that the compiler does not pack it again.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 xform4(float4 v, const float4& a, const float4& b, float slope, float m) {
-    const f32x2_t s2 = {slope, slope}, m2 = {m, m};
-    f32x2_t t0 = __builtin_elementwise_fma((f32x2_t){a.x, a.y}, (f32x2_t){v.x, v.y}, (f32x2_t){b.x, b.y});
-    f32x2_t t1 = __builtin_elementwise_fma((f32x2_t){a.z, a.w}, (f32x2_t){v.z, v.w}, (f32x2_t){b.z, b.w});
-    const f32x2_t u0 = t0 * s2, u1 = t1 * s2;
-    t0 = __builtin_elementwise_max(t0, u0) * m2;
-    t1 = __builtin_elementwise_max(t1, u1) * m2;
-    return make_float4(t0.x, t0.y, t1.x, t1.y);
+    float t;
+    t = fmaf(a.x, v.x, b.x); v.x = fmaxf(t, t * slope) * m;
+    t = fmaf(a.y, v.y, b.y); v.y = fmaxf(t, t * slope) * m;
+    t = fmaf(a.z, v.z, b.z); v.z = fmaxf(t, t * slope) * m;
+    t = fmaf(a.w, v.w, b.w); v.w = fmaxf(t, t * slope) * m;
+    return v;
 }
 __device__ __forceinline__ float4 mask4(float4 v, float m) {
-    const f32x2_t m2 = {m, m};
-    const f32x2_t r0 = (f32x2_t){v.x, v.y} * m2, r1 = (f32x2_t){v.z, v.w} * m2;
-    return make_float4(r0.x, r0.y, r1.x, r1.y);
+    return make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
 }
 
 // One LDS-DMA instruction: 16 bytes per lane from sbase (wave-uniform) + voff straight into LDS at lds_addr + 16 * lane.

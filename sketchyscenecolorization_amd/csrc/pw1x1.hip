@@ -183,7 +183,7 @@ extern "C" int ssc_conv_pw1x1_supported(const ssc_conv_desc* dp) {
         return 0;
     const long M = (long)d.NB * d.PH * d.PW;
     if (M < 2048 || M >= 0x7fffffffL) return 0;
-    if (d.sb_x != nullptr || d.fin_cnt != nullptr || d.stat_mode != 0) return 0;
+    if (d.sb_x != nullptr || d.stat_mode != 0) return 0;
     return 1;
 }
 

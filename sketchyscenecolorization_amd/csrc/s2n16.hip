@@ -207,7 +207,7 @@ extern "C" int ssc_conv_s2n16_supported(const ssc_conv_desc* dp) {
         return 0;
     const long M = (long)d.NB * d.PH * d.PW;
     if (M < 32768 || M >= 0x7fffffffL / 64) return 0;
-    if (d.sb2_x != nullptr || d.fin_cnt != nullptr || d.stat_mode != 0) return 0;
+    if (d.sb2_x != nullptr || d.stat_mode != 0) return 0;
     return 1;
 }
 

@@ -191,7 +191,7 @@ extern "C" int ssc_conv_tr4n16_supported(const ssc_conv_desc* dp) {
         return 0;
     if (d.x.act != SSC_ACT_NONE && d.x.act != SSC_ACT_RELU && d.x.act != SSC_ACT_LRELU) return 0;
     if (d.x.act1 > SSC_ACT_LRELU) return 0;
-    if (d.sb_x != nullptr || d.sb2_x != nullptr || d.fin_cnt != nullptr || d.stat_mode != 0) return 0;
+    if (d.sb_x != nullptr || d.sb2_x != nullptr || d.stat_mode != 0) return 0;
     const long M = (long)d.NB * d.PH * d.PW;
     if (M < 16384 || M >= 0x7fffffffL / 64) return 0;
     return 1;

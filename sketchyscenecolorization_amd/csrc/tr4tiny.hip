@@ -118,7 +118,7 @@ extern "C" int ssc_conv_tr4_tiny_supported(const ssc_conv_desc* dp) {
     if ((reinterpret_cast<uintptr_t>(d.x.s0) & 15) != 0 || (d.x.ab0 != nullptr && (reinterpret_cast<uintptr_t>(d.x.ab0) & 15) != 0))
         return 0;
     if (d.x.act != SSC_ACT_NONE && d.x.act != SSC_ACT_RELU && d.x.act != SSC_ACT_LRELU) return 0;
-    if (d.sb_x != nullptr || d.sb2_x != nullptr || d.fin_cnt != nullptr || d.stat_mode != 0) return 0;
+    if (d.sb_x != nullptr || d.sb2_x != nullptr || d.stat_mode != 0) return 0;
     const long npix = (long)d.NB * d.PH * d.PW;
     if (npix < 1 || (npix + 255) / 256 >= 0x7fffffffL) return 0;
     return 1;

@@ -24,7 +24,6 @@
 #include "sketchycolor_hip.h"
 #include "igemm_util.h"
 #include "host_util.h"
-#include "bn_bwd.h"
 #include <type_traits>
 
 #ifndef SSC_WG128_BK
@@ -33,14 +32,7 @@
 #define BK SSC_WG128_BK
 #define NP (BK / 8)      // 16-byte pieces of a staged tile per thread
 #define KPB (256 / BK)   // K steps per block of the pixel table
-#ifndef SSC_WG128_DEEP
-#define SSC_WG128_DEEP 0        // 1: dense tiles two K steps ahead (ring of 3 LDS buffers), gathered tiles three ahead (two
-                                // register sets): 88 KB of LDS, one workgroup per CU (dense side by DMA only).  Measured
-                                // (encoder_3's filter gradient, one workgroup per CU either way): 112.9 vs 113.0 TFLOP/s, at
-                                // 8x the batch 121.8 vs 126.6 with two per CU -- memory latency is NOT what the K step waits
-                                // for (the cycle-stamp build's "counted wait" share was its own perturbation); off
-#endif
-#define NBB (SSC_WG128_DEEP ? 3 : 2)    // LDS buffers of the dense side
+#define NBB 2           // LDS buffers of the dense side
 #define TB 128          // tile edge (both sides)
 
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -73,13 +65,12 @@ __device__ __forceinline__ float4 bload16(__amdgpu_buffer_rsrc_t r, unsigned vof
 
 // act(a*v+b) without a mask (dense side: rows beyond the last pixel meet zeros on the gathered side)
 __device__ __forceinline__ float4 xform4_nomask(float4 v, const float4& a, const float4& b, float slope) {
-    const f32x2_t s2 = {slope, slope};
-    f32x2_t t0 = __builtin_elementwise_fma((f32x2_t){a.x, a.y}, (f32x2_t){v.x, v.y}, (f32x2_t){b.x, b.y});
-    f32x2_t t1 = __builtin_elementwise_fma((f32x2_t){a.z, a.w}, (f32x2_t){v.z, v.w}, (f32x2_t){b.z, b.w});
-    const f32x2_t u0 = t0 * s2, u1 = t1 * s2;
-    t0 = __builtin_elementwise_max(t0, u0);
-    t1 = __builtin_elementwise_max(t1, u1);
-    return make_float4(t0.x, t0.y, t1.x, t1.y);
+    float t;        // scalar on purpose: no packed fp32 math beside fp32 MFMAs (igemm_util.h)
+    t = fmaf(a.x, v.x, b.x); v.x = fmaxf(t, t * slope);
+    t = fmaf(a.y, v.y, b.y); v.y = fmaxf(t, t * slope);
+    t = fmaf(a.z, v.z, b.z); v.z = fmaxf(t, t * slope);
+    t = fmaf(a.w, v.w, b.w); v.w = fmaxf(t, t * slope);
+    return v;
 }
 
 // GPLAIN: the gathered side has no folded norm / activation.  DMODE: dense side 0 = plain by LDS-DMA, 1 = plain through
@@ -87,12 +78,7 @@ __device__ __forceinline__ float4 xform4_nomask(float4 v, const float4& a, const
 template <bool GPLAIN, int DMODE, int TPT>
 __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(const ssc_wgrad_desc d, const Magics mg,
                                                                 float* __restrict__ slab_base, long slab_stride, int splitk,
-                                                                int xcd, const BnApplySide side) {
-    // side job (bn_bwd.h): the first side.blocks workgroups stream the apply pass of a norm backward and leave
-    if ((int)blockIdx.x < side.blocks) {
-        bn_bwd_apply_blocks(side.a, side.coef, side.dx, side.lddx, (int)blockIdx.x, side.blocks);
-        return;
-    }
+                                                                int xcd) {
     constexpr int T_SZ = BK * TB;          // floats per operand tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                      // [2][BK][TB]  gathered side, [pixel][column]
@@ -113,12 +99,12 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(co
     // workgroup -> (row tile, column tile, K slice).  All tiles of a K slice read the same pixels; dealt round robin to the 8
     // XCDs (id % 8) each L2 fetches every slice.  xcd (host flag, grid a multiple of 8): ids with the same id % 8 walk a
     // contiguous run of (row tile, column tile, slice) order -- whole slices per XCD.
-    // (1-D grid: side blocks first -- a multiple of 8, so id % 8 is still the XCD --, then row tile fastest, column tile, slice)
+    // (1-D grid: row tile fastest, column tile, slice)
     int mt_i, nt_i, ks;
     {
         const unsigned gx = (unsigned)((Mtot + TB - 1) / TB), gy = (unsigned)((d.Nn + TB - 1) / TB);
         const unsigned per_slice = gx * gy, total = per_slice * (unsigned)splitk;
-        const unsigned lin = blockIdx.x - (unsigned)side.blocks;
+        const unsigned lin = blockIdx.x;
         const unsigned t2 = xcd ? (lin & 7u) * (total >> 3) + (lin >> 3) : lin;
         ks = (int)(t2 / per_slice);
         const unsigned r = t2 - (unsigned)ks * per_slice;
@@ -264,85 +250,6 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_wgrad128_kernel(co
                 (DMODE == 2) ? xform4_nomask(rb[s], ba, bb, d_slope) : rb[s];
     };
 
-#if SSC_WG128_DEEP
-    // ---- deep-prefetch form (DMODE 0): at step j the registers of K-tile j + 1 (loaded at step j - 2) go to LDS, the dense tile
-    // of K-tile j + 2 starts its DMA into the ring, the gathered loads of K-tile j + 3 refill the registers just drained ----
-    float4 ra2[2][NP];
-    float ram2[2][NP];
-    auto load_a2 = [&](int j, int set, int s) {
-        ra2[set][s] = bload16(rsA, (unsigned)pe[s].x + a_cb);
-        ram2[set][s] = __builtin_bit_cast(float, pe[s].y);
-    };
-    auto stage_a2 = [&](int buf, int set, int s) {
-        *reinterpret_cast<float4*>(As + buf * T_SZ + (a_r + 8 * s) * TB + a_q * 4) =
-            GPLAIN ? ra2[set][s] : xform4(ra2[set][s], aa, ab, g_slope, ram2[set][s]);
-    };
-    if (nk > 0 && DMODE == 0) {
-        fill_ptab(0);
-#pragma unroll
-        for (int s = 0; s < NP; ++s) dma_b_piece(0, 0, s);
-#pragma unroll
-        for (int s = 0; s < NP; ++s) dma_b_piece(1, 1, s);
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < NP; ++s) { ptab_piece(0, s); load_a2(0, 0, s); }
-#pragma unroll
-        for (int s = 0; s < NP; ++s) { ptab_piece(1, s); load_a2(1, 1, s); }
-#pragma unroll
-        for (int s = 0; s < NP; ++s) stage_a2(0, 0, s);
-#pragma unroll
-        for (int s = 0; s < NP; ++s) { ptab_piece(2, s); load_a2(2, 0, s); }
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP) : "memory");      // both dense tiles have landed (older than the 2 NP loads)
-        __syncthreads();
-        const float* a_rd = As + lhi * TB + wm * 64 + 2 * l31;
-        const float* b_rd = Bs + lhi * TB + wn * 64 + 2 * l31;
-        int ring = 0;       // j % 3
-        auto body = [&](int j, auto PAR) {
-            constexpr int P = decltype(PAR)::value;         // j & 1
-            const float* Ab = a_rd + P * T_SZ;
-            const float* Bb = b_rd + ring * T_SZ;
-            const int ring2 = ring == 0 ? 2 : ring - 1;     // (j + 2) % 3
-            if ((j % KPB) == KPB / 2 - 1) fill_ptab(j / KPB + 1);
-            constexpr int NG = BK / 2, PF = 4;
-            f32x2v av[8], bv[8];
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                av[q] = *reinterpret_cast<const f32x2v*>(Ab + q * 2 * TB);
-                bv[q] = *reinterpret_cast<const f32x2v*>(Bb + q * 2 * TB);
-            }
-#pragma unroll
-            for (int q = 0; q < NG; ++q) {
-                if (q + PF < NG) {
-                    av[(q + PF) & 7] = *reinterpret_cast<const f32x2v*>(Ab + (q + PF) * 2 * TB);
-                    bv[(q + PF) & 7] = *reinterpret_cast<const f32x2v*>(Bb + (q + PF) * 2 * TB);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 7][i], bv[q & 7][jj], acc[i][jj], 0, 0, 0);
-                if (q < NP) {
-                    stage_a2(P ^ 1, P ^ 1, q);                      // K-tile j + 1 (set (j + 1) & 1) -> As[(j + 1) & 1]
-                } else if (q < 2 * NP) {
-                    dma_b_piece(j + 2, ring2, q - NP);
-                    ptab_piece(j + 3, q - NP);
-                } else if (q < 3 * NP) {
-                    load_a2(j + 3, P ^ 1, q - 2 * NP);              // the set just drained
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // the dense tile of K-tile j + 1 (its DMA was issued a whole step ago) has landed: younger than it are the loads of
-            // K-tile j + 2, the DMA of K-tile j + 2 and the loads of K-tile j + 3
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * NP) : "memory");
-            __builtin_amdgcn_s_barrier();
-            ring = ring == 2 ? 0 : ring + 1;
-        };
-        for (int j = 0; j < nk; j += 2) {
-            body(j, std::integral_constant<int, 0>());
-            if (j + 1 < nk) body(j + 1, std::integral_constant<int, 1>());
-        }
-    } else
-#endif
     if (nk > 0) {
         fill_ptab(0);
         if (DMODE == 0) {
@@ -538,7 +445,7 @@ static int wg128_splitk(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws)
 void ssc_launch_wgrad_reduce(const float* ws, long count, int splitk, float* out, int accumulate, hipStream_t st);   // igemm.hip
 
 template <bool GPLAIN, int DMODE, int TPT>
-static int launch_wg128(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st, const BnApplySide& side) {
+static int launch_wg128(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
     constexpr size_t lds = (2 + NBB) * BK * TB * sizeof(float) + 2 * TPT * 256 * sizeof(int2);
     const int Cg = d.g.C0 + d.g.C1;
     const long Mtot = (long)d.TH * d.TW * Cg;
@@ -557,23 +464,23 @@ static int launch_wg128(const ssc_wgrad_desc& d, int splitk, float* ws, hipStrea
         xcd_on = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     const int xcd = (xcd_on && splitk > 1 && (wgs & 7) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((conv_wgrad128_kernel<GPLAIN, DMODE, TPT>), dim3((unsigned)(wgs + side.blocks)), dim3(256), lds, st, d, mg,
-                       ws, out_count, splitk, xcd, side);
+    hipLaunchKernelGGL((conv_wgrad128_kernel<GPLAIN, DMODE, TPT>), dim3((unsigned)wgs), dim3(256), lds, st, d, mg,
+                       ws, out_count, splitk, xcd);
     if (splitk > 1) ssc_launch_wgrad_reduce(ws, out_count, splitk, d.out, d.accumulate, st);
     return (int)hipGetLastError();
 }
 
 template <int TPT>
-static int launch_wg128_t(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st, const BnApplySide& side) {
+static int launch_wg128_t(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
     const bool gp = view_plain(d.g), dp = view_plain(d.d);
     static int dma = -1;        // SSC_WGRAD_DMA=0: plain dense tiles through registers (A/B)
     if (dma < 0) {
         const char* e = getenv("SSC_WGRAD_DMA");
         dma = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
-    if (dp && dma) return gp ? launch_wg128<true, 0, TPT>(d, splitk, ws, st, side) : launch_wg128<false, 0, TPT>(d, splitk, ws, st, side);
-    if (dp) return gp ? launch_wg128<true, 1, TPT>(d, splitk, ws, st, side) : launch_wg128<false, 1, TPT>(d, splitk, ws, st, side);
-    return gp ? launch_wg128<true, 2, TPT>(d, splitk, ws, st, side) : launch_wg128<false, 2, TPT>(d, splitk, ws, st, side);
+    if (dp && dma) return gp ? launch_wg128<true, 0, TPT>(d, splitk, ws, st) : launch_wg128<false, 0, TPT>(d, splitk, ws, st);
+    if (dp) return gp ? launch_wg128<true, 1, TPT>(d, splitk, ws, st) : launch_wg128<false, 1, TPT>(d, splitk, ws, st);
+    return gp ? launch_wg128<true, 2, TPT>(d, splitk, ws, st) : launch_wg128<false, 2, TPT>(d, splitk, ws, st);
 }
 
 #ifdef SSC_WG128_TIMING
@@ -586,17 +493,9 @@ extern "C" int ssc_wg128_timing(unsigned long long* out8, int reset) {
 }
 #endif
 
-// job != NULL: the launch also carries the apply pass of that norm backward (ssc_conv_wgrad_hosting)
-int ssc_conv_wgrad128_job(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, const ssc_bn_apply_job* job, void* stream) {
+extern "C" int ssc_conv_wgrad128(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream) {
     const ssc_wgrad_desc& d = *dp;
     if (!ssc_conv_wgrad128_supported(dp)) return -10;
-    if (job != nullptr && !bn_job_ok(*job)) return -11;
     const int sk = wg128_splitk(d, ws_bytes, ws != nullptr);
-    const BnApplySide side = job != nullptr ? bn_side_of(*job, wg128_num_cu()) : bn_side_none();
-    return wg128_tpt(d) == 2 ? launch_wg128_t<2>(d, sk, ws, (hipStream_t)stream, side)
-                             : launch_wg128_t<1>(d, sk, ws, (hipStream_t)stream, side);
-}
-
-extern "C" int ssc_conv_wgrad128(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream) {
-    return ssc_conv_wgrad128_job(dp, ws, ws_bytes, nullptr, stream);
+    return wg128_tpt(d) == 2 ? launch_wg128_t<2>(d, sk, ws, (hipStream_t)stream) : launch_wg128_t<1>(d, sk, ws, (hipStream_t)stream);
 }

@@ -37,10 +37,8 @@ class ConvDesc(C.Structure):
                 ('sb_act', C.c_int32), ('sk_tag', C.c_int32), ('sb2_col0', C.c_int32),
                 ('sb2_x', C.c_void_p), ('sb2_ab', C.c_void_p), ('sb2_stats', C.c_void_p), ('stat_partial2', C.c_void_p),
                 ('sb2_ldx', C.c_int32), ('sb2_act', C.c_int32),
-                ('fin_cnt', C.c_void_p), ('fin_grp', C.c_void_p), ('fin_scale', C.c_void_p), ('fin_offset', C.c_void_p),
-                ('fin_ab', C.c_void_p), ('fin_stats', C.c_void_p), ('fin_M', C.c_int64), ('fin_eps', C.c_float),
-                ('fin_gs', C.c_int32), ('stat_mode', C.c_int32), ('_pad1', C.c_int32),
-                ('wsplit', C.c_void_p), ('ws_kc', C.c_int32), ('ws_nbp', C.c_int32)]
+                ('stat_mode', C.c_int32), ('ws_kc', C.c_int32),
+                ('wsplit', C.c_void_p), ('ws_nbp', C.c_int32), ('_pad1', C.c_int32)]
 
 
 class SplitJob(C.Structure):
@@ -121,6 +119,7 @@ SIGNATURES = {
     'ssc_filter_split_geom': [_I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     'ssc_filter_split': [_P, _I, _I, _I, _I, _P, _P],
     'ssc_filter_split_batch': [_P, _I, _L, _P],
+    'ssc_bf16_prepare': [],
     'ssc_conv_wgrad': [C.POINTER(WgradDesc), _P, _L, _P],
     'ssc_conv_wgrad128_supported': [C.POINTER(WgradDesc)],
     'ssc_conv_wgn16_supported': [C.POINTER(WgradDesc)],
@@ -145,7 +144,6 @@ SIGNATURES = {
     'ssc_block_out_backward': [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     'ssc_bn_bwd_sums': [C.POINTER(BnApplyJob), _P, _I, _P, _P, _P, _P, _L, _P],
     'ssc_bn_bwd_apply': [C.POINTER(BnApplyJob), _P],
-    'ssc_conv_wgrad_hosting': [C.POINTER(WgradDesc), _P, _L, C.POINTER(BnApplyJob), _P],
     'ssc_conv_narrow_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_narrow_forward': [C.POINTER(ConvDesc), _P],
     'ssc_conv_fewchan_supported': [C.POINTER(ConvDesc)],
@@ -155,7 +153,6 @@ SIGNATURES = {
     'ssc_conv_tr4n16_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_fewchan7_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_tr4_tiny_supported': [C.POINTER(ConvDesc)],
-    'ssc_conv_tr4_mfma_supported': [C.POINTER(ConvDesc)],
     'ssc_conv_forward_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, _I],
     'ssc_conv_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, _I],
     'ssc_conv_forward_plan': [C.POINTER(ConvDesc), _L, C.POINTER(C.c_int)],
@@ -334,10 +331,9 @@ def _kernel_name(fn, d):
 
 
 SK_FLAG_WORDS = 8192
-FIN_CNT_WORDS = 8192    # counters of the in-launch statistics fold, behind the hand-off flags (SSC_FIN_CNT_WORDS)
 _SK_MAX_STREAMS = 32
 _sk_flags = {}
-_sk_pool = {}           # device -> [_SK_MAX_STREAMS, SK_FLAG_WORDS + FIN_CNT_WORDS] int32: every stream's flag array is a row of it
+_sk_pool = {}           # device -> [_SK_MAX_STREAMS, SK_FLAG_WORDS] int32: every stream's flag array is a row of it
 _sk_tags = {}           # sk_tag -> copy of the descriptor of that launch
 _sk_eager = []          # tags of launches issued eagerly, oldest first: only the last _SK_TAG_RING of them are remembered
 _sk_next = [0]          # tags only grow (31 bits: the flag word is 0x80000000 | tag), so a tag frozen into a captured graph
@@ -370,10 +366,10 @@ def sk_flags():
         _sk_configure()
         pool = _sk_pool.get(dev)
         if pool is None:
-            pool = _sk_pool[dev] = torch.zeros((_SK_MAX_STREAMS, SK_FLAG_WORDS + FIN_CNT_WORDS), dtype=torch.int32, device='cuda')
+            pool = _sk_pool[dev] = torch.zeros((_SK_MAX_STREAMS, SK_FLAG_WORDS), dtype=torch.int32, device='cuda')
         n = sum(1 for k in _sk_flags if k[0] == dev)
         # beyond the pool (never seen: a trainer uses five streams) a stream gets an array of its own
-        f = pool[n] if n < _SK_MAX_STREAMS else torch.zeros(SK_FLAG_WORDS + FIN_CNT_WORDS, dtype=torch.int32, device='cuda')
+        f = pool[n] if n < _SK_MAX_STREAMS else torch.zeros(SK_FLAG_WORDS, dtype=torch.int32, device='cuda')
         _sk_flags[key] = f
     return f
 
@@ -442,11 +438,31 @@ def check_sk(where=''):
 ARITH_BF16 = os.environ.get('SSC_ARITH', 'bf16x6').lower() not in ('fp32', 'f32', 'float32')
 _SPLITS = {}            # (data_ptr, taps, c0, c1, orient) -> _Split; the entry keeps the filter tensor alive (its address stays taken)
 _SPLIT_TABLES = {}      # tuple of keys -> (device job table, total threads)
-_SPLITS_MAX = 512
+_PARAM_RANGES = []      # [lo, hi) byte ranges of the flat parameter buffers (ParamStore scopes): filters inside them are PARAMETERS
+_VOLATILE_MAX = 256     # entries of filters that are not parameters (see filter_split)
+_SPLIT_ALWAYS = os.environ.get('SSC_SPLIT_ALWAYS', '0') == '1'      # diagnostic: every filter treated as volatile
 
 
 class _Split(object):
-    __slots__ = ('key', 'w', 'buf', 'kc', 'nbp', 'threads', 'version', 'taps', 'c0', 'c1', 'orient')
+    __slots__ = ('key', 'w', 'buf', 'kc', 'nbp', 'threads', 'version', 'taps', 'c0', 'c1', 'orient', 'param')
+
+
+def register_param_buffer(flat):
+    """A flat parameter buffer (ParamStore scope): filters that are views of it keep PERSISTENT bf16 planes, refreshed by
+    refresh_splits() behind every optimizer launch.  Returns the range for release_param_buffer."""
+    rng = (flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size())
+    _PARAM_RANGES.append(rng)
+    return rng
+
+
+def release_param_buffer(rng):
+    """Forget a parameter buffer and the planes of its filters (called when its scope is collected)."""
+    if rng in _PARAM_RANGES:
+        _PARAM_RANGES.remove(rng)
+    for k in [k for k in _SPLITS if rng[0] <= k[0] < rng[1]]:
+        del _SPLITS[k]
+    for tk in [tk for tk in _SPLIT_TABLES if any(rng[0] <= k[0] < rng[1] for k in tk)]:
+        del _SPLIT_TABLES[tk]
 
 
 def _split_launch(e):
@@ -454,25 +470,48 @@ def _split_launch(e):
 
 
 def filter_split(w, orient):
-    """The bf16 planes of filter w [KH,KW,c0,c1] in orientation ``orient`` (0: k = c0, n = c1; 1: k = c1, n = c0), split now if
-    they do not exist or torch has modified the tensor since."""
+    """The bf16 planes of filter w [KH,KW,c0,c1] in orientation ``orient`` (0: k = c0, n = c1; 1: k = c1, n = c0).
+    * A PARAMETER (a view of a registered flat buffer) keeps its planes: split at first use, again when torch modifies the
+      tensor (version counter), and by refresh_splits() behind the optimizer launches, which torch does not see.
+    * Any other filter -- spectral-normed weights, transposed copies, whatever a kernel writes each forward pass; a test's
+      tensor -- is VOLATILE: nobody can tell when its contents change, so it is split again in front of EVERY launch, on the
+      launch's stream."""
     KH, KW, c0, c1 = w.shape
     key = (w.data_ptr(), KH * KW, c0, c1, orient)
     e = _SPLITS.get(key)
     if e is None:
-        if len(_SPLITS) >= _SPLITS_MAX:
-            _SPLITS.clear()
-            _SPLIT_TABLES.clear()
+        if not _SPLITS:
+            check(lib().ssc_bf16_prepare(), 'ssc_bf16_prepare')     # per-device constants, outside any capture
         kc, nbp, nbytes, threads = C.c_int(0), C.c_int(0), C.c_int64(0), C.c_int64(0)
         check(lib().ssc_filter_split_geom(KH * KW, c0, c1, orient, C.byref(kc), C.byref(nbp), C.byref(nbytes), C.byref(threads)),
               'ssc_filter_split_geom')
         e = _Split()
         e.key, e.w, e.kc, e.nbp, e.threads, e.version = key, w, kc.value, nbp.value, threads.value, None
         e.taps, e.c0, e.c1, e.orient = KH * KW, c0, c1, orient
+        e.param = (not _SPLIT_ALWAYS) and any(lo <= key[0] < hi for lo, hi in _PARAM_RANGES)
         e.buf = torch.empty(nbytes.value, dtype=torch.uint8, device=w.device)
+        if not e.param:
+            vol = [k for k, v in _SPLITS.items() if not v.param]
+            if len(vol) >= _VOLATILE_MAX and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize()        # nothing in flight reads the planes about to be dropped
+                for k in vol[:_VOLATILE_MAX // 2]:
+                    del _SPLITS[k]
         _SPLITS[key] = e
-    if e.version != w._version:
+    if not e.param:
         _split_launch(e)
+        return e
+    if e.version != w._version:
+        # A lazy split happens on whatever stream meets the filter first, while the trainers read one filter from several
+        # streams (run-ahead forward, caption stream, the two discriminator passes): outside a capture the split is therefore
+        # made visible to EVERY stream before anybody can use the entry -- the device drains in front of it (nobody still
+        # reads the old planes) and behind it.  This is a first-use / weights-replaced-through-torch event, not a per-step one
+        # (the optimizer path is refresh_splits, ordered by the stream that ran the optimizer).
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            torch.cuda.synchronize()
+        _split_launch(e)
+        if not capturing:
+            torch.cuda.synchronize()
         e.version = w._version
     return e
 
@@ -484,9 +523,9 @@ def refresh_splits(flat=None):
         return
     if flat is not None:
         lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
-        es = [e for e in _SPLITS.values() if lo <= e.key[0] < hi]
+        es = [e for e in _SPLITS.values() if e.param and lo <= e.key[0] < hi]
     else:
-        es = list(_SPLITS.values())
+        es = [e for e in _SPLITS.values() if e.param]
     if not es:
         return
     tk = tuple(e.key for e in es)
@@ -614,28 +653,8 @@ def _run_conv(d, bn=None, bnbwd=None, minmax=None):
                     (d.NB * d.PH * d.PW * d.nphase, d.Nn, d.TH * d.TW * d.k_real), nbytes))
 
 
-def _run_wgrad(d, side=False, host=None):
-    """host: a pending norm-backward apply pass (bn_act_backward(..., defer=True)) that this launch carries as its side job."""
+def _run_wgrad(d, side=False):
     global _wgrad_pending
-    if host is not None:
-        assert not host.done
-        host.done = True
-        ws = workspace()
-        call_w = lambda: check(lib().ssc_conv_wgrad_hosting(C.byref(d), ptr(ws), ws.numel() * 4, C.byref(host.c), stream_ptr()),
-                               'ssc_conv_wgrad_hosting')
-        if PROFILE is None:
-            call_w()
-            return
-        flops = 2.0 * d.NB * d.PH * d.PW * d.TH * d.TW * d.Cg_real * d.Nn
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        call_w()
-        e1.record()
-        nbytes = 4.0 * (d.NB * d.g.H * d.g.W * (d.g.C0 + d.g.C1) + d.NB * d.PH * d.PW * (d.d.C0 + d.d.C1) +
-                        d.TH * d.TW * d.Cg_real * d.Nn * (2 if d.accumulate else 1))
-        PROFILE.append((_kernel_name('ssc_conv_wgrad_kernel_name', d), flops, e0, e1,
-                        (d.TH * d.TW * d.Cg_real, d.Nn, d.NB * d.PH * d.PW), nbytes))
-        return
     if side and WGRAD_STREAM is not None and PROFILE is None and \
             (WGRAD_SIDE_MAX_PIXELS is None or d.NB * d.PH * d.PW <= WGRAD_SIDE_MAX_PIXELS):
         WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
@@ -814,9 +833,8 @@ def deconv_dgrad(dy, f, out, n_off=0, nn=None, accumulate=False, bnbwd=None):
     _run_conv(d, bnbwd=bnbwd)
 
 
-def conv_wgrad(x, dy, w_grad, stride, pad, accumulate=False, host=None):
-    """dW[kh,kw,ci,co] = sum_pix x[pix@tap][ci] * dy[pix][co]  (w_grad in the conv's TF layout).
-    host: a deferred norm-backward apply pass (ApplyJob) carried inside this launch."""
+def conv_wgrad(x, dy, w_grad, stride, pad, accumulate=False):
+    """dW[kh,kw,ci,co] = sum_pix x[pix@tap][ci] * dy[pix][co]  (w_grad in the conv's TF layout)."""
     KH, KW, ci, co = w_grad.shape
     d = WgradDesc()
     d.g, d.d = x.c(), dy.c()
@@ -825,10 +843,10 @@ def conv_wgrad(x, dy, w_grad, stride, pad, accumulate=False, host=None):
     d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = KH, KW, stride, -pad, -pad
     d.Cg_real, d.Nn, d.ldc, d.accumulate = ci, co, co, int(accumulate)
     assert ci <= x.C and co <= dy.C
-    _run_wgrad(d, side=True, host=host)
+    _run_wgrad(d, side=True)
 
 
-def deconv_wgrad(x, dy, f_grad, accumulate=False, host=None):
+def deconv_wgrad(x, dy, f_grad, accumulate=False):
     """dF[kh,kw,co,ci] = sum_pix dy[pix@tap][co] * x[pix][ci]  (f_grad in the transposed-conv TF layout)."""
     KH, KW, co, ci = f_grad.shape
     d = WgradDesc()
@@ -838,7 +856,7 @@ def deconv_wgrad(x, dy, f_grad, accumulate=False, host=None):
     d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = 4, 4, 2, -1, -1
     d.Cg_real, d.Nn, d.ldc, d.accumulate = co, ci, ci, int(accumulate)
     assert co <= dy.C and ci <= x.C      # ci < x.C: 3-channel tensors padded to 4 (BG region branch)
-    _run_wgrad(d, side=True, host=host)
+    _run_wgrad(d, side=True)
 
 
 def _mat_view(a, ab=None, act=ACT_NONE):
@@ -1035,19 +1053,17 @@ def bn_stats(x2d, scale, offset, ab, stats, eps=1e-5):
                              ptr(ws), ws.numel() * 4, stream_ptr()), 'bn_stats')
 
 
-SIDE_APPLY = os.environ.get('SSC_SIDE_APPLY', '0') == '1'    # norm-backward apply passes ride inside filter-gradient launches (off: no gain in the step)
 
 
 class ApplyJob(object):
-    """A norm backward whose sums are taken (coef written) and whose streaming apply pass is still to run: hand it to the
-    filter-gradient launch of the layer above (conv_wgrad / deconv_wgrad(..., host=job)) or run it with ``apply_now``."""
+    """A norm backward whose sums are taken (coef written) and whose streaming apply pass is still to run (``apply_now``)."""
 
     def __init__(self, c, keep):
         self.c, self.keep, self.done = c, keep, False
 
 
 def apply_now(job):
-    """The apply pass of a deferred norm backward as a launch of its own (nothing could host it)."""
+    """The apply pass of a deferred norm backward."""
     if job is not None and not job.done:
         job.done = True
         check(lib().ssc_bn_bwd_apply(C.byref(job.c), stream_ptr()), 'ssc_bn_bwd_apply')

@@ -292,6 +292,11 @@ class Scope(object):
         self.adam_t = 0
         self.p = OrderedDict((n, self.flat[o:o + k].view(s)) for n, (o, k, s) in self.offsets.items())
         self.g = OrderedDict((n, self.grad[o:o + k].view(s)) for n, (o, k, s) in self.offsets.items())
+        if self.flat.is_cuda:
+            # filters that are views of this buffer keep persistent bf16 planes (hip.filter_split), dropped with the scope
+            import weakref
+            from . import hip
+            weakref.finalize(self, hip.release_param_buffer, hip.register_param_buffer(self.flat))
 
     def names(self):
         return list(self.offsets.keys())

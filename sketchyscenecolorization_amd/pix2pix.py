@@ -22,9 +22,7 @@ def _rows(t):
 
 
 _MERGE_DDGRAD = os.environ.get('SSC_MERGE_DDGRAD', '1') == '1'
-_HOLD_FROM = int(os.environ.get('SSC_HOLD_FROM', '4'))       # decoder filter gradients from this layer on wait for the caption BPTT
 _DBWD_WGRAD_FIRST = os.environ.get('SSC_DBWD_WGRAD_FIRST', '1') == '1'   # discriminator backward: filter gradient of layer k in front of its data gradient (round-3 order; the round-4 order -- behind the data gradient and the sums' fold -- measured 0.3 ms slower per iteration on one box, profiles/r05_ab_envsets.txt)
-_DBWD_DEFER = os.environ.get('SSC_DBWD_DEFER', '0') == '1'     # discriminator norm backward as sums + a deferred apply job (1) or one call (0: 0.1 ms faster per iteration)
 _BNBWD2 = os.environ.get('SSC_BNBWD2', '1') == '1'      # norm-backward sums of both halves out of the merged launch's epilogue (A/B)
 
 
@@ -38,10 +36,6 @@ class Pix2PixGenerator(object):
         # (Backward only when no gradient section ends a graph segment in between: the fork must be joined inside it.)
         self.text_stream = None
         self.text_stream_bwd = None
-        # many towers (graph segments): the word half of the caption backward is started after the decoders' section has been
-        # handed over and joined after encoder_{text_join_after}'s backward, where its section goes out with encoder_5's
-        self.text_defer_stream = None
-        self.text_join_after = int(os.environ.get('SSC_TEXT_JOIN_AFTER', '4'))
         self.text = TextFusion(store, bufs)
 
     def forward(self, sketches, text, noise_vec, tag='g', out=None, out_coff=0):
@@ -165,18 +159,13 @@ class Pix2PixGenerator(object):
         sums_e = [None] * 6
         g_feat = g_noise = None
         hold = side_stream is not None and self.lstm_hybrid
-        # With a side stream the filter gradients of decoder_{_HOLD_FROM}.. are held back for the caption branch's BPTT (below);
-        # the others are launched in line, each HOSTING the streaming pass of the norm backward that follows its layer's data
-        # gradient (hip.ApplyJob): the pass needs the folded sums of that data gradient, the filter gradient needs neither.
-        inline_order = self.bn_stream is None and hip.SIDE_APPLY
         for k in (1, 2, 3, 4, 5):
             f = s['generator/decoder_%d/deconv/filter' % k]
             v = views[k]
             dyv = View(gcur)
-            wg = (lambda v=v, dyv=dyv, k=k, host=None:
-                  hip.deconv_wgrad(v, dyv, s.grad('generator/decoder_%d/deconv/filter' % k), host=host))
-            held_k = hold and (k >= _HOLD_FROM or not inline_order)
-            if held_k:
+            wg = (lambda v=v, dyv=dyv, k=k:
+                  hip.deconv_wgrad(v, dyv, s.grad('generator/decoder_%d/deconv/filter' % k)))
+            if hold:
                 held.append(wg)
             g0 = B.get(tag + '/gb/d%d_in0' % k, (N, v.H, v.W, v.C0))
             g1 = B.get(tag + '/gb/d%d_in1' % k, (N, v.H, v.W, v.C1))
@@ -206,27 +195,11 @@ class Pix2PixGenerator(object):
             else:
                 hip.deconv_dgrad(dyv, f, g0, n_off=0, nn=v.C0, bnbwd=(sums_d.take(ACT_RELU) if sums_d else None))
 
-            def rest(wg=wg, dyv=dyv, f=f, g1=g1, v=v, k=k, merged=merged, host=None, held_k=held_k):
+            def rest(wg=wg, dyv=dyv, f=f, g1=g1, v=v, k=k, merged=merged):
                 if not merged:
                     hip.deconv_dgrad(dyv, f, g1, n_off=v.C0, nn=v.C1, bnbwd=(sums_e[k].take(ACT_RELU) if sums_e[k] else None))
-                if not held_k:
-                    wg(host=host)
-            job = None
-            if inline_order:
-                if k < 5:
-                    g_skip[k] = g1
-                    src = d[k + 1]
-                    dx = B.get(tag + '/gb/dd%d' % (k + 1), src.shape)
-                    job = hip.bn_act_backward(_rows(src), abd[k + 1], std[k + 1], _rows(g0), ACT_RELU, _rows(dx),
-                                              dscale=s.grad('generator/decoder_%d/scale' % (k + 1)),
-                                              doffset=s.grad('generator/decoder_%d/offset' % (k + 1)), pre=sums_d, defer=True,
-                                              coef=B.get(tag + '/gb/coef_d%d' % (k + 1), (2 * src.shape[-1],)))
-                    gcur = dx
-                else:
-                    g_feat, g_noise = g0, g1
-                rest(host=(None if held_k else job))
-                hip.apply_now(job)      # its host was held back (or has no hosting kernel): a launch of its own
-                continue
+                if not hold:
+                    wg()
             forked = self._fork(rest)
             if k < 5:
                 g_skip[k] = g1          # through relu to encoder_k's output
@@ -261,18 +234,13 @@ class Pix2PixGenerator(object):
         text_pending = False
         if self.lstm_hybrid:
             tstream = self.text_stream_bwd if hip.PROFILE is None else None
-            dstream = self.text_defer_stream if (hip.PROFILE is None and tstream is None and on_section is not None) else None
-            dy5 = self.text.backward(ctx['tctx'], g_feat, side_stream=tstream, defer_words=dstream is not None)
+            dy5 = self.text.backward(ctx['tctx'], g_feat, side_stream=tstream)
             hip.mark(tag + '/bwd caption branch: last (main stream)')
             if held:
                 main.wait_stream(side_stream)
                 hip.mark(tag + '/bwd held decoder wgrads joined')
                 done('decoders')
-            deferred = False
-            if dstream is not None:
-                # (the decoders' section is on its way: a new graph segment has begun, the fork lives inside it)
-                deferred = self.text.run_deferred_words(dstream)
-            if tstream is None and not deferred:
+            if tstream is None:
                 done('text')
             else:
                 text_pending = True     # its word-branch gradients are still being computed next to the encoder backward
@@ -305,36 +273,21 @@ class Pix2PixGenerator(object):
             live = sums_e[k - 1] is not None and not sums_e[k - 1].missed
             hip.conv_dgrad(dyv, w, 2, 1, gin, bnbwd=(sums_e[k - 1].take(ACT_LRELU) if live else None))
             dx = B.get(tag + '/gb/de%d' % (k - 1), e[k - 1].shape)
-            inline_order = self.bn_stream is None and hip.SIDE_APPLY
-            forked = False
-            if not inline_order:
-                forked = self._fork(lambda xin=xin, dyv=dyv, k=k:
-                                    hip.conv_wgrad(xin, dyv, s.grad('generator/encoder_%d/conv/filter' % k), 2, 1))
+            forked = self._fork(lambda xin=xin, dyv=dyv, k=k:
+                                hip.conv_wgrad(xin, dyv, s.grad('generator/encoder_%d/conv/filter' % k), 2, 1))
             if k - 1 >= 2:
-                job = hip.bn_act_backward(_rows(e[k - 1]), ab[k - 1], st[k - 1], _rows(gin), ACT_LRELU, _rows(dx),
-                                          g2=_rows(g_skip[k - 1]), act2=ACT_RELU,
-                                          dscale=s.grad('generator/encoder_%d/scale' % (k - 1)),
-                                          doffset=s.grad('generator/encoder_%d/offset' % (k - 1)), pre=sums_e[k - 1],
-                                          defer=inline_order,
-                                          coef=(B.get(tag + '/gb/coef_e%d' % (k - 1), (2 * e[k - 1].shape[-1],)) if inline_order else None))
+                hip.bn_act_backward(_rows(e[k - 1]), ab[k - 1], st[k - 1], _rows(gin), ACT_LRELU, _rows(dx),
+                                    g2=_rows(g_skip[k - 1]), act2=ACT_RELU,
+                                    dscale=s.grad('generator/encoder_%d/scale' % (k - 1)),
+                                    doffset=s.grad('generator/encoder_%d/offset' % (k - 1)), pre=sums_e[k - 1])
             else:
-                job = hip.bn_act_backward(_rows(e[1]), None, None, _rows(gin), ACT_LRELU, _rows(dx),
-                                          g2=_rows(g_skip[1]), act2=ACT_RELU, defer=inline_order)
-            if inline_order:
-                # the filter gradient of encoder_k carries the streaming pass of encoder_{k-1}'s norm backward
-                hip.conv_wgrad(xin, dyv, s.grad('generator/encoder_%d/conv/filter' % k), 2, 1, host=job)
+                hip.bn_act_backward(_rows(e[1]), None, None, _rows(gin), ACT_LRELU, _rows(dx),
+                                    g2=_rows(g_skip[1]), act2=ACT_RELU)
             if forked:
                 self._join()
             gcur = dx
             if k == 5 and not text_pending:
                 done('encoder_5')       # its filter, scale and offset gradients are final (trainer._sections)
-            if text_pending and self.text_defer_stream is not None and self.text._bwd_stream is self.text_defer_stream and \
-                    k == max(2, min(5, self.text_join_after)):
-                # deferred word half: joined here, inside the segment that began after the decoders' hand-over; its section
-                # and encoder_5's (adjacent in the flat buffer) travel as one exchange beside the rest of the encoder backward
-                self.text.join_backward()
-                done('text+encoder_5')
-                text_pending = False
         hip.conv_wgrad(View(ctx['xs']), View(gcur), s.grad('generator/encoder_1/conv/filter'), 2, 1)
         hip.mark(tag + '/bwd encoders: last')
         if text_pending:
@@ -448,34 +401,33 @@ class Pix2PixDiscriminator(object):
                                      stop_after)
 
     def _norm_backward(self, ctx, k, gcur, sums, need_params, accumulate, rowb=None):
-        """The norm + lrelu backward of layer k's output (k = 1: lrelu only): the sums now, the streaming pass as a deferred job
-        (hip.ApplyJob) for the filter-gradient launch of layer k+1 to host -- see _backward_layers.  Returns (dx buffer, job)."""
+        """The norm + lrelu backward of layer k's output (k = 1: lrelu only).  Returns the dx buffer."""
         s, B = self.s, self.b
         tag, l, ab, st = ctx['tag'], ctx['l'], ctx['ab'], ctx['st']
         gname = lambda kk, what: s.grad('discriminator/layer_%d/%s' % (kk, what))
         dx = B.get(tag + '/gb/dl%d' % k, l[k].shape)
         if k == 1:
-            return dx, hip.bn_act_backward(_rows(l[1]), None, None, _rows(gcur), ACT_LRELU, _rows(dx), defer=_DBWD_DEFER)
+            hip.bn_act_backward(_rows(l[1]), None, None, _rows(gcur), ACT_LRELU, _rows(dx))
+            return dx
         ds = do = None
         if need_params and accumulate:
             tmp_s = B.get(tag + '/gb/tmp_scale%d' % k, (2, self.chans[k]))
             ds, do = tmp_s[0], tmp_s[1]
         elif need_params:
             ds, do = gname(k, 'scale'), gname(k, 'offset')
-        coef = B.get(tag + '/gb/coef%d' % k, (2 * self.chans[k],))
-        job = hip.bn_act_backward(_rows(l[k]), ab[k], st[k], _rows(gcur), ACT_LRELU, _rows(dx), dscale=ds, doffset=do,
-                                  pre=sums, rowb=rowb, defer=_DBWD_DEFER, coef=coef)
+        hip.bn_act_backward(_rows(l[k]), ab[k], st[k], _rows(gcur), ACT_LRELU, _rows(dx), dscale=ds, doffset=do, pre=sums,
+                            rowb=rowb)
         if need_params and accumulate:
             hip.call('ssc_axpy', gname(k, 'scale'), ds, 1.0, self.chans[k])
             hip.call('ssc_axpy', gname(k, 'offset'), do, 1.0, self.chans[k])
-        return dx, job
+        return dx
 
     def _backward_layers(self, ctx, layers, dx, sums, dy5, rowb, need_params, need_input, accumulate, after_layer, stop_after):
         """Layers ``layers`` of the backward pass.  dx: gradient w.r.t. the RAW output of layers[0], or None for layer 4 (layer 5's
         data gradient and layer 4's norm backward are taken here).
-        Order per layer k: data gradient into layer k-1 (its epilogue takes the sums of layer k-1's norm backward) -> those sums
-        folded (one small launch) -> filter gradient of layer k, which HOSTS the streaming pass of layer k-1's norm backward
-        (hip.ApplyJob: HBM traffic beside the matrix work of a launch that needs neither its input nor its output)."""
+        Order per layer k: filter gradient of layer k, data gradient into layer k-1 (its epilogue takes the sums of layer k-1's
+        norm backward), that norm backward.  (Round 4 put the filter gradient behind the data gradient and had it host the
+        norm backward's streaming pass: 0.4 ms slower per iteration on one box, profiles/r05_ab_envsets.txt.)"""
         s, B = self.s, self.b
         tag, N, l, ab, st = ctx['tag'], ctx['N'], ctx['l'], ctx['ab'], ctx['st']
         gname = lambda k, what: s.grad('discriminator/layer_%d/%s' % (k, what))
@@ -512,7 +464,7 @@ class Pix2PixDiscriminator(object):
                 xin = View(l[k - 1], None, ab[k - 1], ACT_LRELU)
             dyv = View(dx)
             w = s['discriminator/layer_%d/conv/filter' % k]
-            job, dx_next = None, None
+            dx_next = None
             if need_params and _DBWD_WGRAD_FIRST:
                 # round-3 order: the filter gradient of layer k in front of its data gradient (the chain's next full-size launch
                 # then follows the small launches of the norm backward directly)
@@ -528,16 +480,14 @@ class Pix2PixDiscriminator(object):
                                          B.get(tag + '/gb/bnsums%d' % (k - 1),
                                                (hip.BnBwdSums.rows_needed(x2d.shape[0]), 2 * x2d.shape[1])))
                 hip.conv_dgrad(dyv, w, self.strides[k], 1, gin, bnbwd=(sums.take(ACT_LRELU) if sums else None))
-                dx_next, job = self._norm_backward(ctx, k - 1, gin, sums, need_params, accumulate)
+                dx_next = self._norm_backward(ctx, k - 1, gin, sums, need_params, accumulate)
             elif need_input:
                 dgen = B.get(tag + '/gb/dgen', (N, l[0].shape[1], l[0].shape[2], 4))
                 hip.conv_dgrad(dyv, w, 2, 1, dgen, n_off=3, nn=3, nstore=4)
             if need_params and not _DBWD_WGRAD_FIRST:
-                hip.conv_wgrad(xin, dyv, gname(k, 'conv/filter'), self.strides[k], 1, accumulate=accumulate,
-                               host=(job if hip.SIDE_APPLY else None))
+                hip.conv_wgrad(xin, dyv, gname(k, 'conv/filter'), self.strides[k], 1, accumulate=accumulate)
                 if after_layer is not None:
                     after_layer(k)
-            hip.apply_now(job)      # not hosted (no filter gradient in this pass, or hosting switched off)
             dx = dx_next
             if stop_after == k and k > 1:
                 return {'layers': tuple(j for j in layers if j < k), 'gcur': dx, 'sums': None}

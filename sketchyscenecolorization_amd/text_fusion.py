@@ -171,24 +171,10 @@ class TextFusion(object):
 
     _bwd_stream = None
 
-    def run_deferred_words(self, stream):
-        """The word half that ``backward(..., defer_words=True)`` left undone, now, on ``stream`` (forked from the current
-        stream); ``join_backward()`` before the TextLSTM gradients are read."""
-        args, self._deferred = self._deferred, None
-        if args is None:
-            return False
-        stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(stream):
-            self._backward_words(*args)
-        self._bwd_stream = stream
-        return True
-
-    _deferred = None
-
-    def backward(self, ctx, g_feat, side_stream=None, defer_words=False):
+    def backward(self, ctx, g_feat, side_stream=None):
         """g_feat [N,h,w,C]: gradient w.r.t. the fused feature.  Fills the TextLSTM parameter
         gradients and returns the gradient w.r.t. the *normalised* encoder_5 output [R,C]
-        (None when no step ran).  defer_words: see run_deferred_words.  With ``side_stream`` everything downstream of the multimodal BPTT that the image
+        (None when no step ran).  With ``side_stream`` everything downstream of the multimodal BPTT that the image
         path does not need (word-term filter gradients, word LSTM BPTT, embedding gradient: a chain of small GEMMs)
         runs there; the caller must ``join_backward()`` before it reads the TextLSTM gradients."""
         s, B = self.s, self.b
@@ -224,11 +210,7 @@ class TextFusion(object):
         hip.matmul_nt(dGv, Ka[0:C], dvis)
         dy5 = B.get(tag + '/tfb/dy5', (R, C))
         hip.call('ssc_row_l2norm_bwd', ctx['vis'], ctx['vis_ss'], dvis, R, C, dy5, 0)
-        if defer_words:
-            # many towers with graph segments: the word half is started by the caller AFTER it has handed the decoders'
-            # gradient section to the reducer (a fork may not cross the end of a graph segment): run_deferred_words
-            self._deferred = (ctx, dR, dGv, gE, gKw, gbw, gKa, gba)
-        elif side_stream is not None:
+        if side_stream is not None:
             side_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side_stream):
                 self._backward_words(ctx, dR, dGv, gE, gKw, gbw, gKa, gba)

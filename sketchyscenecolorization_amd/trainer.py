@@ -103,7 +103,7 @@ class GanTrainer(object):
         # (66 KB LDS per workgroup), so co-scheduling them only adds contention.
         if overlap_wgrad is None:
             overlap_wgrad = os.environ.get('SSC_OVERLAP_WGRAD', '0') == '1'
-        if overlap_wgrad and self.use_graphs:
+        if overlap_wgrad and self.use_graphs and overlap_wgrad != 'force':      # 'force': tests/test_gpu_stream_hazards.py
             # round 4: with several filter gradients queued on the side stream the CAPTURED step is not bit-identical to the eager
             # one (a hazard that stream order hides in eager mode; profiles/NOTEBOOK_r04.md section 8): eager steps only
             import warnings as _w
@@ -147,12 +147,8 @@ class GanTrainer(object):
         self.G.text_stream = self._text_stream          # forward half: every generator
         if block_type == 'Pix2Pix':
             self.G.text_stream_bwd = None if self.segment_graphs else self._text_stream
-            # graph segments (many towers): the word half starts after the decoders' hand-over and is joined after
-            # encoder_4's backward, inside one segment (a fork may not cross a segment end).  OFF (SSC_SEG_DEFER_WORDS=1): measured
-            # on one GPU 18.54 vs 18.29 ms per iteration -- the ~90 tiny launches of the word half crawl beside the full-size encoder
-            # launches and the main chain waits for them at the join (scripts/segmented_mode_probe.py)
-            if self.segment_graphs and os.environ.get('SSC_SEG_DEFER_WORDS', '0') == '1':
-                self.G.text_defer_stream = self._text_stream
+            # (graph segments, many towers: the word half runs in line -- a fork may not cross a segment end; starting it after the
+            # decoders' hand-over and joining it after encoder_4's backward measured slower, profiles/NOTEBOOK_r04.md)
             # norm backward of a layer next to the filter gradient of the layer above (Pix2PixGenerator._fork).  OFF: measured
             # 18.28 vs 18.07 ms/step -- a fork + join per layer costs more in cross-queue dependencies of the replayed
             # graph than the three small launches it hides
@@ -777,14 +773,6 @@ class GanTrainer(object):
             hip.call('ssc_l2_reg', s['generator/fully_connected/weights'],
                      s['generator/fully_connected/weights'].numel(), 1e-6, self.loss[0:1],
                      s.grad('generator/fully_connected/weights'))
-        if name == 'text+encoder_5':        # the deferred word half was joined: two adjacent sections as one exchange
-            if self._g_merge or 'encoder_5' not in self._g_sections or \
-                    self._g_sections['encoder_5'][1] != self._g_sections['text'][0]:
-                self._section_done(sc, 'text')
-                self._section_done(sc, 'encoder_5')
-                return
-            self._allreduce_async(sc.grad, self._g_sections['encoder_5'][0], self._g_sections['text'][1])
-            return
         lo, hi = self._g_sections[name]
         if self._g_merge:
             # fewer, larger exchanges (SSC_G_SECTIONS=2 | 1): every exchange ends a graph segment, and the side chains of the

@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def _parity_path():
+    return os.environ.get('SSC_PARITY_LOG', os.path.join(ROOT, 'gpurun_out', 'parity.jsonl'))
+
+
+def pytest_sessionstart(session):
+    """A session writes its own parity log (tests/test_zz_parity_summary.py reads it at the end)."""
+    if os.environ.get('SSC_PARITY_LOG_KEEP') != '1':
+        try:
+            os.remove(_parity_path())
+        except OSError:
+            pass
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():
@@ -27,7 +40,7 @@ def parity_log(test, config, max_abs_err, bound, **extra):
     asserts against the oracle records how far it actually was from it, so the margins are visible outside the GPU box
     (the final tree's file is committed as profiles/r05_parity.jsonl)."""
     import json
-    path = os.environ.get('SSC_PARITY_LOG', os.path.join(ROOT, 'gpurun_out', 'parity.jsonl'))
+    path = _parity_path()
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         rec = {'test': test, 'config': config, 'max_abs_err': float(max_abs_err), 'bound': float(bound)}

@@ -83,3 +83,15 @@ def test_stale_binary_is_refused(tmp_path, monkeypatch):
     import __graft_entry__ as G
     src = open(G.__file__).read()
     assert 'hip.check_build_hash()' in src.split('def smoke')[1]
+
+
+def test_library_has_no_packed_fp32_math():
+    """Packed fp32 vector instructions beside fp32 MFMAs are corrupted by another wave's bf16 MFMAs on MI355X (profiles/
+    NOTEBOOK_r05.md section 3; tests/test_gpu_stream_hazards.py): the build keeps the compiler from packing scalar math
+    (-fno-slp-vectorize) and the sources do not ask for packed math outside narrow.hip (no MFMAs, never seen perturbed)."""
+    from sketchyscenecolorization_amd import build
+    assert build.NO_PACKED_FP32 == {'narrow.hip': []}
+    for f in sorted(os.listdir(build.CSRC)):
+        if f.endswith(('.hip', '.h')) and f != 'narrow.hip':
+            txt = open(os.path.join(build.CSRC, f)).read()
+            assert '__builtin_elementwise_fma' not in txt and '__builtin_elementwise_max' not in txt, f

@@ -166,6 +166,7 @@ def test_filter_planes_follow_the_weights():
     n, h, ci, co = 2, 16, 64, 64
     x = nhwc(rnd(n, ci, h, h, seed=51)).cuda()
     w = rnd(4, 4, ci, co, seed=52, std=0.05).cuda()
+    rng = hip.register_param_buffer(w)              # a parameter: persistent planes (any other tensor is split before every launch)
     out1 = torch.empty(n, 8, 8, co, device='cuda')
     hip.conv_forward(hip.View(x), w, 2, 1, out1)
     w.mul_(2.0)                                     # torch sees this one
@@ -177,3 +178,13 @@ def test_filter_planes_follow_the_weights():
     out3 = torch.empty_like(out1)
     hip.conv_forward(hip.View(x), w, 2, 1, out3)
     assert float((out3 - 4.0 * out1).abs().max()) <= 1e-5 * float(out1.abs().max())
+    # without the refresh the planes of a PARAMETER are stale (that is the contract) ...
+    hip.call('ssc_axpy', w, w, 1.0, w.numel())
+    out4 = torch.empty_like(out1)
+    hip.conv_forward(hip.View(x), w, 2, 1, out4)
+    assert float((out4 - 4.0 * out1).abs().max()) <= 1e-5 * float(out1.abs().max())
+    hip.release_param_buffer(rng)
+    # ... while a tensor that is no parameter is split in front of every launch
+    out5 = torch.empty_like(out1)
+    hip.conv_forward(hip.View(x), w, 2, 1, out5)
+    assert float((out5 - 8.0 * out1).abs().max()) <= 1e-5 * float(out1.abs().max())

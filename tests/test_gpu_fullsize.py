@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import parity_log
+
 pytestmark = pytest.mark.gpu
 
 
@@ -92,6 +94,8 @@ def test_bg_generator_768_oracle_parity(host_threads):
     e2 = (out_seg.cpu().double() - seg64).abs().max().item()
     c1 = (ref_img.double() - img64).abs().max().item()
     c2 = (ref_seg.double() - seg64).abs().max().item()
+    parity_log('bg768_generator_image_vs_f64', dict(n=n, img=img), e1, max(TOL, 1.5 * c1), cpu_fp32_vs_f64=c1, variant='BG', forward=True)
+    parity_log('bg768_generator_region_logits_vs_f64', dict(n=n, img=img), e2, max(TOL, 1.5 * c2), cpu_fp32_vs_f64=c2, variant='BG', forward=True)
     assert e1 <= max(TOL, 1.5 * c1), ('image vs float64 oracle', e1, 'fp32 CPU oracle vs float64', c1)
     assert e2 <= max(TOL, 1.5 * c2), ('region logits vs float64 oracle', e2, 'fp32 CPU oracle vs float64', c2)
 
@@ -311,6 +315,8 @@ def test_fg_generate_mru_batch16_192_oracle(host_threads):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     err = (outs[2].cpu().double() - ref64).abs().amax(dim=(1, 2, 3))
     cpu = (ref.double() - ref64).abs().amax(dim=(1, 2, 3))
+    parity_log('fg_generate_mru_batch16_192_vs_f64', dict(n=n, img=img), float(err.max()), max(TOL, 1.5 * float(cpu.max())),
+               cpu_fp32_vs_f64=float(cpu.max()), variant='MRU', forward=True)
     assert float(err.max()) <= max(TOL, 1.5 * float(cpu.max())), (err.tolist(), cpu.tolist())
 
 
@@ -332,6 +338,8 @@ def test_fg_generate_residual_batch16_192_oracle(host_threads):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     err = (outs[2].cpu().double() - ref64).abs().amax(dim=(1, 2, 3))
     cpu = (ref.double() - ref64).abs().amax(dim=(1, 2, 3))
+    parity_log('fg_generate_residual_batch16_192_vs_f64', dict(n=n, img=img), float(err.max()), max(TOL, 1.5 * float(cpu.max())),
+               cpu_fp32_vs_f64=float(cpu.max()), variant='Residual', forward=True)
     assert float(err.max()) <= max(TOL, 1.5 * float(cpu.max())), (err.tolist(), cpu.tolist())
 
 

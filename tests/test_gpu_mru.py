@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import parity_log
+
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-3
@@ -43,6 +45,8 @@ def test_mru_generator_forward(img, n, lstm):
         assert e <= 2e-3 * max(1.0, b.abs().max().item()), ('dec', k, e)
     err = (out.double() - ref64).abs().max().item()
     cpu = (ref.double() - ref64).abs().max().item()
+    parity_log('mru_generator_forward_vs_f64', dict(n=int(z.shape[0]), img=int(z.shape[-1])), err, max(TOL, 1.5 * cpu), cpu_fp32_vs_f64=cpu,
+               variant='MRU', forward=True)
     assert err <= max(TOL, 1.5 * cpu), (err, cpu)
 
 

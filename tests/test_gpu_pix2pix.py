@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import parity_log
+
 from oracle import pix2pix as O
 
 pytestmark = pytest.mark.gpu
@@ -30,6 +32,7 @@ def test_generator_forward_parity(n, img):
     ref = O.generate_pix2pix(p, b['sketches'], b['text'], b['noise_vec'])
     out = tr.generate(dev['sketches'], dev['text'], dev['noise_vec'])
     err = float((out.cpu() - ref).abs().max())
+    parity_log('pix2pix_generator_forward_vs_fp32_oracle', dict(n=n, img=img), err, 1e-3, variant='Pix2Pix', forward=True)
     assert err < 1e-3, err
 
 
@@ -50,6 +53,8 @@ def test_discriminator_forward_parity():
     hip.nchw_to_nhwc(dev['images_d'], xd, 3)
     sn = tr.D.prepare_sn()
     c = tr.D.forward(xd, sn, 'dr')
+    parity_log('pix2pix_discriminator_patch_logits_vs_fp32_oracle', dict(n=2, img=192), float((c['disc'][..., 0].cpu() - disc[:, 0]).abs().max()),
+               1e-3, variant='Pix2Pix', forward=True)
     assert float((c['disc'][..., 0].cpu() - disc[:, 0]).abs().max()) < 1e-3
     assert float((c['logits'].cpu() - logits).abs().max()) < 1e-3
 

@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import parity_log
+
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-3      # BASELINE.json north_star: outputs within 1e-3 max-abs of the reference on fp32 RGB
@@ -61,6 +63,8 @@ def test_bg_residual_generator_forward(img, n):
     e2 = (out_seg.cpu().double() - seg64).abs().max().item()
     c1 = (ref_img.double() - img64).abs().max().item()
     c2 = (ref_seg.double() - seg64).abs().max().item()
+    parity_log('bg_generator_image_vs_f64', dict(n=n, img=img), e1, max(TOL, 1.5 * c1), cpu_fp32_vs_f64=c1, variant='BG', forward=True)
+    parity_log('bg_generator_region_logits_vs_f64', dict(n=n, img=img), e2, max(TOL, 1.5 * c2), cpu_fp32_vs_f64=c2, variant='BG', forward=True)
     assert e1 <= max(TOL, 1.5 * c1) and e2 <= max(TOL, 1.5 * c2), (e1, c1, e2, c2)
     assert (out_img.cpu() - ref_img).abs().max().item() <= 4 * TOL
 

@@ -1,6 +1,6 @@
 """Round-4 kernels and entry points against torch restatements (through the C ABI):
   ssc_conv_forward_bnbwd2   norm-backward sums of BOTH halves of a merged decoder data gradient (models_collection.py:512-531)
-  ssc_bn_bwd_sums / _apply / ssc_conv_wgrad_hosting   the norm backward in two steps, the streaming pass hosted by a filter gradient
+  ssc_bn_bwd_sums / _apply   the norm backward in two steps
   slab_reduce4_stats_kernel batch statistics taken by the split-K slab sum
   ssc_block_out_backward    the backward through a bottleneck's output (residual_util.py:103-109, 138-146, 165-167)
   ssc_conv_forward_minmax   the MRU gates' per-sample extrema out of the conv epilogue (mru.py:407-415)"""
@@ -82,9 +82,8 @@ def test_merged_decoder_dgrad_delivers_both_sites_sums():
 
 
 @pytest.mark.parametrize('c,two', [(128, True), (64, False)])
-def test_norm_backward_in_two_steps_and_hosted(c, two):
-    """ssc_bn_bwd_sums + ssc_bn_bwd_apply == ssc_bn_act_backward (same bits), and the pass hosted by a filter-gradient launch
-    (ssc_conv_wgrad_hosting) gives the same dx and the same filter gradient, bit for bit."""
+def test_norm_backward_in_two_steps(c, two):
+    """ssc_bn_bwd_sums + ssc_bn_bwd_apply == ssc_bn_act_backward (same bits)."""
     hip = _hip()
     n, h, co = 4, 48, 2 * c
     dev = 'cuda'
@@ -104,25 +103,14 @@ def test_norm_backward_in_two_steps_and_hosted(c, two):
     xh = (x2d - st[:c]) * st[c:]
     want = ab[:c] * (dz - dz.mean(0) - xh * (dz * xh).mean(0))
     close(ref_dx, want, tol=2e-5)
-    # two steps, then hosted
-    xin = hip.View(x, None, ab, 2)
-    dy = rnd(n, h // 2, h // 2, co, seed=16).to(dev)
-    dw_plain = torch.full((4, 4, c, co), float('nan'), device=dev)
-    hip.conv_wgrad(xin, hip.View(dy), dw_plain, 2, 1)
-    for hosted in (False, True):
-        dx = torch.full_like(x2d, float('nan'))
-        coef = torch.zeros(2 * c, device=dev)
-        ds, do = torch.empty(c, device=dev), torch.empty(c, device=dev)
-        job = hip.bn_act_backward(x2d, ab, st, g1.view(-1, c), 2, dx, g2=g2r, act2=1, dscale=ds, doffset=do, defer=True, coef=coef)
-        dw = torch.full((4, 4, c, co), float('nan'), device=dev)
-        if hosted:
-            hip.conv_wgrad(xin, hip.View(dy), dw, 2, 1, host=job)
-        else:
-            hip.apply_now(job)
-            hip.conv_wgrad(xin, hip.View(dy), dw, 2, 1)
-        assert job.done
-        assert torch.equal(dx, ref_dx) and torch.equal(ds, ds0) and torch.equal(do, do0), hosted
-        assert torch.equal(dw, dw_plain), hosted
+    # two steps
+    dx = torch.full_like(x2d, float('nan'))
+    coef = torch.zeros(2 * c, device=dev)
+    ds, do = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    job = hip.bn_act_backward(x2d, ab, st, g1.view(-1, c), 2, dx, g2=g2r, act2=1, dscale=ds, doffset=do, defer=True, coef=coef)
+    hip.apply_now(job)
+    assert job.done
+    assert torch.equal(dx, ref_dx) and torch.equal(ds, ds0) and torch.equal(do, do0)
 
 
 def test_batch_statistics_from_the_slab_sum():
@@ -318,42 +306,6 @@ def test_bottleneck_3x3_conv_streaming_kernel(shape, c, act):
     d.kstep, d.KH, d.KW, d.wC0, d.wC1, d.k_real = 1, 3, 3, c, c, c
     d.Nn, d.Nstore, d.OH, d.OW, d.ldc, d.out_stride = c, c, h, w_, c, 1
     assert hip.lib().ssc_conv_c3x3_supported(C.byref(d)) == (1 if n * h * w_ >= 16384 else 0)
-
-
-@pytest.mark.parametrize('shape,c0,nstore,act', [((12, 32, 48), 64, 4, 1), ((8, 30, 50), 128, 3, 2), ((24, 24, 32), 32, 4, 0)])
-def test_last_transposed_conv_on_4x4_mfma_blocks(shape, c0, nstore, act, monkeypatch):
-    """(Experiment kept in the tree, off by default: SSC_TR4_MFMA=1.)  The generators' last layer (k = 4, stride-2 transposed conv 128 -> 3, tanh; models_collection.py:529-534) on
-    v_mfma_f32_4x4x1 blocks with K split 16 ways (tr4mfma.hip): two sources with their own folded norms, ragged tiles, 3 or 4 stored
-    channels, against torch in float64."""
-    import ctypes as C
-    import torch.nn.functional as F
-    hip = _hip()
-    monkeypatch.setenv('SSC_TR4_MFMA', '1')
-    n, h, w_ = shape
-    dev = 'cuda'
-    c1 = 128 - c0
-    x0 = rnd(n, h, w_, c0, seed=71).to(dev)
-    x1 = rnd(n, h, w_, c1, seed=72).to(dev) if c1 else None
-    ab0 = torch.cat([1.0 + 0.2 * rnd(c0, seed=73), 0.3 * rnd(c0, seed=74)]).to(dev)
-    ab1 = torch.cat([1.0 + 0.2 * rnd(c1, seed=75), 0.3 * rnd(c1, seed=76)]).to(dev) if c1 else None
-    f = rnd(4, 4, 3, 128, seed=77, std=0.05).to(dev)
-    xv = hip.View(x0, x1, ab0, act, ab1) if c1 else hip.View(x0, None, ab0, act)
-    out = torch.full((n, 2 * h, 2 * w_, 4), float('nan'), device=dev)
-    hip.deconv_forward(xv, f, out, nstore=nstore, epi=1)
-    z0 = (ab0[:c0] * x0 + ab0[c0:]).double()
-    zs = [z0] + ([(ab1[:c1] * x1 + ab1[c1:]).double()] if c1 else [])
-    z = torch.cat(zs, -1)
-    z = torch.relu(z) if act == 1 else (torch.maximum(z, 0.2 * z) if act == 2 else z)
-    # conv2d_transpose(k=4, s=2, SAME) with f [4,4,Cout,Cin]: torch weight [Cin, Cout, kh, kw]
-    ref = F.conv_transpose2d(nchw(z), f.double().permute(3, 2, 0, 1), stride=2, padding=1)
-    ref = nhwc(torch.tanh(ref))
-    close(out[..., :3], ref, tol=2e-5)
-    if nstore == 4:
-        assert torch.all(out[..., 3] == 0)
-    else:
-        assert torch.isnan(out[..., 3]).all()
-    d = hip.deconv_forward(xv, f, out, nstore=nstore, epi=1, _desc_only=True)
-    assert hip.lib().ssc_conv_tr4_mfma_supported(C.byref(d)) == 1
 
 
 @pytest.mark.parametrize('shape,co,act,stride', [((8, 128, 128), 16, 2, 2), ((9, 126, 132), 16, 1, 2), ((8, 128, 128), 8, 0, 2),
