@@ -163,6 +163,9 @@ typedef struct ssc_wgrad_desc {
     int32_t Nn;           /* real dense channels (<= d.C0+d.C1) */
     int32_t ldc;
     int32_t accumulate;
+    int32_t exact;        /* 1: the exact-fp32 MFMA kernels only; 0: the large layers may run as a 3-way bf16 split of both operands on
+                             the bf16 matrix pipe (wgrad128_bf16.hip: six products per fp32 product, fp32 accumulate) */
+    int32_t _pad;
 } ssc_wgrad_desc;
 
 /* library / device info */

@@ -12,8 +12,14 @@ from collections import defaultdict
 
 def demangled_short(name):
     # rocpd stores demangled names: "void conv_fwd_kernel<2, 2, 1, 2, 0, true, true>(...)"
-    if name.startswith('lstm_step_fwd_kernel') or 'lstm_step_fwd_kernel(' in name:
+    if 'lstm_step_fwd' in name:       # lstm_step_fwd_kernel and lstm_step_fwd_k2_kernel, with or without a leading "void "
         return 'lstm_step_fwd<64x64>'
+    mb = re.match(r'(?:void )?conv_bf_kernel<([^>]*)>', name)
+    if mb:
+        wm, wn, sm, sn = [int(a) for a in mb.group(1).split(',')[:4]]
+        return 'conv_bf16x6<%dx%d>' % (wm * sm * 32, wn * sn * 32)
+    if 'conv_wgrad128_bf_kernel' in name:
+        return 'conv_wgrad128_bf16x6<128x128>'
     if 'conv_wgrad128_kernel' in name:
         return 'conv_wgrad128<128x128>'
     m = re.match(r'void (conv_fwd_kernel|conv_ut_kernel|conv_wgrad_kernel|narrow_fwd_kernel)<([^>]*)>', name)
@@ -31,16 +37,21 @@ def demangled_short(name):
 
 def mangled_short(name):
     """The same report names from the MANGLED symbol (the kernel_symbol table of a kernel trace keeps `_Z14conv_ut_kernelILi2E...`)."""
-    m = re.match(r'_Z\d+(conv_fwd_kernel|conv_ut_kernel|conv_wgrad_kernel|narrow_fwd_kernel|narrow_sc_kernel|conv_wgrad128_kernel|'
-                 r'lstm_step_fwd_kernel|lstm_step_fwd_k2_kernel)(?:I((?:L[ib]\d+E)+)E)?', name)
+    m = re.match(r'_Z\d+(conv_fwd_kernel|conv_ut_kernel|conv_bf_kernel|conv_wgrad_kernel|narrow_fwd_kernel|narrow_sc_kernel|'
+                 r'conv_wgrad128_bf_kernel|conv_wgrad128_kernel|lstm_step_fwd_kernel|lstm_step_fwd_k2_kernel)(?:I((?:L[ib]\d+E)+)E)?', name)
     if not m:
         return None
     k = m.group(1)
     args = [int(a) for a in re.findall(r'L[ib](\d+)E', m.group(2) or '')]
     if k.startswith('lstm_step_fwd'):
         return 'lstm_step_fwd<64x64>'
+    if k == 'conv_wgrad128_bf_kernel':
+        return 'conv_wgrad128_bf16x6<128x128>'
     if k == 'conv_wgrad128_kernel':
         return 'conv_wgrad128<128x128>'
+    if k == 'conv_bf_kernel':
+        wm, wn, sm, sn = args[:4]
+        return 'conv_bf16x6<%dx%d>' % (wm * sm * 32, wn * sn * 32)
     if k in ('conv_fwd_kernel', 'conv_ut_kernel'):
         wm, wn, sm, sn, bm = args[:5]
         return 'conv_fwd<%dx%d,%s>' % (wm * sm * 32, wn * sn * 32, 'NK' if bm else 'KN')
@@ -87,6 +98,9 @@ def main(base, dst, bench_json=None):
             w = sum(write[k]['WRITE_SIZE']) / len(write[k]['WRITE_SIZE']) * 1024
             e.update(launches_profiled=len(fetch[k]['FETCH_SIZE']), fetch_bytes_per_launch_raw=f,
                      fetch_bytes_per_launch_corrected=2 * f, write_bytes_per_launch=w, hbm_bytes_per_launch=2 * f + w)
+            # launch by launch (dispatch order is the same in every pass: one deterministic command): which layers re-read
+            if len(fetch[k]['FETCH_SIZE']) == len(write[k]['WRITE_SIZE']) and len(fetch[k]['FETCH_SIZE']) <= 200:
+                e['hbm_mb_by_launch'] = [round((2 * a + b) * 1024 / 1e6, 1) for a, b in zip(fetch[k]['FETCH_SIZE'], write[k]['WRITE_SIZE'])]
             if alg.get(k):
                 e.update(algorithmic_bytes_per_launch=alg[k], traffic_ratio=(2 * f + w) / alg[k])
         if k in sq and sq[k].get('GRBM_GUI_ACTIVE'):
@@ -97,7 +111,9 @@ def main(base, dst, bench_json=None):
             simd_cycles = gui * 1024
             e.update(mfma_busy_frac=tot('SQ_VALU_MFMA_BUSY_CYCLES') / simd_cycles if gui else None,
                      valu_busy_frac=tot('SQ_ACTIVE_INST_VALU') * 4 / simd_cycles if gui else None,
-                     mfma_instructions=tot('SQ_VALU_MFMA_BUSY_CYCLES') / 64.0, valu_instructions=tot('SQ_INSTS_VALU'),
+                     # busy cycles per instruction: 64 for v_mfma_f32_32x32x2_f32, 32 for v_mfma_f32_32x32x16_bf16
+                     mfma_instructions=tot('SQ_VALU_MFMA_BUSY_CYCLES') / (32.0 if 'bf16x6' in k else 64.0),
+                     valu_instructions=tot('SQ_INSTS_VALU'),
                      kernel_cycles=gui, launches_profiled_sq=len(sq[k]['GRBM_GUI_ACTIVE']))
         res['kernels'][k] = e
     # the same kernels INSIDE the replayed step: a kernel trace of the graph-replayed bench (every iteration launches the same

@@ -14,7 +14,7 @@ EXTRA_FLAGS = {'igemm.hip': ['-Xclang', '-target-feature', '-Xclang', '-load-sto
 # its explicit packed FMAs.
 NO_PACKED_FP32 = {'narrow.hip': []}
 LAST_BUILD = None       # 'rebuilt' | 'reused' after build_library()
-SOURCES = ['igemm.hip', 'igemm_bf16.hip', 'wgrad128.hip', 'wgn16.hip', 'narrow.hip', 'head1.hip', 'fewchan.hip', 'fewchan7.hip', 'pw1x1.hip', 'c3x3.hip', 's2n16.hip', 'tr4tiny.hip', 'tr4n16.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip', 'mru_ops.hip']
+SOURCES = ['igemm.hip', 'igemm_bf16.hip', 'wgrad128.hip', 'wgrad128_bf16.hip', 'wgn16.hip', 'narrow.hip', 'head1.hip', 'fewchan.hip', 'fewchan7.hip', 'pw1x1.hip', 'c3x3.hip', 's2n16.hip', 'tr4tiny.hip', 'tr4n16.hip', 'elementwise.hip', 'text_lstm.hip', 'losses_optim.hip', 'mru_ops.hip']
 
 
 def _hipcc():

@@ -26,6 +26,7 @@
 // wgrad128.hip
 extern "C" int ssc_conv_wgrad128_supported(const ssc_wgrad_desc* dp);
 extern "C" int ssc_conv_wgrad128(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream);
+int ssc_conv_wgrad128_bf_selected(const ssc_wgrad_desc* dp);
 // wgn16.hip
 extern "C" int ssc_conv_wgn16_supported(const ssc_wgrad_desc* dp);
 int ssc_conv_wgn16(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream);
@@ -2138,7 +2139,7 @@ extern "C" int ssc_conv_wgrad_kernel_name(const ssc_wgrad_desc* dp, char* buf, i
         return 0;
     }
     if (ssc_conv_wgrad128_supported(dp)) {
-        copy_name("conv_wgrad128<128x128>", buf, len);
+        copy_name(ssc_conv_wgrad128_bf_selected(dp) ? "conv_wgrad128_bf16x6<128x128>" : "conv_wgrad128<128x128>", buf, len);
         return 0;
     }
     if (ssc_conv_wgn16_supported(dp)) {

@@ -493,9 +493,25 @@ extern "C" int ssc_wg128_timing(unsigned long long* out8, int reset) {
 }
 #endif
 
+// wgrad128_bf16.hip: the same tile on the bf16 matrix pipe (3-way split of both operands)
+int ssc_launch_wgrad128_bf(const ssc_wgrad_desc& d, int tpt, int splitk, float* ws, hipStream_t st);
+static bool wg128_use_bf() {
+    static int on = -1;         // SSC_ARITH=fp32 (everything exact) or SSC_WGRAD_BF16=0 (this kernel only): the exact-fp32 MFMA form
+    if (on < 0) {
+        const char* a = getenv("SSC_ARITH");
+        const char* w = getenv("SSC_WGRAD_BF16");
+        on = ((a != nullptr && (a[0] == 'f' || a[0] == 'F')) || (w != nullptr && w[0] == '0')) ? 0 : 1;
+    }
+    return on != 0;
+}
+
+int ssc_conv_wgrad128_bf_selected(const ssc_wgrad_desc* dp) { return (wg128_use_bf() && dp->exact == 0) ? 1 : 0; }
+
 extern "C" int ssc_conv_wgrad128(const ssc_wgrad_desc* dp, float* ws, int64_t ws_bytes, void* stream) {
     const ssc_wgrad_desc& d = *dp;
     if (!ssc_conv_wgrad128_supported(dp)) return -10;
     const int sk = wg128_splitk(d, ws_bytes, ws != nullptr);
+    if (wg128_use_bf() && d.exact == 0)
+        return ssc_launch_wgrad128_bf(d, wg128_tpt(d), sk, ws, (hipStream_t)stream);
     return wg128_tpt(d) == 2 ? launch_wg128_t<2>(d, sk, ws, (hipStream_t)stream) : launch_wg128_t<1>(d, sk, ws, (hipStream_t)stream);
 }

@@ -63,7 +63,8 @@ class WgradDesc(C.Structure):
                 ('NB', C.c_int32), ('PH', C.c_int32), ('PW', C.c_int32),
                 ('TH', C.c_int32), ('TW', C.c_int32), ('in_stride', C.c_int32),
                 ('ioff_y', C.c_int32), ('ioff_x', C.c_int32),
-                ('Cg_real', C.c_int32), ('Nn', C.c_int32), ('ldc', C.c_int32), ('accumulate', C.c_int32)]
+                ('Cg_real', C.c_int32), ('Nn', C.c_int32), ('ldc', C.c_int32), ('accumulate', C.c_int32),
+                ('exact', C.c_int32), ('_pad', C.c_int32)]
 
 
 _lib = None
@@ -655,6 +656,7 @@ def _run_conv(d, bn=None, bnbwd=None, minmax=None):
 
 def _run_wgrad(d, side=False):
     global _wgrad_pending
+    d.exact = 0 if ARITH_BF16 else 1
     if side and WGRAD_STREAM is not None and PROFILE is None and \
             (WGRAD_SIDE_MAX_PIXELS is None or d.NB * d.PH * d.PW <= WGRAD_SIDE_MAX_PIXELS):
         WGRAD_STREAM.wait_stream(torch.cuda.current_stream())

@@ -159,6 +159,79 @@ def test_matmul_split_vs_exact(m, k, nn):
     _both(run_nt, ref_nt, 'matmul_nt_split_vs_exact', dict(m=m, k=nn, n=k))
 
 
+def _both_wgrad(run, ref64, name, config):
+    """Filter gradients: hip.ARITH_BF16 selects the bf16-split 128 x 128 kernel (wgrad128_bf16.hip) or the exact-fp32 one."""
+    hip = _hip()
+    errs, names = {}, {}
+    for mode in ('bf16x6', 'fp32'):
+        hip.ARITH_BF16 = mode == 'bf16x6'
+        try:
+            out = run()
+            torch.cuda.synchronize()
+        finally:
+            hip.ARITH_BF16 = True
+        errs[mode] = float((out.detach().cpu().double() - ref64).abs().max())
+    scale = float(ref64.abs().max())
+    assert errs['bf16x6'] != errs['fp32'] or errs['fp32'] == 0.0, 'both modes ran the same kernel'
+    bound = 1.5 * errs['fp32'] + 1.2e-7 * scale
+    parity_log(name, config, errs['bf16x6'], bound, exact_fp32_err=errs['fp32'], scale=scale, kernels=['conv_wgrad128_bf16x6'])
+    assert errs['bf16x6'] <= bound, (errs, scale)
+    return errs
+
+
+@pytest.mark.parametrize('n,h,ci,co,stride,act,tab', [(8, 48, 128, 256, 2, 2, True), (8, 96, 64, 128, 2, 2, False),
+                                                       (4, 24, 256, 512, 1, 2, True), (6, 24, 256, 512, 2, 0, False)])
+def test_conv_wgrad_split_vs_exact(n, h, ci, co, stride, act, tab):
+    """dW of a 4x4 conv (graph_single.py:24-30): gathered side with folded norm + activation (or plain), dense side dy; the
+    64-channel case takes two taps per tile."""
+    hip = _hip()
+    x = rnd(n, ci, h, h, seed=61)
+    ab = torch.cat([1.0 + 0.1 * rnd(ci, seed=62), 0.2 * rnd(ci, seed=63)]) if tab else None
+    xin = x.double()
+    if tab:
+        xin = xin * ab[:ci].double().view(1, -1, 1, 1) + ab[ci:].double().view(1, -1, 1, 1)
+    xin = act_ref(xin, act)
+    w = torch.zeros(4, 4, ci, co, dtype=torch.float64, requires_grad=True)
+    y = T.conv2d_valid_pad(xin, w, stride, 1)
+    dy = rnd(*y.shape, seed=64)
+    y.backward(dy.double())
+    ref = w.grad.detach()
+    xg, dyg, abg = nhwc(x).cuda(), nhwc(dy).cuda(), (ab.cuda() if tab else None)
+
+    def run():
+        out = torch.full((4, 4, ci, co), float('nan'), device='cuda')
+        hip.conv_wgrad(hip.View(xg, None, abg, act), hip.View(dyg), out, stride, 1)
+        return out
+    _both_wgrad(run, ref, 'conv_wgrad_split_vs_exact', dict(n=n, h=h, ci=ci, co=co, stride=stride, act=act, tab=tab))
+
+
+@pytest.mark.parametrize('n,h,c0,c1,co', [(8, 12, 128, 128, 128), (4, 24, 256, 0, 128)])
+def test_deconv_wgrad_split_vs_exact(n, h, c0, c1, co):
+    """dF of the transposed conv: gathered side dy (plain), dense side relu(concat of two normed tensors)."""
+    hip = _hip()
+    a = rnd(n, c0, h, h, seed=71)
+    b = rnd(n, c1, h, h, seed=72) if c1 else None
+    ab0 = torch.cat([1.0 + 0.1 * rnd(c0, seed=73), 0.2 * rnd(c0, seed=74)])
+    ab1 = torch.cat([1.0 + 0.1 * rnd(c1, seed=75), 0.2 * rnd(c1, seed=76)]) if c1 else None
+    parts = [a.double() * ab0[:c0].double().view(1, -1, 1, 1) + ab0[c0:].double().view(1, -1, 1, 1)]
+    if c1:
+        parts.append(b.double() * ab1[:c1].double().view(1, -1, 1, 1) + ab1[c1:].double().view(1, -1, 1, 1))
+    xin = torch.relu(torch.cat(parts, 1))
+    f = torch.zeros(4, 4, co, c0 + c1, dtype=torch.float64, requires_grad=True)
+    y = T.conv2d_transpose_same_s2(xin, f)
+    dy = rnd(*y.shape, seed=77)
+    y.backward(dy.double())
+    ref = f.grad.detach()
+    ag, bg, dyg = nhwc(a).cuda(), (nhwc(b).cuda() if c1 else None), nhwc(dy).cuda()
+    ab0g, ab1g = ab0.cuda(), (ab1.cuda() if c1 else None)
+
+    def run():
+        out = torch.full((4, 4, co, c0 + c1), float('nan'), device='cuda')
+        hip.deconv_wgrad(hip.View(ag, bg, ab0g, 1, ab1g), hip.View(dyg), out)
+        return out
+    _both_wgrad(run, ref, 'deconv_wgrad_split_vs_exact', dict(n=n, h=h, c0=c0, c1=c1, co=co))
+
+
 def test_filter_planes_follow_the_weights():
     """The planes are refreshed when torch modifies the filter (version counter) and by refresh_splits() after a write torch does
     not see (the optimizer kernels)."""
