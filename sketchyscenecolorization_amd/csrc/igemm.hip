@@ -1626,7 +1626,8 @@ static bool fwd_is_bf(const ssc_conv_desc& d) {
         const char* e = getenv("SSC_ARITH");
         off = (e != nullptr && (e[0] == 'f' || e[0] == 'F')) ? 1 : 0;
     }
-    return !off && d.wsplit != nullptr && d.ws_kc > 0 && d.ws_nbp > 0 && fwd_is_ut(d) && (d.n_off & 31) == 0 && d.Nstore > 32;
+    return !off && d.wsplit != nullptr && d.ws_kc > 0 && d.ws_nbp > 0 && fwd_is_ut(d) && (d.n_off & 31) == 0 && d.Nstore > 32 &&
+           d.TH * d.TW <= 32;
 }
 
 static Plan plan_fwd(const ssc_conv_desc& d, int64_t ws_bytes, bool have_ws) {

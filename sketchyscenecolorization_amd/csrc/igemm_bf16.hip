@@ -312,6 +312,25 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
             rowpix[row] = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
     }
 
+    // which taps bring row i inside the image: one bit per tap (the launcher takes at most 32 taps), decoded once per tile
+    // instead of compared every K step
+    unsigned a_vm[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) a_vm[i] = 0u;
+    {
+        const int ntaps = d.TH * TWv;
+        int ty = 0, tx = 0;
+        for (int t = 0; t < ntaps; ++t) {
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                const bool v = a_mv[i] & ((unsigned)(a_iyb[i] + ty) < (unsigned)xH) & ((unsigned)(a_ixb[i] + tx) < (unsigned)xW);
+                a_vm[i] |= v ? (1u << t) : 0u;
+            }
+            tx += 1;
+            if (tx == TWv) { tx = 0; ty += 1; }
+        }
+    }
+
     // filter side: fragment q of this wave = f = wave * B_IPW + q of the K-tile's [kc][plane][block] image
     const int NBP = d.ws_nbp, KC = d.ws_kc;
     const int nb0 = (d.n_off + n0) >> 5;
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
         const int cc = (first ? t.chunk : t.chunk - nch0) * BK;
         const char* sbase = reinterpret_cast<const char*>((first ? xs0 : xs1) + cc);
         const int tapshift = (t.ty * xW + t.tx) * cs * 4;
-        const int fmask = first ? -1 : 0;
+        const int tapidx = t.ty * TWv + t.tx;
         if (!PLAIN) {
             const char* pa = reinterpret_cast<const char*>((first ? tab.a0 : tab.a1) + cc);
             const char* pb = reinterpret_cast<const char*>((first ? tab.b0 : tab.b1) + cc);
@@ -389,11 +408,10 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
         }
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            const int iy = a_iyb[i] + t.ty, ix = a_ixb[i] + t.tx;
-            const bool v = a_mv[i] & ((unsigned)iy < (unsigned)xH) & ((unsigned)ix < (unsigned)xW);
-            const int osel = (a_off0[i] & fmask) | (a_off1[i] & ~fmask);
-            const unsigned off = v ? (unsigned)(osel + tapshift) : (unsigned)(a_col4 * 16);
-            S.v[i] = v ? 1.f : 0.f;
+            const unsigned vb = (a_vm[i] >> tapidx) & 1u;
+            const int osel = first ? a_off0[i] : a_off1[i];
+            const unsigned off = vb ? (unsigned)(osel + tapshift) : (unsigned)(a_col4 * 16);
+            S.v[i] = (float)vb;
             if (SSC_BF_DIAG_BUILD & 8) { S.r[i] = make_float4(1.f, 2.f, 3.f, 4.f); continue; }
             S.r[i] = *reinterpret_cast<const float4*>(sbase + off);
         }
@@ -439,27 +457,26 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
 
     if (kt_begin < kt_end) {
         const int last = kt_end - 1;
-        ASet SA, SB;        // SA: the K-tile being staged; SB: the one in flight behind it
+        ASet S0, S1;        // two register sets of staged K-tiles, used in turn (no copies): one is written to LDS while the other fills
         KTile tl = kt_decode(kt_begin);     // decode of the K-tile the next issue_loads takes
         dma_b(tl, 0, 0);
         if (RUN1 > 0) dma_b(tl, 0, 1);
-        issue_loads(tl, SA);
+        issue_loads(tl, S0);
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             float z, w;
             unsigned h0, m0_, l0;
-            BF_STAGE_A(SA, i, z, w, h0, m0_, l0);
+            BF_STAGE_A(S0, i, z, w, h0, m0_, l0);
             BF_STAGE_B(0, i, z, w, h0, m0_, l0);
         }
         KTile td = tl;                      // decode of the K-tile the next dma_b takes
         tl = kt_next(tl, kt_begin + 1 <= last);
         td = tl;
-        issue_loads(tl, SA);
+        issue_loads(tl, S0);
         BF_WAIT_ALL();
         __builtin_amdgcn_s_barrier();
-        int cur = 0;
-        constexpr int G = SM * SN;          // MFMAs per group (one product over the wave's blocks)
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
+        // one K step: MFMAs of K-tile kt from LDS buffer `cur`; set SA (K-tile kt+1) -> LDS buffer cur ^ 1; K-tile kt+2 -> set SB
+        auto kstep = [&](ASet& SA, ASet& SB, const int cur, const int kt) {
             const char* Ab = sm_b + cur * A_BYTES + (wm * SM * 32 + l31) * BF_A_RS + lhi * 16;
             const char* Bb = sm_b + 2 * A_BYTES + cur * B_BYTES + (wn * SN) * 1024 + lane * 16;
             bf16x8 av[2][SM][3], bv[2][SN][3];
@@ -529,10 +546,12 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
             // everything issued in this step has landed: the DMA tile and this wave's ds_writes are in LDS (published by the
             // barrier), the loads of K-tile kt+2 are in registers and become the staged set
             BF_WAIT_ALL();
-            SA = SB;
             td = tl;
             __builtin_amdgcn_s_barrier();
-            cur ^= 1;
+        };
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            kstep(S0, S1, 0, kt);
+            if (kt + 1 < kt_end) kstep(S1, S0, 1, kt + 1);
         }
     }
 

@@ -627,7 +627,7 @@ def test_wgrad128_conv(case):
     d.out = dw.data_ptr()
     d.NB, d.PH, d.PW, d.TH, d.TW, d.in_stride, d.ioff_y, d.ioff_x = n, y.shape[2], y.shape[3], k, k, stride, -pad, -pad
     d.Cg_real, d.Nn, d.ldc, d.accumulate = ci, co, co, 0
-    assert _wgrad_name(hip, d) == 'conv_wgrad128<128x128>'
+    assert _wgrad_name(hip, d) in ('conv_wgrad128<128x128>', 'conv_wgrad128_bf16x6<128x128>')
     # accumulate: out += (splitk == 1 path and the reduce kernel's)
     dw2 = dw.clone()
     hip.conv_wgrad(xv, hip.View(dyp.cuda()), dw2, stride, pad, accumulate=True)
