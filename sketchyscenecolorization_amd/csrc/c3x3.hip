@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void c3x3n16_kernel(const ssc_conv_desc d, int
 static bool c3_on() {
     static int on = -1;         // SSC_C3X3=0: the tile kernel (A/B)
     if (on < 0) {
-        const char* e = getenv("SSC_C3X3");
+        const char* e = ssc_dev_getenv("SSC_C3X3");
         on = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     return on != 0;
@@ -460,7 +460,7 @@ int ssc_conv_c3x3_forward(const ssc_conv_desc* dp, float* stat, void* stream) {
     const size_t lds = (size_t)2 * (tr + 2) * (tcw + 2) * (d.x.C0 + 1) * sizeof(float);
     static int n16 = -1;        // SSC_C3X3_N16=0: the 32-column instruction also at 16 outputs (A/B)
     if (n16 < 0) {
-        const char* e = getenv("SSC_C3X3_N16");
+        const char* e = ssc_dev_getenv("SSC_C3X3_N16");
         n16 = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     if (d.x.C0 == 16 && d.Nn <= 16 && tcw == 32 && n16) {

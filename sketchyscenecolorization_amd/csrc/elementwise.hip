@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "sketchycolor_hip.h"
+#include "host_util.h"
 #include "bn_bwd.h"
 
 #define CHECK_LAUNCH() ((int)hipGetLastError())
@@ -405,7 +406,7 @@ __device__ __forceinline__ bool fold_rows(const float* __restrict__ partial, int
 static inline int fold_wpc(int nblk) {
     static int force1 = -1;     // SSC_FOLD_WPC=1: always one wave per channel (A/B)
     if (force1 < 0) {
-        const char* e = getenv("SSC_FOLD_WPC");
+        const char* e = ssc_dev_getenv("SSC_FOLD_WPC");
         force1 = (e != nullptr && e[0] == '1') ? 1 : 0;
     }
     return (nblk >= 512 && !force1) ? 4 : 1;

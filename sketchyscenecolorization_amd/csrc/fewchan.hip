@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "sketchycolor_hip.h"
+#include "host_util.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void fewchan_conv_kernel(const ssc_conv_desc d
 }
 
 extern "C" int ssc_conv_fewchan_supported(const ssc_conv_desc* dp) {
-    static const bool on = getenv("SSC_FEWCHAN") == nullptr || atoi(getenv("SSC_FEWCHAN")) != 0;
+    static const bool on = ssc_dev_getenv("SSC_FEWCHAN") == nullptr || atoi(ssc_dev_getenv("SSC_FEWCHAN")) != 0;
     const ssc_conv_desc& d = *dp;
     if (!on) return 0;
     if (d.x.C1 != 0 || (d.x.C0 != 4 && d.x.C0 != 8) || d.x.ab0 != nullptr || d.x.act != SSC_ACT_NONE) return 0;

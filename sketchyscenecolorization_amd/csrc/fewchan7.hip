@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void fewchan7_conv_kernel(const ssc_conv_desc 
 static bool f7_on() {
     static int on = -1;         // SSC_FEWCHAN7=0: the tile kernel (A/B)
     if (on < 0) {
-        const char* e = getenv("SSC_FEWCHAN7");
+        const char* e = ssc_dev_getenv("SSC_FEWCHAN7");
         on = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     return on != 0;

@@ -451,7 +451,7 @@ bool geo_ok(int NB, int H, int W) {     // multiply-high decode exact: q * (H*W)
 int env_off() {
     static int off = -1;
     if (off < 0) {
-        const char* e = getenv("SSC_HEAD1");
+        const char* e = ssc_dev_getenv("SSC_HEAD1");
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
     return off;

@@ -3,6 +3,19 @@
 // for the CU count of the device it launches on).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+// Developer A/B switches (forcing a fallback path, planner constants, tile shapes): honoured only under SSC_DEV_SWITCHES=1.
+// They select paths the test suite does not cover in combination -- lab tools (scripts/), not supported configurations;
+// DESIGN.md section 7 lists the supported switches.
+static inline const char* ssc_dev_getenv(const char* name) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("SSC_DEV_SWITCHES");
+        on = (e != nullptr && e[0] == '1') ? 1 : 0;
+    }
+    return on ? getenv(name) : nullptr;
+}
 
 // true the first time this call site (its own `done` mask) runs on the current device
 static inline bool ssc_first_on_device(unsigned long long* done) {

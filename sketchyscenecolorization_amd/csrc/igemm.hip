@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256) void slab_reduce4_stats_kernel(const float4* _
 static bool slab_stats_ok(const ssc_conv_desc& d) {
     static int off = -1;        // SSC_SLAB_STATS=0: statistics by a pass of their own after the slab sum (A/B)
     if (off < 0) {
-        const char* e = getenv("SSC_SLAB_STATS");
+        const char* e = ssc_dev_getenv("SSC_SLAB_STATS");
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
     const int cg = d.ldc / 4;
@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float4* __rest
 static void launch_wgrad_reduce(const float* ws, long count, int splitk, float* out, int accumulate, hipStream_t st) {
     static int skip = -1;       // SSC_DIAG_SKIP_WGRAD_REDUCE=1: timing diagnostic only (wrong gradients): what do the slab sums cost
     if (skip < 0) {
-        const char* e = getenv("SSC_DIAG_SKIP_WGRAD_REDUCE");
+        const char* e = ssc_dev_getenv("SSC_DIAG_SKIP_WGRAD_REDUCE");
         skip = (e != nullptr && e[0] == '1') ? 1 : 0;
     }
     if (skip) return;
@@ -1480,7 +1480,7 @@ static thread_local int g_launch_ts_s = 1;
 static int tail_split_mode() {
     static int mode = -1;
     if (mode < 0) {
-        const char* e = getenv("SSC_TAIL_SPLIT");
+        const char* e = ssc_dev_getenv("SSC_TAIL_SPLIT");
         mode = (e != nullptr) ? atoi(e) : 1;
     }
     return mode;
@@ -1504,7 +1504,7 @@ static bool fwd_is_ut(const ssc_conv_desc& d) {
 static bool fwd_is_rowtap(const ssc_conv_desc& d) {
     static int off = -1;
     if (off < 0) {
-        const char* e = getenv("SSC_ROWTAP");
+        const char* e = ssc_dev_getenv("SSC_ROWTAP");
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
     return !off && d.bmode == 0 && d.nphase == 1 && d.kstep == 1 && d.kx0 == 0 && d.x.C1 == 0 && d.TW * d.x.C0 == BK &&
@@ -1521,12 +1521,12 @@ static bool fwd_is_utg(const ssc_conv_desc& d) {
     const int padded = ((d.x.C0 + BK - 1) / BK + (d.x.C1 + BK - 1) / BK) * BK;
     static int off = -1;
     if (off < 0) {
-        const char* e = getenv("SSC_UTG");
+        const char* e = ssc_dev_getenv("SSC_UTG");
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
     static double waste = -1.0;     // SSC_UTG_WASTE: largest padded / real K width taken (tuning aid)
     if (waste < 0.0) {
-        const char* e = getenv("SSC_UTG_WASTE");
+        const char* e = ssc_dev_getenv("SSC_UTG_WASTE");
         waste = (e != nullptr) ? atof(e) : 1.5;     // measured 1.2 / 1.25 / 1.5: MRU train 258.9 / 257.8 / 256.9 ms, MRU forward 13.47 / - / 13.20 ms
     }
     // ... or no more K-tiles than the generic kernel's walk over taps * C would take (few channels: one chunk per tap either way)
@@ -1539,7 +1539,7 @@ static bool fwd_is_utg(const ssc_conv_desc& d) {
 static int xcd_order() {
     static int on = -1;
     if (on < 0) {
-        const char* e = getenv("SSC_XCD_ORDER");
+        const char* e = ssc_dev_getenv("SSC_XCD_ORDER");
         on = (e != nullptr) ? atoi(e) : 2;     // 0: off, 1: XCD-aware order, 2: + the 4 phases of a row tile adjacent
     }
     return on;
@@ -1729,7 +1729,7 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
     const long Mall = M * d.nphase;
     static int off = -1;        // SSC_FUSE_STATS=0: always the separate pass (A/B)
     if (off < 0) {
-        const char* e = getenv("SSC_FUSE_STATS");
+        const char* e = ssc_dev_getenv("SSC_FUSE_STATS");
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
     bool fused = false;
@@ -1803,7 +1803,7 @@ extern "C" int ssc_conv_forward_bn(const ssc_conv_desc* dp, float* ws, int64_t w
     {
         static int dbg = -1;        // SSC_DEBUG_BNPATH=1: why a conv + norm call took the separate statistics pass (stderr)
         if (dbg < 0) {
-            const char* e = getenv("SSC_DEBUG_BNPATH");
+            const char* e = ssc_dev_getenv("SSC_DEBUG_BNPATH");
             dbg = (e != nullptr && e[0] == '1') ? 1 : 0;
         }
         if (dbg) {
@@ -1834,7 +1834,7 @@ extern "C" int ssc_conv_forward_bnbwd(const ssc_conv_desc* dp, float* ws, int64_
     const long M = (long)d.NB * d.PH * d.PW;
     static int off = -1;        // SSC_FUSE_BNBWD=0: always the separate pass (A/B)
     if (off < 0) {
-        const char* e = getenv("SSC_FUSE_BNBWD");
+        const char* e = ssc_dev_getenv("SSC_FUSE_BNBWD");
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
     const bool earlier = ssc_head1_forward_supported(dp) || ssc_head1_dgrad_supported(dp) || ssc_conv_narrow_supported(dp) ||
@@ -1886,7 +1886,7 @@ extern "C" int ssc_conv_forward_minmax(const ssc_conv_desc* dp, float* ws, int64
     const long M = (long)d.NB * P;
     static int off = -1;        // SSC_FUSE_MINMAX=0: always the separate pass (A/B)
     if (off < 0) {
-        const char* e = getenv("SSC_FUSE_MINMAX");
+        const char* e = ssc_dev_getenv("SSC_FUSE_MINMAX");
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
     if (!off && ws != nullptr && d.nphase == 1 && !ssc_conv_narrow_supported(dp) && !ssc_conv_fewchan_supported(dp) &&
@@ -1925,7 +1925,7 @@ extern "C" int ssc_conv_forward_bnbwd2(const ssc_conv_desc* dp, float* ws, int64
     const long M = (long)d.NB * d.PH * d.PW;
     static int off = -1;        // SSC_FUSE_BNBWD=0: always the separate pass (A/B)
     if (off < 0) {
-        const char* e = getenv("SSC_FUSE_BNBWD");
+        const char* e = ssc_dev_getenv("SSC_FUSE_BNBWD");
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
     const int C1 = d.Nstore - C0;
@@ -2063,7 +2063,7 @@ static int launch_wgrad_v(const ssc_wgrad_desc& d, int splitk, float* ws, hipStr
     // of the plain order are served by the Infinity Cache while all XCDs walk the same pixel range -- so it stays off
     static int wg_xcd = -1;
     if (wg_xcd < 0) {
-        const char* e = getenv("SSC_WG_XCD");
+        const char* e = ssc_dev_getenv("SSC_WG_XCD");
         wg_xcd = (e != nullptr && e[0] == '1') ? 1 : 0;
     }
     const int xcd = (wg_xcd && splitk > 1 && (((long)mt * nt * splitk) & 7) == 0) ? 1 : 0;
@@ -2078,7 +2078,7 @@ static int launch_wgrad(const ssc_wgrad_desc& d, int splitk, float* ws, hipStrea
     const bool gp = gview_plain(d.g), dp = gview_plain(d.d);
     static int ddma_on = -1;       // SSC_WGRAD_DMA=0: dense tiles through registers (A/B)
     if (ddma_on < 0) {
-        const char* e = getenv("SSC_WGRAD_DMA");
+        const char* e = ssc_dev_getenv("SSC_WGRAD_DMA");
         ddma_on = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     // LDS-DMA of the dense tile: one plain tensor whose byte offsets fit 32 bits
@@ -2107,9 +2107,9 @@ static Plan plan_wgrad(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws) 
     Plan best = {-1, 1, 1e300, 0, 1};
     static int force_cfg = -2, force_sk = -2;       // SSC_WG_CFG / SSC_WG_SPLITK: tuning aids
     if (force_cfg == -2) {
-        const char* e = getenv("SSC_WG_CFG");
+        const char* e = ssc_dev_getenv("SSC_WG_CFG");
         force_cfg = (e != nullptr) ? atoi(e) : -1;
-        e = getenv("SSC_WG_SPLITK");
+        e = ssc_dev_getenv("SSC_WG_SPLITK");
         force_sk = (e != nullptr) ? atoi(e) : -1;
     }
     for (int c = 0; c < 5; ++c) {

@@ -625,7 +625,7 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
     const int xflag = 0x10000 | ((xcd >= 2 && d.nphase == 4) ? 0x20000 : 0);
     static int diag = -1;       // SSC_BF_DIAG bit 0: no in-launch K slices (plain tiles), bit 1: no XCD-aware order (diagnostics)
     if (diag < 0) {
-        const char* e = getenv("SSC_BF_DIAG");
+        const char* e = ssc_dev_getenv("SSC_BF_DIAG");
         diag = e != nullptr ? atoi(e) : 0;
     }
     if (diag & 2) xcd = 0;

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void narrow_sc_kernel(const ssc_conv_desc d, f
 
 // the scalar-filter form applies: channels of a (tap, output) contiguous and 16-byte aligned, <= 4x4 taps
 static bool narrow_sc_ok(const ssc_conv_desc& d) {
-    static const bool on = getenv("SSC_NARROW_WSC") == nullptr || atoi(getenv("SSC_NARROW_WSC")) != 0;
+    static const bool on = ssc_dev_getenv("SSC_NARROW_WSC") == nullptr || atoi(ssc_dev_getenv("SSC_NARROW_WSC")) != 0;
     const int nout = d.Nn < 1 ? 1 : d.Nn;
     const bool kcontig = (d.bmode == 1) ? (d.wC1 % 4 == 0) : (d.wC1 == 1 && nout == 1 && d.n_off == 0);
     if (!on || !kcontig || (reinterpret_cast<uintptr_t>(d.w) & 15) != 0) return false;

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void pw1x1_kernel(const ssc_conv_desc d, long 
 static bool pw_on() {
     static int on = -1;         // SSC_PW1X1=0: the tile kernel (A/B)
     if (on < 0) {
-        const char* e = getenv("SSC_PW1X1");
+        const char* e = ssc_dev_getenv("SSC_PW1X1");
         on = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     return on != 0;

@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "sketchycolor_hip.h"
+#include "host_util.h"
 
 #define CHECK_LAUNCH() ((int)hipGetLastError())
 
@@ -439,7 +440,7 @@ extern "C" int ssc_lstm_step_fwd(const float* h_in, const float* Kh, int ldk, co
     // batch 16 (576 rows) generator forward 9080 -> 9390 images/s; batch 32 (1152 rows) train step 17.96 -> 17.88 ms
     static int k2 = -2;
     if (k2 == -2) {
-        const char* e = getenv("SSC_LSTM_K2");
+        const char* e = ssc_dev_getenv("SSC_LSTM_K2");
         k2 = (e == nullptr) ? -1 : atoi(e);
     }
     const long wgs = ((rows + 63) / 64) * (C / 16);

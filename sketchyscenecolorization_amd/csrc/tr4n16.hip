@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
 static bool t16_on() {
     static int on = -1;         // SSC_TR4N16=0: the tile kernel (A/B)
     if (on < 0) {
-        const char* e = getenv("SSC_TR4N16");
+        const char* e = ssc_dev_getenv("SSC_TR4N16");
         on = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     return on != 0;

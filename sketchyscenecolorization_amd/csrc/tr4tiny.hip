@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void tr4_tiny_kernel(const ssc_conv_desc d, lo
 static bool t4t_on() {
     static int on = -1;         // SSC_TR4_TINY=0: the tile kernel (A/B)
     if (on < 0) {
-        const char* e = getenv("SSC_TR4_TINY");
+        const char* e = ssc_dev_getenv("SSC_TR4_TINY");
         on = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     return on != 0;

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void wgn16_reduce_kernel(const float* __restri
 static bool wg16_on() {
     static int on = -1;         // SSC_WGN16=0: the general filter-gradient kernel (A/B)
     if (on < 0) {
-        const char* e = getenv("SSC_WGN16");
+        const char* e = ssc_dev_getenv("SSC_WGN16");
         on = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     return on != 0;

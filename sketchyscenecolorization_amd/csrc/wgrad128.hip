@@ -385,7 +385,7 @@ extern "C" int ssc_conv_wgrad128_supported(const ssc_wgrad_desc* dp) {
     const ssc_wgrad_desc& d = *dp;
     static int off = -1;        // SSC_WGRAD128=0: always the 64-column kernel of igemm.hip (A/B)
     if (off < 0) {
-        const char* e = getenv("SSC_WGRAD128");
+        const char* e = ssc_dev_getenv("SSC_WGRAD128");
         off = (e != nullptr && e[0] == '0') ? 1 : 0;
     }
     if (off) return 0;
@@ -417,7 +417,7 @@ static int wg128_splitk(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws)
     const int ncu = wg128_num_cu();
     static int force = -2;
     if (force == -2) {
-        const char* e = getenv("SSC_WG128_SPLITK");
+        const char* e = ssc_dev_getenv("SSC_WG128_SPLITK");
         force = (e != nullptr) ? atoi(e) : -1;
     }
     long best = 1;
@@ -431,7 +431,7 @@ static int wg128_splitk(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws)
         double cost = (double)on_cu * (double)(per + 5);
         static double occ1 = -1.0;      // SSC_WG128_OCC1: penalty of one workgroup per CU (tuning aid)
         if (occ1 < 0.0) {
-            const char* e = getenv("SSC_WG128_OCC1");
+            const char* e = ssc_dev_getenv("SSC_WG128_OCC1");
             occ1 = (e != nullptr) ? atof(e) : 0.9;      // in the train step one workgroup per CU co-runs better: 1824 vs 1818 images/s (1.25)
         }
         if (on_cu == 1) cost *= occ1;
@@ -460,7 +460,7 @@ static int launch_wg128(const ssc_wgrad_desc& d, int splitk, float* ws, hipStrea
     const long wgs = ((Mtot + TB - 1) / TB) * ((d.Nn + TB - 1) / TB) * splitk;
     static int xcd_on = -1;     // SSC_WG128_XCD=0: plain grid order (A/B)
     if (xcd_on < 0) {
-        const char* e = getenv("SSC_WG128_XCD");
+        const char* e = ssc_dev_getenv("SSC_WG128_XCD");
         xcd_on = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     const int xcd = (xcd_on && splitk > 1 && (wgs & 7) == 0) ? 1 : 0;
@@ -475,7 +475,7 @@ static int launch_wg128_t(const ssc_wgrad_desc& d, int splitk, float* ws, hipStr
     const bool gp = view_plain(d.g), dp = view_plain(d.d);
     static int dma = -1;        // SSC_WGRAD_DMA=0: plain dense tiles through registers (A/B)
     if (dma < 0) {
-        const char* e = getenv("SSC_WGRAD_DMA");
+        const char* e = ssc_dev_getenv("SSC_WGRAD_DMA");
         dma = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     if (dp && dma) return gp ? launch_wg128<true, 0, TPT>(d, splitk, ws, st) : launch_wg128<false, 0, TPT>(d, splitk, ws, st);
@@ -499,7 +499,7 @@ static bool wg128_use_bf() {
     static int on = -1;         // SSC_ARITH=fp32 (everything exact) or SSC_WGRAD_BF16=0 (this kernel only): the exact-fp32 MFMA form
     if (on < 0) {
         const char* a = getenv("SSC_ARITH");
-        const char* w = getenv("SSC_WGRAD_BF16");
+        const char* w = ssc_dev_getenv("SSC_WGRAD_BF16");
         on = ((a != nullptr && (a[0] == 'f' || a[0] == 'F')) || (w != nullptr && w[0] == '0')) ? 0 : 1;
     }
     return on != 0;

@@ -70,6 +70,12 @@ class WgradDesc(C.Structure):
 _lib = None
 
 
+def _dev_env(name, default=None):
+    """Developer A/B switches are honoured only under SSC_DEV_SWITCHES=1 (lab tools, not supported configurations; DESIGN.md
+    section 7 lists the supported switches)."""
+    return os.environ.get(name, default) if os.environ.get('SSC_DEV_SWITCHES') == '1' else default
+
+
 def lib():
     """Load the HIP library; raise loudly when it is not there (no CPU fallback)."""
     global _lib
@@ -283,7 +289,7 @@ def workspace(nbytes=256 << 20):
 # there (after waiting for everything issued so far on the current stream), so their workgroups fill the CUs that the
 # chain's small layers and kernel tails leave idle; join_wgrad() makes the current stream wait for them.
 WGRAD_STREAM = None
-WGRAD_SIDE_MAX_PIXELS = int(os.environ.get('SSC_WGRAD_SIDE_PIXELS', '0')) or None   # None = every layer
+WGRAD_SIDE_MAX_PIXELS = int(_dev_env('SSC_WGRAD_SIDE_PIXELS', '0')) or None   # None = every layer
 _wgrad_pending = False
 
 
@@ -441,7 +447,7 @@ _SPLITS = {}            # (data_ptr, taps, c0, c1, orient) -> _Split; the entry 
 _SPLIT_TABLES = {}      # tuple of keys -> (device job table, total threads)
 _PARAM_RANGES = []      # [lo, hi) byte ranges of the flat parameter buffers (ParamStore scopes): filters inside them are PARAMETERS
 _VOLATILE_MAX = 256     # entries of filters that are not parameters (see filter_split)
-_SPLIT_ALWAYS = os.environ.get('SSC_SPLIT_ALWAYS', '0') == '1'      # diagnostic: every filter treated as volatile
+_SPLIT_ALWAYS = _dev_env('SSC_SPLIT_ALWAYS', '0') == '1'      # diagnostic: every filter treated as volatile
 
 
 class _Split(object):

@@ -21,13 +21,14 @@ MFMA kernel with bias (+ lrelu for the gates) in its epilogue.  Fusions that cha
 import torch
 
 from . import hip
+from .hip import _dev_env
 from .hip import ACT_MIU, ACT_NONE, ACT_PRELU, View
 from .text_fusion import TextFusion
 
 import os as _os
-_SPLIT_DGRAD = _os.environ.get('SSC_MRU_SPLIT_DGRAD', '1') == '1'
-_FUSE_MINMAX = _os.environ.get('SSC_MRU_FUSE_MINMAX', '1') == '1'           # gate extrema out of the conv epilogue (A/B)
-_FUSE_CBN_STATS = _os.environ.get('SSC_MRU_FUSE_STATS', '1') == '1'      # conditional-norm statistics out of the conv epilogue (A/B)
+_SPLIT_DGRAD = _dev_env('SSC_MRU_SPLIT_DGRAD', '1') == '1'
+_FUSE_MINMAX = _dev_env('SSC_MRU_FUSE_MINMAX', '1') == '1'           # gate extrema out of the conv epilogue (A/B)
+_FUSE_CBN_STATS = _dev_env('SSC_MRU_FUSE_STATS', '1') == '1'      # conditional-norm statistics out of the conv epilogue (A/B)
 
 ENC_UNITS = [(1, 8, 64), (2, 64, 128), (3, 128, 256), (4, 256, 512)]                 # (unit, C_h, D); inp = 3 ch
 DEC_UNITS = [(0, 512, 384), (2, 384, 256), (4, 256, 128), (6, 128, 128), (8, 128, 64)]      # (unit_num, C_h, D)

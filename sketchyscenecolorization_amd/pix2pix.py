@@ -13,6 +13,7 @@ import os
 import torch
 
 from . import hip
+from .hip import _dev_env
 from .hip import ACT_LRELU, ACT_NONE, ACT_RELU, View
 from .text_fusion import TextFusion
 
@@ -21,9 +22,9 @@ def _rows(t):
     return t if t.dim() == 2 else t.view(-1, t.shape[-1])
 
 
-_MERGE_DDGRAD = os.environ.get('SSC_MERGE_DDGRAD', '1') == '1'
-_DBWD_WGRAD_FIRST = os.environ.get('SSC_DBWD_WGRAD_FIRST', '1') == '1'   # discriminator backward: filter gradient of layer k in front of its data gradient (round-3 order; the round-4 order -- behind the data gradient and the sums' fold -- measured 0.3 ms slower per iteration on one box, profiles/r05_ab_envsets.txt)
-_BNBWD2 = os.environ.get('SSC_BNBWD2', '1') == '1'      # norm-backward sums of both halves out of the merged launch's epilogue (A/B)
+_MERGE_DDGRAD = _dev_env('SSC_MERGE_DDGRAD', '1') == '1'
+_DBWD_WGRAD_FIRST = _dev_env('SSC_DBWD_WGRAD_FIRST', '1') == '1'   # discriminator backward: filter gradient of layer k in front of its data gradient (round-3 order; the round-4 order -- behind the data gradient and the sums' fold -- measured 0.3 ms slower per iteration on one box, profiles/r05_ab_envsets.txt)
+_BNBWD2 = _dev_env('SSC_BNBWD2', '1') == '1'      # norm-backward sums of both halves out of the merged launch's epilogue (A/B)
 
 
 class Pix2PixGenerator(object):
@@ -297,7 +298,7 @@ class Pix2PixGenerator(object):
         done('encoders')
 
 
-_HEAD1_FUSED = os.environ.get('SSC_HEAD1_FUSED', '0') == '1'
+_HEAD1_FUSED = _dev_env('SSC_HEAD1_FUSED', '0') == '1'
 
 
 class Pix2PixDiscriminator(object):

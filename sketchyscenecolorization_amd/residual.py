@@ -21,6 +21,7 @@ projection shortcut; gradients of a tensor with several consumers accumulate in 
 import torch
 
 from . import hip
+from .hip import _dev_env
 from .hip import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, View
 from .params import RESIDUAL_UNITS
 from .text_fusion import TextFusion
@@ -28,7 +29,7 @@ from .text_fusion import TextFusion
 
 import os as _os
 
-_BLOCK_OUT_FUSED = _os.environ.get('SSC_BLOCK_OUT_FUSED', '1') == '1'     # ssc_block_out_backward (A/B switch)
+_BLOCK_OUT_FUSED = _dev_env('SSC_BLOCK_OUT_FUSED', '1') == '1'     # ssc_block_out_backward (A/B switch)
 
 
 def _rows(t):

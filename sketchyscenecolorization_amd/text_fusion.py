@@ -20,11 +20,12 @@ import numpy as np
 import torch
 
 from . import hip
+from .hip import _dev_env
 
 import os
 
 CELL = '/RNN/%s/multi_rnn_cell/cell_0/basic_lstm_cell/'
-FUSED_STEP = os.environ.get('SSC_LSTM_FUSED', '1') != '0'     # recurrent GEMM + gate math in one launch per step
+FUSED_STEP = _dev_env('SSC_LSTM_FUSED', '1') != '0'     # recurrent GEMM + gate math in one launch per step
 
 
 class TextFusion(object):

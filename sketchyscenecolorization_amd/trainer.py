@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import hip
+from .hip import _dev_env
 from .dist_utils import GradReducer
 from .params import Buffers, ParamStore
 from .pix2pix import Pix2PixDiscriminator, Pix2PixGenerator
@@ -152,7 +153,7 @@ class GanTrainer(object):
             # norm backward of a layer next to the filter gradient of the layer above (Pix2PixGenerator._fork).  OFF: measured
             # 18.28 vs 18.07 ms/step -- a fork + join per layer costs more in cross-queue dependencies of the replayed
             # graph than the three small launches it hides
-            if overlap_real and os.environ.get('SSC_BN_OVERLAP', '0') == '1':
+            if overlap_real and _dev_env('SSC_BN_OVERLAP', '0') == '1':
                 self.G.bn_stream = torch.cuda.Stream()
         self._seg = None
         self.lr_dev = torch.zeros(2, dtype=torch.float32, device=device)     # Adam step sizes [G, D]
