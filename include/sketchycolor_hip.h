@@ -481,6 +481,15 @@ int ssc_lstm_pointwise_fwd(const float* g0, const float* g1, const float* g2, in
 int ssc_lstm_step_fwd(const float* h_in, const float* Kh, int ldk, const float* g1, const float* g2, int div2,
                       const int* mask, int mdiv, const float* c_in, int64_t rows, int C, int with_gemm, float* c_out,
                       float* h_out, float* acts, void* stream);
+/* The same step on the bf16 matrix pipe, six bf16 products per fp32 product (fp32-grade results); C % 128 == 0.
+ * Kp = the planes of Kh [C, 4C] from ssc_filter_split(Kh, 1, C, 4 * C, 0, ...), nbp = their blocks per plane
+ * (ssc_filter_split_geom).  hp_in = the bf16 planes of h_in in the A-operand fragment layout (ssc_lstm_hsplit, or the previous
+ * step's hp_out: ceil(rows / 64) * 2 * (C / 16) * 3 KiB -- whole 64-row tiles); NULL = h_in is zero, no product (with_gemm = 0 above).  hp_out (may be
+ * NULL) receives the planes of h_out; acts may be NULL (inference: nobody reads the activated gates). */
+int ssc_lstm_step_fwd_bf(const float* h_in, const void* hp_in, const void* Kp, int nbp, const float* g1, const float* g2,
+                         int div2, const int* mask, int mdiv, const float* c_in, int64_t rows, int C, float* c_out,
+                         float* h_out, void* hp_out, float* acts, void* stream);
+int ssc_lstm_hsplit(const float* h, int64_t rows, int C, void* hp, void* stream);
 int ssc_lstm_pointwise_bwd(const float* dh, const float* dc, const float* acts, const float* c_in, const float* c_out,
                            const int* mask, int mdiv, int64_t rows, int C, float* dg, float* dc_in, float* dh_pass,
                            float* gacc, void* stream);

@@ -12,6 +12,8 @@ from collections import defaultdict
 
 def demangled_short(name):
     # rocpd stores demangled names: "void conv_fwd_kernel<2, 2, 1, 2, 0, true, true>(...)"
+    if 'lstm_step_fwd_bf' in name:
+        return 'lstm_step_fwd_bf16x6<64x32>'
     if 'lstm_step_fwd' in name:       # lstm_step_fwd_kernel and lstm_step_fwd_k2_kernel, with or without a leading "void "
         return 'lstm_step_fwd<64x64>'
     mb = re.match(r'(?:void )?conv_bf_kernel<([^>]*)>', name)
@@ -38,11 +40,13 @@ def demangled_short(name):
 def mangled_short(name):
     """The same report names from the MANGLED symbol (the kernel_symbol table of a kernel trace keeps `_Z14conv_ut_kernelILi2E...`)."""
     m = re.match(r'_Z\d+(conv_fwd_kernel|conv_ut_kernel|conv_bf_kernel|conv_wgrad_kernel|narrow_fwd_kernel|narrow_sc_kernel|'
-                 r'conv_wgrad128_bf_kernel|conv_wgrad128_kernel|lstm_step_fwd_kernel|lstm_step_fwd_k2_kernel)(?:I((?:L[ib]\d+E)+)E)?', name)
+                 r'conv_wgrad128_bf_kernel|conv_wgrad128_kernel|lstm_step_fwd_bf_kernel|lstm_step_fwd_kernel|lstm_step_fwd_k2_kernel)(?:I((?:L[ib]\d+E)+)E)?', name)
     if not m:
         return None
     k = m.group(1)
     args = [int(a) for a in re.findall(r'L[ib](\d+)E', m.group(2) or '')]
+    if k == 'lstm_step_fwd_bf_kernel':
+        return 'lstm_step_fwd_bf16x6<64x32>'
     if k.startswith('lstm_step_fwd'):
         return 'lstm_step_fwd<64x64>'
     if k == 'conv_wgrad128_bf_kernel':

@@ -212,6 +212,22 @@ __global__ void lstm_bwd_kernel(const float* __restrict__ dh, const float* __res
 // K-tile 32, register prefetch of the next K-tile, one barrier per K-tile.
 typedef float lstm_f32x16 __attribute__((ext_vector_type(16)));
 
+// Workgroup -> (row block, unit block) of the step kernels, XCD-aware: consecutive workgroup ids go to consecutive XCDs (8 of them,
+// one L2 each), so unit block ub is given to the ids with id % 8 == ub % 8 -- every XCD then reads ONE EIGHTH of K_h (which stays
+// in its L2 from step to step) instead of all of it.  With the plain (row block, unit block) grid each of the 8 L2s pulled the
+// whole 4-6 MB of K_h through the fabric in every one of a caption's 28 dependent steps.  Unit-block counts that are not a multiple of 8 keep the plain order.
+__device__ __forceinline__ void lstm_wg_map(int id, int row_blocks, int unit_blocks, int& rb, int& ub) {
+    if (unit_blocks & 7) {      // small C (tests): plain order
+        ub = id / row_blocks;
+        rb = id - ub * row_blocks;
+        return;
+    }
+    const int xcd = id & 7, q = id >> 3;
+    const int ul = q / row_blocks;
+    rb = q - ul * row_blocks;
+    ub = ul * 8 + xcd;
+}
+
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const float* __restrict__ h_in, const float* __restrict__ Kh,
                                                             int ldk, const float* __restrict__ g1,
                                                             const float* __restrict__ g2, int div2,
@@ -225,7 +241,9 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const float* __restr
     float* Bs = smem + 2 * BM * A_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
-    const int m0 = blockIdx.x * BM, u0 = blockIdx.y * 16;
+    int rb_, ub_;
+    lstm_wg_map(blockIdx.x, (rows + BM - 1) / BM, C / 16, rb_, ub_);
+    const int m0 = rb_ * BM, u0 = ub_ * 16;
 
     lstm_f32x16 acc;
 #pragma unroll
@@ -331,7 +349,9 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_k2_kernel(const float* __re
     float* Bs = smem + 2 * BM * A_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, kh = wave >> 1, l31 = lane & 31, lhi = lane >> 5;
-    const int m0 = blockIdx.x * BM, u0 = blockIdx.y * 8;
+    int rb_, ub_;
+    lstm_wg_map(blockIdx.x, (rows + BM - 1) / BM, C / 8, rb_, ub_);
+    const int m0 = rb_ * BM, u0 = ub_ * 8;
 
     lstm_f32x16 acc;
 #pragma unroll
@@ -432,6 +452,251 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_k2_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------ the same step on the bf16 matrix pipe (bf16x6)
+// h @ Kh as six bf16 products per fp32 product (igemm_bf16.hip: x = h + m + l exactly, hh in one fp32 accumulator, the five
+// correction products in another, added at the end).  The exact-fp32 step is bound by its own MFMA chain -- 64 x 32 x 512 per
+// workgroup is 8192 cycles of v_mfma_f32_32x32x2_f32 per wave -- and a first bf16 form that split h in registers from
+// row-major loads (a lane's 8 consecutive k of ITS row: 64 cache lines per load instruction) was slower still, bound by the
+// address rate of the vector memory path.  This form has NO LDS, NO barrier and NO split in its K loop, only lane-linear 16-byte
+// loads (1 KiB per wave and instruction):
+//   * K_h comes pre-split in the fragment-major planes of ssc_filter_split (taps 1, c0 = C, c1 = 4C, orient 0); the workgroup's
+//     32 gate columns (4 gates x 8 units) sit in four fragments, a lane takes the 16 bytes of its column's lane there;
+//   * h comes pre-split too: the step's epilogue writes h_out a second time as bf16 planes in the A-operand fragment layout
+//     (hp_out: fragment (rb, kc, plane) = 1 KiB at ((rb * C/16 + kc) * 3 + plane) * 1024, rb = 32-row block, lane L holds
+//     h[rb * 32 + (L & 31)][kc * 16 + (L >> 5) * 8 .. + 7]) -- a workgroup's 8 units are exactly one lane's 16 bytes per row.
+// Workgroup = 64 rows x 8 units; wave = one K quarter of both 32-row blocks (the B fragments are loaded once for the two);
+// loads run PF chunks ahead; the four partial tiles meet in LDS before the gate math.
+typedef short lstm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 lstm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float lstm_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned lstm_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned lstm_cvt_pk_bf16(float a, float b) {
+    const lstm_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, lstm_bf16x2));
+}
+__device__ __forceinline__ void lstm_split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = lstm_cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = lstm_cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = lstm_cvt_pk_bf16(s0, s1);
+}
+
+// h [rows, C] -> its planes (the form the step's epilogue writes): thread = (row, 8 consecutive k)
+__global__ void lstm_hsplit_kernel(const float* __restrict__ h, int rows, int C, char* __restrict__ hp) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_row = C / 8;
+    const long r = t / per_row;
+    if (r >= rows) return;
+    const int k8 = (int)(t - r * per_row);
+    const float4 x0 = *reinterpret_cast<const float4*>(h + r * C + k8 * 8);
+    const float4 x1 = *reinterpret_cast<const float4*>(h + r * C + k8 * 8 + 4);
+    lstm_u32x4 ph, pm, pl;
+    unsigned a, b, c;
+    lstm_split3_pair(x0.x, x0.y, a, b, c); ph[0] = a; pm[0] = b; pl[0] = c;
+    lstm_split3_pair(x0.z, x0.w, a, b, c); ph[1] = a; pm[1] = b; pl[1] = c;
+    lstm_split3_pair(x1.x, x1.y, a, b, c); ph[2] = a; pm[2] = b; pl[2] = c;
+    lstm_split3_pair(x1.z, x1.w, a, b, c); ph[3] = a; pm[3] = b; pl[3] = c;
+    const long rb = r >> 5;
+    const int kc = k8 >> 1, ln = (int)(r & 31) + 32 * (k8 & 1);
+    char* f = hp + ((rb * (C / 16) + kc) * 3) * 1024 + ln * 16;
+    *reinterpret_cast<lstm_u32x4*>(f) = ph;
+    *reinterpret_cast<lstm_u32x4*>(f + 1024) = pm;
+    *reinterpret_cast<lstm_u32x4*>(f + 2048) = pl;
+}
+
+template <int PF>
+__global__ __launch_bounds__(256, 3) void lstm_step_fwd_bf_kernel(const float* __restrict__ h_in, const char* __restrict__ hp_in,
+                                                                const char* __restrict__ Kp, int nbp,
+                                                                const float* __restrict__ g1, const float* __restrict__ g2,
+                                                                int div2, const int* __restrict__ mask, int mdiv,
+                                                                const float* __restrict__ c_in, int rows, int C,
+                                                                float* __restrict__ c_out, float* __restrict__ h_out,
+                                                                char* __restrict__ hp_out, float* __restrict__ acts) {
+    constexpr int BM = 64, C_LD = 36;
+    __shared__ __attribute__((aligned(16))) float smem[4 * BM * C_LD];      // the four K quarters' C images (36 KB)
+    const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int rb_, ub_;
+    lstm_wg_map(blockIdx.x, (rows + BM - 1) / BM, C / 8, rb_, ub_);
+    const int m0 = rb_ * BM, u0 = ub_ * 8;
+    const int KC = C / 16;
+
+    lstm_f32x16 acc[2], accc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = accc[i][r] = 0.f;
+
+    // The gate math's inputs are asked for NOW: thread = (row tid >> 2, units 2 * (tid & 3), + 1), so the quad of a row holds the
+    // row's 8 units (= one lane's 16 bytes of the next step's A fragment per plane).  With ~250 registers only two waves share
+    // a SIMD and nothing hides an epilogue that starts its loads behind the K loop (17 us of a 28 us step that way).
+    const int rl = tid >> 2, u = (tid & 3) * 2;
+    const long r = m0 + rl;
+    const bool valid = r < rows;
+    bool live = false;
+    float2 c0 = make_float2(0.f, 0.f), h0 = c0, gv1[4], gv2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gv1[g] = gv2[g] = make_float2(0.f, 0.f);
+    if (valid) {
+        const long i = r * C + u0 + u;
+        live = mask[r / mdiv] != 0;
+        c0 = *reinterpret_cast<const float2*>(c_in + i);
+        h0 = *reinterpret_cast<const float2*>(h_in + i);
+        // (not behind `live`: a second round trip to memory costs more than the skipped rows' addends)
+        const long gb = r * 4 * C + u0 + u;
+        if (g1 != nullptr) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gv1[g] = *reinterpret_cast<const float2*>(g1 + gb + g * C);
+        }
+        if (g2 != nullptr) {
+            const long q = (r / div2) * 4 * C + u0 + u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gv2[g] = *reinterpret_cast<const float2*>(g2 + q + g * C);
+        }
+    }
+
+    if (hp_in != nullptr) {
+        // A: fragments (2 * rb_ + i, kc, plane), lane-linear;  B: column l31 of the tile = gate l31 >> 3, unit u0 + (l31 & 7)
+        const char* ap = hp_in + ((long)(2 * rb_) * KC * 3) * 1024 + lane * 16;
+        const long a_rb = (long)KC * 3 * 1024;
+        const int col = (l31 >> 3) * C + u0 + (l31 & 7);
+        const char* bp = Kp + (long)(col >> 5) * 1024 + ((col & 31) + 32 * lhi) * 16;
+        const long pl_stride = (long)nbp * 1024, kc_stride = 3 * pl_stride;
+        const int nkc = KC / 4;             // chunks of 16 k per K quarter (host: a multiple of PF)
+        const int kc0 = kq * nkc;
+
+        lstm_u32x4 ra[PF][2][3], rb[PF][3];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const char* a = ap + (long)(kc0 + s) * 3 * 1024;
+            const char* b = bp + (kc0 + s) * kc_stride;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                ra[s][0][p] = *reinterpret_cast<const lstm_u32x4*>(a + p * 1024);
+                ra[s][1][p] = *reinterpret_cast<const lstm_u32x4*>(a + a_rb + p * 1024);
+                rb[s][p] = *reinterpret_cast<const lstm_u32x4*>(b + p * pl_stride);
+            }
+        }
+        // compiler fences keep the loads where they are written: without them the prologue's loads sink into the loop and every
+        // iteration waits for the data it has just asked for
+        asm volatile("" ::: "memory");
+        for (int k0 = 0; k0 < nkc; k0 += PF) {
+#pragma unroll
+            for (int s = 0; s < PF; ++s) {
+                lstm_bf16x8 A[2][3], Bv[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    A[0][p] = __builtin_bit_cast(lstm_bf16x8, ra[s][0][p]);
+                    A[1][p] = __builtin_bit_cast(lstm_bf16x8, ra[s][1][p]);
+                    Bv[p] = __builtin_bit_cast(lstm_bf16x8, rb[s][p]);
+                }
+                // the chunk PF further on into the set just consumed (branch-free: the tail re-reads the last chunk)
+                {
+                    const int kn = kc0 + min(k0 + s + PF, nkc - 1);
+                    const char* a = ap + (long)kn * 3 * 1024;
+                    const char* b = bp + kn * kc_stride;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        ra[s][0][p] = *reinterpret_cast<const lstm_u32x4*>(a + p * 1024);
+                        ra[s][1][p] = *reinterpret_cast<const lstm_u32x4*>(a + a_rb + p * 1024);
+                        rb[s][p] = *reinterpret_cast<const lstm_u32x4*>(b + p * pl_stride);
+                    }
+                    asm volatile("" ::: "memory");
+                }
+                // products smallest first, the two row blocks in turn (no back-to-back dependence)
+                constexpr int pa[5] = {2, 0, 1, 1, 0}, pb[5] = {0, 2, 1, 0, 1};
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][pa[t]], Bv[pb[t]], accc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bv[0], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);      // the next chunk's MFMAs stay behind these (else all sets are waited for at once)
+            }
+        }
+    }
+    // accumulators -> LDS [K quarter][row][gate * 8 + unit]
+    float* Cs = smem + kq * BM * C_LD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * C_LD + l31] = acc[i][r] + accc[i][r];
+    __syncthreads();
+    if (!valid) return;
+    const long i = r * C + u0 + u;
+    float2 hv = h0;
+    if (!live) {
+        *reinterpret_cast<float2*>(c_out + i) = c0;
+        *reinterpret_cast<float2*>(h_out + i) = h0;      // acts are never read for skipped steps
+    } else {
+        const long gb = r * 4 * C + u0 + u;
+        const int o = rl * C_LD + u;
+        float2 z[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            z[g] = make_float2(gv1[g].x + gv2[g].x, gv1[g].y + gv2[g].y);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float2 p = *reinterpret_cast<const float2*>(smem + q * BM * C_LD + o + g * 8);
+                z[g].x += p.x; z[g].y += p.y;
+            }
+        }
+        const float2 ai = make_float2(sigmoidf_(z[0].x), sigmoidf_(z[0].y)), aj = make_float2(tanhf(z[1].x), tanhf(z[1].y)),
+                     af = make_float2(sigmoidf_(z[2].x + 1.0f), sigmoidf_(z[2].y + 1.0f)),
+                     ao = make_float2(sigmoidf_(z[3].x), sigmoidf_(z[3].y));
+        const float2 c1 = make_float2(c0.x * af.x + ai.x * aj.x, c0.y * af.y + ai.y * aj.y);
+        hv = make_float2(tanhf(c1.x) * ao.x, tanhf(c1.y) * ao.y);
+        *reinterpret_cast<float2*>(c_out + i) = c1;
+        *reinterpret_cast<float2*>(h_out + i) = hv;
+        if (acts != nullptr) {      // the backward pass's copy of the activated gates; inference passes NULL
+            *reinterpret_cast<float2*>(acts + gb) = ai;
+            *reinterpret_cast<float2*>(acts + gb + C) = aj;
+            *reinterpret_cast<float2*>(acts + gb + 2 * C) = af;
+            *reinterpret_cast<float2*>(acts + gb + 3 * C) = ao;
+        }
+    }
+    if (hp_out != nullptr) {
+        unsigned ph, pm, pl;
+        lstm_split3_pair(hv.x, hv.y, ph, pm, pl);
+        const int ln = (int)(r & 31) + 32 * ((u0 >> 3) & 1);
+        char* f = hp_out + (((r >> 5) * KC + (u0 >> 4)) * 3) * 1024 + ln * 16 + (tid & 3) * 4;
+        *reinterpret_cast<unsigned*>(f) = ph;
+        *reinterpret_cast<unsigned*>(f + 1024) = pm;
+        *reinterpret_cast<unsigned*>(f + 2048) = pl;
+    }
+}
+
+// h [rows, C] (fp32) -> hp, the bf16 planes ssc_lstm_step_fwd_bf reads: ceil(rows / 64) * 2 * (C / 16) * 3 KiB (whole 64-row tiles)
+extern "C" int ssc_lstm_hsplit(const float* h, int64_t rows, int C, void* hp, void* stream) {
+    if ((C & 15) || rows <= 0) return -1;
+    const long threads = (long)rows * (C / 8);
+    hipLaunchKernelGGL(lstm_hsplit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h, (int)rows,
+                       C, (char*)hp);
+    return CHECK_LAUNCH();
+}
+
+// Kp: the planes of K_h [C, 4C] from ssc_filter_split(Kh, 1, C, 4 * C, 0, ...), nbp their blocks-per-plane count
+// (ssc_filter_split_geom).  hp_in: the planes of h_in (ssc_lstm_hsplit, or the previous step's hp_out); NULL = h_in is zero, no
+// product (ssc_lstm_step_fwd's with_gemm = 0).  hp_out (may be NULL): receives the planes of h_out.  Otherwise the arguments and
+// results of ssc_lstm_step_fwd.
+extern "C" int ssc_lstm_step_fwd_bf(const float* h_in, const void* hp_in, const void* Kp, int nbp, const float* g1,
+                                    const float* g2, int div2, const int* mask, int mdiv, const float* c_in, int64_t rows,
+                                    int C, float* c_out, float* h_out, void* hp_out, float* acts, void* stream) {
+    if ((C & 127) || Kp == nullptr || nbp < (4 * C) / 32 || rows <= 0 || rows > 0x7fffffffL / (4L * C)) return -1;
+    const dim3 grid((unsigned)(((rows + 63) / 64) * (C / 8)));
+#define LSTM_BF_LAUNCH(PF)                                                                                                \
+    hipLaunchKernelGGL(lstm_step_fwd_bf_kernel<PF>, grid, dim3(256), 0, (hipStream_t)stream, h_in, (const char*)hp_in,    \
+                       (const char*)Kp, nbp, g1, g2, div2 > 0 ? div2 : 1, mask, mdiv > 0 ? mdiv : 1, c_in, (int)rows, C,  \
+                       c_out, h_out, (char*)hp_out, acts)
+    LSTM_BF_LAUNCH(2);      // C / 64 chunks per K quarter, a multiple of PF = 2 (18 KiB of loads in flight per wave)
+#undef LSTM_BF_LAUNCH
+    return CHECK_LAUNCH();
+}
+
 extern "C" int ssc_lstm_step_fwd(const float* h_in, const float* Kh, int ldk, const float* g1, const float* g2, int div2,
                                  const int* mask, int mdiv, const float* c_in, int64_t rows, int C, int with_gemm,
                                  float* c_out, float* h_out, float* acts, void* stream) {
@@ -446,11 +711,11 @@ extern "C" int ssc_lstm_step_fwd(const float* h_in, const float* Kh, int ldk, co
     const long wgs = ((rows + 63) / 64) * (C / 16);
     const bool use_k2 = with_gemm && (C % 128) == 0 && (k2 == 1 || (k2 == -1 && wgs < 1200));     // its loads run 4 K tiles ahead
     if (use_k2)
-        hipLaunchKernelGGL(lstm_step_fwd_k2_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(C / 8)), dim3(256), 0,
+        hipLaunchKernelGGL(lstm_step_fwd_k2_kernel, dim3((unsigned)(((rows + 63) / 64) * (C / 8))), dim3(256), 0,
                            (hipStream_t)stream, h_in, Kh, ldk, g1, g2, div2 > 0 ? div2 : 1, mask, mdiv > 0 ? mdiv : 1, c_in,
                            (int)rows, C, with_gemm, c_out, h_out, acts);
     else
-        hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(C / 16)), dim3(256), 0,
+        hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3((unsigned)(((rows + 63) / 64) * (C / 16))), dim3(256), 0,
                            (hipStream_t)stream, h_in, Kh, ldk, g1, g2, div2 > 0 ? div2 : 1, mask, mdiv > 0 ? mdiv : 1, c_in,
                            (int)rows, C, with_gemm, c_out, h_out, acts);
     return CHECK_LAUNCH();

@@ -183,6 +183,8 @@ SIGNATURES = {
     'ssc_row_l2norm_bwd': [_P, _P, _P, _L, _I, _P, _I, _P],
     'ssc_lstm_pointwise_fwd': [_P, _P, _P, _I, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P],
     'ssc_lstm_step_fwd': [_P, _P, _I, _P, _P, _I, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P],
+    'ssc_lstm_step_fwd_bf': [_P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _L, _I, _P, _P, _P, _P, _P],
+    'ssc_lstm_hsplit': [_P, _L, _I, _P, _P],
     'ssc_lstm_pointwise_bwd': [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P],
     'ssc_squash_fwd': [_P, _L, _P, _P],
     'ssc_squash_bwd': [_P, _P, _P, _L, _P, _P],
@@ -1125,18 +1127,41 @@ def call(name, *args):
     check(getattr(lib(), name)(*conv, stream_ptr()), name)
 
 
-def lstm_step_fwd(h_in, Kh, ldk, g1, g2, div2, mask, mdiv, c_in, rows, C, with_gemm, c_out, h_out, acts):
-    """One recurrent step (GEMM + gate math) in one launch; counted with the implicit-GEMM launches when profiling."""
-    args = (h_in, Kh, ldk, g1, g2, div2, mask, mdiv, c_in, rows, C, int(with_gemm), c_out, h_out, acts)
+def lstm_bf(C, ldk):
+    """Does the recurrent step of a [C, 4C] kernel (row stride ldk) run on the bf16 pipe?"""
+    return ARITH_BF16 and C % 128 == 0 and ldk == 4 * C
+
+
+def lstm_hplanes_floats(rows, C):
+    """Size (in fp32 elements, for the buffer pools) of the bf16 planes of an h state [rows, C] (ssc_lstm_step_fwd_bf)."""
+    return ((rows + 63) // 64) * 2 * (C // 16) * 3 * 256         # whole 64-row workgroup tiles: the kernel loads both 32-row blocks
+
+
+def lstm_step_fwd(h_in, Kh, ldk, g1, g2, div2, mask, mdiv, c_in, rows, C, with_gemm, c_out, h_out, acts, exact=False, hp_in=None,
+                  hp_out=None):
+    """One recurrent step (GEMM + gate math) in one launch; counted with the implicit-GEMM launches when profiling.
+    Default arithmetic: h @ Kh as six bf16 products per fp32 product on the planes of Kh and of h (``exact`` / SSC_ARITH=fp32:
+    the exact-fp32 MFMA kernels).  hp_in / hp_out: plane buffers of h_in / h_out (lstm_hplanes_floats); a loop over steps hands
+    each step's hp_out to the next as hp_in, a lone call lets h_in be split here."""
+    bf = lstm_bf(C, ldk) and not exact and Kh.is_contiguous()
+    if bf:
+        e = filter_split(Kh.view(1, 1, C, 4 * C), 0)
+        if with_gemm and hp_in is None:
+            hp_in = torch.empty(lstm_hplanes_floats(rows, C), device=h_in.device)
+            call('ssc_lstm_hsplit', h_in, rows, C, hp_in)
+        name = 'ssc_lstm_step_fwd_bf'
+        args = (h_in, hp_in if with_gemm else None, e.buf, e.nbp, g1, g2, div2, mask, mdiv, c_in, rows, C, c_out, h_out, hp_out, acts)
+    else:
+        name, args = 'ssc_lstm_step_fwd', (h_in, Kh, ldk, g1, g2, div2, mask, mdiv, c_in, rows, C, int(with_gemm), c_out, h_out, acts)
     if PROFILE is None or not with_gemm:
-        call('ssc_lstm_step_fwd', *args)
+        call(name, *args)
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    call('ssc_lstm_step_fwd', *args)
+    call(name, *args)
     e1.record()
-    PROFILE.append(('lstm_step_fwd<64x64>', 2.0 * rows * C * 4 * C, e0, e1, (rows, 4 * C, C),
-                    4.0 * (rows * C + C * 4 * C + 3 * rows * 4 * C)))
+    PROFILE.append(('lstm_step_fwd_bf16x6<64x32>' if bf else 'lstm_step_fwd<64x64>', 2.0 * rows * C * 4 * C, e0, e1, (rows, 4 * C, C),
+                    (6.0 if bf else 4.0) * (rows * C + C * 4 * C) + 4.0 * 3 * rows * 4 * C))
 
 
 def concat_parts(out, parts):

@@ -79,10 +79,13 @@ class TextFusion(object):
         tmp_w = B.get(tag + '/tf/tmp_w', (N, G4))
         hip.fill(cw[0], 0.0)
         hip.fill(hw[0], 0.0)
+        # bf16 arithmetic: every step also leaves its h as bf16 planes for the next one (two buffers in turn)
+        hpw = B.get(tag + '/tf/hpw', (2, hip.lstm_hplanes_floats(N, C)), zero_on_alloc=True) if FUSED_STEP and hip.lstm_bf(C, G4) else None
         for i in range(S):
             if FUSED_STEP:      # the step's GEMM and its gate math in one launch
                 hip.lstm_step_fwd(hw[i], Kw[C:2 * C], G4, EW[i * N:(i + 1) * N], None, 1, mask[i], 1, cw[i], N, C, i > 0,
-                                  cw[i + 1], hw[i + 1], acts_w[i])
+                                  cw[i + 1], hw[i + 1], acts_w[i], hp_in=None if hpw is None or i == 0 else hpw[(i - 1) & 1],
+                                  hp_out=None if hpw is None else hpw[i & 1])
                 continue
             hip.matmul(hw[i], Kw[C:2 * C], tmp_w)
             hip.call('ssc_lstm_pointwise_fwd', tmp_w, EW[i * N:(i + 1) * N], None, 1, mask[i], 1, cw[i], hw[i], N, C,
@@ -148,10 +151,12 @@ class TextFusion(object):
         tmp_a = B.get(tag + '/tf/tmp_a', (R, G4))
         hip.fill(ca[0], 0.0)
         hip.fill(ha[0], 0.0)
+        hpa = B.get(tag + '/tf/hpa', (2, hip.lstm_hplanes_floats(R, C)), zero_on_alloc=True) if FUSED_STEP and hip.lstm_bf(C, G4) else None
         for i in range(S):
             if FUSED_STEP:
                 hip.lstm_step_fwd(ha[i], Ka[3 * C:4 * C], G4, Gv, Rall[i * N:(i + 1) * N], P, mask[i], P, ca[i], R, C, i > 0,
-                                  ca[i + 1], ha[i + 1], acts_a[i])
+                                  ca[i + 1], ha[i + 1], acts_a[i], hp_in=None if hpa is None or i == 0 else hpa[(i - 1) & 1],
+                                  hp_out=None if hpa is None else hpa[i & 1])
                 continue
             if i == 0:
                 hip.fill(tmp_a, 0.0)        # h_a = 0: skip the GEMM

@@ -518,13 +518,18 @@ def test_few_channel_stride2_conv(n, h, cp, cr):
         close(nchw(g1), xin.grad[:, 64:])
 
 
-@pytest.mark.parametrize('rows,div2,form', [(200, 1, 'k2'), (2592, 36, 'plain'), (72, 36, 'k2')])
-def test_recurrent_step_both_kernel_forms(rows, div2, form):
+@pytest.mark.parametrize('rows,div2,form', [(200, 1, 'k2'), (2592, 36, 'plain'), (72, 36, 'k2'), (200, 1, 'bf16x6'),
+                                            (2592, 36, 'bf16x6'), (72, 36, 'bf16x6'), (16, 1, 'bf16x6')])
+def test_recurrent_step_all_kernel_forms(rows, div2, form):
     """ssc_lstm_step_fwd = h.K_h + the BasicLSTMCell gate math with the tf.cond pad skip (models_collection.py:184-236) in one
-    launch; few rows take the K-split kernel, many rows the plain one (2592 rows x 512 units = 1312 workgroups >= 1200)."""
+    launch; exact fp32: few rows take the K-split kernel, many rows the plain one (2592 rows x 512 units = 1312 workgroups >=
+    1200); default arithmetic: ssc_lstm_step_fwd_bf on the planes of K_h (six bf16 products per fp32 product), same tolerance."""
     hip = _hip()
     C = 512
-    assert ((rows + 63) // 64) * (C // 16) >= 1200 if form == 'plain' else ((rows + 63) // 64) * (C // 16) < 1200
+    if form != 'bf16x6':
+        assert ((rows + 63) // 64) * (C // 16) >= 1200 if form == 'plain' else ((rows + 63) // 64) * (C // 16) < 1200
+    elif not hip.ARITH_BF16:
+        pytest.skip('SSC_ARITH=fp32')
     h = rnd(rows, C, seed=91, std=0.5)
     c = rnd(rows, C, seed=92, std=0.5)
     K = rnd(3 * C, 4 * C, seed=93, std=0.04)       # the recurrent rows are a slice of a wider kernel: ldk = 4C, rows [C, 2C)
@@ -542,11 +547,30 @@ def test_recurrent_step_both_kernel_forms(rows, div2, form):
     ho = torch.full((rows, C), float('nan'), device='cuda')
     acts = torch.zeros(rows, 4 * C, device='cuda')
     Kd = K.cuda()
-    hip.lstm_step_fwd(h.cuda(), Kd[C:2 * C], 4 * C, g1.cuda(), g2.cuda(), div2, mask.cuda(), mdiv, c.cuda(), rows, C, True, co, ho, acts)
+    hip.lstm_step_fwd(h.cuda(), Kd[C:2 * C], 4 * C, g1.cuda(), g2.cuda(), div2, mask.cuda(), mdiv, c.cuda(), rows, C, True, co, ho, acts,
+                      exact=form != 'bf16x6')
     close(co, c_ref, tol=2e-5)
     close(ho, h_ref, tol=2e-5)
     a_ref = torch.cat([torch.sigmoid(i), torch.tanh(j), torch.sigmoid(f + 1.0), torch.sigmoid(o)], dim=1)
     close(acts[keep.squeeze(1).cuda()], a_ref[keep.squeeze(1)], tol=2e-5)
+    if form == 'bf16x6':
+        # the planes of h_out a step leaves for the next one (hp_out) are the planes ssc_lstm_hsplit makes of h_out: a second
+        # step gives bit-identical results either way; and a first step (h = 0: no product, hp_in = None) writes them too
+        hp = torch.zeros(2, hip.lstm_hplanes_floats(rows, C), device='cuda')
+        z0 = torch.zeros(rows, C, device='cuda')
+        c1d, h1d = torch.empty(rows, C, device='cuda'), torch.empty(rows, C, device='cuda')
+        hip.lstm_step_fwd(z0, Kd[C:2 * C], 4 * C, g1.cuda(), g2.cuda(), div2, mask.cuda(), mdiv, c.cuda(), rows, C, False, c1d, h1d, acts,
+                          hp_out=hp[0])
+        outs = []
+        for hp_in in (hp[0], None):
+            c2, h2 = torch.empty(rows, C, device='cuda'), torch.empty(rows, C, device='cuda')
+            hip.lstm_step_fwd(h1d, Kd[C:2 * C], 4 * C, g1.cuda(), g2.cuda(), div2, mask.cuda(), mdiv, c1d, rows, C, True, c2, h2, acts,
+                              hp_in=hp_in, hp_out=hp[1])
+            outs.append((c2, h2))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        z2 = h1d.double().cpu() @ K[C:2 * C].double() + g1.double() + g2.double().repeat_interleave(div2, dim=0)
+        c2r = c1d.double().cpu() * torch.sigmoid(z2[:, 2 * C:3 * C] + 1.0) + torch.sigmoid(z2[:, :C]) * torch.tanh(z2[:, C:2 * C])
+        close(outs[0][0], torch.where(keep, c2r, c1d.double().cpu()), tol=2e-5)
 
 
 def test_handoff_timeout_is_reported_and_fatal():
