@@ -201,7 +201,9 @@ template <int BM, int BN> struct BfLds {
 // tab: the norm tables of the two sources as {a0, b0, a1, b1} ([C] each), never NULL: a source without a table gets the launcher's
 // identity rows (ones, zeros) -- no per-step "has a table" selects, and the pointers stay plain global pointers
 struct BfTabs { const float* a0; const float* b0; const float* a1; const float* b1; };
-template <int WM, int WN, int SM, int SN, bool PLAIN>
+// ONE: the gathered side has ONE source tensor (no channel concat): the per-step selects between the two sources' pointers, strides,
+// tables and row offsets (half of the step's scalar instructions) are compiled out
+template <int WM, int WN, int SM, int SN, bool PLAIN, bool ONE>
 __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, const Magics mg, float* __restrict__ slab_base,
                                                        long slab_stride, int splitk, int ts_full, int ts_s,
                                                        unsigned* __restrict__ flags, const BfTabs tab) {
@@ -364,7 +366,8 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
 
     // K-tile index -> (tap row, tap column, chunk), advanced by one K-tile at a time on the scalar unit (K-tiles run chunk fastest,
     // then tap column, then tap row) instead of decoded by division every step
-    struct KTile { int ty, tx, chunk; long woff; };      // woff: byte offset of the K-tile's filter data inside the planes
+    struct KTile { int tx, chunk, tappix, tapidx; long woff; };      // tappix = ty * xW + tx, tapidx = ty * TW + tx; woff: byte offset
+                                                                     // of the K-tile's filter data inside the planes
     const long KB = ktile_bytes;
     const long SX = (long)kstep * (KC >> 1) * KB, SY = (long)kstep * KWv * (KC >> 1) * KB;     // one tap column / row further
     const long DX = SX - (long)tpt * KB, DY = SY - (long)TWv * SX;
@@ -372,33 +375,42 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
         KTile t;
         const int tap = div32(kt, mg.mC, mg.oneC);      // mC: magic of tpt
         t.chunk = kt - tap * tpt;
-        t.ty = div32(tap, mg.mTW, mg.oneTW);
-        t.tx = tap - t.ty * TWv;
-        t.woff = ((long)((ph.ky0 + t.ty * kstep) * KWv + ph.kx0 + t.tx * kstep) * (KC >> 1) + t.chunk) * KB;
+        const int ty = div32(tap, mg.mTW, mg.oneTW);
+        t.tx = tap - ty * TWv;
+        t.tappix = ty * xW + t.tx;
+        t.tapidx = tap;
+        t.woff = ((long)((ph.ky0 + ty * kstep) * KWv + ph.kx0 + t.tx * kstep) * (KC >> 1) + t.chunk) * KB;
         return t;
     };
-    auto kt_next = [&](KTile t, bool adv) {      // adv false: stay (the clamp at the last K-tile); arithmetic selects, no branch
-        t.chunk += adv ? 1 : 0;
-        const bool wc = t.chunk == tpt;
-        t.chunk = wc ? 0 : t.chunk;
-        t.tx += wc ? 1 : 0;
-        const bool wx = t.tx == TWv;
-        t.tx = wx ? 0 : t.tx;
-        t.ty += wx ? 1 : 0;
-        t.woff += (adv ? KB : 0) + (wc ? DX : 0) + (wx ? DY : 0);
-        return t;
+    // one K-tile further, with (wave-uniform) BRANCHES: the usual case -- the next chunk of the same tap -- is four scalar
+    // instructions; the branch-free form (selects on every field) cost forty per step
+    auto kt_advance = [&](KTile& t) {
+        t.chunk += 1;
+        t.woff += KB;
+        if (t.chunk == tpt) {
+            t.chunk = 0;
+            t.tx += 1;
+            t.tapidx += 1;
+            t.tappix += 1;
+            t.woff += DX;
+            if (t.tx == TWv) {
+                t.tx = 0;
+                t.tappix += xW - TWv;
+                t.woff += DY;
+            }
+        }
     };
 
     // a staged K-tile of the gathered side in registers: raw rows, their 1.0 / 0.0 validity, the source's norm table and slope
     struct ASet { float4 r[A_ROWS]; float v[A_ROWS]; float4 aa, ab; float slope; };
 
     auto issue_loads = [&](const KTile& t, ASet& S) {
-        const bool first = t.chunk < nch0;
+        const bool first = ONE ? true : t.chunk < nch0;
         const int cs = first ? xC0 : xC1;
         const int cc = (first ? t.chunk : t.chunk - nch0) * BK;
         const char* sbase = reinterpret_cast<const char*>((first ? xs0 : xs1) + cc);
-        const int tapshift = (t.ty * xW + t.tx) * cs * 4;
-        const int tapidx = t.ty * TWv + t.tx;
+        const int tapshift = t.tappix * cs * 4;
+        const int tapidx = t.tapidx;
         if (!PLAIN) {
             const char* pa = reinterpret_cast<const char*>((first ? tab.a0 : tab.a1) + cc);
             const char* pb = reinterpret_cast<const char*>((first ? tab.b0 : tab.b1) + cc);
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
             BF_STAGE_B(0, i, z, w, h0, m0_, l0);
         }
         KTile td = tl;                      // decode of the K-tile the next dma_b takes
-        tl = kt_next(tl, kt_begin + 1 <= last);
+        if (kt_begin + 1 <= last) kt_advance(tl);      // (the clamp at the last K-tile: stay)
         td = tl;
         issue_loads(tl, S0);
         BF_WAIT_ALL();
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
             unsigned ha, ma, la, hb, mb, lb;
             group(0, 0); dma_b(td, cur ^ 1, 0); BF_SB;
             group(0, 1); if (RUN1 > 0) dma_b(td, cur ^ 1, 1); BF_SB;
-            tl = kt_next(tl, kt + 2 <= last);
+            if (kt + 2 <= last) kt_advance(tl);
             group(0, 2); issue_loads(tl, SB); BF_SB;
             group(0, 3); fetch_a(1); BF_SB;
             group(0, 4); fetch_b(1); BF_SB;
@@ -566,8 +578,8 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
 }
 
 #ifdef SSC_ISA_ONLY
-template __global__ void conv_bf_kernel<2, 2, 1, 2, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs);
-template __global__ void conv_bf_kernel<2, 2, 2, 2, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs);
+template __global__ void conv_bf_kernel<2, 2, 1, 2, false, true>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs);
+template __global__ void conv_bf_kernel<2, 2, 1, 2, false, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs);
 #else
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -604,7 +616,7 @@ static bool bf_tabs(const ssc_conv_desc& d, BfTabs& t) {
     return true;
 }
 
-template <int WM, int WN, int SM, int SN, bool PLAIN>
+template <int WM, int WN, int SM, int SN, bool PLAIN, bool ONE>
 static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s, int64_t ws_bytes,
                        int xcd) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
@@ -617,7 +629,7 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
     const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
     static unsigned long long attr_done = 0;
     {
-        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_bf_kernel<WM, WN, SM, SN, PLAIN>), (int)lds, &attr_done);
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE>), (int)lds, &attr_done);
         if (arc != 0) return arc;
     }
     BfTabs tab = {nullptr, nullptr, nullptr, nullptr};
@@ -634,7 +646,7 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
         const long full = ts_full, tail = tiles - full, s = ts_s;
         if (full >= 0 && tail > 0 && (int64_t)tail * s * BM * BN * 4 <= ws_bytes && tail * s < SSC_SK_FLAG_WORDS - 1 &&
             full + tail * s < 0x7fffffffL) {
-            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg,
+            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg,
                                ws, out_count, 1, (int)full, (int)s | ((xcd && (full & 7) == 0) ? xflag : 0), d.sk_flags, tab);
             return (int)hipGetLastError();
         }
@@ -643,13 +655,13 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
         const long tiles = mt * nt * d.nphase;
         const long full = tiles & ~7L;
         if (tiles < 0x7fffffffL && full > 0) {
-            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws,
+            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws,
                                out_count, 1, (int)full, 1 | xflag, (unsigned*)nullptr, tab);
             return (int)hipGetLastError();
         }
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
-    hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0,
+    hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0,
                        (unsigned*)nullptr, tab);
     if (splitk > 1) ssc_launch_slab_reduce(ws, out_count, splitk, d, st);
     return (int)hipGetLastError();
@@ -658,9 +670,12 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
 // cfg: 0 = 128x128, 1 = 64x128, 2 = 128x64, 4 = 64x64 (the ids of igemm.hip's tile table)
 int ssc_launch_conv_bf(int cfg, bool plain, const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s,
                        int64_t ws_bytes, int xcd) {
+    const bool one = d.x.C1 == 0;
 #define BF_CASE(WM, WN, SM, SN)                                                                                   \
-    return plain ? launch_bf_t<WM, WN, SM, SN, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)             \
-                 : launch_bf_t<WM, WN, SM, SN, false>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)
+    return one ? (plain ? launch_bf_t<WM, WN, SM, SN, true, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)        \
+                        : launch_bf_t<WM, WN, SM, SN, false, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd))      \
+               : (plain ? launch_bf_t<WM, WN, SM, SN, true, false>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)       \
+                        : launch_bf_t<WM, WN, SM, SN, false, false>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd))
     switch (cfg) {
         case 0: BF_CASE(2, 2, 2, 2);
         case 1: BF_CASE(2, 2, 1, 2);
