@@ -1626,7 +1626,12 @@ static bool fwd_is_bf(const ssc_conv_desc& d) {
         const char* e = getenv("SSC_ARITH");
         off = (e != nullptr && (e[0] == 'f' || e[0] == 'F')) ? 1 : 0;
     }
-    return !off && d.wsplit != nullptr && d.ws_kc > 0 && d.ws_nbp > 0 && fwd_is_ut(d) && (d.n_off & 31) == 0 && d.Nstore > 32 &&
+    // ... or ONE source whose channel count is any multiple of 4 above 32 (MRU's materialised concats: state + image channels),
+    // the partly empty last chunk of every tap masked in the staging (conv_bf_kernel<KM>); the planes pad k >= K with zeros
+    const bool km = d.x.C1 == 0 && (d.x.C0 & 3) == 0 && d.x.C0 > BK && (d.x.C0 % BK) != 0 && d.k_real >= 1 && d.k_real <= d.x.C0 &&
+                    d.ws_kc == 2 * ((d.x.C0 + BK - 1) / BK) && (long)d.NB * d.x.H * d.x.W * d.x.C0 < 0x1fffffffL &&
+                    (long)d.KH * d.KW * d.wC0 * d.wC1 < 0x1fffffffL;
+    return !off && d.wsplit != nullptr && d.ws_kc > 0 && d.ws_nbp > 0 && (fwd_is_ut(d) || km) && (d.n_off & 31) == 0 && d.Nstore > 32 &&
            d.TH * d.TW <= 32;
 }
 

@@ -203,7 +203,10 @@ template <int BM, int BN> struct BfLds {
 struct BfTabs { const float* a0; const float* b0; const float* a1; const float* b1; };
 // ONE: the gathered side has ONE source tensor (no channel concat): the per-step selects between the two sources' pointers, strides,
 // tables and row offsets (half of the step's scalar instructions) are compiled out
-template <int WM, int WN, int SM, int SN, bool PLAIN, bool ONE>
+// KM (with ONE): the source's channel count is any multiple of 4 (MRU's materialised concats [state | image] = 64 + 4, 128 + 4 ...,
+// mru.py:400-411, 555-575): the last 32-wide chunk of every tap is partly empty -- its float4s beyond the row are staged as zeros
+// (never loaded) and the filter planes hold zeros there (ssc_filter_split pads k >= K)
+template <int WM, int WN, int SM, int SN, bool PLAIN, bool ONE, bool KM = false>
 __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, const Magics mg, float* __restrict__ slab_base,
                                                        long slab_stride, int splitk, int ts_full, int ts_s,
                                                        unsigned* __restrict__ flags, const BfTabs tab) {
@@ -232,7 +235,8 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
     const int TWv = d.TW, kstep = d.kstep, KWv = d.KW;
     const float slope0 = act_slope(d.x.act), slope1 = act_slope(d.x.act1 >= 0 ? d.x.act1 : d.x.act);
 
-    const int nch0 = xC0 / BK, nch1 = xC1 / BK;
+    static_assert(!KM || ONE, "partial chunks: one source only");
+    const int nch0 = KM ? (xC0 + BK - 1) / BK : xC0 / BK, nch1 = xC1 / BK;
     const int tpt = nch0 + nch1;
     const long M = (long)d.NB * d.PH * d.PW;
     const int PHW = d.PH * d.PW;
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
     // bits 0 and 1 of the row swapped, so that the two rows a 16-lane group of a ds_write_b64 covers lie two rows (416 bytes =
     // 40 banks) apart instead of one (208 bytes = 52 banks: the second row's 16 banks wrapped onto 4 of the first's)
     const int a_col4 = tid & 7;
+    const bool a_lastv = !KM || (nch0 - 1) * BK + a_col4 * 4 < xC0;      // KM: this thread's float4 of the LAST chunk exists
     const int arow = ((tid >> 3) & ~3) | (((tid >> 3) & 1) << 1) | (((tid >> 3) >> 1) & 1);
     int a_iyb[A_ROWS], a_ixb[A_ROWS], a_off0[A_ROWS], a_off1[A_ROWS];
     bool a_mv[A_ROWS];
@@ -411,16 +416,19 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
         const char* sbase = reinterpret_cast<const char*>((first ? xs0 : xs1) + cc);
         const int tapshift = t.tappix * cs * 4;
         const int tapidx = t.tapidx;
+        // KM: does this thread's float4 of the chunk exist?  (a wave-uniform test on the chunk, a per-thread constant for the last one)
+        const bool cv = !KM || t.chunk != nch0 - 1 || a_lastv;
         if (!PLAIN) {
             const char* pa = reinterpret_cast<const char*>((first ? tab.a0 : tab.a1) + cc);
             const char* pb = reinterpret_cast<const char*>((first ? tab.b0 : tab.b1) + cc);
-            S.aa = *reinterpret_cast<const float4*>(pa + a_col4 * 16);
-            S.ab = *reinterpret_cast<const float4*>(pb + a_col4 * 16);
+            const int tc = (KM && !cv) ? 0 : a_col4 * 16;       // no table entries beyond the source
+            S.aa = *reinterpret_cast<const float4*>(pa + tc);
+            S.ab = *reinterpret_cast<const float4*>(pb + tc);
             S.slope = first ? slope0 : slope1;
         }
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            const unsigned vb = (a_vm[i] >> tapidx) & 1u;
+            const unsigned vb = KM ? (cv ? (a_vm[i] >> tapidx) & 1u : 0u) : (a_vm[i] >> tapidx) & 1u;
             const int osel = first ? a_off0[i] : a_off1[i];
             const unsigned off = vb ? (unsigned)(osel + tapshift) : (unsigned)(a_col4 * 16);
             S.v[i] = (float)vb;
@@ -616,20 +624,20 @@ static bool bf_tabs(const ssc_conv_desc& d, BfTabs& t) {
     return true;
 }
 
-template <int WM, int WN, int SM, int SN, bool PLAIN, bool ONE>
+template <int WM, int WN, int SM, int SN, bool PLAIN, bool ONE, bool KM = false>
 static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s, int64_t ws_bytes,
                        int xcd) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
     constexpr size_t lds = BfLds<BM, BN>::TOTAL;
     const long M = (long)d.NB * d.PH * d.PW;
-    const int tpt = d.x.C0 / BK + d.x.C1 / BK;
+    const int tpt = (d.x.C0 + BK - 1) / BK + d.x.C1 / BK;
     const Magics mg = make_magics((unsigned)tpt, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW, (unsigned long)M);
     const long mt = (M + BM - 1) / BM;
     const int nt = (d.Nstore + BN - 1) / BN;
     const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
     static unsigned long long attr_done = 0;
     {
-        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE>), (int)lds, &attr_done);
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM>), (int)lds, &attr_done);
         if (arc != 0) return arc;
     }
     BfTabs tab = {nullptr, nullptr, nullptr, nullptr};
@@ -646,7 +654,7 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
         const long full = ts_full, tail = tiles - full, s = ts_s;
         if (full >= 0 && tail > 0 && (int64_t)tail * s * BM * BN * 4 <= ws_bytes && tail * s < SSC_SK_FLAG_WORDS - 1 &&
             full + tail * s < 0x7fffffffL) {
-            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg,
+            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg,
                                ws, out_count, 1, (int)full, (int)s | ((xcd && (full & 7) == 0) ? xflag : 0), d.sk_flags, tab);
             return (int)hipGetLastError();
         }
@@ -655,13 +663,13 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
         const long tiles = mt * nt * d.nphase;
         const long full = tiles & ~7L;
         if (tiles < 0x7fffffffL && full > 0) {
-            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws,
+            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws,
                                out_count, 1, (int)full, 1 | xflag, (unsigned*)nullptr, tab);
             return (int)hipGetLastError();
         }
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
-    hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0,
+    hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0,
                        (unsigned*)nullptr, tab);
     if (splitk > 1) ssc_launch_slab_reduce(ws, out_count, splitk, d, st);
     return (int)hipGetLastError();
@@ -671,7 +679,10 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
 int ssc_launch_conv_bf(int cfg, bool plain, const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s,
                        int64_t ws_bytes, int xcd) {
     const bool one = d.x.C1 == 0;
+    const bool km = one && (d.x.C0 % BK) != 0;
 #define BF_CASE(WM, WN, SM, SN)                                                                                   \
+    if (km) return plain ? launch_bf_t<WM, WN, SM, SN, true, true, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)  \
+                         : launch_bf_t<WM, WN, SM, SN, false, true, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd); \
     return one ? (plain ? launch_bf_t<WM, WN, SM, SN, true, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)        \
                         : launch_bf_t<WM, WN, SM, SN, false, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd))      \
                : (plain ? launch_bf_t<WM, WN, SM, SN, true, false>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)       \

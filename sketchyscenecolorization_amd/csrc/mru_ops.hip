@@ -855,14 +855,16 @@ extern "C" int ssc_cbn_act_backward(const float* x, const float* abn, const floa
 }
 
 // ------------------------------------------------------------------ prelu backward (models_collection.py:56-60)
-// y = max(leak*x, x): the first argument takes the gradient where leak*x >= x (tf.maximum's tie rule)
+// y = max(leak*x, x): the first argument takes the gradient where leak*x >= x (tf.maximum's tie rule).  The leak's gradient is ONE
+// scalar summed over the whole tensor with heavy cancellation: products in fp32 (as TensorFlow forms them), the sum in double
+// (the pass is bound by its loads; a float sum left the scalar at the noise floor of the end-to-end gradient test)
 __global__ void prelu_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ leak_p,
                                  const float* __restrict__ gy, int ldg, long M, int C, float* __restrict__ dx, int lddx,
-                                 int accumulate, float* __restrict__ part) {
-    __shared__ float sh[256];
+                                 int accumulate, double* __restrict__ part) {
+    __shared__ double sh[256];
     const float leak = *leak_p;
     const long tot = M * C, stride = (long)gridDim.x * blockDim.x;
-    float acc = 0.f;
+    double acc = 0.0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
         const long r = i / C;
         const int c = (int)(i - r * C);
@@ -887,10 +889,10 @@ __global__ void prelu_bwd_kernel(const float* __restrict__ x, int ldx, const flo
 __global__ __launch_bounds__(256) void prelu_bwd_v4_kernel(const float* __restrict__ x, int ldx,
                                                            const float* __restrict__ leak_p, const float* __restrict__ gy,
                                                            int ldg, long M, int C, float* __restrict__ dx, int lddx,
-                                                           int accumulate, float* __restrict__ part, PwMap m) {
-    __shared__ float sh[256];
+                                                           int accumulate, double* __restrict__ part, PwMap m) {
+    __shared__ double sh[256];
     const float leak = *leak_p;
-    float acc = 0.f;
+    double acc = 0.0;
     pw_rows(M, C / 4, m, [&](long row, int c) {
         const float4 xv = ld4u(x + row * ldx + c), g = ld4u(gy + row * ldg + c);
         const bool fx = leak * xv.x >= xv.x, fy = leak * xv.y >= xv.y, fz = leak * xv.z >= xv.z, fw = leak * xv.w >= xv.w;
@@ -917,9 +919,9 @@ __global__ __launch_bounds__(256) void prelu_bwd_v4_kernel(const float* __restri
     if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
 
-__global__ void scalar_fold_kernel(const float* __restrict__ part, int n, float* __restrict__ out, int accumulate) {
-    __shared__ float sh[256];
-    float acc = 0.f;
+__global__ void scalar_fold_kernel(const double* __restrict__ part, int n, float* __restrict__ out, int accumulate) {
+    __shared__ double sh[256];
+    double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
     sh[threadIdx.x] = acc;
     __syncthreads();
@@ -927,7 +929,7 @@ __global__ void scalar_fold_kernel(const float* __restrict__ part, int n, float*
         if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = accumulate ? *out + sh[0] : sh[0];
+    if (threadIdx.x == 0) *out = accumulate ? (float)((double)*out + sh[0]) : (float)sh[0];
 }
 
 extern "C" int ssc_prelu_backward(const float* x, int ldx, const float* leak, const float* gy, int ldg, int64_t M, int C,
@@ -936,19 +938,20 @@ extern "C" int ssc_prelu_backward(const float* x, int ldx, const float* leak, co
     long blocks = ((long)M * C + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    if (blocks * 4 > workspace_bytes) return -2;
+    if (blocks * 8 > workspace_bytes) return -2;
+    double* const part = reinterpret_cast<double*>(workspace);
     if ((C & 3) == 0 && C >= 4) {
         const PwMap m = pw_map(C / 4, 1, 1);
         long vb = pw_blocks((long)M, m);
         if (vb > 2048) vb = 2048;
-        if (vb * 4 > workspace_bytes) return -2;
+        if (vb * 8 > workspace_bytes) return -2;
         blocks = vb;
         hipLaunchKernelGGL(prelu_bwd_v4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, leak, gy,
-                           ldg, (long)M, C, dx, lddx, accumulate_dx, workspace, m);
+                           ldg, (long)M, C, dx, lddx, accumulate_dx, part, m);
     } else
     hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, leak, gy, ldg,
-                       (long)M, C, dx, lddx, accumulate_dx, workspace);
-    hipLaunchKernelGGL(scalar_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, (int)blocks, dleak,
+                       (long)M, C, dx, lddx, accumulate_dx, part);
+    hipLaunchKernelGGL(scalar_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, (int)blocks, dleak,
                        accumulate_leak);
     return CHECK_LAUNCH();
 }

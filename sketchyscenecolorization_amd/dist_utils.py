@@ -34,12 +34,10 @@ def launch_towers(num_gpu, argv=None):
         n_dev = torch.cuda.device_count()
         if n_dev < num_gpu:
             raise SystemExit('--num_gpu %d but only %d GPU(s) visible' % (num_gpu, n_dev))
-    import socket
-    with socket.socket() as so:
-        so.bind(('127.0.0.1', 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(num_gpu),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(argv[0])] + argv[1:]
+    # --standalone: torch.distributed.run picks (and holds) a free rendezvous port itself; a port found here by bind / close
+    # could be taken before the launcher binds it
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(num_gpu), os.path.abspath(argv[0])] + argv[1:]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC (RCCL across processes)
     env.setdefault('OMP_NUM_THREADS', '8')

@@ -103,7 +103,14 @@ def check_build_hash(l=None, tree=None):
     error into a warning (A/B runs of an older build against new host code)."""
     from . import build
     have = build_hash(l)
-    want = tree if tree is not None else build.tree_hash()
+    if tree is None:
+        try:
+            tree = build.tree_hash()
+        except OSError:         # a deployment that ships the library without csrc/ or include/: nothing to compare with
+            import warnings
+            warnings.warn('%s: kernel sources not found beside the package, build hash %s not checked' % (LIB_PATH, have))
+            return have
+    want = tree
     if have != want:
         msg = ('%s was built from kernel sources %s, the tree is %s: rebuild (python -m sketchyscenecolorization_amd.build)'
                % (LIB_PATH, have, want))
@@ -555,11 +562,18 @@ def refresh_splits(flat=None):
     check(lib().ssc_filter_split_batch(ptr(tab[0]), len(es), tab[1], stream_ptr()), 'ssc_filter_split_batch')
 
 
+_BF_PARTIAL = _dev_env('SSC_BF_PARTIAL', '1') == '1'      # A/B: the partial-chunk form of the bf16 conv kernel
+
+
 def _attach_split(d, w):
     """Give the launch its filter's bf16 planes when it can run on the bf16 pipe (the library decides again: fwd_is_bf)."""
     if not ARITH_BF16 or w is None:
         return
-    if (d.x.C0 % 32) or (d.x.C1 % 32) or d.k_real != d.x.C0 + d.x.C1 or (d.n_off % 32) or d.Nstore <= 32:
+    uniform = not ((d.x.C0 % 32) or (d.x.C1 % 32) or d.k_real != d.x.C0 + d.x.C1)
+    # one source with any multiple of 4 channels above 32 (MRU's materialised concats): the kernel masks the last chunk of a tap
+    partial = d.x.C1 == 0 and d.x.C0 > 32 and d.x.C0 % 4 == 0 and d.x.C0 % 32 != 0 and \
+        (d.wC1 if d.bmode else d.wC0) == d.k_real and -(-d.k_real // 32) == -(-d.x.C0 // 32) and _BF_PARTIAL
+    if not (uniform or partial) or (d.n_off % 32) or d.Nstore <= 32:
         return
     if d.NB * d.PH * d.PW * d.nphase < 64:        # a handful of rows: nothing to win
         return

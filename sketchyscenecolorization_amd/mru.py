@@ -396,6 +396,7 @@ class MRUGenerator(_MRUBlocks):
         """sketches NCHW [N,3,H,W] (device), text int [N,T] (host), labels int32 [N] (device) = class ids,
         noise_vec [N,256] (device).  The tanh image goes to ``out[..., out_coff:out_coff+3]`` (NHWC)."""
         s, B = self.s, self.b
+        self._pre_stats.clear()     # entries are keyed by buffer address: none may outlive the pass that made it
         nhwc_in = sketches.dim() == 4 and sketches.shape[3] == 4 and sketches.shape[1] != 3     # hip.sketch_preprocess_u8
         N, H, W = (sketches.shape[0], sketches.shape[1], sketches.shape[2]) if nhwc_in else \
             (sketches.shape[0], sketches.shape[2], sketches.shape[3])
@@ -588,6 +589,7 @@ class MRUDiscriminator(_MRUBlocks):
         s, B = self.s, self.b
         N, H, W, _ = xd.shape
         self._sn = sn
+        self._pre_stats.clear()
         tape = []
         x0 = B.get(tag + '/x0', (N, H, W, 4), zero_on_alloc=True)
         hip.call('ssc_strided_copy', xd.view(-1)[3:], 8, x0, 4, N * H * W, 3, 0)

@@ -78,6 +78,36 @@ def test_conv_forward_split_vs_exact(n, h, ci, co, stride, act):
     _both(run, ref, 'conv_forward_split_vs_exact', dict(n=n, h=h, ci=ci, co=co, stride=stride, act=act))
 
 
+@pytest.mark.parametrize('n,h,ch,extra,co,k,table', [(3, 24, 64, 3, 64, 3, False), (2, 12, 128, 3, 128, 3, False),
+                                                      (2, 10, 256, 131, 256, 3, False), (2, 9, 64, 3, 128, 3, True),
+                                                      (1, 8, 512, 3, 64, 1, False)])
+def test_conv_partial_chunk_split_vs_exact(n, h, ch, extra, co, k, table):
+    """The MRU blocks' SAME convs over a materialised concat [state | image(3) (| skip)] (mru.py:400-411, 555-575): ch + extra real
+    channels in a buffer whose rows are padded to a multiple of 4 -- the last 32-wide chunk of every tap is partly empty
+    (conv_bf_kernel<KM>).  The buffer's padding channels hold garbage here: the filter planes' zeros must cancel them."""
+    hip = _hip()
+    ci = ch + extra
+    cp = (ci + 3) // 4 * 4
+    x = rnd(n, ci, h, h, seed=41)
+    w = rnd(k, k, ci, co, seed=42, std=0.05)
+    bias = rnd(co, seed=43, std=0.1)
+    ab = torch.cat([1.0 + 0.1 * rnd(cp, seed=44), 0.2 * rnd(cp, seed=45)])
+    xd = x.double()
+    if table:
+        xd = act_ref(xd * ab[:ci].double().view(1, -1, 1, 1) + ab[cp:cp + ci].double().view(1, -1, 1, 1), 2)
+    ref = T.lrelu(T.conv2d_same(xd, w.double(), 1, bias.double()), 0.2)
+    xp = torch.full((n, h, h, cp), 7.5)
+    xp[..., :ci] = nhwc(x)
+    xg, wg, bg, abg = xp.cuda(), w.cuda(), bias.cuda(), ab.cuda()
+
+    def run():
+        out = torch.full((n, h, h, co), float('nan'), device='cuda')
+        v = hip.View(xg, None, abg, 2) if table else hip.View(xg)
+        hip.conv_forward(v, wg, 1, 0, out, bias=bg, epi=2, same=True)
+        return nchw(out)
+    _both(run, ref, 'conv_partial_chunk_split_vs_exact', dict(n=n, h=h, ch=ch, extra=extra, co=co, k=k, table=table))
+
+
 @pytest.mark.parametrize('n,h,c0,c1,co', [(4, 12, 64, 64, 64), (2, 6, 512, 512, 256)])
 def test_deconv_forward_concat_split_vs_exact(n, h, c0, c1, co):
     """relu(concat[decoder_{k+1}, encoder_k]) -> conv2d_transpose (models_collection.py:512-531): two sources, two norm tables,
