@@ -134,8 +134,9 @@ def main(argv=None):
         return evaluate(args.mode, params)
     # -gpu N without a launcher: the towers are processes here, so the command starts itself once per GPU
     from sketchyscenecolorization_amd.dist_utils import launch_towers
-    # an explicit argv (a programmatic caller) is what the ranks must re-execute, not the host script's sys.argv
-    rc = launch_towers(args.num_gpu, None if argv is None else [os.path.abspath(__file__)] + list(argv))
+    # a programmatic caller's explicit argv is what the ranks must see, under the host script (which may wrap this module)
+    import sys
+    rc = launch_towers(args.num_gpu, None if argv is None else [sys.argv[0]] + list(argv))
     if rc is not None:
         if rc != 0:
             raise SystemExit(rc)

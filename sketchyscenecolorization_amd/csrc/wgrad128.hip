@@ -374,10 +374,24 @@ static bool view_plain(const ssc_gview& g) {
            (g.C1 == 0 || (g.ab1 == nullptr && (g.act1 >= 0 ? g.act1 : g.act) == SSC_ACT_NONE));
 }
 
+static bool wg128_use_bf();
+// taps a 128-row tile of the gathered side can span (the kernels' TPT), 0 = not this kernel.  The exact-fp32 kernel takes whole
+// 128-channel blocks of a tap (1) or a 64-channel tensor (2); the bf16 kernel also any single gathered source with a multiple of
+// 4 channels from 64 up, real channels <= stored ones (wgrad128_bf16.hip: tiles over the padded row space)
 static int wg128_tpt(const ssc_wgrad_desc& d) {
     const int Cg = d.g.C0 + d.g.C1;
-    if (Cg % TB == 0 && (d.g.C1 == 0 || d.g.C0 % TB == 0)) return 1;
-    if (d.g.C1 == 0 && d.g.C0 == 64) return 2;
+    if (d.Cg_real == Cg) {
+        if (Cg % TB == 0 && (d.g.C1 == 0 || d.g.C0 % TB == 0)) return 1;
+        if (d.g.C1 == 0 && d.g.C0 == 64) return 2;
+    }
+    static int span = -1;       // SSC_WG128_SPAN=0: no tap-spanning tiles (A/B)
+    if (span < 0) {
+        const char* e = ssc_dev_getenv("SSC_WG128_SPAN");
+        span = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    if (span && wg128_use_bf() && d.exact == 0 && d.g.C1 == 0 && (Cg & 3) == 0 && Cg >= 64 && d.Cg_real >= 1 && d.Cg_real <= Cg &&
+        (long)d.TH * d.TW * Cg < 0x7fffff00L)
+        return Cg >= TB ? 2 : 3;
     return 0;
 }
 
@@ -391,7 +405,7 @@ extern "C" int ssc_conv_wgrad128_supported(const ssc_wgrad_desc* dp) {
     if (off) return 0;
     const int Cg = d.g.C0 + d.g.C1, Cd = d.d.C0 + d.d.C1;
     const long P = (long)d.NB * d.PH * d.PW;
-    if (wg128_tpt(d) == 0 || d.Cg_real != Cg) return 0;
+    if (wg128_tpt(d) == 0) return 0;
     if ((d.g.C0 & 3) || (d.g.C1 & 3) || (d.d.C0 & 3) || (d.d.C1 & 3)) return 0;
     if (d.Nn < TB || (d.Nn & 1) || d.ldc != d.Nn || d.Nn > Cd) return 0;
     if (d.d.C1 != 0 && d.d.C0 % TB != 0) return 0;          // a column tile inside one source
@@ -413,7 +427,7 @@ static int wg128_splitk(const ssc_wgrad_desc& d, int64_t ws_bytes, bool have_ws)
     const long P = (long)d.NB * d.PH * d.PW;
     const long nkt = (P + BK - 1) / BK;
     const long tiles = ((Mtot + TB - 1) / TB) * ((d.Nn + TB - 1) / TB);
-    const long out_elems = Mtot * d.ldc;
+    const long out_elems = (long)d.TH * d.TW * d.Cg_real * d.ldc;
     const int ncu = wg128_num_cu();
     static int force = -2;
     if (force == -2) {
@@ -513,5 +527,6 @@ extern "C" int ssc_conv_wgrad128(const ssc_wgrad_desc* dp, float* ws, int64_t ws
     const int sk = wg128_splitk(d, ws_bytes, ws != nullptr);
     if (wg128_use_bf() && d.exact == 0)
         return ssc_launch_wgrad128_bf(d, wg128_tpt(d), sk, ws, (hipStream_t)stream);
+    if (d.Cg_real != d.g.C0 + d.g.C1 || wg128_tpt(d) == 3) return -10;       // (unreachable: those shapes qualify for the bf16 form only)
     return wg128_tpt(d) == 2 ? launch_wg128_t<2>(d, sk, ws, (hipStream_t)stream) : launch_wg128_t<1>(d, sk, ws, (hipStream_t)stream);
 }

@@ -67,7 +67,13 @@ __device__ __forceinline__ s16x4 wb_tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
-// GPLAIN / DPLAIN: the gathered / dense side has no folded norm / activation.  TPT: taps per tile (2: a 64-channel gathered tensor).
+// GPLAIN / DPLAIN: the gathered / dense side has no folded norm / activation.
+// TPT: taps per tile.  1: the gathered channel count is a multiple of 128 (inside one source) -- a tile's 128 rows lie in one tap.
+// 2 / 3: ONE gathered source with any multiple-of-4 channel count Cg >= 128 / >= 64 (a 64-channel tensor: two taps per tile;
+// MRU's materialised concats [state | image], Cg = 132, 260 ... with Cg_real = Cg - 1 real channels, mru.py:400-411, 555-575):
+// the tile is 128 consecutive rows of the PADDED row space tap * Cg + c, which spans up to TPT taps; a thread's float4 column
+// lies in one of them (Cg % 4 == 0) and picks that tap's row of the pixel table; the epilogue maps padded rows back to
+// tap * Cg_real + c and drops the padding channels.
 template <bool GPLAIN, bool DPLAIN, int TPT>
 __global__ __launch_bounds__(256) void conv_wgrad128_bf_kernel(const ssc_wgrad_desc d, const Magics mg, float* __restrict__ slab_base,
                                                                 long slab_stride, int splitk, int xcd) {
@@ -98,14 +104,8 @@ __global__ __launch_bounds__(256) void conv_wgrad128_bf_kernel(const ssc_wgrad_d
     const int m0 = mt_i * TB, n0 = nt_i * TB;
 
     // ---- gathered side: the tile's tap(s), source, descriptor ----
-    int tap0, c0;
-    if (TPT == 1) {
-        tap0 = div32(m0, mg.mC, mg.oneC);
-        c0 = m0 - tap0 * Cg;
-    } else {
-        tap0 = mt_i * 2;
-        c0 = 0;
-    }
+    const int tap0 = div32(m0, mg.mC, mg.oneC);
+    const int c0 = (TPT == 1) ? m0 - tap0 * Cg : 0;      // TPT > 1: the source starts at channel 0, the thread's column says where
     const bool g_first = c0 < gC0;
     const int g_cs = g_first ? gC0 : gC1;
     const int g_coff = g_first ? c0 : c0 - gC0;
@@ -124,8 +124,13 @@ __global__ __launch_bounds__(256) void conv_wgrad128_bf_kernel(const ssc_wgrad_d
 
     // per-thread piece of a staged tile: pixel rows a_r + 8 s (s = 0..3), 16-byte fp32 column a_q (4 channels)
     const int a_q = tid & 31, a_r = tid >> 5;
-    const int a_tsel = (TPT == 2) ? (a_q >> 4) : 0;
-    const int a_cq = (TPT == 2) ? (a_q & 15) : a_q;
+    int a_tsel = 0, a_cq = a_q;             // which of the tile's taps, float4 column inside that tap's channels
+    if (TPT > 1) {
+        const int mq = m0 + a_q * 4;
+        const int tq = div32(mq, mg.mC, mg.oneC);
+        a_tsel = tq - tap0;
+        a_cq = (mq - tq * Cg) >> 2;
+    }
     const unsigned a_cb = (unsigned)a_cq * 16u;
     float4 aa = make_float4(1.f, 1.f, 1.f, 1.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
     float g_slope = 1.f;
@@ -313,6 +318,8 @@ __global__ __launch_bounds__(256) void conv_wgrad128_bf_kernel(const ssc_wgrad_d
     // ---- epilogue: block (i, jj) of the wave's 64 x 64, row (r & 3) + 8 (r >> 2) + 4 lhi, column l31 ----
     float* outp = (splitk > 1) ? (slab_base + (long)ks * slab_stride) : d.out;
     const bool accum = (splitk == 1) && d.accumulate;
+    const int Cgr = d.Cg_real;
+    const bool remap = Cgr != Cg;           // padded rows -> tap * Cg_real + c (the padding channels have no row)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -321,8 +328,14 @@ __global__ __launch_bounds__(256) void conv_wgrad128_bf_kernel(const ssc_wgrad_d
             if (col >= d.Nn) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (m >= Mtot) continue;
+                if (remap) {
+                    const int tp = div32(m, mg.mC, mg.oneC);
+                    const int c = m - tp * Cg;
+                    if (c >= Cgr) continue;
+                    m = tp * Cgr + c;
+                }
                 float* o = outp + (long)m * d.ldc + col;
                 float v = acc[i][jj][r] + accc[i][jj][r];
                 if (accum) v += *o;
@@ -353,7 +366,7 @@ static int launch_wb(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t
         const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_wgrad128_bf_kernel<GPLAIN, DPLAIN, TPT>), (int)lds, &attr_done);
         if (arc != 0) return arc;
     }
-    const long out_count = Mtot * d.ldc;
+    const long out_count = (long)d.TH * d.TW * d.Cg_real * d.ldc;       // rows of the OUTPUT (the slabs' and the reduce's extent)
     const long wgs = ((Mtot + TB - 1) / TB) * ((d.Nn + TB - 1) / TB) * splitk;
     const int xcd = (splitk > 1 && (wgs & 7) == 0) ? 1 : 0;
     hipLaunchKernelGGL((conv_wgrad128_bf_kernel<GPLAIN, DPLAIN, TPT>), dim3((unsigned)wgs), dim3(256), lds, st, d, mg, ws, out_count,
@@ -367,6 +380,7 @@ int ssc_launch_wgrad128_bf(const ssc_wgrad_desc& d, int tpt, int splitk, float* 
 #define WB_CASE(T)                                                                                        \
     return gp ? (dp ? launch_wb<true, true, T>(d, splitk, ws, st) : launch_wb<true, false, T>(d, splitk, ws, st)) \
               : (dp ? launch_wb<false, true, T>(d, splitk, ws, st) : launch_wb<false, false, T>(d, splitk, ws, st))
+    if (tpt == 3) { WB_CASE(3); }
     if (tpt == 2) { WB_CASE(2); }
     WB_CASE(1);
 #undef WB_CASE

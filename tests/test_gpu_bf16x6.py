@@ -235,6 +235,38 @@ def test_conv_wgrad_split_vs_exact(n, h, ci, co, stride, act, tab):
     _both_wgrad(run, ref, 'conv_wgrad_split_vs_exact', dict(n=n, h=h, ci=ci, co=co, stride=stride, act=act, tab=tab))
 
 
+@pytest.mark.parametrize('n,h,ch,extra,co,k,tab', [(4, 24, 128, 3, 128, 3, False), (2, 20, 64, 3, 128, 3, False),
+                                                    (2, 12, 256, 131, 256, 3, False), (2, 16, 128, 3, 128, 3, True),
+                                                    (3, 12, 512, 3, 256, 1, False), (2, 24, 96, 0, 128, 3, False)])
+def test_conv_wgrad_partial_gathered_split_vs_exact(n, h, ch, extra, co, k, tab):
+    """dW of the MRU blocks' SAME convs over a materialised concat [state | image(3) (| skip)] (mru.py:400-411, 555-575):
+    ch + extra real gathered channels in rows padded to a multiple of 4, any channel count from 64 up -- the 128-row tiles of
+    wgrad128_bf16.hip run over the padded row space and span two or three taps; the padding channels hold garbage and have no
+    row in the result."""
+    hip = _hip()
+    ci = ch + extra
+    cp = (ci + 3) // 4 * 4
+    x = rnd(n, ci, h, h, seed=71)
+    ab = torch.cat([1.0 + 0.1 * rnd(cp, seed=72), 0.2 * rnd(cp, seed=73)]) if tab else None
+    xin = x.double()
+    if tab:
+        xin = act_ref(xin * ab[:ci].double().view(1, -1, 1, 1) + ab[cp:cp + ci].double().view(1, -1, 1, 1), 2)
+    w = torch.zeros(k, k, ci, co, dtype=torch.float64, requires_grad=True)
+    y = T.conv2d_same(xin, w, 1)
+    dy = rnd(*y.shape, seed=74)
+    y.backward(dy.double())
+    ref = w.grad.detach()
+    xp = torch.full((n, h, h, cp), -3.25)
+    xp[..., :ci] = nhwc(x)
+    xg, dyg, abg = xp.cuda(), nhwc(dy).cuda(), (ab.cuda() if tab else None)
+
+    def run():
+        out = torch.full((k, k, ci, co), float('nan'), device='cuda')
+        hip.conv_wgrad(hip.View(xg, None, abg, 2 if tab else 0), hip.View(dyg), out, 1, hip.same_pad_before(h, k, 1))
+        return out
+    _both_wgrad(run, ref, 'conv_wgrad_partial_gathered_split_vs_exact', dict(n=n, h=h, ch=ch, extra=extra, co=co, k=k, tab=tab))
+
+
 @pytest.mark.parametrize('n,h,c0,c1,co', [(8, 12, 128, 128, 128), (4, 24, 256, 0, 128)])
 def test_deconv_wgrad_split_vs_exact(n, h, c0, c1, co):
     """dF of the transposed conv: gathered side dy (plain), dense side relu(concat of two normed tensors)."""
