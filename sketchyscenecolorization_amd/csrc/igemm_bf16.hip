@@ -209,7 +209,7 @@ struct BfTabs { const float* a0; const float* b0; const float* a1; const float* 
 template <int WM, int WN, int SM, int SN, bool PLAIN, bool ONE, bool KM = false>
 __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, const Magics mg, float* __restrict__ slab_base,
                                                        long slab_stride, int splitk, int ts_full, int ts_s,
-                                                       unsigned* __restrict__ flags, const BfTabs tab) {
+                                                       unsigned* __restrict__ flags, const BfTabs tab, const int korder) {
     constexpr int BM = WM * SM * 32;
     constexpr int BN = WN * SN * 32;
     constexpr int NBT = BN / 32;
@@ -369,18 +369,47 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = accc[i][j][r] = 0.f;
 
-    // K-tile index -> (tap row, tap column, chunk), advanced by one K-tile at a time on the scalar unit (K-tiles run chunk fastest,
-    // then tap column, then tap row) instead of decoded by division every step
-    struct KTile { int tx, chunk, tappix, tapidx; long woff; };      // tappix = ty * xW + tx, tapidx = ty * TW + tx; woff: byte offset
+    // K-tile index -> (tap row, tap column, chunk), advanced by one K-tile at a time on the scalar unit instead of decoded by
+    // division every step.  Order of the K-tiles (korder, wave-uniform):
+    //   0: chunk fastest, then tap column, then tap row (rounds 1-5);
+    //   1: TAP fastest (row-major), chunk slowest: the taps of a stride-1 window read almost the same pixels of a chunk -- one
+    //      K step apart instead of a whole tap's chunks apart, i.e. out of L2 instead of over the fabric again;
+    //   2: (in_stride 2, even tap counts) tap fastest in the order of the four PARITY classes (ty & 1, tx & 1): the taps of a
+    //      class read the same input pixels shifted by whole output pixels, the classes share nothing.
+    // Any order is a valid summation order; K slices (split-K, tail split) are ranges of the sequence.
+    struct KTile { int ty, tx, chunk, tappix, tapidx; long woff; };  // tappix = ty * xW + tx, tapidx = ty * TW + tx; woff: byte offset
                                                                      // of the K-tile's filter data inside the planes
     const long KB = ktile_bytes;
+    const int THv = d.TH, ntaps = d.TH * d.TW;
+    auto kt_place = [&](KTile& t) {       // (ty, tx, chunk) -> the derived fields
+        t.tappix = t.ty * xW + t.tx;
+        t.tapidx = t.ty * TWv + t.tx;
+        t.woff = ((long)((ph.ky0 + t.ty * kstep) * KWv + ph.kx0 + t.tx * kstep) * (KC >> 1) + t.chunk) * KB;
+    };
     const long SX = (long)kstep * (KC >> 1) * KB, SY = (long)kstep * KWv * (KC >> 1) * KB;     // one tap column / row further
     const long DX = SX - (long)tpt * KB, DY = SY - (long)TWv * SX;
     auto kt_decode = [&](int kt) {
         KTile t;
+        if (korder != 0) {      // once per workgroup: plain divisions
+            t.chunk = kt / ntaps;
+            const int sidx = kt - t.chunk * ntaps;
+            if (korder == 1) {
+                t.ty = sidx / TWv;
+                t.tx = sidx - t.ty * TWv;
+            } else {
+                const int hw = TWv >> 1, per = ntaps >> 2;
+                const int cls = sidx / per, j = sidx - cls * per;
+                const int jy = j / hw, jx = j - jy * hw;
+                t.ty = 2 * jy + (cls >> 1);
+                t.tx = 2 * jx + (cls & 1);
+            }
+            kt_place(t);
+            return t;
+        }
         const int tap = div32(kt, mg.mC, mg.oneC);      // mC: magic of tpt
         t.chunk = kt - tap * tpt;
         const int ty = div32(tap, mg.mTW, mg.oneTW);
+        t.ty = ty;
         t.tx = tap - ty * TWv;
         t.tappix = ty * xW + t.tx;
         t.tapidx = tap;
@@ -390,6 +419,34 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
     // one K-tile further, with (wave-uniform) BRANCHES: the usual case -- the next chunk of the same tap -- is four scalar
     // instructions; the branch-free form (selects on every field) cost forty per step
     auto kt_advance = [&](KTile& t) {
+        if (korder == 1) {
+            t.tx += 1;
+            if (t.tx == TWv) {
+                t.tx = 0;
+                t.ty += 1;
+                if (t.ty == THv) { t.ty = 0; t.chunk += 1; }
+            }
+            kt_place(t);
+            return;
+        }
+        if (korder == 2) {
+            t.tx += 2;
+            if (t.tx >= TWv) {
+                t.tx &= 1;
+                t.ty += 2;
+                if (t.ty >= THv) {      // next parity class: (0,0) (0,1) (1,0) (1,1), then the next chunk
+                    t.ty &= 1;
+                    if (t.tx == 0) t.tx = 1;
+                    else {
+                        t.tx = 0;
+                        if (t.ty == 0) t.ty = 1;
+                        else { t.ty = 0; t.chunk += 1; }
+                    }
+                }
+            }
+            kt_place(t);
+            return;
+        }
         t.chunk += 1;
         t.woff += KB;
         if (t.chunk == tpt) {
@@ -586,8 +643,8 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
 }
 
 #ifdef SSC_ISA_ONLY
-template __global__ void conv_bf_kernel<2, 2, 1, 2, false, true>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs);
-template __global__ void conv_bf_kernel<2, 2, 1, 2, false, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs);
+template __global__ void conv_bf_kernel<2, 2, 1, 2, false, true>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs, const int);
+template __global__ void conv_bf_kernel<2, 2, 1, 2, false, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs, const int);
 #else
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -649,13 +706,22 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
         diag = e != nullptr ? atoi(e) : 0;
     }
     if (diag & 2) xcd = 0;
+    static int kord = -2;       // SSC_BF_KORDER=0 / 1 / 2 pins the K-tile order (A/B); default: by the launch's geometry
+    if (kord == -2) {
+        const char* e = ssc_dev_getenv("SSC_BF_KORDER");
+        kord = e != nullptr ? atoi(e) : -1;
+    }
+    const bool par_ok = d.in_stride == 2 && (d.TH & 1) == 0 && (d.TW & 1) == 0;
+    int korder = par_ok ? 2 : 1;
+    if (kord >= 0) korder = (kord == 2 && !par_ok) ? 1 : kord;
+    if (d.TH * d.TW == 1) korder = 0;
     if (!(diag & 1) && splitk == 1 && ws != nullptr && d.sk_flags != nullptr && ts_s > 1) {        // whole tiles + K slices combined in the launch
         const long tiles = mt * nt * d.nphase;
         const long full = ts_full, tail = tiles - full, s = ts_s;
         if (full >= 0 && tail > 0 && (int64_t)tail * s * BM * BN * 4 <= ws_bytes && tail * s < SSC_SK_FLAG_WORDS - 1 &&
             full + tail * s < 0x7fffffffL) {
             hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg,
-                               ws, out_count, 1, (int)full, (int)s | ((xcd && (full & 7) == 0) ? xflag : 0), d.sk_flags, tab);
+                               ws, out_count, 1, (int)full, (int)s | ((xcd && (full & 7) == 0) ? xflag : 0), d.sk_flags, tab, korder);
             return (int)hipGetLastError();
         }
     }
@@ -664,13 +730,13 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
         const long full = tiles & ~7L;
         if (tiles < 0x7fffffffL && full > 0) {
             hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws,
-                               out_count, 1, (int)full, 1 | xflag, (unsigned*)nullptr, tab);
+                               out_count, 1, (int)full, 1 | xflag, (unsigned*)nullptr, tab, korder);
             return (int)hipGetLastError();
         }
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
     hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0,
-                       (unsigned*)nullptr, tab);
+                       (unsigned*)nullptr, tab, korder);
     if (splitk > 1) ssc_launch_slab_reduce(ws, out_count, splitk, d, st);
     return (int)hipGetLastError();
 }
