@@ -650,6 +650,11 @@ def main():
         rl['peak_is'] = ('the fp32-MFMA dense peak, as in rounds 1-4: FLOPs are fp32-equivalent (2 x MAC of the fp32 contraction).  The '
                          'bf16x6 kernels run on the bf16 pipe (%.0f TFLOP/s dense = %.1f fp32-equivalent at six products), so a fraction '
                          'above 1.0 of this peak would be legitimate for them' % (PEAK_BF16_MFMA_TFLOPS, PEAK_BF16_MFMA_TFLOPS / 6))
+        # ... and beside it the fraction of the pipe the dominant kernel actually runs on: the bf16 MFMA at six products per
+        # fp32 product (the issue-bound staging beside the MFMAs, not the matrix pipe, is what bounds these kernels: DESIGN 3.0)
+        if 'bf16x6' in str(rl.get('kernel', '')) and rl.get('achieved'):
+            rl['peak_bf16x6_fp32_equivalent'] = PEAK_BF16_MFMA_TFLOPS / 6
+            rl['frac_of_bf16x6_peak'] = rl['achieved'] / (PEAK_BF16_MFMA_TFLOPS / 6)
         rl['arithmetic'] = out['dtype']
         if world == 1 and not under_launcher:
             try:
