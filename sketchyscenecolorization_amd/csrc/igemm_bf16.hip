@@ -418,22 +418,42 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
     };
     // one K-tile further, with (wave-uniform) BRANCHES: the usual case -- the next chunk of the same tap -- is four scalar
     // instructions; the branch-free form (selects on every field) cost forty per step
+    // one K-tile further: the usual case is a handful of scalar additions; whole recomputations (kt_place: multiplications)
+    // only where a tap class or a chunk ends
+    const long W0 = (long)(ph.ky0 * KWv + ph.kx0) * (KC >> 1) * KB;
+    const long SX2 = 2 * SX, DY2 = 2 * SY - (long)TWv * SX;
     auto kt_advance = [&](KTile& t) {
         if (korder == 1) {
             t.tx += 1;
+            t.tapidx += 1;
+            t.tappix += 1;
+            t.woff += SX;
             if (t.tx == TWv) {
                 t.tx = 0;
                 t.ty += 1;
-                if (t.ty == THv) { t.ty = 0; t.chunk += 1; }
+                t.tappix += xW - TWv;
+                t.woff += DY;
+                if (t.ty == THv) {
+                    t.ty = 0;
+                    t.chunk += 1;
+                    t.tapidx = 0;
+                    t.tappix = 0;
+                    t.woff = W0 + (long)t.chunk * KB;
+                }
             }
-            kt_place(t);
             return;
         }
         if (korder == 2) {
             t.tx += 2;
+            t.tapidx += 2;
+            t.tappix += 2;
+            t.woff += SX2;
             if (t.tx >= TWv) {
-                t.tx &= 1;
+                t.tx -= TWv;
                 t.ty += 2;
+                t.tapidx += TWv;
+                t.tappix += 2 * xW - TWv;
+                t.woff += DY2;
                 if (t.ty >= THv) {      // next parity class: (0,0) (0,1) (1,0) (1,1), then the next chunk
                     t.ty &= 1;
                     if (t.tx == 0) t.tx = 1;
@@ -442,9 +462,9 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
                         if (t.ty == 0) t.ty = 1;
                         else { t.ty = 0; t.chunk += 1; }
                     }
+                    kt_place(t);
                 }
             }
-            kt_place(t);
             return;
         }
         t.chunk += 1;
