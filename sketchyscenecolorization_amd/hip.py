@@ -565,17 +565,25 @@ def refresh_splits(flat=None):
 _BF_PARTIAL = _dev_env('SSC_BF_PARTIAL', '1') == '1'      # A/B: the partial-chunk form of the bf16 conv kernel
 
 
-def _attach_split(d, w):
-    """Give the launch its filter's bf16 planes when it can run on the bf16 pipe (the library decides again: fwd_is_bf)."""
-    if not ARITH_BF16 or w is None:
-        return
-    uniform = not ((d.x.C0 % 32) or (d.x.C1 % 32) or d.k_real != d.x.C0 + d.x.C1)
-    # one source with any multiple of 4 channels above 32 (MRU's materialised concats): the kernel masks the last chunk of a tap
-    partial = d.x.C1 == 0 and d.x.C0 > 32 and d.x.C0 % 4 == 0 and d.x.C0 % 32 != 0 and \
-        (d.wC1 if d.bmode else d.wC0) == d.k_real and -(-d.k_real // 32) == -(-d.x.C0 // 32) and _BF_PARTIAL
-    if not (uniform or partial) or (d.n_off % 32) or d.Nstore <= 32:
-        return
+def bf_form(d):
+    """Which bf16-split form of the conv kernel a launch descriptor qualifies for (the library decides again: fwd_is_bf):
+    'uniform' -- every 32-wide K-tile inside one tap and one source; 'partial' -- ONE source with any multiple of 4 channels
+    above 32 (MRU's materialised concats: the kernel masks the last chunk of a tap); None -- the exact-fp32 kernels."""
+    if (d.n_off % 32) or d.Nstore <= 32:
+        return None
     if d.NB * d.PH * d.PW * d.nphase < 64:        # a handful of rows: nothing to win
+        return None
+    if not ((d.x.C0 % 32) or (d.x.C1 % 32) or d.k_real != d.x.C0 + d.x.C1):
+        return 'uniform'
+    if _BF_PARTIAL and d.x.C1 == 0 and d.x.C0 > 32 and d.x.C0 % 4 == 0 and d.x.C0 % 32 != 0 and \
+            (d.wC1 if d.bmode else d.wC0) == d.k_real and -(-d.k_real // 32) == -(-d.x.C0 // 32):
+        return 'partial'
+    return None
+
+
+def _attach_split(d, w):
+    """Give the launch its filter's bf16 planes when it can run on the bf16 pipe."""
+    if not ARITH_BF16 or w is None or bf_form(d) is None:
         return
     e = filter_split(w, 1 if d.bmode else 0)
     d.wsplit, d.ws_kc, d.ws_nbp = e.buf.data_ptr(), e.kc, e.nbp

@@ -271,3 +271,50 @@ def test_independent_bundle_writer_against_the_reader(tmp_path):
     import pytest
     with pytest.raises(IOError):
         C.read_checkpoint(pre)
+
+
+def test_bf16_form_of_a_launch_descriptor():
+    """Which launches get bf16 planes (hip.bf_form; the library's fwd_is_bf decides again on the device side): 32-multiple
+    sources, or ONE source with a multiple of 4 channels above 32 whose chunk count matches the filter's (MRU's materialised
+    concats, mru.py:400-411); few columns, few rows, odd column offsets and two ragged sources stay on the exact-fp32 kernels."""
+    from sketchyscenecolorization_amd import hip
+
+    def desc(c0, c1, k_real, nstore=128, n_off=0, rows=4096, bmode=0):
+        d = hip.ConvDesc()
+        d.x.C0, d.x.C1 = c0, c1
+        d.k_real, d.Nstore, d.n_off, d.bmode = k_real, nstore, n_off, bmode
+        d.wC0, d.wC1 = (k_real, nstore) if bmode == 0 else (nstore, k_real)
+        d.NB, d.PH, d.PW, d.nphase = 1, rows, 1, 1
+        return d
+    assert hip.bf_form(desc(128, 0, 128)) == 'uniform'
+    assert hip.bf_form(desc(256, 256, 512, bmode=1)) == 'uniform'
+    assert hip.bf_form(desc(132, 0, 131)) == 'partial'          # [state 128 | image 3] in rows of 132
+    assert hip.bf_form(desc(68, 0, 67)) == 'partial'
+    assert hip.bf_form(desc(388, 0, 387)) == 'partial'
+    assert hip.bf_form(desc(132, 0, 96)) is None                # the filter's chunk count differs from the rows'
+    assert hip.bf_form(desc(36, 0, 35)) == 'partial' and hip.bf_form(desc(32 + 0, 4, 35)) is None      # two ragged sources
+    assert hip.bf_form(desc(8, 0, 8)) is None and hip.bf_form(desc(12, 0, 11)) is None
+    assert hip.bf_form(desc(128, 0, 128, nstore=32)) is None and hip.bf_form(desc(128, 0, 128, nstore=3)) is None
+    assert hip.bf_form(desc(128, 0, 128, n_off=16)) is None
+    assert hip.bf_form(desc(128, 0, 128, rows=32)) is None
+
+
+def test_cli_hands_an_explicit_argv_to_the_self_launched_ranks(monkeypatch):
+    """main(argv) with -gpu N: the ranks must be started with THAT argv under the host script, not with the host script's
+    own sys.argv (dist_utils.launch_towers re-executes what it is given)."""
+    import sys
+    import obj_colorization_main as cli
+    from sketchyscenecolorization_amd import dist_utils
+    seen = {}
+
+    def fake(num_gpu, argv=None):
+        seen['num_gpu'], seen['argv'] = num_gpu, argv
+        return 0
+    monkeypatch.setattr(dist_utils, 'launch_towers', fake)
+    monkeypatch.setattr(sys, 'argv', ['host_script.py', '--unrelated'])
+    cli.main(['--mode', 'train', '-bt', 'Pix2Pix', '-gpu', '2', '-bs', '4'])
+    assert seen['num_gpu'] == 2 and seen['argv'] == ['host_script.py', '--mode', 'train', '-bt', 'Pix2Pix', '-gpu', '2', '-bs', '4']
+    seen.clear()
+    monkeypatch.setattr(sys, 'argv', ['obj_colorization_main.py', '--mode', 'train', '-gpu', '2'])
+    cli.main()
+    assert seen['argv'] is None         # the command line itself: launch_towers re-executes sys.argv
