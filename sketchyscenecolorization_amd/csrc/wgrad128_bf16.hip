@@ -74,11 +74,14 @@ __device__ __forceinline__ s16x4 wb_tr_read(const char* p) {
 // the tile is 128 consecutive rows of the PADDED row space tap * Cg + c, which spans up to TPT taps; a thread's float4 column
 // lies in one of them (Cg % 4 == 0) and picks that tap's row of the pixel table; the epilogue maps padded rows back to
 // tap * Cg_real + c and drops the padding channels.
-template <bool GPLAIN, bool DPLAIN, int TPT>
+// DB: two LDS stages used in turn (101 KB: one workgroup per CU) or ONE (51 KB: two workgroups per CU = two waves per SIMD).  A
+// step's operands are all in registers after its two fetches, so with one stage the only extra cost is a barrier behind them,
+// in front of the first store of the next K-tile; the second workgroup of the CU computes while this one waits there.
+template <bool GPLAIN, bool DPLAIN, int TPT, bool DB>
 __global__ __launch_bounds__(256) void conv_wgrad128_bf_kernel(const ssc_wgrad_desc d, const Magics mg, float* __restrict__ slab_base,
                                                                 long slab_stride, int splitk, int xcd) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    int2* ptab = reinterpret_cast<int2*>(smem_b + 2 * WB_STAGE);        // [2][TPT][256]
+    int2* ptab = reinterpret_cast<int2*>(smem_b + (DB ? 2 : 1) * WB_STAGE);        // [2][TPT][256]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(256) void conv_wgrad128_bf_kernel(const ssc_wgrad_d
         const char* a_rd = smem_b + (wm * 2) * WB_ST + rd_off;
         const char* b_rd = smem_b + WB_SIDE + (wn * 2) * WB_ST + rd_off;
         for (int j = 0; j < nk; ++j) {
-            const int cur = j & 1;
+            const int cur = DB ? (j & 1) : 0;
+            const int nxt = DB ? (cur ^ 1) : 0;
             const char* Ab = a_rd + cur * WB_STAGE;
             const char* Bb = b_rd + cur * WB_STAGE;
             if ((j % KPB) == KPB / 2) fill_ptab(j / KPB + 1);      // wave-uniform; the table of the next 256 pixels (read from j + 2 on)
@@ -289,14 +293,19 @@ __global__ __launch_bounds__(256) void conv_wgrad128_bf_kernel(const ssc_wgrad_d
             fetch(0);
             WB_SB;
             group(0, 0); fetch(1); WB_SB;
-            group(0, 1); stage_a_piece(cur ^ 1, 0); WB_SB;
-            group(0, 2); stage_a_piece(cur ^ 1, 1); WB_SB;
-            group(0, 3); stage_a_piece(cur ^ 1, 2); WB_SB;
-            group(0, 4); stage_a_piece(cur ^ 1, 3); WB_SB;
-            group(0, 5); stage_b_piece(cur ^ 1, 0); WB_SB;
-            group(1, 0); stage_b_piece(cur ^ 1, 1); WB_SB;
-            group(1, 1); stage_b_piece(cur ^ 1, 2); WB_SB;
-            group(1, 2); stage_b_piece(cur ^ 1, 3); WB_SB;
+            if (!DB) {      // every wave holds its operands of this K-tile: the stage may be overwritten
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                WB_SB;
+            }
+            group(0, 1); stage_a_piece(nxt, 0); WB_SB;
+            group(0, 2); stage_a_piece(nxt, 1); WB_SB;
+            group(0, 3); stage_a_piece(nxt, 2); WB_SB;
+            group(0, 4); stage_a_piece(nxt, 3); WB_SB;
+            group(0, 5); stage_b_piece(nxt, 0); WB_SB;
+            group(1, 0); stage_b_piece(nxt, 1); WB_SB;
+            group(1, 1); stage_b_piece(nxt, 2); WB_SB;
+            group(1, 2); stage_b_piece(nxt, 3); WB_SB;
             group(1, 3);
 #pragma unroll
             for (int s = 0; s < NP; ++s) ptab_piece(j + 2, s);
@@ -354,22 +363,22 @@ static bool wb_view_plain(const ssc_gview& g) {
            (g.C1 == 0 || (g.ab1 == nullptr && (g.act1 >= 0 ? g.act1 : g.act) == SSC_ACT_NONE));
 }
 
-template <bool GPLAIN, bool DPLAIN, int TPT>
+template <bool GPLAIN, bool DPLAIN, int TPT, bool DB>
 static int launch_wb(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t st) {
-    constexpr size_t lds = 2 * WB_STAGE + 2 * TPT * 256 * sizeof(int2);
+    constexpr size_t lds = (DB ? 2 : 1) * WB_STAGE + 2 * TPT * 256 * sizeof(int2);
     const int Cg = d.g.C0 + d.g.C1;
     const long Mtot = (long)d.TH * d.TW * Cg;
     const long P = (long)d.NB * d.PH * d.PW;
     const Magics mg = make_magics((unsigned)Cg, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW, (unsigned long)P);
     static unsigned long long attr_done = 0;
     {
-        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_wgrad128_bf_kernel<GPLAIN, DPLAIN, TPT>), (int)lds, &attr_done);
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_wgrad128_bf_kernel<GPLAIN, DPLAIN, TPT, DB>), (int)lds, &attr_done);
         if (arc != 0) return arc;
     }
     const long out_count = (long)d.TH * d.TW * d.Cg_real * d.ldc;       // rows of the OUTPUT (the slabs' and the reduce's extent)
     const long wgs = ((Mtot + TB - 1) / TB) * ((d.Nn + TB - 1) / TB) * splitk;
     const int xcd = (splitk > 1 && (wgs & 7) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((conv_wgrad128_bf_kernel<GPLAIN, DPLAIN, TPT>), dim3((unsigned)wgs), dim3(256), lds, st, d, mg, ws, out_count,
+    hipLaunchKernelGGL((conv_wgrad128_bf_kernel<GPLAIN, DPLAIN, TPT, DB>), dim3((unsigned)wgs), dim3(256), lds, st, d, mg, ws, out_count,
                        splitk, xcd);
     if (splitk > 1) ssc_launch_wgrad_reduce(ws, out_count, splitk, d.out, d.accumulate, st);
     return (int)hipGetLastError();
@@ -377,11 +386,18 @@ static int launch_wb(const ssc_wgrad_desc& d, int splitk, float* ws, hipStream_t
 
 int ssc_launch_wgrad128_bf(const ssc_wgrad_desc& d, int tpt, int splitk, float* ws, hipStream_t st) {
     const bool gp = wb_view_plain(d.g), dp = wb_view_plain(d.d);
-#define WB_CASE(T)                                                                                        \
-    return gp ? (dp ? launch_wb<true, true, T>(d, splitk, ws, st) : launch_wb<true, false, T>(d, splitk, ws, st)) \
-              : (dp ? launch_wb<false, true, T>(d, splitk, ws, st) : launch_wb<false, false, T>(d, splitk, ws, st))
-    if (tpt == 3) { WB_CASE(3); }
-    if (tpt == 2) { WB_CASE(2); }
+    static int db = -1;         // SSC_WGBF_DB=1: two LDS stages, one workgroup per CU (A/B)
+    if (db < 0) {
+        const char* e = ssc_dev_getenv("SSC_WGBF_DB");
+        db = (e != nullptr && e[0] == '1') ? 1 : 0;
+    }
+#define WB_CASE2(T, D)                                                                                              \
+    return gp ? (dp ? launch_wb<true, true, T, D>(d, splitk, ws, st) : launch_wb<true, false, T, D>(d, splitk, ws, st)) \
+              : (dp ? launch_wb<false, true, T, D>(d, splitk, ws, st) : launch_wb<false, false, T, D>(d, splitk, ws, st))
+#define WB_CASE(T) do { if (db) { WB_CASE2(T, true); } else { WB_CASE2(T, false); } } while (0)
+    if (tpt == 3) WB_CASE(3);
+    if (tpt == 2) WB_CASE(2);
     WB_CASE(1);
 #undef WB_CASE
+#undef WB_CASE2
 }
