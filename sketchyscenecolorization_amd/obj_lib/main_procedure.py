@@ -242,8 +242,8 @@ def train(**kwargs):
             if np.isnan(np.sum(loss_d_out)):
                 print("NaN occurred during training D")
                 return -1
-        # d_follows: the trainer may run the next iteration's real D pass inside this G-step (trainer.real_ahead; off by
-        # default).  That dequeues the next D batch one sess.run early -- the queue ORDER is unchanged (..., G batch, next D
+        # d_follows: the trainer may run the next iteration's real D pass inside this G-step (trainer.real_ahead; on by
+        # default for the Pix2Pix pair on one GPU).  That dequeues the next D batch one sess.run early -- the queue ORDER is unchanged (..., G batch, next D
         # batch), but a snapshot written after this step would see the queue one batch ahead of the reference, so iterations
         # that write a snapshot do not prefetch (the scalar summary reads no queue).
         snapshot_iter = i % save_model_freq == save_model_freq - 1

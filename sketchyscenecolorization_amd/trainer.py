@@ -133,11 +133,15 @@ class GanTrainer(object):
         # D-step of the co-running chain that filled ITS launch tails: measured (scripts/branch_marks.py) D-step 10.45 -> 7.53
         # ms, G-step 6.97 -> 9.90 ms, the iteration 17.42 -> 17.43 ms; 1798 vs 1813 images/s over three interleaved runs.  Two
         # full-size chains side by side run at the speed of one after the other wherever they meet (the launches fill the LDS
-        # of every CU on their own), so work moved between the steps is zero-sum.  Built, tested bit for bit, OFF by default
-        # (SSC_REAL_AHEAD=1 / real_ahead=True).  Pix2Pix pair, one GPU (a fork may not cross the end of a graph segment, and
-        # with world > 1 the G-step is cut at every gradient section).
+        # of every CU on their own), so work moved between the steps is zero-sum.  That was the exact-fp32 era (66-101 KB of LDS
+        # per workgroup).  Round 5: with the bf16-split kernels and the filter gradient on ONE 51 KB stage a filter-gradient
+        # workgroup fits beside a conv workgroup of another chain, and the real pass inside the G-step no longer loses: 13.14 -> 12.93 ms
+        # per iteration on one box (2436 -> 2475 images/s, three interleaved runs each, every pair faster), 13.29 vs 13.29 on a
+        # second one (profiles/NOTEBOOK_r05.md section 11).  ON by default (SSC_REAL_AHEAD=0 /
+        # real_ahead=False: off); tested bit for bit against the in-line trainer at full size.  Pix2Pix pair, one GPU (a fork
+        # may not cross the end of a graph segment, and with world > 1 the G-step is cut at every gradient section).
         if real_ahead is None:
-            real_ahead = os.environ.get('SSC_REAL_AHEAD', '0') == '1'
+            real_ahead = os.environ.get('SSC_REAL_AHEAD', '1') == '1'
         self.real_ahead = bool(real_ahead and overlap_real and block_type == 'Pix2Pix' and self._dbwd_concurrent and
                                not self.segment_graphs)
         self._real_stream = torch.cuda.Stream() if self.real_ahead else None
