@@ -113,7 +113,11 @@ typedef struct ssc_conv_desc {
        fp32-grade results at 6/16 of the fp32 MFMA's cycles); `w` must still point at the fp32 filter.  ws_kc / ws_nbp: the
        planes' chunk and block counts as ssc_filter_split_geom reports them. */
     const void* wsplit;
-    int32_t ws_nbp, _pad1;
+    int32_t ws_nbp;
+    int32_t lds_hint;     /* 0: the form that is fastest alone.  1: the launch shares the chip with launches of other streams (a train
+                             step's side-by-side chains): prefer the form with the smaller LDS footprint -- the bf16-split kernel on
+                             ONE operand stage (42 KB instead of 75 KB: a filter-gradient workgroup fits beside two conv workgroups),
+                             3-5 % slower alone, 2.5 % faster per Pix2Pix train iteration */
 } ssc_conv_desc;
 #define SSC_SK_FLAG_WORDS 8192   /* >= resident workgroups of the largest grid; the last word reports a hand-off timeout:
                                     0 = none, else 0x80000000 | sk_tag of the first launch whose owner workgroup gave up

@@ -191,10 +191,14 @@ extern "C" int ssc_filter_split_batch(const ssc_split_job* jobs_dev, int njobs, 
 // first use of the staged registers -- which, counted without the LDS-DMA instructions it cannot see, would wait for those too.
 // The inline-asm statement keeps the DMA's LDS writes (which the compiler does not know about) ordered before the barrier.
 #define BF_WAIT_ALL() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0070); } while (0)
-template <int BM, int BN> struct BfLds {
+// SS: ONE stage of each operand instead of two (the K step fetches both 16-k halves of its operands up front and meets a barrier
+// before the next K-tile is stored: conv_bf_kernel); the buffers also hold the epilogue's C image + reduction scratch
+template <int BM, int BN, bool SS = false> struct BfLds {
     static constexpr int A_BYTES = BM * BF_A_RS;
     static constexpr int B_BYTES = 6 * (BN / 32) * 1024;
-    static constexpr int OPER_BYTES = 2 * (A_BYTES + B_BYTES);
+    static constexpr int EPI_BYTES = (BM * (BN + 4) + 2 * 256 * 4) * 4;
+    static constexpr int ONE = A_BYTES + B_BYTES;
+    static constexpr int OPER_BYTES = SS ? (ONE > EPI_BYTES ? ONE : EPI_BYTES) : 2 * ONE;
     static constexpr int TOTAL = OPER_BYTES + BM * 8;
 };
 
@@ -206,15 +210,16 @@ struct BfTabs { const float* a0; const float* b0; const float* a1; const float* 
 // KM (with ONE): the source's channel count is any multiple of 4 (MRU's materialised concats [state | image] = 64 + 4, 128 + 4 ...,
 // mru.py:400-411, 555-575): the last 32-wide chunk of every tap is partly empty -- its float4s beyond the row are staged as zeros
 // (never loaded) and the filter planes hold zeros there (ssc_filter_split pads k >= K)
-template <int WM, int WN, int SM, int SN, bool PLAIN, bool ONE, bool KM = false>
+template <int WM, int WN, int SM, int SN, bool PLAIN, bool ONE, bool KM = false, bool SS = false>
 __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, const Magics mg, float* __restrict__ slab_base,
                                                        long slab_stride, int splitk, int ts_full, int ts_s,
                                                        unsigned* __restrict__ flags, const BfTabs tab, const int korder) {
     constexpr int BM = WM * SM * 32;
     constexpr int BN = WN * SN * 32;
     constexpr int NBT = BN / 32;
-    constexpr int A_BYTES = BfLds<BM, BN>::A_BYTES, B_BYTES = BfLds<BM, BN>::B_BYTES;
-    constexpr int LDS_FLOATS = BfLds<BM, BN>::OPER_BYTES / 4;
+    constexpr int A_BYTES = BfLds<BM, BN, SS>::A_BYTES, B_BYTES = BfLds<BM, BN, SS>::B_BYTES;
+    constexpr int LDS_FLOATS = BfLds<BM, BN, SS>::OPER_BYTES / 4;
+    constexpr int B_BASE = (SS ? 1 : 2) * A_BYTES;      // the filter stage(s) behind the gathered side's
     constexpr int A_ROWS = BM / 32;
     constexpr int B_IPW = 6 * NBT / 4;          // DMA instructions per wave and K-tile
     static_assert(WM * WN == 4 && (6 * NBT) % 4 == 0, "4 waves share the fragments of a K-tile evenly");
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
     auto dma_b = [&](const KTile& t, int buf, int half) {
         if (SSC_BF_DIAG_BUILD & 2) return;
         const char* wtap = wsp + t.woff;
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(2 * A_BYTES + buf * B_BYTES + wave * B_IPW * 1024));
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(B_BASE + buf * B_BYTES + wave * B_IPW * 1024));
         if (half == 0) glds16_run<RUN0>(wtap, bd_off, dst);
         else glds16_run<RUN1>(wtap, bd_off + RUN0, dst + RUN0 * 1024);
     };
@@ -573,9 +578,10 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
         BF_WAIT_ALL();
         __builtin_amdgcn_s_barrier();
         // one K step: MFMAs of K-tile kt from LDS buffer `cur`; set SA (K-tile kt+1) -> LDS buffer cur ^ 1; K-tile kt+2 -> set SB
-        auto kstep = [&](ASet& SA, ASet& SB, const int cur, const int kt) {
+        auto kstep = [&](ASet& SA, ASet& SB, const int cur_set, const int kt) {
+            const int cur = SS ? 0 : cur_set, nxt = SS ? 0 : cur_set ^ 1;       // LDS stages read / written in this step
             const char* Ab = sm_b + cur * A_BYTES + (wm * SM * 32 + l31) * BF_A_RS + lhi * 16;
-            const char* Bb = sm_b + 2 * A_BYTES + cur * B_BYTES + (wn * SN) * 1024 + lane * 16;
+            const char* Bb = sm_b + B_BASE + cur * B_BYTES + (wn * SN) * 1024 + lane * 16;
             bf16x8 av[2][SM][3], bv[2][SN][3];
             auto fetch_a = [&](int kc) {
 #pragma unroll
@@ -612,30 +618,36 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
             // DMA into it and the gather loads of K-tile kt+2 into the second register set -- both have the whole step to land.
             fetch_a(0);
             fetch_b(0);
+            if (SS) {       // one stage: every wave takes ALL its operands of this K-tile now; then the stage may be overwritten
+                fetch_a(1);
+                fetch_b(1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             BF_SB;
             float z0, w0, z1, w1;
             unsigned ha, ma, la, hb, mb, lb;
-            group(0, 0); dma_b(td, cur ^ 1, 0); BF_SB;
-            group(0, 1); if (RUN1 > 0) dma_b(td, cur ^ 1, 1); BF_SB;
+            group(0, 0); dma_b(td, nxt, 0); BF_SB;
+            group(0, 1); if (RUN1 > 0) dma_b(td, nxt, 1); BF_SB;
             if (kt + 2 <= last) kt_advance(tl);
             group(0, 2); issue_loads(tl, SB); BF_SB;
-            group(0, 3); fetch_a(1); BF_SB;
-            group(0, 4); fetch_b(1); BF_SB;
+            group(0, 3); if (!SS) fetch_a(1); BF_SB;
+            group(0, 4); if (!SS) fetch_b(1); BF_SB;
             // K-tile kt+1: registers -> the LDS buffer nobody reads now
             if (A_ROWS == 2) {
                 group(0, 5); BF_STAGE_A(SA, 0, z0, w0, ha, ma, la); BF_SB;
-                group(1, 0); BF_STAGE_B(cur ^ 1, 0, z0, w0, ha, ma, la); BF_SB;
+                group(1, 0); BF_STAGE_B(nxt, 0, z0, w0, ha, ma, la); BF_SB;
                 group(1, 1); BF_STAGE_A(SA, 1, z1, w1, hb, mb, lb); BF_SB;
-                group(1, 2); BF_STAGE_B(cur ^ 1, 1, z1, w1, hb, mb, lb); BF_SB;
+                group(1, 2); BF_STAGE_B(nxt, 1, z1, w1, hb, mb, lb); BF_SB;
                 group(1, 3); BF_SB;
                 group(1, 4); BF_SB;
                 group(1, 5); BF_SB;
             } else {
                 group(0, 5); BF_STAGE_A(SA, 0, z0, w0, ha, ma, la); BF_SB;
-                group(1, 0); BF_STAGE_B(cur ^ 1, 0, z0, w0, ha, ma, la); BF_STAGE_A(SA, 1, z1, w1, hb, mb, lb); BF_SB;
-                group(1, 1); BF_STAGE_B(cur ^ 1, 1, z1, w1, hb, mb, lb); BF_STAGE_A(SA, 2, z0, w0, ha, ma, la); BF_SB;
-                group(1, 2); BF_STAGE_B(cur ^ 1, 2, z0, w0, ha, ma, la); BF_STAGE_A(SA, 3, z1, w1, hb, mb, lb); BF_SB;
-                group(1, 3); BF_STAGE_B(cur ^ 1, 3, z1, w1, hb, mb, lb); BF_SB;
+                group(1, 0); BF_STAGE_B(nxt, 0, z0, w0, ha, ma, la); BF_STAGE_A(SA, 1, z1, w1, hb, mb, lb); BF_SB;
+                group(1, 1); BF_STAGE_B(nxt, 1, z1, w1, hb, mb, lb); BF_STAGE_A(SA, 2, z0, w0, ha, ma, la); BF_SB;
+                group(1, 2); BF_STAGE_B(nxt, 2, z0, w0, ha, ma, la); BF_STAGE_A(SA, 3, z1, w1, hb, mb, lb); BF_SB;
+                group(1, 3); BF_STAGE_B(nxt, 3, z1, w1, hb, mb, lb); BF_SB;
                 group(1, 4); BF_SB;
                 group(1, 5); BF_SB;
             }
@@ -701,11 +713,11 @@ static bool bf_tabs(const ssc_conv_desc& d, BfTabs& t) {
     return true;
 }
 
-template <int WM, int WN, int SM, int SN, bool PLAIN, bool ONE, bool KM = false>
+template <int WM, int WN, int SM, int SN, bool PLAIN, bool ONE, bool KM = false, bool SS = false>
 static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s, int64_t ws_bytes,
                        int xcd) {
     constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
-    constexpr size_t lds = BfLds<BM, BN>::TOTAL;
+    constexpr size_t lds = BfLds<BM, BN, SS>::TOTAL;
     const long M = (long)d.NB * d.PH * d.PW;
     const int tpt = (d.x.C0 + BK - 1) / BK + d.x.C1 / BK;
     const Magics mg = make_magics((unsigned)tpt, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW, (unsigned long)M);
@@ -714,7 +726,7 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
     const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
     static unsigned long long attr_done = 0;
     {
-        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM>), (int)lds, &attr_done);
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM, SS>), (int)lds, &attr_done);
         if (arc != 0) return arc;
     }
     BfTabs tab = {nullptr, nullptr, nullptr, nullptr};
@@ -740,7 +752,7 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
         const long full = ts_full, tail = tiles - full, s = ts_s;
         if (full >= 0 && tail > 0 && (int64_t)tail * s * BM * BN * 4 <= ws_bytes && tail * s < SSC_SK_FLAG_WORDS - 1 &&
             full + tail * s < 0x7fffffffL) {
-            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg,
+            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM, SS>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg,
                                ws, out_count, 1, (int)full, (int)s | ((xcd && (full & 7) == 0) ? xflag : 0), d.sk_flags, tab, korder);
             return (int)hipGetLastError();
         }
@@ -749,16 +761,27 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
         const long tiles = mt * nt * d.nphase;
         const long full = tiles & ~7L;
         if (tiles < 0x7fffffffL && full > 0) {
-            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws,
+            hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM, SS>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws,
                                out_count, 1, (int)full, 1 | xflag, (unsigned*)nullptr, tab, korder);
             return (int)hipGetLastError();
         }
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
-    hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0,
+    hipLaunchKernelGGL((conv_bf_kernel<WM, WN, SM, SN, PLAIN, ONE, KM, SS>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0,
                        (unsigned*)nullptr, tab, korder);
     if (splitk > 1) ssc_launch_slab_reduce(ws, out_count, splitk, d, st);
     return (int)hipGetLastError();
+}
+
+template <int WM, int WN, int SM, int SN, bool SS>
+static int launch_bf_form(bool plain, bool one, bool km, const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full,
+                          int ts_s, int64_t ws_bytes, int xcd) {
+    if (km) return plain ? launch_bf_t<WM, WN, SM, SN, true, true, true, SS>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)
+                         : launch_bf_t<WM, WN, SM, SN, false, true, true, SS>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd);
+    return one ? (plain ? launch_bf_t<WM, WN, SM, SN, true, true, false, SS>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)
+                        : launch_bf_t<WM, WN, SM, SN, false, true, false, SS>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd))
+               : (plain ? launch_bf_t<WM, WN, SM, SN, true, false, false, SS>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)
+                        : launch_bf_t<WM, WN, SM, SN, false, false, false, SS>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd));
 }
 
 // cfg: 0 = 128x128, 1 = 64x128, 2 = 128x64, 4 = 64x64 (the ids of igemm.hip's tile table)
@@ -766,15 +789,19 @@ int ssc_launch_conv_bf(int cfg, bool plain, const ssc_conv_desc& d, int splitk, 
                        int64_t ws_bytes, int xcd) {
     const bool one = d.x.C1 == 0;
     const bool km = one && (d.x.C0 % BK) != 0;
-#define BF_CASE(WM, WN, SM, SN)                                                                                   \
-    if (km) return plain ? launch_bf_t<WM, WN, SM, SN, true, true, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)  \
-                         : launch_bf_t<WM, WN, SM, SN, false, true, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd); \
-    return one ? (plain ? launch_bf_t<WM, WN, SM, SN, true, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)        \
-                        : launch_bf_t<WM, WN, SM, SN, false, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd))      \
-               : (plain ? launch_bf_t<WM, WN, SM, SN, true, false>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)       \
-                        : launch_bf_t<WM, WN, SM, SN, false, false>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd))
+    // one LDS stage per operand (64x128 / 128x64 / 64x64 tiles) when the caller says the launch shares the chip with other streams'
+    // launches (ssc_conv_desc.lds_hint); SSC_BF_SS=0 / 1 under SSC_DEV_SWITCHES pins it (A/B)
+    static int ss_env = -2;
+    if (ss_env == -2) {
+        const char* e = ssc_dev_getenv("SSC_BF_SS");
+        ss_env = e != nullptr ? (e[0] == '1' ? 1 : 0) : -1;
+    }
+    const bool ss = ss_env >= 0 ? ss_env == 1 : (d.lds_hint & 1) != 0;
+#define BF_CASE(WM, WN, SM, SN)                                                                                              \
+    return ss ? launch_bf_form<WM, WN, SM, SN, true>(plain, one, km, d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)         \
+              : launch_bf_form<WM, WN, SM, SN, false>(plain, one, km, d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)
     switch (cfg) {
-        case 0: BF_CASE(2, 2, 2, 2);
+        case 0: return launch_bf_form<2, 2, 2, 2, false>(plain, one, km, d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd);
         case 1: BF_CASE(2, 2, 1, 2);
         case 2: BF_CASE(2, 2, 2, 1);
         case 4: BF_CASE(2, 2, 1, 1);

@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
                 ('sb2_x', C.c_void_p), ('sb2_ab', C.c_void_p), ('sb2_stats', C.c_void_p), ('stat_partial2', C.c_void_p),
                 ('sb2_ldx', C.c_int32), ('sb2_act', C.c_int32),
                 ('stat_mode', C.c_int32), ('ws_kc', C.c_int32),
-                ('wsplit', C.c_void_p), ('ws_nbp', C.c_int32), ('_pad1', C.c_int32)]
+                ('wsplit', C.c_void_p), ('ws_nbp', C.c_int32), ('lds_hint', C.c_int32)]
 
 
 class SplitJob(C.Structure):
@@ -608,12 +608,18 @@ class BnBwdSums(object):
         return (self, act)
 
 
+# Set by a trainer around the steps whose chains run side by side on several streams (ssc_conv_desc.lds_hint): the conv launches
+# then take the form with the smaller LDS footprint, so that workgroups of different chains fit one CU together.
+CO_RUN = False
+
+
 def _run_conv(d, bn=None, bnbwd=None, minmax=None):
     """bn = (scale, offset, ab, stats[, eps]): also fold the batch-statistics norm of the conv's output (the whole
     [rows, ldc] output must be the normed tensor).  bnbwd = BnBwdSums.take(act): the output is a gradient w.r.t. that
     activated norm; its backward sums come out of the epilogue when the launch qualifies."""
     ws = workspace()
     d.sk_flags = sk_flags().data_ptr() if SK_ENABLED else None
+    d.lds_hint = 1 if CO_RUN else 0
     if SK_ENABLED:
         _sk_tag(d)
 

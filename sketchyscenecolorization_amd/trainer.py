@@ -119,6 +119,11 @@ class GanTrainer(object):
         self._dbwd_concurrent = (overlap_real and block_type in ('Pix2Pix', 'Residual') and self._wgrad_stream is None and
                                  os.environ.get('SSC_DBWD_CONCURRENT', '1') == '1')
         self._text_stream = torch.cuda.Stream() if (overlap_real and os.environ.get('SSC_TEXT_STREAM', '1') == '1') else None
+        # Pix2Pix pair with its chains side by side (two discriminator passes, run-ahead generator forward, real pass ahead, held
+        # filter gradients): the conv launches take the small-LDS form (ssc_conv_desc.lds_hint) -- 13.0 -> 12.67 ms per iteration
+        # on one box although the kernel alone is 3-5 % slower.  MRU (one chain most of the time) loses 2 % with it: off there.
+        _cr = os.environ.get('SSC_CO_RUN', '1')        # 0: never, 1: the Pix2Pix pair, all: every block type (A/B)
+        self._co_run = bool(overlap_real and ((block_type == 'Pix2Pix' and _cr == '1') or _cr == 'all'))
         # generator forward of the next G-step inside the D-step (train_iteration)
         self.run_ahead = (overlap_real and os.environ.get('SSC_RUN_AHEAD', '1') == '1')
         self._ahead_stream = torch.cuda.Stream() if self.run_ahead else None
@@ -330,6 +335,14 @@ class GanTrainer(object):
         forward this discriminator step also runs (on a side stream); ``use_ahead``: this generator step starts from it.
         ``real``: the NEXT discriminator step's batch, whose real pass this generator step also runs; ``use_real``: this
         discriminator step starts from it."""
+        keep = hip.CO_RUN
+        hip.CO_RUN = self._co_run       # (read when a launch descriptor is filled: eager steps and captures)
+        try:
+            return self._run_step_inner(kind, batch, counter, ahead, use_ahead, real, use_real)
+        finally:
+            hip.CO_RUN = keep
+
+    def _run_step_inner(self, kind, batch, counter, ahead, use_ahead, real, use_real):
         scope, idx, lr = ((self.store.discriminator, 1, self.lr_d) if kind == 'd' else
                           (self.store.generator, 0, self.lr_g))
         if kind == 'd':
