@@ -1,10 +1,13 @@
 """The recurrent step alone: full launch vs. its epilogue only (with_gemm = 0), bf16x6 vs exact fp32, at the caption branch's two
 row counts.  usage: lstm_step_probe.py [rows ...]"""
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
 import torch
 from sketchyscenecolorization_amd import hip
 
-C = 512
+C = int(os.environ.get("LSTM_C", "512"))
 for rows in [int(a) for a in sys.argv[1:]] or [576, 16, 1152]:
     g = torch.Generator(device='cuda').manual_seed(1)
     h = torch.randn(rows, C, device='cuda', generator=g) * 0.5

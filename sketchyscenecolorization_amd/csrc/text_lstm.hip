@@ -506,8 +506,11 @@ __global__ void lstm_hsplit_kernel(const float* __restrict__ h, int rows, int C,
     *reinterpret_cast<lstm_u32x4*>(f + 2048) = pl;
 }
 
-template <int PF>
-__global__ __launch_bounds__(256, 3) void lstm_step_fwd_bf_kernel(const float* __restrict__ h_in, const char* __restrict__ hp_in,
+// UB: blocks of 8 units (32 gate columns) per workgroup that share the A fragments.  1: 64 x 32 tiles, three workgroups per CU
+// (few rows: as many workgroups as possible).  2: 64 x 64 -- a third less operand traffic per product from L2, which is what
+// bounds the step at many rows (the Background module's C = 1024 cell over 2304 rows: 590 KB of fragments per 4.2 MFLOP tile).
+template <int PF, int UB>
+__global__ __launch_bounds__(256, UB == 1 ? 3 : 2) void lstm_step_fwd_bf_kernel(const float* __restrict__ h_in, const char* __restrict__ hp_in,
                                                                 const char* __restrict__ Kp, int nbp,
                                                                 const float* __restrict__ g1, const float* __restrict__ g2,
                                                                 int div2, const int* __restrict__ mask, int mdiv,
@@ -519,15 +522,17 @@ __global__ __launch_bounds__(256, 3) void lstm_step_fwd_bf_kernel(const float* _
     const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     int rb_, ub_;
-    lstm_wg_map(blockIdx.x, (rows + BM - 1) / BM, C / 8, rb_, ub_);
-    const int m0 = rb_ * BM, u0 = ub_ * 8;
+    lstm_wg_map(blockIdx.x, (rows + BM - 1) / BM, C / (8 * UB), rb_, ub_);
+    const int m0 = rb_ * BM, u0 = ub_ * 8 * UB;
     const int KC = C / 16;
 
-    lstm_f32x16 acc[2], accc[2];
+    lstm_f32x16 acc[UB][2], accc[UB][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < UB; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = accc[i][r] = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = accc[j][i][r] = 0.f;
 
     // The gate math's inputs are asked for NOW: thread = (row tid >> 2, units 2 * (tid & 3), + 1), so the quad of a row holds the
     // row's 8 units (= one lane's 16 bytes of the next step's A fragment per plane).  With ~250 registers only two waves share
@@ -536,24 +541,31 @@ __global__ __launch_bounds__(256, 3) void lstm_step_fwd_bf_kernel(const float* _
     const long r = m0 + rl;
     const bool valid = r < rows;
     bool live = false;
-    float2 c0 = make_float2(0.f, 0.f), h0 = c0, gv1[4], gv2[4];
+    float2 c0[UB], h0[UB], gv1[UB][4], gv2[UB][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) gv1[g] = gv2[g] = make_float2(0.f, 0.f);
+    for (int j = 0; j < UB; ++j) {
+        c0[j] = h0[j] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gv1[j][g] = gv2[j][g] = make_float2(0.f, 0.f);
+    }
     if (valid) {
-        const long i = r * C + u0 + u;
         live = mask[r / mdiv] != 0;
-        c0 = *reinterpret_cast<const float2*>(c_in + i);
-        h0 = *reinterpret_cast<const float2*>(h_in + i);
-        // (not behind `live`: a second round trip to memory costs more than the skipped rows' addends)
-        const long gb = r * 4 * C + u0 + u;
-        if (g1 != nullptr) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gv1[g] = *reinterpret_cast<const float2*>(g1 + gb + g * C);
-        }
-        if (g2 != nullptr) {
-            const long q = (r / div2) * 4 * C + u0 + u;
+        for (int j = 0; j < UB; ++j) {
+            const long i = r * C + u0 + 8 * j + u;
+            c0[j] = *reinterpret_cast<const float2*>(c_in + i);
+            h0[j] = *reinterpret_cast<const float2*>(h_in + i);
+            // (not behind `live`: a second round trip to memory costs more than the skipped rows' addends)
+            const long gb = r * 4 * C + u0 + 8 * j + u;
+            if (g1 != nullptr) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gv2[g] = *reinterpret_cast<const float2*>(g2 + q + g * C);
+                for (int g = 0; g < 4; ++g) gv1[j][g] = *reinterpret_cast<const float2*>(g1 + gb + g * C);
+            }
+            if (g2 != nullptr) {
+                const long q = (r / div2) * 4 * C + u0 + 8 * j + u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gv2[j][g] = *reinterpret_cast<const float2*>(g2 + q + g * C);
+            }
         }
     }
 
@@ -561,22 +573,27 @@ __global__ __launch_bounds__(256, 3) void lstm_step_fwd_bf_kernel(const float* _
         // A: fragments (2 * rb_ + i, kc, plane), lane-linear;  B: column l31 of the tile = gate l31 >> 3, unit u0 + (l31 & 7)
         const char* ap = hp_in + ((long)(2 * rb_) * KC * 3) * 1024 + lane * 16;
         const long a_rb = (long)KC * 3 * 1024;
-        const int col = (l31 >> 3) * C + u0 + (l31 & 7);
-        const char* bp = Kp + (long)(col >> 5) * 1024 + ((col & 31) + 32 * lhi) * 16;
+        const char* bp[UB];
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+            const int col = (l31 >> 3) * C + u0 + 8 * j + (l31 & 7);
+            bp[j] = Kp + (long)(col >> 5) * 1024 + ((col & 31) + 32 * lhi) * 16;
+        }
         const long pl_stride = (long)nbp * 1024, kc_stride = 3 * pl_stride;
         const int nkc = KC / 4;             // chunks of 16 k per K quarter (host: a multiple of PF)
         const int kc0 = kq * nkc;
 
-        lstm_u32x4 ra[PF][2][3], rb[PF][3];
+        lstm_u32x4 ra[PF][2][3], rb[PF][UB][3];
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
             const char* a = ap + (long)(kc0 + s) * 3 * 1024;
-            const char* b = bp + (kc0 + s) * kc_stride;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 ra[s][0][p] = *reinterpret_cast<const lstm_u32x4*>(a + p * 1024);
                 ra[s][1][p] = *reinterpret_cast<const lstm_u32x4*>(a + a_rb + p * 1024);
-                rb[s][p] = *reinterpret_cast<const lstm_u32x4*>(b + p * pl_stride);
+#pragma unroll
+                for (int j = 0; j < UB; ++j)
+                    rb[s][j][p] = *reinterpret_cast<const lstm_u32x4*>(bp[j] + (kc0 + s) * kc_stride + p * pl_stride);
             }
         }
         // compiler fences keep the loads where they are written: without them the prologue's loads sink into the loop and every
@@ -585,23 +602,25 @@ __global__ __launch_bounds__(256, 3) void lstm_step_fwd_bf_kernel(const float* _
         for (int k0 = 0; k0 < nkc; k0 += PF) {
 #pragma unroll
             for (int s = 0; s < PF; ++s) {
-                lstm_bf16x8 A[2][3], Bv[3];
+                lstm_bf16x8 A[2][3], Bv[UB][3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
                     A[0][p] = __builtin_bit_cast(lstm_bf16x8, ra[s][0][p]);
                     A[1][p] = __builtin_bit_cast(lstm_bf16x8, ra[s][1][p]);
-                    Bv[p] = __builtin_bit_cast(lstm_bf16x8, rb[s][p]);
+#pragma unroll
+                    for (int j = 0; j < UB; ++j) Bv[j][p] = __builtin_bit_cast(lstm_bf16x8, rb[s][j][p]);
                 }
                 // the chunk PF further on into the set just consumed (branch-free: the tail re-reads the last chunk)
                 {
                     const int kn = kc0 + min(k0 + s + PF, nkc - 1);
                     const char* a = ap + (long)kn * 3 * 1024;
-                    const char* b = bp + kn * kc_stride;
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
                         ra[s][0][p] = *reinterpret_cast<const lstm_u32x4*>(a + p * 1024);
                         ra[s][1][p] = *reinterpret_cast<const lstm_u32x4*>(a + a_rb + p * 1024);
-                        rb[s][p] = *reinterpret_cast<const lstm_u32x4*>(b + p * pl_stride);
+#pragma unroll
+                        for (int j = 0; j < UB; ++j)
+                            rb[s][j][p] = *reinterpret_cast<const lstm_u32x4*>(bp[j] + kn * kc_stride + p * pl_stride);
                     }
                     asm volatile("" ::: "memory");
                 }
@@ -610,63 +629,73 @@ __global__ __launch_bounds__(256, 3) void lstm_step_fwd_bf_kernel(const float* _
 #pragma unroll
                 for (int t = 0; t < 5; ++t)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][pa[t]], Bv[pb[t]], accc[i], 0, 0, 0);
+                    for (int j = 0; j < UB; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bv[0], acc[i], 0, 0, 0);
+                        for (int i = 0; i < 2; ++i)
+                            accc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][pa[t]], Bv[j][pb[t]], accc[j][i], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < UB; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bv[j][0], acc[j][i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);      // the next chunk's MFMAs stay behind these (else all sets are waited for at once)
             }
         }
     }
-    // accumulators -> LDS [K quarter][row][gate * 8 + unit]
+    // accumulators -> LDS [K quarter][row][gate * 8 + unit], one block of 8 units at a time
     float* Cs = smem + kq * BM * C_LD;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < UB; ++j) {
+        if (j > 0) __syncthreads();         // the previous block's images have been read
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * C_LD + l31] = acc[i][r] + accc[i][r];
-    __syncthreads();
-    if (!valid) return;
-    const long i = r * C + u0 + u;
-    float2 hv = h0;
-    if (!live) {
-        *reinterpret_cast<float2*>(c_out + i) = c0;
-        *reinterpret_cast<float2*>(h_out + i) = h0;      // acts are never read for skipped steps
-    } else {
-        const long gb = r * 4 * C + u0 + u;
-        const int o = rl * C_LD + u;
-        float2 z[4];
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            z[g] = make_float2(gv1[g].x + gv2[g].x, gv1[g].y + gv2[g].y);
+            for (int rr = 0; rr < 16; ++rr)
+                Cs[(i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lhi) * C_LD + l31] = acc[j][i][rr] + accc[j][i][rr];
+        __syncthreads();
+        if (!valid) continue;
+        const int uj = u0 + 8 * j;
+        const long i = r * C + uj + u;
+        float2 hv = h0[j];
+        if (!live) {
+            *reinterpret_cast<float2*>(c_out + i) = c0[j];
+            *reinterpret_cast<float2*>(h_out + i) = h0[j];      // acts are never read for skipped steps
+        } else {
+            const long gb = r * 4 * C + uj + u;
+            const int o = rl * C_LD + u;
+            float2 z[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float2 p = *reinterpret_cast<const float2*>(smem + q * BM * C_LD + o + g * 8);
-                z[g].x += p.x; z[g].y += p.y;
+            for (int g = 0; g < 4; ++g) {
+                z[g] = make_float2(gv1[j][g].x + gv2[j][g].x, gv1[j][g].y + gv2[j][g].y);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float2 p = *reinterpret_cast<const float2*>(smem + q * BM * C_LD + o + g * 8);
+                    z[g].x += p.x; z[g].y += p.y;
+                }
+            }
+            const float2 ai = make_float2(sigmoidf_(z[0].x), sigmoidf_(z[0].y)), aj = make_float2(tanhf(z[1].x), tanhf(z[1].y)),
+                         af = make_float2(sigmoidf_(z[2].x + 1.0f), sigmoidf_(z[2].y + 1.0f)),
+                         ao = make_float2(sigmoidf_(z[3].x), sigmoidf_(z[3].y));
+            const float2 c1 = make_float2(c0[j].x * af.x + ai.x * aj.x, c0[j].y * af.y + ai.y * aj.y);
+            hv = make_float2(tanhf(c1.x) * ao.x, tanhf(c1.y) * ao.y);
+            *reinterpret_cast<float2*>(c_out + i) = c1;
+            *reinterpret_cast<float2*>(h_out + i) = hv;
+            if (acts != nullptr) {      // the backward pass's copy of the activated gates; inference passes NULL
+                *reinterpret_cast<float2*>(acts + gb) = ai;
+                *reinterpret_cast<float2*>(acts + gb + C) = aj;
+                *reinterpret_cast<float2*>(acts + gb + 2 * C) = af;
+                *reinterpret_cast<float2*>(acts + gb + 3 * C) = ao;
             }
         }
-        const float2 ai = make_float2(sigmoidf_(z[0].x), sigmoidf_(z[0].y)), aj = make_float2(tanhf(z[1].x), tanhf(z[1].y)),
-                     af = make_float2(sigmoidf_(z[2].x + 1.0f), sigmoidf_(z[2].y + 1.0f)),
-                     ao = make_float2(sigmoidf_(z[3].x), sigmoidf_(z[3].y));
-        const float2 c1 = make_float2(c0.x * af.x + ai.x * aj.x, c0.y * af.y + ai.y * aj.y);
-        hv = make_float2(tanhf(c1.x) * ao.x, tanhf(c1.y) * ao.y);
-        *reinterpret_cast<float2*>(c_out + i) = c1;
-        *reinterpret_cast<float2*>(h_out + i) = hv;
-        if (acts != nullptr) {      // the backward pass's copy of the activated gates; inference passes NULL
-            *reinterpret_cast<float2*>(acts + gb) = ai;
-            *reinterpret_cast<float2*>(acts + gb + C) = aj;
-            *reinterpret_cast<float2*>(acts + gb + 2 * C) = af;
-            *reinterpret_cast<float2*>(acts + gb + 3 * C) = ao;
+        if (hp_out != nullptr) {
+            unsigned ph, pm, pl;
+            lstm_split3_pair(hv.x, hv.y, ph, pm, pl);
+            const int ln = (int)(r & 31) + 32 * ((uj >> 3) & 1);
+            char* f = hp_out + (((r >> 5) * KC + (uj >> 4)) * 3) * 1024 + ln * 16 + (tid & 3) * 4;
+            *reinterpret_cast<unsigned*>(f) = ph;
+            *reinterpret_cast<unsigned*>(f + 1024) = pm;
+            *reinterpret_cast<unsigned*>(f + 2048) = pl;
         }
-    }
-    if (hp_out != nullptr) {
-        unsigned ph, pm, pl;
-        lstm_split3_pair(hv.x, hv.y, ph, pm, pl);
-        const int ln = (int)(r & 31) + 32 * ((u0 >> 3) & 1);
-        char* f = hp_out + (((r >> 5) * KC + (u0 >> 4)) * 3) * 1024 + ln * 16 + (tid & 3) * 4;
-        *reinterpret_cast<unsigned*>(f) = ph;
-        *reinterpret_cast<unsigned*>(f + 1024) = pm;
-        *reinterpret_cast<unsigned*>(f + 2048) = pl;
     }
 }
 
@@ -687,12 +716,23 @@ extern "C" int ssc_lstm_step_fwd_bf(const float* h_in, const void* hp_in, const 
                                     const float* g2, int div2, const int* mask, int mdiv, const float* c_in, int64_t rows,
                                     int C, float* c_out, float* h_out, void* hp_out, float* acts, void* stream) {
     if ((C & 127) || Kp == nullptr || nbp < (4 * C) / 32 || rows <= 0 || rows > 0x7fffffffL / (4L * C)) return -1;
-    const dim3 grid((unsigned)(((rows + 63) / 64) * (C / 8)));
-#define LSTM_BF_LAUNCH(PF)                                                                                                \
-    hipLaunchKernelGGL(lstm_step_fwd_bf_kernel<PF>, grid, dim3(256), 0, (hipStream_t)stream, h_in, (const char*)hp_in,    \
+    // 64 x 64 tiles (two blocks of 8 units per workgroup) from 1152 workgroups of the 64 x 32 grid on (4.5 per CU).  Measured
+    // (scripts/lstm_ub_ab.sh, us per step 64x32 -> 64x64): C = 512: 576 rows 23.9 -> 25.7, 1152 rows 39.7 -> 38.4, 2304 rows 91.5 -> 72.7;
+    // C = 1024: 576 rows 57.5 -> 56.2, 2304 rows 312 -> 192, 4608 rows 598 -> 383
+    static int ub_env = -2;     // SSC_LSTM_UB=1 / 2 pins the tile (A/B)
+    if (ub_env == -2) {
+        const char* e = ssc_dev_getenv("SSC_LSTM_UB");
+        ub_env = e != nullptr ? atoi(e) : -1;
+    }
+    const long wgs1 = ((rows + 63) / 64) * (C / 8);
+    const int ub = ((C / 8) & 1) ? 1 : (ub_env == 1 || ub_env == 2 ? ub_env : (wgs1 >= 1152 ? 2 : 1));
+    const dim3 grid((unsigned)(wgs1 / ub));
+#define LSTM_BF_LAUNCH(PF, UBV)                                                                                           \
+    hipLaunchKernelGGL((lstm_step_fwd_bf_kernel<PF, UBV>), grid, dim3(256), 0, (hipStream_t)stream, h_in, (const char*)hp_in, \
                        (const char*)Kp, nbp, g1, g2, div2 > 0 ? div2 : 1, mask, mdiv > 0 ? mdiv : 1, c_in, (int)rows, C,  \
                        c_out, h_out, (char*)hp_out, acts)
-    LSTM_BF_LAUNCH(2);      // C / 64 chunks per K quarter, a multiple of PF = 2 (18 KiB of loads in flight per wave)
+    if (ub == 2) LSTM_BF_LAUNCH(2, 2);
+    else LSTM_BF_LAUNCH(2, 1);      // C / 64 chunks per K quarter, a multiple of PF = 2 (18 KiB of loads in flight per wave)
 #undef LSTM_BF_LAUNCH
     return CHECK_LAUNCH();
 }
