@@ -263,22 +263,38 @@ __global__ __launch_bounds__(256) void minmax_partial_v4_kernel(const float* __r
     }
 }
 
-__global__ void minmax_final_kernel(const float* __restrict__ part, int nsplit, int N, int C, float* __restrict__ mnmx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
-    const int n = i / C, c = i - n * C;
+// fold of the partial extrema [n][split][2][C]: block = (32 channels, one sample), its 8 thread groups take every 8th split and
+// meet in LDS.  (One thread per (sample, channel) walking all splits alone took up to 257 us behind a conv epilogue's 576 row
+// tiles per 192 x 192 sample with eight workgroups on the chip: 5 % of an MRU inference pass.)  min / max: any order, same bits.
+__global__ __launch_bounds__(256) void minmax_final_kernel(const float* __restrict__ part, int nsplit, int N, int C,
+                                                           float* __restrict__ mnmx) {
+    __shared__ float smn[8][32], smx[8][32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int n = blockIdx.y, c = blockIdx.x * 32 + cl;
     float mn = INFINITY, mx = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) {
-        const float* p = part + (((long)n * nsplit + s) * 2) * C + c;
-        mn = fminf(mn, p[0]);
-        mx = fmaxf(mx, p[C]);
+    if (c < C) {
+        for (int s = g; s < nsplit; s += 8) {
+            const float* p = part + (((long)n * nsplit + s) * 2) * C + c;
+            mn = fminf(mn, p[0]);
+            mx = fmaxf(mx, p[C]);
+        }
     }
-    mnmx[(long)n * 2 * C + c] = mn;
-    mnmx[(long)n * 2 * C + C + c] = mx;
+    smn[g][cl] = mn;
+    smx[g][cl] = mx;
+    __syncthreads();
+    if (g == 0 && c < C) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            mn = fminf(mn, smn[q][cl]);
+            mx = fmaxf(mx, smx[q][cl]);
+        }
+        mnmx[(long)n * 2 * C + c] = mn;
+        mnmx[(long)n * 2 * C + C + c] = mx;
+    }
 }
 
 extern "C" int ssc_minmax_finalize(const float* part, int nsplit, int N, int C, float* mnmx, void* stream) {
-    hipLaunchKernelGGL(minmax_final_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nsplit, N, C, mnmx);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3((C + 31) / 32, N), dim3(256), 0, (hipStream_t)stream, part, nsplit, N, C, mnmx);
     return CHECK_LAUNCH();
 }
 
@@ -295,7 +311,7 @@ extern "C" int ssc_minmax_hw(const float* x, int ld, int N, int P, int C, float*
         hipLaunchKernelGGL(minmax_partial_kernel, dim3((C + 63) / 64, nsplit, N), dim3(256), 0, (hipStream_t)stream, x, ld,
                            P, C, nsplit, workspace);
     }
-    hipLaunchKernelGGL(minmax_final_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
+    hipLaunchKernelGGL(minmax_final_kernel, dim3((C + 31) / 32, N), dim3(256), 0, (hipStream_t)stream, workspace,
                        nsplit, N, C, mnmx);
     return CHECK_LAUNCH();
 }
