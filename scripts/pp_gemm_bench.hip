@@ -1,0 +1,610 @@
+// pp_gemm_bench.hip -- feasibility: the bf16x6 contraction with BOTH operands pre-split into bf16 planes.
+//
+// The product kernel (csrc/igemm_bf16.hip) splits the gathered operand inside its staging: ~110 vector + ~100 scalar instructions
+// per 24 MFMAs, MFMA pipe 0.44 busy.  Here the gathered operand arrives as three bf16 planes too -- [row][K/32][plane 3][32] -- and
+// both operands go global -> LDS by DMA, fragment-major, through an NSTAGE-deep ring with a counted vmcnt and ONE barrier per K-tile.
+// What the loop then holds per K-tile and wave: 6 (A) + 6 (B) DMA instructions, 12 x SM-dependent ds_read_b128, 24 x SM MFMAs.
+//
+//   hipcc -O3 --offload-arch=gfx950 scripts/pp_gemm_bench.hip -o /tmp/pp_gemm_bench && /tmp/pp_gemm_bench
+//
+// Prints fp32-equivalent TFLOP/s (2 * M * N * K / time) per shape and variant, and checks a small case against float64.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// N LDS-DMA instructions: 16 bytes per lane from sbase + voff[q] to LDS at lds_addr + q * 1024 + 16 * lane
+template <int N>
+__device__ __forceinline__ void glds_run(const char* sbase, const unsigned* voff, unsigned lds_addr) {
+    unsigned keep;
+    static_assert(N == 3 || N == 6, "3 or 6 per run");
+    if (N == 3) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(sbase), "s"(lds_addr) : "memory", "scc");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %7\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %7\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %7\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %7\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %7\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "s"(sbase), "s"(lds_addr)
+                     : "memory", "scc");
+    }
+}
+
+// A planes: [M][K/32][3][32] bf16 (192 bytes per row and 32-k chunk).  B planes: fragment-major [K/16][3][N/32][1 KiB]: lane L of a
+// fragment holds B[kc*16 + (L>>5)*8 + e][nb*32 + (L&31)], e = 0..7.  C [M][N] fp32.
+// Workgroup: 4 waves (2 x 2), tile (SM*64) x 128, wave tile (SM*32) x 64.
+template <int SM, int NSTAGE>
+__global__ __launch_bounds__(256) void pp_gemm_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp, float* __restrict__ C,
+                                                       int M, int N, int K) {
+    constexpr int BM = SM * 64, BN = 128, SN = 2;
+    constexpr int A_FR = (BM / 32) * 6;        // fragments per K-tile: [rb][kc 2][plane 3]
+    constexpr int B_FR = 24;                   // [kc 2][plane 3][nb 4]
+    constexpr int A_IPW = A_FR / 4, B_IPW = 6; // DMA instructions per wave
+    constexpr int STAGE = (A_FR + B_FR) * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tn = N / BN;
+    // XCD-aware order: the workgroups of one XCD take consecutive tiles
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int tile_n = bid % tn, tile_m = bid / tn;
+    const long m0 = (long)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int nkt = K / 32;
+    const long rowbytes = (long)nkt * 192;
+    const int NB = N / 32;
+
+    // A: this wave's DMA instruction q covers fragment f = wave * A_IPW + q = (rb, kc, plane); lane = (row & 31, khalf)
+    unsigned avoff[A_IPW];
+#pragma unroll
+    for (int q = 0; q < A_IPW; ++q) {
+        const int f = wave * A_IPW + q;
+        const int rb = f / 6, kc = (f / 3) % 2, pl = f % 3;
+        avoff[q] = (unsigned)((m0 + rb * 32 + (lane & 31)) * rowbytes + pl * 64 + kc * 32 + (lane >> 5) * 16);
+    }
+    unsigned bvoff[B_IPW];
+#pragma unroll
+    for (int q = 0; q < B_IPW; ++q) {
+        const int f = wave * B_IPW + q;
+        const int kc = f / 12, pl = (f / 4) % 3, nb = f % 4;
+        bvoff[q] = (unsigned)((((kc * 3 + pl) * NB) + (n0 >> 5) + nb) * 1024 + lane * 16);
+    }
+    const long b_ktile = (long)6 * NB * 1024;
+
+    auto issue = [&](int kt, int slot) {
+        const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(slot * STAGE + wave * A_IPW * 1024));
+        const unsigned lb = __builtin_amdgcn_readfirstlane((unsigned)(slot * STAGE + A_FR * 1024 + wave * B_IPW * 1024));
+        glds_run<A_IPW>(Ap + (long)kt * 192, avoff, la);
+        glds_run<B_IPW>(Bp + (long)kt * b_ktile, bvoff, lb);
+    };
+
+    f32x16 acc[SM][SN], accc[SM][SN];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = accc[i][j][r] = 0.f;
+
+    // prologue: NSTAGE - 1 K-tiles in flight
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nkt) issue(s, s);
+
+    int slot = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        // K-tile kt has landed when at most the (NSTAGE - 2) younger K-tiles' DMA instructions of this wave are outstanding
+        if (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (kt + NSTAGE - 2 < nkt) {
+            if ((NSTAGE - 2) * (A_IPW + B_IPW) == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if ((NSTAGE - 2) * (A_IPW + B_IPW) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if ((NSTAGE - 2) * (A_IPW + B_IPW) == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else if ((NSTAGE - 2) * (A_IPW + B_IPW) == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // every wave is past its reads of K-tile kt - 1: its slot takes K-tile kt + NSTAGE - 1
+        {
+            const int nk = kt + NSTAGE - 1;
+            int ns = slot + NSTAGE - 1;
+            if (ns >= NSTAGE) ns -= NSTAGE;
+            if (nk < nkt) issue(nk, ns);
+        }
+        const char* Ab = smem + slot * STAGE + (wm * SM) * 6 * 1024 + lane * 16;
+        const char* Bb = smem + slot * STAGE + A_FR * 1024 + (wn * SN) * 1024 + lane * 16;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 av[SM][3], bv[SN][3];
+#pragma unroll
+            for (int i = 0; i < SM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) av[i][p] = *reinterpret_cast<const bf16x8*>(Ab + ((i * 2 + kc) * 3 + p) * 1024);
+#pragma unroll
+            for (int j = 0; j < SN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bv[j][p] = *reinterpret_cast<const bf16x8*>(Bb + ((kc * 3 + p) * 4 + j) * 1024);
+            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < SM; ++i)
+#pragma unroll
+                    for (int j = 0; j < SN; ++j) {
+                        if (t == 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][0], acc[i][j], 0, 0, 0);
+                        else accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][pa[t]], bv[j][pb[t]], accc[i][j], 0, 0, 0);
+                    }
+        }
+        slot += 1;
+        if (slot == NSTAGE) slot = 0;
+    }
+    // C: 32x32 block layout: register r of lane L is row (r / 4) * 8 + (L >> 5) * 4 + (r & 3), column L & 31
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + (wm * SM + i) * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+                const int col = n0 + (wn * SN + j) * 32 + (lane & 31);
+                C[row * N + col] = acc[i][j][r] + accc[i][j][r];
+            }
+}
+
+// One DMA instruction: 16 bytes per lane from sbase + voff to LDS at lds_addr + 16 * lane
+__device__ __forceinline__ void glds_one(const char* sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+// The same contraction, 64 x 128 tile, with the step HAND-PLACED: twelve groups of two MFMAs, one DMA instruction of the next
+// K-tile behind each of the first nine, the second half's operand reads behind groups 1..3 (a burst of nine DMA instructions right
+// behind the barrier blocks the wave for 9 x 60..180 cycles with an idle matrix pipe: the plain kernel above).
+template <int NSTAGE>
+__global__ __launch_bounds__(256) void pp_gemm_il_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp, float* __restrict__ C,
+                                                          int M, int N, int K) {
+    constexpr int BM = 64, BN = 128, SN = 2;
+    constexpr int A_FR = 12, B_FR = 24, A_IPW = 3, B_IPW = 6;
+    constexpr int STAGE = (A_FR + B_FR) * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tn = N / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int tile_n = bid % tn, tile_m = bid / tn;
+    const long m0 = (long)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int nkt = K / 32;
+    const long rowbytes = (long)nkt * 192;
+    const int NB = N / 32;
+    unsigned voff[9];
+#pragma unroll
+    for (int q = 0; q < A_IPW; ++q) {
+        const int f = wave * A_IPW + q;
+        const int rb = f / 6, kc = (f / 3) % 2, pl = f % 3;
+        voff[q] = (unsigned)((m0 + rb * 32 + (lane & 31)) * rowbytes + pl * 64 + kc * 32 + (lane >> 5) * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < B_IPW; ++q) {
+        const int f = wave * B_IPW + q;
+        const int kc = f / 12, pl = (f / 4) % 3, nb = f % 4;
+        voff[3 + q] = (unsigned)((((kc * 3 + pl) * NB) + (n0 >> 5) + nb) * 1024 + lane * 16);
+    }
+    const long b_ktile = (long)6 * NB * 1024;
+    // piece q of K-tile kt into stage slot
+    auto piece = [&](int q, int kt, int slot) {
+        if (q < 3) glds_one(Ap + (long)kt * 192, voff[q], __builtin_amdgcn_readfirstlane((unsigned)(slot * STAGE + (wave * A_IPW + q) * 1024)));
+        else glds_one(Bp + (long)kt * b_ktile, voff[q], __builtin_amdgcn_readfirstlane((unsigned)(slot * STAGE + A_FR * 1024 + (wave * B_IPW + q - 3) * 1024)));
+    };
+    f32x16 acc[SN], accc[SN];
+#pragma unroll
+    for (int j = 0; j < SN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = accc[j][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nkt)
+#pragma unroll
+            for (int q = 0; q < 9; ++q) piece(q, s, s);
+    int slot = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (NSTAGE == 3 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (NSTAGE == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int nk = kt + NSTAGE - 1;
+        int ns = slot + NSTAGE - 1;
+        if (ns >= NSTAGE) ns -= NSTAGE;
+        const bool more = nk < nkt;
+        const char* Ab = smem + slot * STAGE + wm * 6 * 1024 + lane * 16;
+        const char* Bb = smem + slot * STAGE + A_FR * 1024 + (wn * SN) * 1024 + lane * 16;
+        bf16x8 av[2][3], bv[2][SN][3];
+        auto fetch_a = [&](int kc) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) av[kc][p] = *reinterpret_cast<const bf16x8*>(Ab + (kc * 3 + p) * 1024);
+        };
+        auto fetch_b = [&](int kc) {
+#pragma unroll
+            for (int j = 0; j < SN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bv[kc][j][p] = *reinterpret_cast<const bf16x8*>(Bb + ((kc * 3 + p) * 4 + j) * 1024);
+        };
+        auto group = [&](int kc, int t) {
+            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int j = 0; j < SN; ++j) {
+                if (t == 5) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kc][0], bv[kc][j][0], acc[j], 0, 0, 0);
+                else accc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kc][pa[t]], bv[kc][j][pb[t]], accc[j], 0, 0, 0);
+            }
+        };
+#define SB __builtin_amdgcn_sched_barrier(0)
+        fetch_a(0); fetch_b(0); SB;
+        group(0, 0); if (more) piece(0, nk, ns); SB;
+        group(0, 1); if (more) piece(1, nk, ns); fetch_a(1); SB;
+        group(0, 2); if (more) piece(2, nk, ns); fetch_b(1); SB;
+        group(0, 3); if (more) piece(3, nk, ns); SB;
+        group(0, 4); if (more) piece(4, nk, ns); SB;
+        group(0, 5); if (more) piece(5, nk, ns); SB;
+        group(1, 0); if (more) piece(6, nk, ns); SB;
+        group(1, 1); if (more) piece(7, nk, ns); SB;
+        group(1, 2); if (more) piece(8, nk, ns); SB;
+        group(1, 3); SB;
+        group(1, 4); SB;
+        group(1, 5); SB;
+#undef SB
+        slot += 1;
+        if (slot == NSTAGE) slot = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < SN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = m0 + wm * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+            const int col = n0 + (wn * SN + j) * 32 + (lane & 31);
+            C[row * N + col] = acc[j][r] + accc[j][r];
+        }
+}
+
+// General wave layout: WM x WN waves (4 or 8), wave tile (SM*32) x (SN*32): how does the rate follow the DMA pieces per MFMA?
+template <int WM, int WN, int SM, int SN, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void pp_gemm_w_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp,
+                                                                  float* __restrict__ C, int M, int N, int K) {
+    constexpr int NW = WM * WN, BM = WM * SM * 32, BN = WN * SN * 32;
+    constexpr int A_FR = (BM / 32) * 6, B_FR = (BN / 32) * 6, NBT = BN / 32;
+    constexpr int FR = A_FR + B_FR, IPW = FR / NW;
+    static_assert(FR % NW == 0, "pieces divide over the waves");
+    constexpr int STAGE = FR * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tn = N / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int tile_n = bid % tn, tile_m = bid / tn;
+    const long m0 = (long)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int nkt = K / 32;
+    const long rowbytes = (long)nkt * 192;
+    const int NB = N / 32;
+    // piece f of the stage image: f < A_FR: A fragment (rb, kc, plane); else B fragment (kc, plane, nb)
+    unsigned voff[IPW];
+    bool isA[IPW];
+#pragma unroll
+    for (int q = 0; q < IPW; ++q) {
+        const int f = wave * IPW + q;
+        isA[q] = f < A_FR;
+        if (f < A_FR) {
+            const int rb = f / 6, kc = (f / 3) % 2, pl = f % 3;
+            voff[q] = (unsigned)((m0 + rb * 32 + (lane & 31)) * rowbytes + pl * 64 + kc * 32 + (lane >> 5) * 16);
+        } else {
+            const int g = f - A_FR;
+            const int kc = g / (3 * NBT), pl = (g / NBT) % 3, nb = g % NBT;
+            voff[q] = (unsigned)((((kc * 3 + pl) * NB) + (n0 >> 5) + nb) * 1024 + lane * 16);
+        }
+    }
+    const long b_ktile = (long)6 * NB * 1024;
+    auto issue = [&](int kt, int slot) {
+#pragma unroll
+        for (int q = 0; q < IPW; ++q) {
+            const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(slot * STAGE + (wave * IPW + q) * 1024));
+            const char* sb = isA[q] ? Ap + (long)kt * 192 : Bp + (long)kt * b_ktile;
+            sb = (const char*)(((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long)sb >> 32)) << 32) |
+                               (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long)sb));
+            glds_one(sb, voff[q], l);
+        }
+    };
+    f32x16 acc[SM][SN], accc[SM][SN];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = accc[i][j][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nkt) issue(s, s);
+    int slot = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // NSTAGE == 2 only
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nkt) issue(kt + 1, slot ^ 1);
+        const char* Ab = smem + slot * STAGE + (wm * SM) * 6 * 1024 + lane * 16;
+        const char* Bb = smem + slot * STAGE + A_FR * 1024 + (wn * SN) * 1024 + lane * 16;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 av[SM][3], bv[SN][3];
+#pragma unroll
+            for (int i = 0; i < SM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) av[i][p] = *reinterpret_cast<const bf16x8*>(Ab + ((i * 2 + kc) * 3 + p) * 1024);
+#pragma unroll
+            for (int j = 0; j < SN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bv[j][p] = *reinterpret_cast<const bf16x8*>(Bb + ((kc * 3 + p) * NBT + j) * 1024);
+            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < SM; ++i)
+#pragma unroll
+                    for (int j = 0; j < SN; ++j) {
+                        if (t == 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][0], acc[i][j], 0, 0, 0);
+                        else accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][pa[t]], bv[j][pb[t]], accc[i][j], 0, 0, 0);
+                    }
+        }
+        slot ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + (wm * SM + i) * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+                const int col = n0 + (wn * SN + j) * 32 + (lane & 31);
+                C[row * N + col] = acc[i][j][r] + accc[i][j][r];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+static inline uint16_t rne_bf16(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    return (uint16_t)u;
+}
+static inline float bf16_f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static void split3(float x, uint16_t* p) {
+    p[0] = rne_bf16(x);
+    const float r1 = x - bf16_f(p[0]);
+    p[1] = rne_bf16(r1);
+    const float r2 = r1 - bf16_f(p[1]);
+    p[2] = rne_bf16(r2);
+}
+
+static void make_planes(const std::vector<float>& A, const std::vector<float>& B, int M, int N, int K, std::vector<uint16_t>& Ap,
+                        std::vector<uint16_t>& Bp) {
+    Ap.assign((size_t)M * K * 3, 0);
+    Bp.assign((size_t)K * N * 3, 0);
+    for (long m = 0; m < M; ++m)
+        for (int k = 0; k < K; ++k) {
+            uint16_t p[3];
+            split3(A[m * K + k], p);
+            for (int q = 0; q < 3; ++q) Ap[((m * (K / 32) + k / 32) * 3 + q) * 32 + (k & 31)] = p[q];
+        }
+    const int NB = N / 32;
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) {
+            uint16_t p[3];
+            split3(B[(long)k * N + n], p);
+            const int kc = k / 16, lhi = (k % 16) / 8, e = k % 8, nb = n / 32, l31 = n % 32;
+            for (int q = 0; q < 3; ++q) Bp[((((long)kc * 3 + q) * NB + nb) * 64 + lhi * 32 + l31) * 8 + e] = p[q];
+        }
+}
+
+template <int SM, int NSTAGE>
+static float run(const char* Ap, const char* Bp, float* C, int M, int N, int K, int iters) {
+    constexpr int BM = SM * 64;
+    constexpr size_t lds = (size_t)NSTAGE * ((BM / 32) * 6 + 24) * 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_kernel<SM, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (M / BM) * (N / 128);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pp_gemm_kernel<SM, NSTAGE>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((pp_gemm_kernel<SM, NSTAGE>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipGetLastError());
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+template <int NSTAGE>
+static float run_il(const char* Ap, const char* Bp, float* C, int M, int N, int K, int iters) {
+    constexpr size_t lds = (size_t)NSTAGE * 36 * 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_il_kernel<NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (M / 64) * (N / 128);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pp_gemm_il_kernel<NSTAGE>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((pp_gemm_il_kernel<NSTAGE>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipGetLastError());
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+template <int WM, int WN, int SM, int SN>
+static float run_w(const char* Ap, const char* Bp, float* C, int M, int N, int K, int iters) {
+    constexpr int BM = WM * SM * 32, BN = WN * SN * 32;
+    if (M % BM || N % BN) return -1.f;
+    constexpr size_t lds = (size_t)2 * ((BM / 32) * 6 + (BN / 32) * 6) * 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_w_kernel<WM, WN, SM, SN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (M / BM) * (N / BN);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pp_gemm_w_kernel<WM, WN, SM, SN, 2>), dim3(grid), dim3(WM * WN * 64), lds, 0, Ap, Bp, C, M, N, K);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((pp_gemm_w_kernel<WM, WN, SM, SN, 2>), dim3(grid), dim3(WM * WN * 64), lds, 0, Ap, Bp, C, M, N, K);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipGetLastError());
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+int main(int argc, char** argv) {
+    // 1. correctness + accuracy on a small case
+    {
+        const int M = 256, N = 256, K = 512;
+        std::vector<float> A((size_t)M * K), B((size_t)K * N);
+        srand(1);
+        for (auto& v : A) v = (float)rand() / RAND_MAX * 2.f - 1.f;
+        for (auto& v : B) v = (float)rand() / RAND_MAX * 2.f - 1.f;
+        std::vector<uint16_t> Ap, Bp;
+        make_planes(A, B, M, N, K, Ap, Bp);
+        char *dA, *dB;
+        float* dC;
+        CHECK(hipMalloc(&dA, Ap.size() * 2));
+        CHECK(hipMalloc(&dB, Bp.size() * 2));
+        CHECK(hipMalloc(&dC, (size_t)M * N * 4));
+        CHECK(hipMemcpy(dA, Ap.data(), Ap.size() * 2, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dB, Bp.data(), Bp.size() * 2, hipMemcpyHostToDevice));
+        std::vector<double> ref((size_t)M * N, 0.0);
+        for (int m = 0; m < M; ++m)
+            for (int k = 0; k < K; ++k) {
+                const double a = A[(size_t)m * K + k];
+                for (int n = 0; n < N; ++n) ref[(size_t)m * N + n] += a * B[(size_t)k * N + n];
+            }
+        std::vector<float> out((size_t)M * N);
+        auto check = [&](const char* name) {
+            CHECK(hipMemcpy(out.data(), dC, out.size() * 4, hipMemcpyDeviceToHost));
+            double mx = 0, rms = 0;
+            for (size_t i = 0; i < out.size(); ++i) {
+                const double e = fabs(out[i] - ref[i]);
+                mx = e > mx ? e : mx;
+                rms += e * e;
+            }
+            printf("check %-12s max err %.3e rms %.3e (K = %d)\n", name, mx, sqrt(rms / out.size()), K);
+        };
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run<2, 3>(dA, dB, dC, M, N, K, 1); check("128x128 s3");
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run<2, 2>(dA, dB, dC, M, N, K, 1); check("128x128 s2");
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run<1, 2>(dA, dB, dC, M, N, K, 1); check("64x128 s2");
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run<1, 4>(dA, dB, dC, M, N, K, 1); check("64x128 s4");
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run_il<2>(dA, dB, dC, M, N, K, 1); check("il 64x128 s2");
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run_il<3>(dA, dB, dC, M, N, K, 1); check("il 64x128 s3");
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run_il<4>(dA, dB, dC, M, N, K, 1); check("il 64x128 s4");
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run_w<4, 2, 1, 2>(dA, dB, dC, M, N, K, 1); check("w8 128x128");
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run_w<2, 4, 2, 2>(dA, dB, dC, M, N, K, 1); check("w8 128x256");
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run_w<4, 2, 2, 2>(dA, dB, dC, M, N, K, 1); check("w8 256x128");
+        CHECK(hipFree(dA)); CHECK(hipFree(dB)); CHECK(hipFree(dC));
+    }
+    // 2. speed on layer-like shapes (random data; planes generated on the host once for a [Mu, K] block and tiled)
+    struct Shape { int M, N, K; const char* what; };
+    const Shape shapes[] = {
+        {73728, 128, 1024, "encoder_2 / D layer_2 (batch 32)"},
+        {18432, 256, 2048, "encoder_3 / D layer_3"},
+        {16896, 512, 4096, "D layer_4 (rows rounded)"},
+        {4608, 512, 4096, "encoder_4 (no split-K here)"},
+        {73728, 128, 512, "decoder_3 phase-like (K = 4 taps x 128)"},
+        {65536, 512, 4096, "large"},
+        {294912, 128, 1024, "encoder_2 at batch 128"},
+    };
+    for (const Shape& s : shapes) {
+        const int M = s.M, N = s.N, K = s.K;
+        std::vector<uint16_t> Ap((size_t)M * K * 3), Bp((size_t)K * N * 3);
+        // random bf16 bit patterns of plausible magnitudes: h ~ U[-1,1), m ~ 2^-8, l ~ 2^-16
+        srand(7);
+        // group: elements per plane run (A: 32 values of a plane inside a 96-value chunk; B: 512 x N/32 values of a plane)
+        auto fill = [&](std::vector<uint16_t>& P, size_t group) {
+            const size_t gen = P.size() < ((size_t)3 << 22) ? P.size() : ((size_t)3 << 22) / (3 * group) * (3 * group) + (((size_t)3 << 22) < 3 * group ? 3 * group : 0);
+            for (size_t i = 0; i < gen; ++i) {
+                const int q = (int)((i / group) % 3);
+                const float v = ((float)rand() / RAND_MAX * 2.f - 1.f) * (q == 0 ? 1.f : q == 1 ? 0.0039f : 1.5e-5f);
+                P[i] = rne_bf16(v);
+            }
+            for (size_t done = gen; done < P.size();) {
+                const size_t n = done < P.size() - done ? done : P.size() - done;
+                memcpy(&P[done], &P[0], n * 2);
+                done += n;
+            }
+        };
+        fill(Ap, 32);
+        fill(Bp, (size_t)512 * (N / 32));
+        char *dA, *dB;
+        float* dC;
+        CHECK(hipMalloc(&dA, Ap.size() * 2));
+        CHECK(hipMalloc(&dB, Bp.size() * 2));
+        CHECK(hipMalloc(&dC, (size_t)M * N * 4));
+        CHECK(hipMemcpy(dA, Ap.data(), Ap.size() * 2, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dB, Bp.data(), Bp.size() * 2, hipMemcpyHostToDevice));
+        const double flop = 2.0 * M * N * K;
+        printf("%-44s M %6d N %4d K %5d :", s.what, M, N, K);
+        float ms;
+        if (M % 128 == 0) {
+            ms = run<2, 3>(dA, dB, dC, M, N, K, 20); printf("  128x128 s3 %6.1f", flop / ms * 1e-9);
+            ms = run<2, 2>(dA, dB, dC, M, N, K, 20); printf("  128x128 s2 %6.1f", flop / ms * 1e-9);
+        }
+        ms = run<1, 2>(dA, dB, dC, M, N, K, 20); printf("  64x128 s2 %6.1f", flop / ms * 1e-9);
+        ms = run<1, 4>(dA, dB, dC, M, N, K, 20); printf("  64x128 s4 %6.1f", flop / ms * 1e-9);
+        ms = run_il<2>(dA, dB, dC, M, N, K, 20); printf("  il s2 %6.1f", flop / ms * 1e-9);
+        ms = run_il<3>(dA, dB, dC, M, N, K, 20); printf("  il s3 %6.1f", flop / ms * 1e-9);
+        ms = run_il<4>(dA, dB, dC, M, N, K, 20); printf("  il s4 %6.1f", flop / ms * 1e-9);
+        ms = run_w<2, 2, 1, 2>(dA, dB, dC, M, N, K, 20); printf("  w4 64x128 %6.1f", ms > 0 ? flop / ms * 1e-9 : 0.0);
+        ms = run_w<4, 2, 1, 2>(dA, dB, dC, M, N, K, 20); printf("  w8 128x128 %6.1f", ms > 0 ? flop / ms * 1e-9 : 0.0);
+        ms = run_w<2, 4, 2, 2>(dA, dB, dC, M, N, K, 20); printf("  w8 128x256 %6.1f", ms > 0 ? flop / ms * 1e-9 : 0.0);
+        ms = run_w<4, 2, 2, 2>(dA, dB, dC, M, N, K, 20); printf("  w8 256x128 %6.1f", ms > 0 ? flop / ms * 1e-9 : 0.0);
+        printf("  TFLOP/s fp32-equivalent\n");
+        CHECK(hipFree(dA)); CHECK(hipFree(dB)); CHECK(hipFree(dC));
+    }
+    return 0;
+}

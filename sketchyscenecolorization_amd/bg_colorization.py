@@ -88,6 +88,7 @@ class BGTrainer(object):
         self.use_graphs = bool(use_graphs)
         self.lr_dev = torch.zeros(2, dtype=torch.float32, device=device)
         self._static, self._graphs, self._seen = {}, {}, set()
+        self._graph_gen = {}        # graph key -> hip.split_generation() at its capture
 
     def learning_rate(self, step):
         decay_steps = int(round(self.max_steps * 0.75))
@@ -207,5 +208,9 @@ class BGTrainer(object):
                 impl()
                 return self._gctx
             self._graphs[key] = g
+            self._graph_gen[key] = hip.split_generation()
+        hip.resplit_stale()         # weights replaced through torch since the planes were made (trainer.py: _run_step_inner)
         g.replay()
+        for sc in (self.store.discriminator, self.store.generator):
+            hip.refresh_new_splits(sc.flat, self._graph_gen[key])
         return self._gctx

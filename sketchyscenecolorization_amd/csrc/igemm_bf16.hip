@@ -295,6 +295,15 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
     // 40 banks) apart instead of one (208 bytes = 52 banks: the second row's 16 banks wrapped onto 4 of the first's)
     const int a_col4 = tid & 7;
     const bool a_lastv = !KM || (nch0 - 1) * BK + a_col4 * 4 < xC0;      // KM: this thread's float4 of the LAST chunk exists
+    // KM: stored channels in [k_real, C0) (the padding lane of a concat [state | image(3) | pad]) meet zero filter planes, but
+    // 0 * NaN = NaN: whatever sits there is cleared by a bit mask on the way to LDS (element e of this thread's float4 of the
+    // last chunk is real iff its channel < k_real)
+    uint4 a_lastm = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (KM) {
+        const int c_ = (nch0 - 1) * BK + a_col4 * 4;
+        a_lastm = make_uint4(c_ < d.k_real ? ~0u : 0u, c_ + 1 < d.k_real ? ~0u : 0u, c_ + 2 < d.k_real ? ~0u : 0u,
+                             c_ + 3 < d.k_real ? ~0u : 0u);
+    }
     const int arow = ((tid >> 3) & ~3) | (((tid >> 3) & 1) << 1) | (((tid >> 3) >> 1) & 1);
     int a_iyb[A_ROWS], a_ixb[A_ROWS], a_off0[A_ROWS], a_off1[A_ROWS];
     bool a_mv[A_ROWS];
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
     };
 
     // a staged K-tile of the gathered side in registers: raw rows, their 1.0 / 0.0 validity, the source's norm table and slope
-    struct ASet { float4 r[A_ROWS]; float v[A_ROWS]; float4 aa, ab; float slope; };
+    struct ASet { float4 r[A_ROWS]; float v[A_ROWS]; float4 aa, ab; float slope; uint4 km; };
 
     auto issue_loads = [&](const KTile& t, ASet& S) {
         const bool first = ONE ? true : t.chunk < nch0;
@@ -500,6 +509,7 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
         const int tapidx = t.tapidx;
         // KM: does this thread's float4 of the chunk exist?  (a wave-uniform test on the chunk, a per-thread constant for the last one)
         const bool cv = !KM || t.chunk != nch0 - 1 || a_lastv;
+        if (KM) S.km = t.chunk == nch0 - 1 ? a_lastm : make_uint4(~0u, ~0u, ~0u, ~0u);
         if (!PLAIN) {
             const char* pa = reinterpret_cast<const char*>((first ? tab.a0 : tab.a1) + cc);
             const char* pb = reinterpret_cast<const char*>((first ? tab.b0 : tab.b1) + cc);
@@ -542,6 +552,12 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
             t_ = fmaf((S).aa.y, v_.y, (S).ab.y); v_.y = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
             t_ = fmaf((S).aa.z, v_.z, (S).ab.z); v_.z = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
             t_ = fmaf((S).aa.w, v_.w, (S).ab.w); v_.w = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
+        }                                                                                         \
+        if (KM) {                                                                                 \
+            v_.x = __uint_as_float(__float_as_uint(v_.x) & (S).km.x);                             \
+            v_.y = __uint_as_float(__float_as_uint(v_.y) & (S).km.y);                             \
+            v_.z = __uint_as_float(__float_as_uint(v_.z) & (S).km.z);                             \
+            v_.w = __uint_as_float(__float_as_uint(v_.w) & (S).km.w);                             \
         }                                                                                         \
         split3_pair(v_.x, v_.y, H0, M0, L0);                                                      \
         Z = v_.z; W = v_.w;                                                                       \

@@ -460,7 +460,19 @@ _SPLIT_ALWAYS = _dev_env('SSC_SPLIT_ALWAYS', '0') == '1'      # diagnostic: ever
 
 
 class _Split(object):
-    __slots__ = ('key', 'w', 'buf', 'kc', 'nbp', 'threads', 'version', 'taps', 'c0', 'c1', 'orient', 'param')
+    # gen: creation order of PARAMETER entries (a captured optimizer step refreshes the entries that existed at its capture;
+    # refresh_new_splits covers the younger ones).  pinned: created or used while a stream was capturing -- a captured graph
+    # holds its buffer's address, so the entry is never evicted.
+    __slots__ = ('key', 'w', 'buf', 'kc', 'nbp', 'threads', 'version', 'taps', 'c0', 'c1', 'orient', 'param', 'gen', 'pinned')
+
+
+_split_gen = [0]        # number of parameter entries ever created (see _Split.gen)
+
+
+def split_generation():
+    """The creation counter of parameter plane entries: a trainer notes it when it captures an optimizer step and hands it to
+    refresh_new_splits() after every replay."""
+    return _split_gen[0]
 
 
 def register_param_buffer(flat):
@@ -506,13 +518,20 @@ def filter_split(w, orient):
         e.taps, e.c0, e.c1, e.orient = KH * KW, c0, c1, orient
         e.param = (not _SPLIT_ALWAYS) and any(lo <= key[0] < hi for lo, hi in _PARAM_RANGES)
         e.buf = torch.empty(nbytes.value, dtype=torch.uint8, device=w.device)
-        if not e.param:
-            vol = [k for k, v in _SPLITS.items() if not v.param]
+        e.pinned, e.gen = False, 0
+        if e.param:
+            _split_gen[0] += 1
+            e.gen = _split_gen[0]
+        else:
+            # evict the oldest volatile entries nobody can still name: never one that a captured graph launches into (pinned)
+            vol = [k for k, v in _SPLITS.items() if not v.param and not v.pinned]
             if len(vol) >= _VOLATILE_MAX and not torch.cuda.is_current_stream_capturing():
                 torch.cuda.synchronize()        # nothing in flight reads the planes about to be dropped
                 for k in vol[:_VOLATILE_MAX // 2]:
                     del _SPLITS[k]
         _SPLITS[key] = e
+    if torch.cuda.is_current_stream_capturing():
+        e.pinned = True
     if not e.param:
         _split_launch(e)
         return e
@@ -532,6 +551,37 @@ def filter_split(w, orient):
     return e
 
 
+def resplit_stale():
+    """Split again every parameter filter whose tensor torch has modified since its planes were made (ParamStore.load_dict /
+    load_state_dict / initialize, any copy_ into a view of the flat buffer).  filter_split() notices that when Python meets the
+    filter; a REPLAYED graph never comes by there -- its launches hold the planes' addresses -- so the trainers call this in
+    front of every replay (a loop over some dozens of integers when nothing changed).  Returns the number of filters split."""
+    stale = [e for e in _SPLITS.values() if e.param and e.version is not None and e.version != e.w._version]
+    if not stale:
+        return 0
+    assert not torch.cuda.is_current_stream_capturing(), 'weights were replaced through torch during a capture'
+    torch.cuda.synchronize()        # nobody still reads the old planes (any stream)
+    for e in stale:
+        _split_launch(e)
+        e.version = e.w._version
+    torch.cuda.synchronize()        # ... and every stream sees the new ones
+    return len(stale)
+
+
+def refresh_new_splits(flat, since):
+    """refresh_splits() for the parameter entries of ``flat`` created after generation ``since`` (split_generation() at the capture
+    of an optimizer step): a captured step refreshes only the entries that existed when it was captured, so a filter that first
+    met a bf16 launch later (inference at another batch size or image size, another orientation) would keep the planes of the
+    weights of that moment.  Called behind every replay of a captured optimizer step; nothing to do in the usual case."""
+    if _split_gen[0] <= since:
+        return 0
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+    es = [e for e in _SPLITS.values() if e.param and e.gen > since and lo <= e.key[0] < hi]
+    if es:
+        _refresh_entries(es)
+    return len(es)
+
+
 def refresh_splits(flat=None):
     """Split again every registered filter that lives inside the flat parameter buffer ``flat`` (all of them when None): one
     batched launch.  Called behind every optimizer launch (the kernel writes the weights without torch noticing)."""
@@ -544,6 +594,13 @@ def refresh_splits(flat=None):
         es = [e for e in _SPLITS.values() if e.param]
     if not es:
         return
+    _refresh_entries(es)
+
+
+def _refresh_entries(es):
+    if torch.cuda.is_current_stream_capturing():
+        for e in es:
+            e.pinned = True
     tk = tuple(e.key for e in es)
     tab = _SPLIT_TABLES.get(tk)
     if tab is None:

@@ -340,6 +340,7 @@ class ParamStore(object):
             sc.adam_t = 0
         for n, shape, init in self._nt_specs:
             self.nontrainable[n].copy_(_init_tensor(shape, init, gen))
+        self._planes_follow()
 
     def __getitem__(self, name):
         if name in self.nontrainable:
@@ -352,11 +353,19 @@ class ParamStore(object):
     def names(self):
         return self.generator.names() + self.discriminator.names() + list(self.nontrainable.keys())
 
+    def _planes_follow(self):
+        """The bf16 planes of this store's filters follow weights written through torch NOW (not at the next launch Python
+        happens to issue: a replayed hipGraph holds the planes' addresses and never looks at a tensor's version)."""
+        if self.generator.flat.is_cuda:
+            from . import hip
+            hip.resplit_stale()
+
     def load_dict(self, d):
         """Copy values from a {tf_name: tensor/ndarray} mapping (checkpoints, test fixtures)."""
         for n in self.names():
             if n in d:
                 self[n].copy_(torch.as_tensor(d[n], dtype=torch.float32).reshape(self[n].shape))
+        self._planes_follow()
 
     def state_dict(self):
         out = OrderedDict((n, self[n].detach().cpu()) for n in self.names())

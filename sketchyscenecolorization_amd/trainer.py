@@ -94,6 +94,7 @@ class GanTrainer(object):
         self.use_graphs = bool(use_graphs)
         self._capturing = False
         self._graphs, self._seen, self._static = {}, set(), {}
+        self._graph_gen = {}        # graph key -> hip.split_generation() at its capture
         # world > 1: collectives are NOT captured.  A step is captured as a chain of graph segments that end where
         # the backward pass hands a gradient section to the reducer; replay = segment, eager RCCL all-reduce on the
         # side stream, next segment, ...  (same overlap as eager mode, no dependence on graph-capturable RCCL).
@@ -399,10 +400,16 @@ class GanTrainer(object):
                 self._adam_prepare(scope, idx, lr * self.decay(counter))
                 return impl(sbatch)
             self._graphs[key] = g
+            self._graph_gen[key] = hip.split_generation()
+        # bf16 planes and replayed graphs (hip.resplit_stale / refresh_new_splits): weights replaced through torch since the
+        # last launch are split again in front of the replay; filters that met their first bf16 launch after this graph was
+        # captured are not in its optimizer refresh and are split behind it
+        hip.resplit_stale()
         if isinstance(g, list):
             self._replay_segments(g)
         else:
             g.replay()
+        hip.refresh_new_splits(scope.flat, self._graph_gen[key])
         return self.loss[1:2] if kind == 'd' else self.loss[0:1]
 
     def _g_forward(self, batch, tag='g', **kw):
@@ -881,6 +888,7 @@ class GanTrainer(object):
                 torch.cuda.synchronize()
                 return body(sketches, text, noise_vec, labels)
             self._graphs[key] = g
+        hip.resplit_stale()         # weights replaced through torch (load_dict, a restore) since the planes were made
         g.replay()
         return self._static[key].clone() if clone else self._static[key]
 

@@ -108,6 +108,35 @@ def test_conv_partial_chunk_split_vs_exact(n, h, ch, extra, co, k, table):
     _both(run, ref, 'conv_partial_chunk_split_vs_exact', dict(n=n, h=h, ch=ch, extra=extra, co=co, k=k, table=table))
 
 
+@pytest.mark.parametrize('table', [False, True])
+def test_conv_partial_chunk_ignores_nan_in_the_padding_lane(table):
+    """conv_bf_kernel<KM>: a NaN / Inf in the stored padding channel of a concat row (channels [k_real, C0)) must not reach the
+    output -- the zero filter planes do not cancel it (0 * NaN), the staging clears the lane."""
+    hip = _hip()
+    if not hip.ARITH_BF16:
+        pytest.skip('SSC_ARITH=fp32')
+    n, h, ci, co, k = 2, 12, 67, 64, 3
+    cp = 68
+    x = rnd(n, ci, h, h, seed=46)
+    w = rnd(k, k, ci, co, seed=47, std=0.05).cuda()
+    ab = torch.cat([1.0 + 0.1 * rnd(cp, seed=48), 0.2 * rnd(cp, seed=49)]).cuda()
+    outs = []
+    for pad in (0.0, float('nan'), float('inf')):
+        xp = torch.full((n, h, h, cp), pad)
+        xp[..., :ci] = nhwc(x)
+        out = torch.full((n, h, h, co), float('nan'), device='cuda')
+        hip.PROFILE = []
+        try:
+            hip.conv_forward(hip.View(xp.cuda(), None, ab, 2) if table else hip.View(xp.cuda()), w, 1, 0, out, same=True)
+            torch.cuda.synchronize()
+            assert any(p[0].startswith('conv_bf16x6') for p in hip.PROFILE), [p[0] for p in hip.PROFILE]
+        finally:
+            hip.PROFILE = None
+        outs.append(out)
+    assert bool(torch.isfinite(outs[0]).all())
+    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+
+
 @pytest.mark.parametrize('n,h,c0,c1,co', [(4, 12, 64, 64, 64), (2, 6, 512, 512, 256)])
 def test_deconv_forward_concat_split_vs_exact(n, h, c0, c1, co):
     """relu(concat[decoder_{k+1}, encoder_k]) -> conv2d_transpose (models_collection.py:512-531): two sources, two norm tables,
@@ -323,3 +352,101 @@ def test_filter_planes_follow_the_weights():
     out5 = torch.empty_like(out1)
     hip.conv_forward(hip.View(x), w, 2, 1, out5)
     assert float((out5 - 8.0 * out1).abs().max()) <= 1e-5 * float(out1.abs().max())
+
+
+def _fresh_trainer(img=64, seed=3):
+    from sketchyscenecolorization_amd.trainer import Pix2PixTrainer
+    from oracle import pix2pix as O
+    tr = Pix2PixTrainer(img=img, seed=seed)
+    p = O.init_params(seed, img=img)
+    tr.store.load_dict(p)
+    return tr, O
+
+
+def test_replayed_inference_follows_weights_loaded_through_torch():
+    """A captured inference graph holds the ADDRESSES of the filters' bf16 planes and never looks at a tensor's version: weights
+    replaced through torch on a live trainer (ParamStore.load_dict) must reach the planes before the next replay, or the bf16
+    layers would keep computing with the old checkpoint while the fp32-path layers read the new one."""
+    hip = _hip()
+    if not hip.ARITH_BF16:
+        pytest.skip('SSC_ARITH=fp32: no planes')
+    tr, O = _fresh_trainer()
+    b = O.synthetic_batch(4, seed=77, img=64)
+    sk, nv, text = b['sketches'].cuda(), b['noise_vec'].cuda(), b['text'].numpy()
+    for _ in range(3):              # eager, capture, replay
+        out_a = tr.generate(sk, text, nv)
+    assert any(k[0] == 'infer' for k in tr._graphs), 'the inference pass was not captured'
+    p2 = O.init_params(11, img=64)   # another set of weights
+    tr.store.load_dict(p2)
+    out_b = tr.generate(sk, text, nv)            # replayed
+    ref_b = O.generate_pix2pix(p2, b['sketches'], b['text'], b['noise_vec'])
+    err = float((out_b.cpu() - ref_b).abs().max())
+    assert err < 1e-3, ('the replayed pass mixes two checkpoints', err, float((out_b - out_a).abs().max()))
+    # ... and a write straight into one filter's view (no ParamStore call) is picked up in front of the replay
+    w = tr.store['generator/encoder_3/conv/filter']
+    w.mul_(0.5)
+    p3 = dict(p2)
+    p3['generator/encoder_3/conv/filter'] = p2['generator/encoder_3/conv/filter'] * 0.5
+    out_c = tr.generate(sk, text, nv)
+    ref_c = O.generate_pix2pix(p3, b['sketches'], b['text'], b['noise_vec'])
+    assert float((out_c.cpu() - ref_c).abs().max()) < 1e-3
+
+
+def test_planes_created_after_the_capture_follow_the_replayed_optimizer():
+    """A captured train step refreshes the planes that existed at its capture.  A filter that meets its first bf16 launch later
+    (here: encoder_4 and decoder_5, whose training launches at batch 1 / 64^2 have fewer than 64 rows -- no bf16 form -- while
+    their inference launches at batch 8 take it) must still follow every replayed optimizer step."""
+    hip = _hip()
+    if not hip.ARITH_BF16:
+        pytest.skip('SSC_ARITH=fp32: no planes')
+    from sketchyscenecolorization_amd.trainer import Pix2PixTrainer
+    from oracle import pix2pix as O
+    img = 64
+    tr = Pix2PixTrainer(img=img, seed=5)
+    b1 = O.synthetic_batch(1, seed=5, img=img)
+    dev = {k: (v.cuda() if k != 'text' else v.numpy()) for k, v in b1.items()}
+    for it in range(3):             # eager, capture, replay
+        tr.train_iteration(dev, dev, it)
+    n_before = hip.split_generation()
+    b8 = O.synthetic_batch(8, seed=9, img=img)
+    sk, nv, text = b8['sketches'].cuda(), b8['noise_vec'].cuda(), b8['text'].numpy()
+    tr.generate(sk, text, nv)
+    if hip.split_generation() == n_before:
+        pytest.skip('no filter met its first bf16 launch in the larger inference pass')
+    for it in range(3, 6):          # replays: the weights move, the young planes must follow
+        tr.train_iteration(dev, dev, it)
+    torch.cuda.synchronize()
+    out = tr.generate(sk, text, nv)
+    p_now = {n: tr.store[n].detach().cpu() for n in tr.store.names()}
+    ref = O.generate_pix2pix(p_now, b8['sketches'], b8['text'], b8['noise_vec'])
+    err = float((out.cpu() - ref).abs().max())
+    assert err < 1e-3, ('planes created after the capture kept the weights of that moment', err)
+
+
+def test_volatile_planes_used_in_a_capture_are_never_evicted():
+    """Entries of non-parameter filters are dropped once 256 exist -- but never one a captured graph launches into."""
+    hip = _hip()
+    if not hip.ARITH_BF16:
+        pytest.skip('SSC_ARITH=fp32: no planes')
+    n, h, ci, co = 2, 16, 64, 64
+    x = nhwc(rnd(n, ci, h, h, seed=61)).cuda()
+    w = rnd(4, 4, ci, co, seed=62, std=0.05).cuda()
+    out = torch.empty(n, 8, 8, co, device='cuda')
+    hip.conv_forward(hip.View(x), w, 2, 1, out)     # eager first: kernel attributes, workspace
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        hip.conv_forward(hip.View(x), w, 2, 1, out)
+    key = (w.data_ptr(), 16, ci, co, 0)
+    assert hip._SPLITS[key].pinned
+    keep = []
+    for i in range(hip._VOLATILE_MAX + 8):          # force evictions
+        wi = torch.zeros(1, 1, 64, 64, device='cuda')
+        keep.append(wi)
+        hip.filter_split(wi, 0)
+    assert key in hip._SPLITS, 'a pinned entry was evicted'
+    ref = out.clone()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)

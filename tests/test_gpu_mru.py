@@ -217,6 +217,18 @@ def test_mru_train_step_gradients_parity(n, img, noise):
     has a unique extremum) the whole tower is therefore held to the tight bar -- median relative L2 < 2e-3 per scope
     (measured 1e-5 .. 6e-4, the torch-CPU fp32 oracle itself 1e-5 .. 4e-4), worst tensor-valued variable < 1e-2, scalars (prelu leaks) < 3e-2 (see below) -- at 64x64 and at the full 192x192; on sketches the bar stays loose (median < 2e-2; a wrong formula
     gives O(1)) and the exact formulas are pinned at 2e-4 by test_mru_blocks_backward."""
+    _mru_gradients_parity(n, img, noise)
+
+
+def test_mru_train_step_gradients_parity_exact_fp32(monkeypatch):
+    """The same check with every contraction on the exact-fp32 kernels (SSC_ARITH=fp32 semantics, switched at run time): there
+    the scalar prelu leaks are held to the plain bar (no selection noise of the bf16x6 variants to allow for)."""
+    from sketchyscenecolorization_amd import hip
+    monkeypatch.setattr(hip, 'ARITH_BF16', False)
+    _mru_gradients_parity(2, 64, True)
+
+
+def _mru_gradients_parity(n, img, noise):
     from oracle import mru as M
     p, tr, b, dev = _make_trainer(n, img)
     if noise:
@@ -243,8 +255,12 @@ def test_mru_train_step_gradients_parity(n, img, noise):
         assert float(np.median(list(e.values()))) < med_tol, float(np.median(list(e.values())))
         worst = max(((k, v) for k, v in e.items() if k not in scalars), key=lambda kv: kv[1])
         assert worst[1] < worst_tol, worst
+        # the exact-fp32 arithmetic (SSC_ARITH=fp32: measured 5e-4 .. 2e-3) keeps the plain bar, so that a regression of the
+        # leak-gradient path itself still shows there; the 3 x is the bf16x6 variants' selection noise only
+        from sketchyscenecolorization_amd import hip as _h
+        scalar_tol = 3 * worst_tol if _h.ARITH_BF16 else worst_tol
         for k in scalars & set(e):
-            assert e[k] < 3 * worst_tol, (k, e[k])
+            assert e[k] < scalar_tol, (k, e[k], scalar_tol)
     for k, u in r['u_new'].items():          # the G-step commits every spectral-norm u (graph_single.py:178-210)
         assert _rel(tr.store[k], u) < 1e-3, k
 
