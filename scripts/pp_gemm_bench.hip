@@ -177,7 +177,9 @@ __device__ __forceinline__ void glds_one(const char* sbase, unsigned voff, unsig
 // The same contraction, 64 x 128 tile, with the step HAND-PLACED: twelve groups of two MFMAs, one DMA instruction of the next
 // K-tile behind each of the first nine, the second half's operand reads behind groups 1..3 (a burst of nine DMA instructions right
 // behind the barrier blocks the wave for 9 x 60..180 cycles with an idle matrix pipe: the plain kernel above).
-template <int NSTAGE>
+// DIAG (what bounds the loop?): bit 0 no DMA inside the loop, bit 1 operand fragments read once (no ds_read in the loop),
+// bit 2 no barrier / vmcnt wait
+template <int NSTAGE, int DIAG = 0>
 __global__ __launch_bounds__(256) void pp_gemm_il_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp, float* __restrict__ C,
                                                           int M, int N, int K) {
     constexpr int BM = 64, BN = 128, SN = 2;
@@ -226,23 +228,37 @@ __global__ __launch_bounds__(256) void pp_gemm_il_kernel(const char* __restrict_
 #pragma unroll
             for (int q = 0; q < 9; ++q) piece(q, s, s);
     int slot = 0;
+    bf16x8 av[2][3], bv[2][SN][3];
     for (int kt = 0; kt < nkt; ++kt) {
+        if (!(DIAG & 4)) {
         if (NSTAGE == 3 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else if (NSTAGE == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        }
         const int nk = kt + NSTAGE - 1;
         int ns = slot + NSTAGE - 1;
         if (ns >= NSTAGE) ns -= NSTAGE;
-        const bool more = nk < nkt;
+        const bool more = (DIAG & 1) ? false : nk < nkt;
         const char* Ab = smem + slot * STAGE + wm * 6 * 1024 + lane * 16;
         const char* Bb = smem + slot * STAGE + A_FR * 1024 + (wn * SN) * 1024 + lane * 16;
-        bf16x8 av[2][3], bv[2][SN][3];
         auto fetch_a = [&](int kc) {
+            if ((DIAG & 2) && kt > 0) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(av[kc][p]));
+                return;
+            }
 #pragma unroll
             for (int p = 0; p < 3; ++p) av[kc][p] = *reinterpret_cast<const bf16x8*>(Ab + (kc * 3 + p) * 1024);
         };
         auto fetch_b = [&](int kc) {
+            if ((DIAG & 2) && kt > 0) {
+#pragma unroll
+                for (int j = 0; j < SN; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(bv[kc][j][p]));
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < SN; ++j)
 #pragma unroll
@@ -386,6 +402,122 @@ __global__ __launch_bounds__(WM * WN * 64) void pp_gemm_w_kernel(const char* __r
             }
 }
 
+// PING-PONG: one workgroup of 8 waves = two groups of four, tile 128 x 128 (each group the 64 x 128 tile of the kernels above on
+// its own 64 rows; the filter-side stage is SHARED: half the B bytes per MFMA through the vector memory path).  Time runs in
+// half-steps separated by a barrier of all eight waves: in an even half-step group 0 runs the MFMAs of K-tile k while group 1
+// issues its DMA (its A rows of K-tile k+1, its half of B(k+1)); in the odd one group 1 runs the MFMAs of k and group 0 issues (A
+// rows and its half of B for k+2).  Wave w and w+4 share a SIMD: at any time one of them computes and the other stages.
+// Pieces issued in a stage phase have landed by the end of the issuer's next (MFMA) phase: s_waitcnt vmcnt(0) there.
+// VALU_FILL: dependent v_fma per stage phase and lane (stands in for the product kernel's transform + split).
+template <int VALU_FILL>
+__global__ __launch_bounds__(512) void pp_gemm_pp_kernel(const char* __restrict__ Ap, const char* __restrict__ Bp, float* __restrict__ C,
+                                                          int M, int N, int K, float* __restrict__ sink) {
+    constexpr int BM = 128, BN = 128, SN = 2;
+    constexpr int A_BUF = 12 * 1024, B_BUF = 24 * 1024;
+    constexpr int A_BASE = 0, B_BASE = 4 * A_BUF;          // A: [group][buffer 2]; B: [buffer 3]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    const int tn = N / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int tile_n = bid % tn, tile_m = bid / tn;
+    const long m0 = (long)tile_m * BM + grp * 64;
+    const int n0 = tile_n * BN;
+    const int nkt = K / 32;
+    const long rowbytes = (long)nkt * 192;
+    const int NB = N / 32;
+    // A pieces of this wave: fragments f = w4 * 3 + q of its group's 12 (rb 2, kc 2, plane 3)
+    unsigned avoff[3], bvoff[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int f = w4 * 3 + q;
+        const int rb = f / 6, kc = (f / 3) % 2, pl = f % 3;
+        avoff[q] = (unsigned)((m0 + rb * 32 + (lane & 31)) * rowbytes + pl * 64 + kc * 32 + (lane >> 5) * 16);
+    }
+    // B pieces of this wave: fragments g = grp * 12 + w4 * 3 + q of the K-tile's 24 (kc 2, plane 3, nb 4)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int g = grp * 12 + w4 * 3 + q;
+        const int kc = g / 12, pl = (g / 4) % 3, nb = g % 4;
+        bvoff[q] = (unsigned)((((kc * 3 + pl) * NB) + (n0 >> 5) + nb) * 1024 + lane * 16);
+    }
+    const long b_ktile = (long)6 * NB * 1024;
+    auto issue_a = [&](int kt) {
+        const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(A_BASE + (grp * 2 + (kt & 1)) * A_BUF + w4 * 3 * 1024));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) glds_one(Ap + (long)kt * 192, avoff[q], l + q * 1024);
+    };
+    auto issue_b = [&](int kt, int half) {      // half: whose 12 fragments (this wave issues its 3 of them)
+        const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(B_BASE + (kt % 3) * B_BUF + (half * 12 + w4 * 3) * 1024));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const unsigned vo = bvoff[q] + (unsigned)((half - grp) * 12 / 4) * 0u;     // (bvoff is already this group's half)
+            glds_one(Bp + (long)kt * b_ktile, vo, l + q * 1024);
+        }
+    };
+    f32x16 acc[SN], accc[SN];
+#pragma unroll
+    for (int j = 0; j < SN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = accc[j][r] = 0.f;
+
+    // prologue: A_g(0); group 0 also A_0(1); B(0) both halves (each group its own); group 0's half of B(1)
+    issue_a(0);
+    issue_b(0, grp);
+    if (grp == 0 && nkt > 1) { issue_a(1); issue_b(1, 0); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    float fill = (float)lane;
+    auto mfma_phase = [&](int k) {
+        const char* Ab = smem + A_BASE + (grp * 2 + (k & 1)) * A_BUF + wm * 6 * 1024 + lane * 16;
+        const char* Bb = smem + B_BASE + (k % 3) * B_BUF + (wn * SN) * 1024 + lane * 16;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 av[3], bv[SN][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const bf16x8*>(Ab + (kc * 3 + p) * 1024);
+#pragma unroll
+            for (int j = 0; j < SN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bv[j][p] = *reinterpret_cast<const bf16x8*>(Bb + ((kc * 3 + p) * 4 + j) * 1024);
+            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int j = 0; j < SN; ++j) {
+                    if (t == 5) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[j][0], acc[j], 0, 0, 0);
+                    else accc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[pa[t]], bv[j][pb[t]], accc[j], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // what this wave issued in its last stage phase has landed
+    };
+    auto stage_phase = [&](int kt) {        // kt: the K-tile this group runs AFTER its next one
+        if (kt < nkt) { issue_a(kt); issue_b(kt, grp); }
+#pragma unroll
+        for (int i = 0; i < VALU_FILL; ++i) fill = fmaf(fill, 1.0001f, 0.5f);
+    };
+    for (int k = 0; k < nkt; ++k) {
+        // even half-step
+        if (grp == 0) mfma_phase(k); else stage_phase(k + 1);
+        __builtin_amdgcn_s_barrier();
+        // odd half-step
+        if (grp == 0) stage_phase(k + 2); else mfma_phase(k);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (VALU_FILL > 0 && fill == 12345.678f) sink[tid] = fill;
+#pragma unroll
+    for (int j = 0; j < SN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = m0 + wm * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+            const int col = n0 + (wn * SN + j) * 32 + (lane & 31);
+            C[row * N + col] = acc[j][r] + accc[j][r];
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
@@ -450,18 +582,18 @@ static float run(const char* Ap, const char* Bp, float* C, int M, int N, int K, 
     return ms / iters;
 }
 
-template <int NSTAGE>
+template <int NSTAGE, int DIAG = 0>
 static float run_il(const char* Ap, const char* Bp, float* C, int M, int N, int K, int iters) {
     constexpr size_t lds = (size_t)NSTAGE * 36 * 1024;
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_il_kernel<NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_il_kernel<NSTAGE, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = (M / 64) * (N / 128);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pp_gemm_il_kernel<NSTAGE>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pp_gemm_il_kernel<NSTAGE, DIAG>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((pp_gemm_il_kernel<NSTAGE>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((pp_gemm_il_kernel<NSTAGE, DIAG>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     CHECK(hipGetLastError());
@@ -484,6 +616,27 @@ static float run_w(const char* Ap, const char* Bp, float* C, int M, int N, int K
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((pp_gemm_w_kernel<WM, WN, SM, SN, 2>), dim3(grid), dim3(WM * WN * 64), lds, 0, Ap, Bp, C, M, N, K);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipGetLastError());
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+template <int VALU_FILL>
+static float run_pp(const char* Ap, const char* Bp, float* C, int M, int N, int K, int iters) {
+    if (M % 128 || N % 128) return -1.f;
+    constexpr size_t lds = 120 * 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_pp_kernel<VALU_FILL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (M / 128) * (N / 128);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pp_gemm_pp_kernel<VALU_FILL>), dim3(grid), dim3(512), lds, 0, Ap, Bp, C, M, N, K, C);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((pp_gemm_pp_kernel<VALU_FILL>), dim3(grid), dim3(512), lds, 0, Ap, Bp, C, M, N, K, C);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     CHECK(hipGetLastError());
@@ -546,6 +699,10 @@ int main(int argc, char** argv) {
         run_w<2, 4, 2, 2>(dA, dB, dC, M, N, K, 1); check("w8 128x256");
         CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
         run_w<4, 2, 2, 2>(dA, dB, dC, M, N, K, 1); check("w8 256x128");
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run_pp<0>(dA, dB, dC, M, N, K, 1); check("pingpong");
+        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+        run_pp<100>(dA, dB, dC, M, N, K, 1); check("pingpong+valu");
         CHECK(hipFree(dA)); CHECK(hipFree(dB)); CHECK(hipFree(dC));
     }
     // 2. speed on layer-like shapes (random data; planes generated on the host once for a [Mu, K] block and tiled)
@@ -599,10 +756,19 @@ int main(int argc, char** argv) {
         ms = run_il<2>(dA, dB, dC, M, N, K, 20); printf("  il s2 %6.1f", flop / ms * 1e-9);
         ms = run_il<3>(dA, dB, dC, M, N, K, 20); printf("  il s3 %6.1f", flop / ms * 1e-9);
         ms = run_il<4>(dA, dB, dC, M, N, K, 20); printf("  il s4 %6.1f", flop / ms * 1e-9);
+        ms = run_il<2, 1>(dA, dB, dC, M, N, K, 20); printf("\n      diag: noDMA %6.1f", flop / ms * 1e-9);
+        ms = run_il<2, 2>(dA, dB, dC, M, N, K, 20); printf("  noLDSread %6.1f", flop / ms * 1e-9);
+        ms = run_il<2, 4>(dA, dB, dC, M, N, K, 20); printf("  noBarrier %6.1f", flop / ms * 1e-9);
+        ms = run_il<2, 3>(dA, dB, dC, M, N, K, 20); printf("  noDMA+noLDS %6.1f", flop / ms * 1e-9);
+        ms = run_il<2, 5>(dA, dB, dC, M, N, K, 20); printf("  noDMA+noBar %6.1f", flop / ms * 1e-9);
+        ms = run_il<2, 7>(dA, dB, dC, M, N, K, 20); printf("  MFMA only %6.1f\n     ", flop / ms * 1e-9);
         ms = run_w<2, 2, 1, 2>(dA, dB, dC, M, N, K, 20); printf("  w4 64x128 %6.1f", ms > 0 ? flop / ms * 1e-9 : 0.0);
         ms = run_w<4, 2, 1, 2>(dA, dB, dC, M, N, K, 20); printf("  w8 128x128 %6.1f", ms > 0 ? flop / ms * 1e-9 : 0.0);
         ms = run_w<2, 4, 2, 2>(dA, dB, dC, M, N, K, 20); printf("  w8 128x256 %6.1f", ms > 0 ? flop / ms * 1e-9 : 0.0);
         ms = run_w<4, 2, 2, 2>(dA, dB, dC, M, N, K, 20); printf("  w8 256x128 %6.1f", ms > 0 ? flop / ms * 1e-9 : 0.0);
+        ms = run_pp<0>(dA, dB, dC, M, N, K, 20); printf("\n      PINGPONG 128x128: %6.1f", ms > 0 ? flop / ms * 1e-9 : 0.0);
+        ms = run_pp<100>(dA, dB, dC, M, N, K, 20); printf("  +100 valu %6.1f", ms > 0 ? flop / ms * 1e-9 : 0.0);
+        ms = run_pp<200>(dA, dB, dC, M, N, K, 20); printf("  +200 valu %6.1f", ms > 0 ? flop / ms * 1e-9 : 0.0);
         printf("  TFLOP/s fp32-equivalent\n");
         CHECK(hipFree(dA)); CHECK(hipFree(dB)); CHECK(hipFree(dC));
     }

@@ -27,7 +27,9 @@
 
 #define BK 32
 #ifndef SSC_BF_DIAG_BUILD
-#define SSC_BF_DIAG_BUILD 0     // diagnostic builds: bit 0 no MFMAs, bit 1 no LDS-DMA, bit 2 no staging stores, bit 3 no gather loads
+#define SSC_BF_DIAG_BUILD 0     // diagnostic builds: bit 0 no MFMAs, bit 1 no LDS-DMA, bit 2 no staging stores, bit 3 no gather loads,
+                                // bit 4 no 3-way split (the raw bits three times), bit 5 no transform (norm / activation / mask),
+                                // bit 6 no operand reads from LDS (scripts/bf_diag_builds.sh: what bounds the K step?)
 #endif
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -71,6 +73,7 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    if (SSC_BF_DIAG_BUILD & 16) { h = m = l = __float_as_uint(x0) ^ __float_as_uint(x1); return; }
     h = cvt_pk_bf16(x0, x1);
     const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
     m = cvt_pk_bf16(r0, r1);
@@ -544,7 +547,8 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
 #define BF_STAGE_A(S, i, Z, W, H0, M0, L0)                                                        \
     do {                                                                                          \
         float4 v_ = (S).r[i];                                                                     \
-        if (PLAIN) {                                                                              \
+        if (SSC_BF_DIAG_BUILD & 32) {                                                             \
+        } else if (PLAIN) {                                                                       \
             v_.x *= (S).v[i]; v_.y *= (S).v[i]; v_.z *= (S).v[i]; v_.w *= (S).v[i];               \
         } else {                                                                                  \
             float t_;                                                                             \
@@ -603,15 +607,19 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
 #pragma unroll
                 for (int i = 0; i < SM; ++i)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
+                    for (int p = 0; p < 3; ++p) {
+                        if (SSC_BF_DIAG_BUILD & 64) { asm volatile("" : "=v"(av[kc][i][p])); continue; }
                         av[kc][i][p] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * BF_A_RS + p * 64 + kc * 32);
+                    }
             };
             auto fetch_b = [&](int kc) {
 #pragma unroll
                 for (int j = 0; j < SN; ++j)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
+                    for (int p = 0; p < 3; ++p) {
+                        if (SSC_BF_DIAG_BUILD & 64) { asm volatile("" : "=v"(bv[kc][j][p])); continue; }
                         bv[kc][j][p] = *reinterpret_cast<const bf16x8*>(Bb + ((kc * 3 + p) * NBT + j) * 1024);
+                    }
             };
             // one product over the wave's blocks (consecutive MFMAs go to different accumulators); products smallest first
             auto group = [&](int kc, int t) {
