@@ -8,6 +8,7 @@ MASKS=${MASKS:-"0 1 2 4 8 16 32 48 64 24 26 94"}
 cd "$(dirname "$0")/.."
 PKG=sketchyscenecolorization_amd
 if [ "$1" = build ]; then
+  mkdir -p lab/diag
   python -m $PKG.build > /dev/null || exit 1
   for m in $MASKS; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-value -Wno-unused-function -fno-slp-vectorize \
