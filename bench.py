@@ -23,6 +23,25 @@ import time
 
 import torch
 
+T_START = time.time()
+# Optional sections of the default run (larger-batch generator graphs, the exact-fp32 step, the secondary workloads) start only
+# while the run is younger than this: on a box where every fresh process takes a minute to page in, the headline line still
+# arrives within minutes.  What was skipped is named in the line (`skipped_for_time`).
+TIME_BUDGET_S = float(os.environ.get('SSC_BENCH_TIME_BUDGET_S', '420'))
+PHASES = {}                 # phase -> wall seconds (reported as `phase_wall_s`)
+SKIPPED = []
+
+
+def _phase(name, t0):
+    PHASES[name] = round(PHASES.get(name, 0.0) + time.time() - t0, 2)
+
+
+def _in_budget(what):
+    if time.time() - T_START <= TIME_BUDGET_S:
+        return True
+    SKIPPED.append(what)
+    return False
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -258,10 +277,13 @@ def secondary_workloads(args):
             ('bg768_train', ['--workload', 'bg768_train', '--steps', '30', '--warmup', '5'])]
     out = {}
     for name, extra in runs:
+        if not _in_budget('secondary.' + name):
+            out[name] = {'error': 'skipped: the run was older than SSC_BENCH_TIME_BUDGET_S = %.0f s' % TIME_BUDGET_S}
+            continue
         cmd = [sys.executable, os.path.abspath(__file__), '--no-cpu-baseline', '--no-secondary'] + extra
         t0 = time.time()
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, universal_newlines=True)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, universal_newlines=True)
             line = [l for l in r.stdout.splitlines() if l.startswith('{')]
             if r.returncode != 0 or not line:
                 out[name] = {'error': 'rc %d: %s' % (r.returncode, r.stderr[-300:])}
@@ -317,7 +339,7 @@ def exact_fp32_step(args):
     cmd = [sys.executable, os.path.abspath(__file__), '--no-cpu-baseline', '--no-secondary', '--no-kernel-events', '--no-gen-fb',
            '--steps', '10', '--warmup', '3', '--preheat-seconds', '1']
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, universal_newlines=True,
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, universal_newlines=True,
                            env=dict(os.environ, SSC_ARITH='fp32'))
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
         if r.returncode != 0 or not line:
@@ -495,9 +517,12 @@ def main():
 
     # every iteration also hands over the NEXT iteration's discriminator batch (here: the same resident one), as an input
     # pipeline that is one batch ahead does: its real pass runs inside this iteration's G-step (trainer.real_ahead)
+    PHASES['import_and_setup'] = round(time.time() - T_START, 2)       # interpreter start -> trainer built, inputs resident
+    _t = time.time()
     for i in range(max(args.warmup, 0 if args.no_graphs else 5)):   # graphs: eager, capture, first replay (of every variant)
         tr.train_iteration(bd, bg, counter=i, next_batch_d=bd)
     barrier()
+    _phase('warmup_and_capture', _t)
     preheat_steps = 0
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.preheat_seconds:       # untimed; same step count on every rank
@@ -526,6 +551,7 @@ def main():
         marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    PHASES['timed_region'] = round(dt, 3)
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     prof_steps = args.steps
     if not args.no_graphs and prof is not None:
@@ -541,8 +567,10 @@ def main():
     hip.check_sk('bench.py timed region')       # a conv launch that stored a partial sum (hand-off timeout) fails the run
     gen_fb = None
     if args.block_type == 'Pix2Pix' and not args.no_graphs and world == 1 and not args.no_gen_fb:
+        _t = time.time()
         gen_fb = generator_fwd_bwd(tr, bg, args)
-        if args.batch == 32 and not args.no_secondary:
+        _phase('generator_fwd_bwd', _t)
+        if args.batch == 32 and not args.no_secondary and _in_budget('generator_fwd_bwd.by_batch'):
             # the same graph at larger batches: BASELINE.json's 70 % target names the generator forward + backward at 192x192
             # without a batch; the train step's batch (32) is the one reported above, these show where the kernels go once a
             # launch holds more tiles per CU (labelled by batch, never merged into the batch-32 figure)
@@ -552,6 +580,7 @@ def main():
                 r = generator_fwd_bwd(tr, _sb(nb, 4321, args.img), args, iters=10)
                 by_batch[str(nb)] = {k: r[k] for k in ('ms', 'images_per_sec', 'tflops_executed', 'frac_of_fp32_mfma_peak_executed')}
             gen_fb['by_batch'] = by_batch
+            _phase('generator_fwd_bwd_by_batch', _t)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -657,10 +686,12 @@ def main():
             rl['frac_of_bf16x6_peak'] = rl['achieved'] / (PEAK_BF16_MFMA_TFLOPS / 6)
         rl['arithmetic'] = out['dtype']
         if world == 1 and not under_launcher:
+            _t = time.time()
             try:
                 rl['arithmetic_error_vs_f64'] = arithmetic_error_table()
             except Exception as e:     # noqa: BLE001 -- never cost the headline line
                 rl['arithmetic_error_vs_f64'] = {'error': repr(e)[:200]}
+            _phase('arithmetic_error_table', _t)
         tg = rl['targets'] = {'step_frac_of_fp32_peak_executed': out.get('step_frac_of_fp32_peak'),
                               'step_ms': ms, 'step_images_per_sec': value, 'batch_per_gpu': args.batch}
         if gen_fb is not None:
@@ -675,15 +706,24 @@ def main():
                 args.batch == 32 and args.img == 192 and not args.no_graphs):
             del tr
             torch.cuda.empty_cache()
-            if _dtype_label() != 'fp32':
+            if _dtype_label() != 'fp32' and _in_budget('exact_fp32_step'):
+                _t = time.time()
                 tg['exact_fp32_step'] = exact_fp32_step(args)       # SSC_ARITH=fp32: the same step on the exact-fp32 MFMA
+                _phase('exact_fp32_step', _t)
+            _t = time.time()
             out['secondary'] = secondary_workloads(args)
+            _phase('secondary', _t)
             rl['secondary'] = {k: ({'images_per_sec': v['images_per_sec'], 'ms': v['ms'], 'frac_executed': v['frac_executed'],
                                     'launches_per_step': v.get('launches_per_step')}
                                    if 'error' not in v else {'error': v['error'][:120]})
                                for k, v in out['secondary'].items()}
         if not args.no_cpu_baseline and world == 1 and args.block_type == 'Pix2Pix':
+            _t = time.time()
             out['cpu_baseline'] = cpu_baseline(args.img)
+            _phase('cpu_baseline', _t)
+        PHASES['total'] = round(time.time() - T_START, 2)
+        out['phase_wall_s'] = PHASES
+        out['skipped_for_time'] = SKIPPED
         print(json.dumps(out), flush=True)
     if under_launcher:
         torch.distributed.destroy_process_group()

@@ -148,10 +148,18 @@ __device__ __forceinline__ void filter_split_body(const ssc_split_job& jb, long 
 
 // many filters in one launch: jobs in device memory, first_thread ascending
 __global__ __launch_bounds__(256) void filter_split_kernel(const ssc_split_job* __restrict__ jobs, int njobs) {
+    // the job of this block (jobs own whole blocks: first_thread is a multiple of 256 -- one search per block, block-uniform):
+    // the last one with first_thread <= t, by bisection (a linear walk cost a dependent load per job: the Background generator's
+    // table holds some two hundred)
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    int j = 0;
-    while (j + 1 < njobs && t >= jobs[j + 1].first_thread) ++j;
-    const ssc_split_job jb = jobs[j];
+    const long tb = (long)blockIdx.x * 256;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_thread <= tb) lo = mid;
+        else hi = mid - 1;
+    }
+    const ssc_split_job jb = jobs[lo];
     filter_split_body(jb, t - jb.first_thread);
 }
 __global__ __launch_bounds__(256) void filter_split_one_kernel(const ssc_split_job jb) {
