@@ -264,6 +264,7 @@ def secondary_workloads(args):
     """The other BASELINE.json configurations and block types, each in a process of its own (``python bench.py --workload ...``
     / ``--block-type ...``; a failure there cannot take the headline line down), summarised under ``secondary``:
       fg_infer       configs[1]: Pix2Pix generator inference, batch 16, 192x192
+      fg_infer_mru   configs[1] for the reference's default --block_type MRU ('MRU second'), batch 16
       bg768          configs[4]: Background_Colorization 768x768 generator forward, batch 4
       train_mru      configs[2] for the reference's default --block_type MRU, batch 32
       train_residual configs[2] for --block_type Residual, batch 32
@@ -271,6 +272,7 @@ def secondary_workloads(args):
     frac_executed / frac_as_written: fraction of the fp32-MFMA peak on the FLOPs the launches execute / on SURVEY's count."""
     import subprocess
     runs = [('fg_infer', ['--workload', 'fg_infer', '--steps', '100', '--warmup', '10']),
+            ('fg_infer_mru', ['--workload', 'fg_mru', '--steps', '30', '--warmup', '5']),
             ('bg768', ['--workload', 'bg768', '--steps', '30', '--warmup', '5']),
             ('train_mru', ['--block-type', 'MRU', '--steps', '10', '--warmup', '3', '--preheat-seconds', '1']),
             ('train_residual', ['--block-type', 'Residual', '--steps', '20', '--warmup', '3', '--preheat-seconds', '1']),
