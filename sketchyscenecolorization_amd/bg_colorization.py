@@ -6,6 +6,8 @@ A13 "next").  The reference builds the variables under tf.variable_scope('genera
 ``ParamStore('BG')`` keyed by those TF names so a converted checkpoint loads with ``store.load_dict``.
 """
 import numpy as np
+import os
+
 import torch
 
 from . import hip
@@ -89,6 +91,12 @@ class BGTrainer(object):
         self.lr_dev = torch.zeros(2, dtype=torch.float32, device=device)
         self._static, self._graphs, self._seen = {}, {}, set()
         self._graph_gen = {}        # graph key -> hip.split_generation() at its capture
+        # D(real) -- forward, its loss term, backward into the discriminator's gradient buffer -- does not depend on the generator:
+        # it runs on a stream of its own beside the generator forward, in the CUs that pass's many small launches leave idle
+        # (SSC_BG_OVERLAP_REAL=0: everything in line, as rounds 3-5)
+        self._real_stream = torch.cuda.Stream() if os.environ.get('SSC_BG_OVERLAP_REAL', '1') == '1' else None
+        # (filter gradients on a stream of their own beside the data-gradient chain, hip.WGRAD_STREAM: measured 24.3-24.8 vs 22.5 ms,
+        # same bits -- not kept; profiles/NOTEBOOK_r06.md section 6)
 
     def learning_rate(self, step):
         decay_steps = int(round(self.max_steps * 0.75))
@@ -113,17 +121,32 @@ class BGTrainer(object):
         M = N * H * W
         L = self.losses
         L.zero_()
+        def real_pass():
+            cr = self.D.forward(self._pack('xd_real', inputs, targets), 'dr')
+            nz = cr['z'].numel()
+            dz_r = B.get('dz_r', cr['z'].shape)
+            hip.call('ssc_bg_gan_loss', cr['z'], nz, 0, 1.0 / nz, L[0:1], dz_r, 1.0 / nz)
+            self.D.backward(cr, dz_r, True, False, accumulate=False)
+            return cr
+
+        side = self._real_stream if hip.PROFILE is None else None      # per-kernel timing runs everything in line
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                cr = real_pass()
         gctx = self.G.forward(inputs, text, None, 'bg')
         image, logits = gctx['image'], gctx['region_logits']
-        cr = self.D.forward(self._pack('xd_real', inputs, targets), 'dr')
+        if side is None:
+            cr = real_pass()
         cf = self.D.forward(self._pack('xd_fake', inputs, image), 'df')
         nz = cr['z'].numel()
         ws = hip.workspace()
-        # ---- discriminator loss and gradients
-        dz_r, dz_f = B.get('dz_r', cr['z'].shape), B.get('dz_f', cf['z'].shape)
-        hip.call('ssc_bg_gan_loss', cr['z'], nz, 0, 1.0 / nz, L[0:1], dz_r, 1.0 / nz)
+        # ---- discriminator loss and gradients (the fake term adds to the loss word and the gradient buffer the real pass wrote)
+        if side is not None:
+            main.wait_stream(side)
+        dz_f = B.get('dz_f', cf['z'].shape)
         hip.call('ssc_bg_gan_loss', cf['z'], nz, 1, 1.0 / nz, L[0:1], dz_f, 1.0 / nz)
-        self.D.backward(cr, dz_r, True, False, accumulate=False)
         self.D.backward(cf, dz_f, True, False, accumulate=True)
         # ---- generator loss and gradients
         dz_g = B.get('dz_g', cf['z'].shape)

@@ -227,6 +227,28 @@ def test_residual_cli_train_smoke(tmp_path, monkeypatch):
 
 
 # --------------------------------------------------------------------------- Background_Colorization training
+def test_bg_train_step_real_pass_beside_generator_forward_equals_in_line(monkeypatch):
+    """BGTrainer runs D(real) -- forward, loss term, backward -- on a stream of its own beside the generator forward: same
+    launches in the same order per buffer, so the weights after three (eager, captured, replayed) steps are those of the in-line
+    trainer bit for bit."""
+    from oracle import residual as R
+    from sketchyscenecolorization_amd.bg_colorization import BGTrainer
+    img = 128
+    b = R.bg_synthetic_batch(2, img, 3)
+    dev = (b['inputs'].cuda(), b['targets'].cuda(), b['text'].numpy(), b['labels_gt'].cuda())
+    flats = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('SSC_BG_OVERLAP_REAL', mode)
+        tr = BGTrainer(image_size=img, max_steps=100, seed=4)
+        assert (tr._real_stream is not None) == (mode == '1')
+        for _ in range(3):
+            tr.train_step(*dev)
+        torch.cuda.synchronize()
+        flats[mode] = [sc.flat.clone() for sc in (tr.store.generator, tr.store.discriminator)] + [tr.losses.clone()]
+    for a, c in zip(flats['0'], flats['1']):
+        assert torch.equal(a, c)
+
+
 def test_bg_train_step_gradients_and_two_steps():
     """BG module: losses, both gradient sets (vs float64 autograd on the oracle, criteria of _check_grads) and two
     Adam(beta1=0.5) steps with the polynomial lr decay tracking the oracle's weights."""
