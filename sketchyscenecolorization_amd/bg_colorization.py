@@ -147,11 +147,21 @@ class BGTrainer(object):
             main.wait_stream(side)
         dz_f = B.get('dz_f', cf['z'].shape)
         hip.call('ssc_bg_gan_loss', cf['z'], nz, 1, 1.0 / nz, L[0:1], dz_f, 1.0 / nz)
-        self.D.backward(cf, dz_f, True, False, accumulate=True)
+        if side is not None:
+            # the fake pair's backward into the discriminator's gradient buffer is off the critical path (nothing reads it before
+            # the optimizer): on the side stream, beside the generator's loss terms and backward pass.  The two passes through
+            # the same forward context then need gradient scratch of their own: the generator's pass takes the 'dg' set.
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.D.backward(cf, dz_f, True, False, accumulate=True)
+            cfg = dict(cf, tag='dg', tape=[dict(rec, tag='dg') for rec in cf['tape']])
+        else:
+            self.D.backward(cf, dz_f, True, False, accumulate=True)
+            cfg = cf
         # ---- generator loss and gradients
         dz_g = B.get('dz_g', cf['z'].shape)
         hip.call('ssc_bg_gan_loss', cf['z'], nz, 0, 1.0 / nz, L[2:3], dz_g, self.w_gan / nz)
-        dgan = self.D.backward(cf, dz_g, False, True, accumulate=False)
+        dgan = self.D.backward(cfg, dz_g, False, True, accumulate=False)
         count = B.get('l1_count', (1,))
         hip.call('ssc_count_nonzero_i32', labels, M, count, ws, ws.numel() * 4)
         dpre = B.get('dpre', (N, H, W, 4))
@@ -162,6 +172,8 @@ class BGTrainer(object):
         dlog = B.get('dlog', (N, H, W, 4), zero_on_alloc=True)
         hip.call('ssc_seg_ce_loss', logits, self.seg, labels, M, float(self.w_seg), L[4:5], dlog, 4)
         self.G.backward(gctx, dpre, None, dlogits=dlog)
+        if side is not None:
+            main.wait_stream(side)      # the discriminator's gradient buffer is complete
         return gctx
 
     def loss_values(self):

@@ -53,6 +53,8 @@ def _view(a, b=None):
 class _Bottlenecks(object):
     """bottleneck_residual_en / de / pu (residual_util.py:81-171): forward records + backward."""
 
+    _gtag = ''
+
     def _init_blocks(self, store, bufs):
         self.s, self.b = store, bufs
 
@@ -151,7 +153,9 @@ class _Bottlenecks(object):
         key = t.data_ptr()
         if key in self._gdone:
             return self._gdone[key], True
-        g = self.b.get('grad_of/%d' % key, t.shape)
+        # (_gtag: two backward passes through ONE forward context that run on different streams -- BGTrainer's fake pair -- must
+        # not share these buffers: the pass names its set)
+        g = self.b.get('grad_of/%s%d' % (self._gtag, key), t.shape)
         self._gdone[key] = g
         return g, False
 
@@ -560,6 +564,7 @@ class BGDiscriminator(_Bottlenecks):
         B = self.b
         self._gdone = {}
         self._gdone[ctx['z'].data_ptr()] = dz
+        self._gtag = ctx['tag'] + '/'
         dgen = None
         tape = ctx['tape']
         for i, rec in enumerate(reversed(tape)):
