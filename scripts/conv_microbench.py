@@ -91,3 +91,6 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 print('%s: %.3f ms  %.1f TFLOP/s' % (layer, ms, flops / ms / 1e9))
+if os.environ.get('SSC_MICROBENCH_SUM') == '1':        # a checksum of the output (compare two builds / switches on the same inputs)
+    res = [t for t in (locals().get('out'), locals().get('dx'), locals().get('dw'), locals().get('g4'), locals().get('g0')) if t is not None][0]
+    print('checksum %s: sum %.6e  abs %.6e' % (layer, float(res.double().sum()), float(res.double().abs().sum())))

@@ -16,6 +16,10 @@ def demangled_short(name):
         return 'lstm_step_fwd_bf16x6<64x32>'
     if 'lstm_step_fwd' in name:       # lstm_step_fwd_kernel and lstm_step_fwd_k2_kernel, with or without a leading "void "
         return 'lstm_step_fwd<64x64>'
+    if 'conv_bfh_kernel' in name:         # the 128 x 128 tile on 16-k stages (round 6): <WM, WN, ...> waves of 64 x 64
+        mh = re.match(r'(?:void )?conv_bfh_kernel<([^>]*)>', name)
+        wm, wn = [int(a) for a in mh.group(1).split(',')[:2]] if mh else (2, 2)
+        return 'conv_bf16x6<%dx%d>' % (wm * 64, wn * 64)
     mb = re.match(r'(?:void )?conv_bf_kernel<([^>]*)>', name)
     if mb:
         wm, wn, sm, sn = [int(a) for a in mb.group(1).split(',')[:4]]
@@ -39,7 +43,7 @@ def demangled_short(name):
 
 def mangled_short(name):
     """The same report names from the MANGLED symbol (the kernel_symbol table of a kernel trace keeps `_Z14conv_ut_kernelILi2E...`)."""
-    m = re.match(r'_Z\d+(conv_fwd_kernel|conv_ut_kernel|conv_bf_kernel|conv_wgrad_kernel|narrow_fwd_kernel|narrow_sc_kernel|'
+    m = re.match(r'_Z\d+(conv_fwd_kernel|conv_ut_kernel|conv_bfh_kernel|conv_bf_kernel|conv_wgrad_kernel|narrow_fwd_kernel|narrow_sc_kernel|'
                  r'conv_wgrad128_bf_kernel|conv_wgrad128_kernel|lstm_step_fwd_bf_kernel|lstm_step_fwd_kernel|lstm_step_fwd_k2_kernel)(?:I((?:L[ib]\d+E)+)E)?', name)
     if not m:
         return None
@@ -53,6 +57,8 @@ def mangled_short(name):
         return 'conv_wgrad128_bf16x6<128x128>'
     if k == 'conv_wgrad128_kernel':
         return 'conv_wgrad128<128x128>'
+    if k == 'conv_bfh_kernel':
+        return 'conv_bf16x6<%dx%d>' % (args[0] * 64, args[1] * 64)
     if k == 'conv_bf_kernel':
         wm, wn, sm, sn = args[:4]
         return 'conv_bf16x6<%dx%d>' % (wm * sm * 32, wn * sn * 32)

@@ -60,6 +60,7 @@ int ssc_conv_c3x3_walkers(const ssc_conv_desc* dp);
 int ssc_conv_c3x3_forward(const ssc_conv_desc* dp, float* stat, void* stream);
 
 // igemm_bf16.hip
+bool ssc_bf_hk_enabled();       // igemm_bf16.hip
 int ssc_launch_conv_bf(int cfg, bool plain, const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s,
                        int64_t ws_bytes, int xcd);
 int ssc_sk_configure_bf(const unsigned* cfg4);
@@ -1650,7 +1651,19 @@ static Plan plan_fwd(const ssc_conv_desc& d, int64_t ws_bytes, bool have_ws) {
     if (fwd_is_bf(d)) {
         const bool allowed_bf[5] = {d.Nstore > 64, d.Nstore > 64, true, false, true};
         // six bf16 passes = 6/16 of the fp32 MFMA's cycles; the staging beside them and the shorter K steps make it ~0.45
-        return plan_launch(BF_CFGS, 5, allowed_bf, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,
+        // 128 x 128 on 16-k stages (round 6): two workgroups per CU, measured 3-10 % ahead of 64 x 128 on launches of whole
+        // rounds (d4 +9.5 %, dec3 +6.5 %, enc2 +6 %); the uniform form only (the partial-chunk launches keep the 32-k kernel)
+        TileCfg cfgs[5];
+        for (int i = 0; i < 5; ++i) cfgs[i] = BF_CFGS[i];
+        // (Also for launches that share the chip with other streams' -- lds_hint, the Pix2Pix train step -- although the 42 KB
+        // one-stage 64 x 128 form is what lets three workgroups of different chains share a CU: 13.13 / 12.91 vs 13.00 / 13.05 ms
+        // per step, equal.  The tile choice must not depend on the hint: it changes the summation order, and a trainer that
+        // overlaps its chains must stay bit-identical with one that does not.)
+        if (ssc_bf_hk_enabled() && fwd_is_ut(d)) {
+            cfgs[0].res = 2;
+            cfgs[0].penalty = plan_const("SSC_PLAN_BF_HK", 0.94);
+        }
+        return plan_launch(cfgs, 5, allowed_bf, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,
                            have_ws, can_ts, plan_const("SSC_PLAN_BF_SCALE", 0.45));
     }
     return plan_launch(FWD_CFGS, 5, allowed, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,

@@ -706,6 +706,417 @@ __global__ __launch_bounds__(256) void conv_bf_kernel(const ssc_conv_desc d, con
                                                    slab_stride, m0, n0, phase, M, g_sk_cfg_bf);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 128 x 128 tile on 16-k LDS stages (round 6)
+// ---------------------------------------------------------------------------------------------
+// What bounds conv_bf_kernel is the number of issue slots beside its MFMAs, spread over the gathered side's path, the filter DMA
+// and the LDS operand reads (profiles/NOTEBOOK_r06.md section 1).  A wave tile of 64 x 64 instead of 32 x 64 halves the filter DMA
+// and cuts the LDS reads by a third per MFMA -- but with 32-k K-tiles it needs 100 KB of LDS or 300 registers, one workgroup per CU
+// (-9 % in round 5).  Here an LDS stage holds 16 k: 26 KB per stage, the fragments of ONE 16-k half in registers, 24 MFMAs per wave
+// and barrier as before -- two workgroups per CU (75 KB with the epilogue's C image, ~220 registers).
+//   A stage [128 rows][112 bytes]: three planes of 32 bytes (16 bf16) + 16 bytes of padding (28 banks per row: the 16-lane groups
+//     of a ds_read_b128 over 32 rows are conflict-free);  B stage [plane 3][4 blocks][1 KiB fragment].
+//   Channel counts multiples of 32 (the uniform form); K-tiles are 16-channel chunks of one tap and one source.
+#define BFH_A_RS 112
+template <int BM, int BN> struct BfhLds {
+    static constexpr int A_BYTES = BM * BFH_A_RS;
+    static constexpr int B_BYTES = 3 * (BN / 32) * 1024;
+    static constexpr int OPER_BYTES = 2 * (A_BYTES + B_BYTES);
+    static constexpr int EPI_BYTES = (BM * (BN + 4) + 2 * 256 * 4) * 4;
+    static constexpr int LDS_BYTES = OPER_BYTES > EPI_BYTES ? OPER_BYTES : EPI_BYTES;
+    static constexpr int TOTAL = LDS_BYTES + BM * 8;
+};
+
+// <WM, WN>: 2 x 2 waves = the 128 x 128 tile.  (1 x 4 waves = 64 x 256 -- every wave the same 64 rows, half the gathered-side work
+// per MFMA instead of half the filter DMA -- measured equal on the 256- and 512-column layers, 131 / 132 / 176 vs 131 / 129 / 175
+// TFLOP/s: not instantiated.)
+template <int WM, int WN, bool PLAIN, bool ONE>
+__global__ __launch_bounds__(256, 2) void conv_bfh_kernel(const ssc_conv_desc d, const Magics mg, float* __restrict__ slab_base,
+                                                           long slab_stride, int splitk, int ts_full, int ts_s,
+                                                           unsigned* __restrict__ flags, const BfTabs tab, const int korder) {
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int SM = 2, SN = 2, BM = WM * SM * 32, BN = WN * SN * 32, NBT = BN / 32, KS = 16;
+    constexpr int A_BYTES = BfhLds<BM, BN>::A_BYTES, B_BYTES = BfhLds<BM, BN>::B_BYTES;
+    constexpr int LDS_FLOATS = BfhLds<BM, BN>::LDS_BYTES / 4;
+    constexpr int B_BASE = 2 * A_BYTES;
+    constexpr int A_ROWS = BM / 64;         // float4s per thread and stage: 4 threads cover a row's 16 k
+    constexpr int B_IPW = 3 * NBT / 4;      // 3 planes x NBT fragments per stage over 4 waves
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const sm_b = reinterpret_cast<char*>(smem);
+    long* rowpix = reinterpret_cast<long*>(smem + LDS_FLOATS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const float* const xs0 = d.x.s0;
+    const float* const xs1 = d.x.s1;
+    const int xC0 = d.x.C0, xC1 = d.x.C1, xH = d.x.H, xW = d.x.W;
+    const int TWv = d.TW, kstep = d.kstep, KWv = d.KW;
+    const float slope0 = act_slope(d.x.act), slope1 = act_slope(d.x.act1 >= 0 ? d.x.act1 : d.x.act);
+
+    const int nch0 = xC0 / KS, nch1 = xC1 / KS;
+    const int tpt = nch0 + nch1;
+    const long M = (long)d.NB * d.PH * d.PW;
+    const int PHW = d.PH * d.PW;
+    // workgroup -> (tile, K range): conv_bf_kernel's layouts
+    int phase, ks, sk, n0, slot = 0;
+    long m0;
+    float* part = nullptr;
+    if (ts_s > 0) {
+        const int bid = blockIdx.x;
+        int tile;
+        if (bid < ts_full) {
+            tile = bid; ks = 0; sk = 1;
+        } else {
+            const int r = bid - ts_full;
+            const int q = r / (ts_s & 0xffff);
+            tile = ts_full + q; ks = r - q * (ts_s & 0xffff); sk = ts_s & 0xffff;
+            part = slab_base + (long)r * (BM * BN);
+            slot = r;
+        }
+        const int mt = (int)((M + BM - 1) / BM), nt = (d.Nstore + BN - 1) / BN;
+        if (ts_s & 0x10000) {
+            if (bid < ts_full) tile = (bid & 7) * (ts_full >> 3) + (bid >> 3);
+            const int r2 = tile / nt;
+            n0 = (tile - r2 * nt) * BN;
+            if (ts_s & 0x20000) {
+                phase = r2 & 3;
+                m0 = (long)(r2 >> 2) * BM;
+            } else {
+                phase = r2 / mt;
+                m0 = (long)(r2 - phase * mt) * BM;
+            }
+            ts_s &= 0xffff;
+            sk = bid < ts_full ? 1 : ts_s;
+        } else {
+            const int rest = tile / mt;
+            m0 = (long)(tile - rest * mt) * BM;
+            phase = rest / nt;
+            n0 = (rest - phase * nt) * BN;
+        }
+    } else {
+        phase = blockIdx.z / splitk;
+        ks = blockIdx.z % splitk;
+        sk = splitk;
+        m0 = (long)blockIdx.x * BM;
+        n0 = blockIdx.y * BN;
+    }
+    const FwdPhase ph = fwd_phase(d, phase);
+
+    // gathered side: thread t stages the float4 (4 k) at piece t & 3 of the rows arow + 64 i.  arow: the 64 rows t >> 2 with the
+    // row's low bits rotated so that the four rows of a 16-lane ds_write_b64 group lie two rows (224 bytes = 56 banks = 24 mod
+    // 32) apart: their 32-byte pieces fall on banks 0-7, 24-31, 16-23, 8-15
+    const int a_col4 = tid & 3;
+    const int aq = tid >> 2;
+    const int arow = (aq & ~7) | ((aq & 3) << 1) | ((aq >> 2) & 1);
+    int a_iyb[A_ROWS], a_ixb[A_ROWS], a_off0[A_ROWS], a_off1[A_ROWS];
+    bool a_mv[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        const int row = arow + 64 * i;
+        const long m = m0 + row;
+        a_mv[i] = m < M;
+        const long mm = a_mv[i] ? m : 0;
+        int n, rem, py;
+        if (mg.use32) {
+            n = (int)__umulhi((unsigned)mm, mg.mPHPW32) + (int)((unsigned)mm & (unsigned)mg.onePHPW);
+            rem = (int)mm - n * PHW;
+            py = (int)__umulhi((unsigned)rem, mg.mPW32) + (int)((unsigned)rem & (unsigned)mg.onePW);
+        } else {
+            n = (int)div64(mm, mg.mPHPW, mg.onePHPW);
+            rem = (int)(mm - (long)n * PHW);
+            py = (int)div64(rem, mg.mPW, mg.onePW);
+        }
+        const int px = rem - py * d.PW;
+        a_iyb[i] = py * d.in_stride + ph.ioff_y;
+        a_ixb[i] = px * d.in_stride + ph.ioff_x;
+        const int pix0 = (n * xH + a_iyb[i]) * xW + a_ixb[i];
+        a_off0[i] = (pix0 * xC0 + a_col4 * 4) * 4;
+        a_off1[i] = (pix0 * xC1 + a_col4 * 4) * 4;
+        if (a_col4 == 0)
+            rowpix[row] = ((long)n * d.OH + py * d.out_stride + ph.ooff_y) * d.OW + px * d.out_stride + ph.ooff_x;
+    }
+    unsigned a_vm[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) a_vm[i] = 0u;
+    {
+        const int ntaps = d.TH * TWv;
+        int ty = 0, tx = 0;
+        for (int t = 0; t < ntaps; ++t) {
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                const bool v = a_mv[i] & ((unsigned)(a_iyb[i] + ty) < (unsigned)xH) & ((unsigned)(a_ixb[i] + tx) < (unsigned)xW);
+                a_vm[i] |= v ? (1u << t) : 0u;
+            }
+            tx += 1;
+            if (tx == TWv) { tx = 0; ty += 1; }
+        }
+    }
+
+    // filter side: fragment q of this wave = f = wave * 3 + q of the stage's [plane][block] image
+    const int NBP = d.ws_nbp, KC = d.ws_kc;         // KC: 16-k chunks per tap in the planes
+    const int nb0 = (d.n_off + n0) >> 5;
+    unsigned bd_off[B_IPW];
+#pragma unroll
+    for (int q = 0; q < B_IPW; ++q) {
+        const int f = wave * B_IPW + q;
+        const int pl = f / NBT, nbl = f % NBT;
+        bd_off[q] = (unsigned)(((pl * NBP) + nb0 + nbl) * 1024 + lane * 16);
+    }
+    const char* const wsp = reinterpret_cast<const char*>(d.wsplit);
+    const long KB = (long)3 * NBP * 1024;           // one 16-k chunk: 3 planes x NBP blocks
+
+    const int nkt = d.TH * d.TW * tpt;
+    const int per = (nkt + sk - 1) / sk;
+    const int kt_begin = ks * per;
+    const int kt_end = min(nkt, kt_begin + per);
+
+    f32x16 acc[SM][SN], accc[SM][SN];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = accc[i][j][r] = 0.f;
+
+    // K-tile sequence: conv_bf_kernel's three orders over 16-k chunks
+    struct KTile { int ty, tx, chunk, tappix, tapidx; long woff; };
+    const int THv = d.TH, ntaps = d.TH * d.TW;
+    auto kt_place = [&](KTile& t) {
+        t.tappix = t.ty * xW + t.tx;
+        t.tapidx = t.ty * TWv + t.tx;
+        t.woff = ((long)((ph.ky0 + t.ty * kstep) * KWv + ph.kx0 + t.tx * kstep) * KC + t.chunk) * KB;
+    };
+    const long SX = (long)kstep * KC * KB, SY = (long)kstep * KWv * KC * KB;
+    const long DX = SX - (long)tpt * KB, DY = SY - (long)TWv * SX;
+    auto kt_decode = [&](int kt) {
+        KTile t;
+        if (korder != 0) {
+            t.chunk = kt / ntaps;
+            const int sidx = kt - t.chunk * ntaps;
+            if (korder == 1) {
+                t.ty = sidx / TWv;
+                t.tx = sidx - t.ty * TWv;
+            } else {
+                const int hw = TWv >> 1, pc = ntaps >> 2;
+                const int cls = sidx / pc, j = sidx - cls * pc;
+                const int jy = j / hw, jx = j - jy * hw;
+                t.ty = 2 * jy + (cls >> 1);
+                t.tx = 2 * jx + (cls & 1);
+            }
+            kt_place(t);
+            return t;
+        }
+        const int tap = div32(kt, mg.mC, mg.oneC);      // mC: magic of tpt
+        t.chunk = kt - tap * tpt;
+        t.ty = div32(tap, mg.mTW, mg.oneTW);
+        t.tx = tap - t.ty * TWv;
+        kt_place(t);
+        return t;
+    };
+    const long W0 = (long)(ph.ky0 * KWv + ph.kx0) * KC * KB;
+    const long SX2 = 2 * SX, DY2 = 2 * SY - (long)TWv * SX;
+    auto kt_advance = [&](KTile& t) {
+        if (korder == 1) {
+            t.tx += 1;
+            t.tapidx += 1;
+            t.tappix += 1;
+            t.woff += SX;
+            if (t.tx == TWv) {
+                t.tx = 0;
+                t.ty += 1;
+                t.tappix += xW - TWv;
+                t.woff += DY;
+                if (t.ty == THv) {
+                    t.ty = 0;
+                    t.chunk += 1;
+                    t.tapidx = 0;
+                    t.tappix = 0;
+                    t.woff = W0 + (long)t.chunk * KB;
+                }
+            }
+            return;
+        }
+        if (korder == 2) {
+            t.tx += 2;
+            t.tapidx += 2;
+            t.tappix += 2;
+            t.woff += SX2;
+            if (t.tx >= TWv) {
+                t.tx -= TWv;
+                t.ty += 2;
+                t.tapidx += TWv;
+                t.tappix += 2 * xW - TWv;
+                t.woff += DY2;
+                if (t.ty >= THv) {
+                    t.ty &= 1;
+                    if (t.tx == 0) t.tx = 1;
+                    else {
+                        t.tx = 0;
+                        if (t.ty == 0) t.ty = 1;
+                        else { t.ty = 0; t.chunk += 1; }
+                    }
+                    kt_place(t);
+                }
+            }
+            return;
+        }
+        t.chunk += 1;
+        t.woff += KB;
+        if (t.chunk == tpt) {
+            t.chunk = 0;
+            t.tx += 1;
+            t.tapidx += 1;
+            t.tappix += 1;
+            t.woff += DX;
+            if (t.tx == TWv) {
+                t.tx = 0;
+                t.tappix += xW - TWv;
+                t.woff += DY;
+            }
+        }
+    };
+
+    struct ASet { float4 r[A_ROWS]; float v[A_ROWS]; float4 aa, ab; float slope; };
+    auto issue_loads = [&](const KTile& t, ASet& S) {
+        const bool first = ONE ? true : t.chunk < nch0;
+        const int cs = first ? xC0 : xC1;
+        const int cc = (first ? t.chunk : t.chunk - nch0) * KS;
+        const char* sbase = reinterpret_cast<const char*>((first ? xs0 : xs1) + cc);
+        const int tapshift = t.tappix * cs * 4;
+        const int tapidx = t.tapidx;
+        if (!PLAIN) {
+            const char* pa = reinterpret_cast<const char*>((first ? tab.a0 : tab.a1) + cc);
+            const char* pb = reinterpret_cast<const char*>((first ? tab.b0 : tab.b1) + cc);
+            S.aa = *reinterpret_cast<const float4*>(pa + a_col4 * 16);
+            S.ab = *reinterpret_cast<const float4*>(pb + a_col4 * 16);
+            S.slope = first ? slope0 : slope1;
+        }
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const unsigned vb = (a_vm[i] >> tapidx) & 1u;
+            const int osel = first ? a_off0[i] : a_off1[i];
+            const unsigned off = vb ? (unsigned)(osel + tapshift) : (unsigned)(a_col4 * 16);
+            S.v[i] = (float)vb;
+            S.r[i] = *reinterpret_cast<const float4*>(sbase + off);
+        }
+    };
+    auto dma_b = [&](const KTile& t, int buf) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(B_BASE + buf * B_BYTES + wave * B_IPW * 1024));
+        glds16_run<3>(wsp + t.woff, bd_off, dst);
+        if (B_IPW == 6) glds16_run<3>(wsp + t.woff, bd_off + 3, dst + 3 * 1024);
+    };
+#define BFH_STAGE_A(S, i, Z, W, H0, M0, L0)                                                       \
+    do {                                                                                          \
+        float4 v_ = (S).r[i];                                                                     \
+        if (PLAIN) {                                                                              \
+            v_.x *= (S).v[i]; v_.y *= (S).v[i]; v_.z *= (S).v[i]; v_.w *= (S).v[i];               \
+        } else {                                                                                  \
+            float t_;                                                                             \
+            t_ = fmaf((S).aa.x, v_.x, (S).ab.x); v_.x = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
+            t_ = fmaf((S).aa.y, v_.y, (S).ab.y); v_.y = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
+            t_ = fmaf((S).aa.z, v_.z, (S).ab.z); v_.z = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
+            t_ = fmaf((S).aa.w, v_.w, (S).ab.w); v_.w = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
+        }                                                                                         \
+        split3_pair(v_.x, v_.y, H0, M0, L0);                                                      \
+        Z = v_.z; W = v_.w;                                                                       \
+    } while (0)
+#define BFH_STAGE_B(buf, i, Z, W, H0, M0, L0)                                                     \
+    do {                                                                                          \
+        unsigned h1_, m1_, l1_;                                                                   \
+        split3_pair(Z, W, h1_, m1_, l1_);                                                         \
+        char* p_ = sm_b + (buf) * A_BYTES + (arow + 64 * (i)) * BFH_A_RS + a_col4 * 8;            \
+        *reinterpret_cast<uint2*>(p_) = make_uint2(H0, h1_);                                      \
+        *reinterpret_cast<uint2*>(p_ + 32) = make_uint2(M0, m1_);                                 \
+        *reinterpret_cast<uint2*>(p_ + 64) = make_uint2(L0, l1_);                                 \
+    } while (0)
+
+    if (kt_begin < kt_end) {
+        const int last = kt_end - 1;
+        ASet S0, S1;
+        KTile tl = kt_decode(kt_begin);
+        dma_b(tl, 0);
+        issue_loads(tl, S0);
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            float z, w;
+            unsigned h0, m0_, l0;
+            BFH_STAGE_A(S0, i, z, w, h0, m0_, l0);
+            BFH_STAGE_B(0, i, z, w, h0, m0_, l0);
+        }
+        KTile td = tl;
+        if (kt_begin + 1 <= last) kt_advance(tl);
+        td = tl;
+        issue_loads(tl, S0);
+        BF_WAIT_ALL();
+        __builtin_amdgcn_s_barrier();
+        // one step = one 16-k stage: MFMAs of K-tile kt from stage `cur`; set SA (K-tile kt+1) -> stage cur ^ 1; K-tile kt+2 -> set SB
+        auto kstep = [&](ASet& SA, ASet& SB, const int cur, const int kt) {
+            const int nxt = cur ^ 1;
+            const char* Ab = sm_b + cur * A_BYTES + (wm * SM * 32 + l31) * BFH_A_RS + lhi * 16;
+            const char* Bb = sm_b + B_BASE + cur * B_BYTES + (wn * SN) * 1024 + lane * 16;
+            bf16x8 av[SM][3], bv[SN][3];
+#pragma unroll
+            for (int i = 0; i < SM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) av[i][p] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * BFH_A_RS + p * 32);
+#pragma unroll
+            for (int j = 0; j < SN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bv[j][p] = *reinterpret_cast<const bf16x8*>(Bb + (p * NBT + j) * 1024);
+            auto group = [&](int t) {
+                constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int i = 0; i < SM; ++i)
+#pragma unroll
+                    for (int j = 0; j < SN; ++j) {
+                        if (t == 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][0], acc[i][j], 0, 0, 0);
+                        else accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][pa[t]], bv[j][pb[t]], accc[i][j], 0, 0, 0);
+                    }
+            };
+#define BFH_SB __builtin_amdgcn_sched_barrier(0)
+            BFH_SB;
+            float z0, w0, z1, w1;
+            unsigned ha, ma, la, hb, mb, lb;
+            group(0); dma_b(td, nxt); BFH_SB;
+            if (kt + 2 <= last) kt_advance(tl);
+            group(1); issue_loads(tl, SB); BFH_SB;
+            group(2); BFH_STAGE_A(SA, 0, z0, w0, ha, ma, la); BFH_SB;
+            group(3); BFH_STAGE_B(nxt, 0, z0, w0, ha, ma, la); BFH_SB;
+            if (A_ROWS == 2) {
+                group(4); BFH_STAGE_A(SA, A_ROWS - 1, z1, w1, hb, mb, lb); BFH_SB;
+                group(5); BFH_STAGE_B(nxt, A_ROWS - 1, z1, w1, hb, mb, lb); BFH_SB;
+            } else {
+                group(4); BFH_SB;
+                group(5); BFH_SB;
+            }
+#undef BFH_SB
+            BF_WAIT_ALL();
+            td = tl;
+            __builtin_amdgcn_s_barrier();
+        };
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            kstep(S0, S1, 0, kt);
+            if (kt + 1 < kt_end) kstep(S1, S0, 1, kt + 1);
+        }
+    }
+#undef BFH_STAGE_A
+#undef BFH_STAGE_B
+
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += accc[i][j][r];
+    ut_epilogue<BM, BN, WM, WN, SM, SN, LDS_FLOATS>(acc, d, smem, rowpix, part, ks, sk, slot, flags, ts_s, splitk, slab_base,
+                                                   slab_stride, m0, n0, phase, M, g_sk_cfg_bf);
+}
+
 #ifdef SSC_ISA_ONLY
 template __global__ void conv_bf_kernel<2, 2, 1, 2, false, true>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs, const int);
 template __global__ void conv_bf_kernel<2, 2, 1, 2, false, false>(const ssc_conv_desc, const Magics, float*, long, int, int, int, unsigned*, const BfTabs, const int);
@@ -805,6 +1216,55 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
     return (int)hipGetLastError();
 }
 
+// the 128 x 128 tile on 16-k stages (conv_bfh_kernel): launch_bf_t's three grid layouts
+template <int WM, int WN, bool PLAIN, bool ONE>
+static int launch_bfh_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s, int64_t ws_bytes,
+                        int xcd) {
+    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr size_t lds = BfhLds<BM, BN>::TOTAL;
+    const long M = (long)d.NB * d.PH * d.PW;
+    const int tpt = d.x.C0 / 16 + d.x.C1 / 16;
+    const Magics mg = make_magics((unsigned)tpt, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW, (unsigned long)M);
+    const long mt = (M + BM - 1) / BM;
+    const int nt = (d.Nstore + BN - 1) / BN;
+    const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
+    static unsigned long long attr_done = 0;
+    {
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_bfh_kernel<WM, WN, PLAIN, ONE>), (int)lds, &attr_done);
+        if (arc != 0) return arc;
+    }
+    BfTabs tab = {nullptr, nullptr, nullptr, nullptr};
+    if (!PLAIN && !bf_tabs(d, tab)) return -5;
+    const int xflag = 0x10000 | ((xcd >= 2 && d.nphase == 4) ? 0x20000 : 0);
+    const bool par_ok = d.in_stride == 2 && (d.TH & 1) == 0 && (d.TW & 1) == 0;
+    int korder = par_ok ? 2 : 1;
+    if (d.TH * d.TW == 1) korder = 0;
+    if (splitk == 1 && ws != nullptr && d.sk_flags != nullptr && ts_s > 1) {
+        const long tiles = mt * nt * d.nphase;
+        const long full = ts_full, tail = tiles - full, s = ts_s;
+        if (full >= 0 && tail > 0 && (int64_t)tail * s * BM * BN * 4 <= ws_bytes && tail * s < SSC_SK_FLAG_WORDS - 1 &&
+            full + tail * s < 0x7fffffffL) {
+            hipLaunchKernelGGL((conv_bfh_kernel<WM, WN, PLAIN, ONE>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg, ws, out_count,
+                               1, (int)full, (int)s | ((xcd && (full & 7) == 0) ? xflag : 0), d.sk_flags, tab, korder);
+            return (int)hipGetLastError();
+        }
+    }
+    if (splitk == 1 && xcd) {
+        const long tiles = mt * nt * d.nphase;
+        const long full = tiles & ~7L;
+        if (tiles < 0x7fffffffL && full > 0) {
+            hipLaunchKernelGGL((conv_bfh_kernel<WM, WN, PLAIN, ONE>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws, out_count, 1,
+                               (int)full, 1 | xflag, (unsigned*)nullptr, tab, korder);
+            return (int)hipGetLastError();
+        }
+    }
+    dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
+    hipLaunchKernelGGL((conv_bfh_kernel<WM, WN, PLAIN, ONE>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0, (unsigned*)nullptr,
+                       tab, korder);
+    if (splitk > 1) ssc_launch_slab_reduce(ws, out_count, splitk, d, st);
+    return (int)hipGetLastError();
+}
+
 template <int WM, int WN, int SM, int SN, bool SS>
 static int launch_bf_form(bool plain, bool one, bool km, const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full,
                           int ts_s, int64_t ws_bytes, int xcd) {
@@ -814,6 +1274,17 @@ static int launch_bf_form(bool plain, bool one, bool km, const ssc_conv_desc& d,
                         : launch_bf_t<WM, WN, SM, SN, false, true, false, SS>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd))
                : (plain ? launch_bf_t<WM, WN, SM, SN, true, false, false, SS>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)
                         : launch_bf_t<WM, WN, SM, SN, false, false, false, SS>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd));
+}
+
+// the 128 x 128 tile runs on 16-k stages (conv_bfh_kernel) unless SSC_BF_HK=0 under SSC_DEV_SWITCHES (A/B: round 5's 32-k form);
+// the planner prices the tile accordingly (igemm.hip: plan_fwd)
+bool ssc_bf_hk_enabled() {
+    static int hk_env = -2;
+    if (hk_env == -2) {
+        const char* e = ssc_dev_getenv("SSC_BF_HK");
+        hk_env = e != nullptr ? (e[0] == '1' ? 1 : 0) : -1;
+    }
+    return hk_env != 0;
 }
 
 // cfg: 0 = 128x128, 1 = 64x128, 2 = 128x64, 4 = 64x64 (the ids of igemm.hip's tile table)
@@ -832,6 +1303,16 @@ int ssc_launch_conv_bf(int cfg, bool plain, const ssc_conv_desc& d, int splitk, 
 #define BF_CASE(WM, WN, SM, SN)                                                                                              \
     return ss ? launch_bf_form<WM, WN, SM, SN, true>(plain, one, km, d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)         \
               : launch_bf_form<WM, WN, SM, SN, false>(plain, one, km, d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)
+    // 128 x 128 tiles: on 16-k stages, two workgroups per CU (conv_bfh_kernel; SSC_BF_HK=0 under SSC_DEV_SWITCHES: the 32-k form)
+#define BFH_CASE(WMV, WNV)                                                                                        \
+    return one ? (plain ? launch_bfh_t<WMV, WNV, true, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)        \
+                        : launch_bfh_t<WMV, WNV, false, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd))      \
+               : (plain ? launch_bfh_t<WMV, WNV, true, false>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)       \
+                        : launch_bfh_t<WMV, WNV, false, false>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd))
+    if (cfg == 0 && !km && ssc_bf_hk_enabled()) {
+        BFH_CASE(2, 2);
+    }
+#undef BFH_CASE
     switch (cfg) {
         case 0: return launch_bf_form<2, 2, 2, 2, false>(plain, one, km, d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd);
         case 1: BF_CASE(2, 2, 1, 2);

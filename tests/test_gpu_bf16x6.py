@@ -3,6 +3,8 @@ exact-fp32 MFMA kernel on the same inputs: one case per kernel form (conv with f
 two-source concat, both data gradients, a column sub-range, the dense matmuls, long K).  The split kernel must be within 1.5 x
 the exact kernel's own distance from float64 (plus one unit of fp32 rounding of the output scale), and the dispatcher must
 really have taken it.  Reference semantics: models_collection.py:380-405 (nchw_conv / nchw_deconv)."""
+import os
+
 import pytest
 import torch
 
@@ -450,3 +452,26 @@ def test_volatile_planes_used_in_a_capture_are_never_evicted():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_kernel_forms_on_the_128x128_tile_of_16k_stages(tmp_path):
+    """conv_bfh_kernel (128 x 128 tile on 16-k LDS stages, two workgroups per CU): the planner picks it for launches of whole
+    rounds, which the small parity shapes rarely are -- so the split-vs-exact-vs-float64 cases of this file and the epilogue /
+    tail-split / statistics cases of test_gpu_igemm.py run once more in a process whose tile choice is pinned to 128 x 128
+    (SSC_FWD_CFG=0, read once per process), and the parity log must show the kernel was really taken."""
+    import json
+    import subprocess
+    import sys
+    hip = _hip()
+    if not hip.ARITH_BF16:
+        pytest.skip('SSC_ARITH=fp32')
+    here = os.path.dirname(os.path.abspath(__file__))
+    log = str(tmp_path / 'parity.jsonl')
+    env = dict(os.environ, SSC_FWD_CFG='0', SSC_PARITY_LOG=log)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_bf16x6.py'), os.path.join(here, 'test_gpu_igemm.py'),
+                        '-m', 'gpu', '-q', '-x', '-k', 'not 128x128_tile and not replayed and not planes and not volatile'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-2000:]
+    recs = [json.loads(l) for l in open(log)]
+    taken = [x for x in recs if 'conv_bf16x6<128x128>' in (x.get('kernels') or [])]
+    assert len(taken) >= 8, (len(taken), len(recs))
