@@ -1659,9 +1659,22 @@ static Plan plan_fwd(const ssc_conv_desc& d, int64_t ws_bytes, bool have_ws) {
         // one-stage 64 x 128 form is what lets three workgroups of different chains share a CU: 13.13 / 12.91 vs 13.00 / 13.05 ms
         // per step, equal.  The tile choice must not depend on the hint: it changes the summation order, and a trainer that
         // overlaps its chains must stay bit-identical with one that does not.)
-        if (ssc_bf_hk_enabled() && fwd_is_ut(d)) {
+        if (ssc_bf_hk_enabled()) {
+            // ... for launches of at least SSC_PLAN_BF_HK_MIN x (2 x CUs) such tiles (below that the 64 x 128 tile's twice as many
+            // workgroups balance better).  Swept over 0 / 0.5 / 1 / 2 / never (scripts/hk_min_sweep.sh, same box, twice): generator
+            // inference at batch 16 1.325 / 1.300 / 1.300 / 1.308 / 1.293 ms, Background train step 22.3 / 21.8 / 22.1 / 22.1 / 22.0,
+            // Pix2Pix train step 12.35 / 12.38 / 12.54 / 12.84 / 12.90, MRU 183.9 / 183.6 / 182.9 / 184.0 / 190.2
+            const long t128 = ((M + 127) / 128) * ((d.Nstore + 127) / 128) * d.nphase;
+            if ((double)t128 < plan_const("SSC_PLAN_BF_HK_MIN", 0.5) * 2.0 * num_cu()) {
+                return plan_launch(cfgs, 5, allowed_bf, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,
+                                   have_ws, can_ts, plan_const("SSC_PLAN_BF_SCALE", 0.45));
+            }
             cfgs[0].res = 2;
-            cfgs[0].penalty = plan_const("SSC_PLAN_BF_HK", 0.94);
+            // 0.78: swept on the train steps (scripts/hk_plan_sweep.sh): Pix2Pix 12.57 -> 12.2 ms between 0.86 and 0.78 (the tile then
+            // takes most whole-round launches), MRU / Residual / Background flat from 0.62 to 0.86
+            cfgs[0].penalty = plan_const("SSC_PLAN_BF_HK", 0.78);
+            // the partial-chunk form walks ceil(C / 16) chunks of 16 per tap there, 2 * ceil(C / 32) on the 32-k tiles
+            if (!fwd_is_ut(d)) cfgs[0].penalty *= (double)((d.x.C0 + 15) / 16) / (double)(2 * ((d.x.C0 + 31) / 32));
         }
         return plan_launch(cfgs, 5, allowed_bf, M, d.Nstore, d.nphase, nkt, (long)d.NB * d.OH * d.OW * d.ldc, ws_bytes,
                            have_ws, can_ts, plan_const("SSC_PLAN_BF_SCALE", 0.45));

@@ -730,7 +730,9 @@ template <int BM, int BN> struct BfhLds {
 // <WM, WN>: 2 x 2 waves = the 128 x 128 tile.  (1 x 4 waves = 64 x 256 -- every wave the same 64 rows, half the gathered-side work
 // per MFMA instead of half the filter DMA -- measured equal on the 256- and 512-column layers, 131 / 132 / 176 vs 131 / 129 / 175
 // TFLOP/s: not instantiated.)
-template <int WM, int WN, bool PLAIN, bool ONE>
+// KM (with ONE): the source's channel count is any multiple of 4 (conv_bf_kernel<KM>'s contract): the last 16-wide chunk of every tap
+// is partly empty -- and a tap costs ceil(C / 16) chunks here instead of 2 * ceil(C / 32) (68 channels: 80 k instead of 96)
+template <int WM, int WN, bool PLAIN, bool ONE, bool KM = false>
 __global__ __launch_bounds__(256, 2) void conv_bfh_kernel(const ssc_conv_desc d, const Magics mg, float* __restrict__ slab_base,
                                                            long slab_stride, int splitk, int ts_full, int ts_s,
                                                            unsigned* __restrict__ flags, const BfTabs tab, const int korder) {
@@ -758,7 +760,8 @@ __global__ __launch_bounds__(256, 2) void conv_bfh_kernel(const ssc_conv_desc d,
     const int TWv = d.TW, kstep = d.kstep, KWv = d.KW;
     const float slope0 = act_slope(d.x.act), slope1 = act_slope(d.x.act1 >= 0 ? d.x.act1 : d.x.act);
 
-    const int nch0 = xC0 / KS, nch1 = xC1 / KS;
+    static_assert(!KM || ONE, "partial chunks: one source only");
+    const int nch0 = KM ? (xC0 + KS - 1) / KS : xC0 / KS, nch1 = xC1 / KS;
     const int tpt = nch0 + nch1;
     const long M = (long)d.NB * d.PH * d.PW;
     const int PHW = d.PH * d.PW;
@@ -813,6 +816,13 @@ __global__ __launch_bounds__(256, 2) void conv_bfh_kernel(const ssc_conv_desc d,
     const int a_col4 = tid & 3;
     const int aq = tid >> 2;
     const int arow = (aq & ~7) | ((aq & 3) << 1) | ((aq >> 2) & 1);
+    const bool a_lastv = !KM || (nch0 - 1) * KS + a_col4 * 4 < xC0;      // KM: this thread's float4 of the LAST chunk exists
+    uint4 a_lastm = make_uint4(~0u, ~0u, ~0u, ~0u);                      // ... and which of its elements are real channels (< k_real)
+    if (KM) {
+        const int c_ = (nch0 - 1) * KS + a_col4 * 4;
+        a_lastm = make_uint4(c_ < d.k_real ? ~0u : 0u, c_ + 1 < d.k_real ? ~0u : 0u, c_ + 2 < d.k_real ? ~0u : 0u,
+                             c_ + 3 < d.k_real ? ~0u : 0u);
+    }
     int a_iyb[A_ROWS], a_ixb[A_ROWS], a_off0[A_ROWS], a_off1[A_ROWS];
     bool a_mv[A_ROWS];
 #pragma unroll
@@ -981,7 +991,7 @@ __global__ __launch_bounds__(256, 2) void conv_bfh_kernel(const ssc_conv_desc d,
         }
     };
 
-    struct ASet { float4 r[A_ROWS]; float v[A_ROWS]; float4 aa, ab; float slope; };
+    struct ASet { float4 r[A_ROWS]; float v[A_ROWS]; float4 aa, ab; float slope; uint4 km; };
     auto issue_loads = [&](const KTile& t, ASet& S) {
         const bool first = ONE ? true : t.chunk < nch0;
         const int cs = first ? xC0 : xC1;
@@ -989,16 +999,19 @@ __global__ __launch_bounds__(256, 2) void conv_bfh_kernel(const ssc_conv_desc d,
         const char* sbase = reinterpret_cast<const char*>((first ? xs0 : xs1) + cc);
         const int tapshift = t.tappix * cs * 4;
         const int tapidx = t.tapidx;
+        const bool cv = !KM || t.chunk != nch0 - 1 || a_lastv;
+        if (KM) S.km = t.chunk == nch0 - 1 ? a_lastm : make_uint4(~0u, ~0u, ~0u, ~0u);
         if (!PLAIN) {
             const char* pa = reinterpret_cast<const char*>((first ? tab.a0 : tab.a1) + cc);
             const char* pb = reinterpret_cast<const char*>((first ? tab.b0 : tab.b1) + cc);
-            S.aa = *reinterpret_cast<const float4*>(pa + a_col4 * 16);
-            S.ab = *reinterpret_cast<const float4*>(pb + a_col4 * 16);
+            const int tc = (KM && !cv) ? 0 : a_col4 * 16;       // no table entries beyond the source
+            S.aa = *reinterpret_cast<const float4*>(pa + tc);
+            S.ab = *reinterpret_cast<const float4*>(pb + tc);
             S.slope = first ? slope0 : slope1;
         }
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            const unsigned vb = (a_vm[i] >> tapidx) & 1u;
+            const unsigned vb = cv ? (a_vm[i] >> tapidx) & 1u : 0u;
             const int osel = first ? a_off0[i] : a_off1[i];
             const unsigned off = vb ? (unsigned)(osel + tapshift) : (unsigned)(a_col4 * 16);
             S.v[i] = (float)vb;
@@ -1021,6 +1034,12 @@ __global__ __launch_bounds__(256, 2) void conv_bfh_kernel(const ssc_conv_desc d,
             t_ = fmaf((S).aa.y, v_.y, (S).ab.y); v_.y = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
             t_ = fmaf((S).aa.z, v_.z, (S).ab.z); v_.z = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
             t_ = fmaf((S).aa.w, v_.w, (S).ab.w); v_.w = fmaxf(t_, t_ * (S).slope) * (S).v[i];     \
+        }                                                                                         \
+        if (KM) {                                                                                 \
+            v_.x = __uint_as_float(__float_as_uint(v_.x) & (S).km.x);                             \
+            v_.y = __uint_as_float(__float_as_uint(v_.y) & (S).km.y);                             \
+            v_.z = __uint_as_float(__float_as_uint(v_.z) & (S).km.z);                             \
+            v_.w = __uint_as_float(__float_as_uint(v_.w) & (S).km.w);                             \
         }                                                                                         \
         split3_pair(v_.x, v_.y, H0, M0, L0);                                                      \
         Z = v_.z; W = v_.w;                                                                       \
@@ -1217,20 +1236,20 @@ static int launch_bf_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_
 }
 
 // the 128 x 128 tile on 16-k stages (conv_bfh_kernel): launch_bf_t's three grid layouts
-template <int WM, int WN, bool PLAIN, bool ONE>
+template <int WM, int WN, bool PLAIN, bool ONE, bool KM = false>
 static int launch_bfh_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream_t st, long ts_full, int ts_s, int64_t ws_bytes,
                         int xcd) {
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr size_t lds = BfhLds<BM, BN>::TOTAL;
     const long M = (long)d.NB * d.PH * d.PW;
-    const int tpt = d.x.C0 / 16 + d.x.C1 / 16;
+    const int tpt = (d.x.C0 + 15) / 16 + d.x.C1 / 16;
     const Magics mg = make_magics((unsigned)tpt, (unsigned)d.TW, (unsigned long)d.PW, (unsigned long)d.PH * d.PW, (unsigned long)M);
     const long mt = (M + BM - 1) / BM;
     const int nt = (d.Nstore + BN - 1) / BN;
     const long out_count = (long)d.NB * d.OH * d.OW * d.ldc;
     static unsigned long long attr_done = 0;
     {
-        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_bfh_kernel<WM, WN, PLAIN, ONE>), (int)lds, &attr_done);
+        const int arc = ssc_set_max_lds(reinterpret_cast<const void*>(&conv_bfh_kernel<WM, WN, PLAIN, ONE, KM>), (int)lds, &attr_done);
         if (arc != 0) return arc;
     }
     BfTabs tab = {nullptr, nullptr, nullptr, nullptr};
@@ -1244,7 +1263,7 @@ static int launch_bfh_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream
         const long full = ts_full, tail = tiles - full, s = ts_s;
         if (full >= 0 && tail > 0 && (int64_t)tail * s * BM * BN * 4 <= ws_bytes && tail * s < SSC_SK_FLAG_WORDS - 1 &&
             full + tail * s < 0x7fffffffL) {
-            hipLaunchKernelGGL((conv_bfh_kernel<WM, WN, PLAIN, ONE>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg, ws, out_count,
+            hipLaunchKernelGGL((conv_bfh_kernel<WM, WN, PLAIN, ONE, KM>), dim3((unsigned)(full + tail * s)), dim3(256), lds, st, d, mg, ws, out_count,
                                1, (int)full, (int)s | ((xcd && (full & 7) == 0) ? xflag : 0), d.sk_flags, tab, korder);
             return (int)hipGetLastError();
         }
@@ -1253,13 +1272,13 @@ static int launch_bfh_t(const ssc_conv_desc& d, int splitk, float* ws, hipStream
         const long tiles = mt * nt * d.nphase;
         const long full = tiles & ~7L;
         if (tiles < 0x7fffffffL && full > 0) {
-            hipLaunchKernelGGL((conv_bfh_kernel<WM, WN, PLAIN, ONE>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws, out_count, 1,
+            hipLaunchKernelGGL((conv_bfh_kernel<WM, WN, PLAIN, ONE, KM>), dim3((unsigned)tiles), dim3(256), lds, st, d, mg, ws, out_count, 1,
                                (int)full, 1 | xflag, (unsigned*)nullptr, tab, korder);
             return (int)hipGetLastError();
         }
     }
     dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(d.nphase * splitk));
-    hipLaunchKernelGGL((conv_bfh_kernel<WM, WN, PLAIN, ONE>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0, (unsigned*)nullptr,
+    hipLaunchKernelGGL((conv_bfh_kernel<WM, WN, PLAIN, ONE, KM>), grid, dim3(256), lds, st, d, mg, ws, out_count, splitk, 0, 0, (unsigned*)nullptr,
                        tab, korder);
     if (splitk > 1) ssc_launch_slab_reduce(ws, out_count, splitk, d, st);
     return (int)hipGetLastError();
@@ -1305,11 +1324,13 @@ int ssc_launch_conv_bf(int cfg, bool plain, const ssc_conv_desc& d, int splitk, 
               : launch_bf_form<WM, WN, SM, SN, false>(plain, one, km, d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)
     // 128 x 128 tiles: on 16-k stages, two workgroups per CU (conv_bfh_kernel; SSC_BF_HK=0 under SSC_DEV_SWITCHES: the 32-k form)
 #define BFH_CASE(WMV, WNV)                                                                                        \
+    if (km) return plain ? launch_bfh_t<WMV, WNV, true, true, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)     \
+                         : launch_bfh_t<WMV, WNV, false, true, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd);   \
     return one ? (plain ? launch_bfh_t<WMV, WNV, true, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)        \
                         : launch_bfh_t<WMV, WNV, false, true>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd))      \
                : (plain ? launch_bfh_t<WMV, WNV, true, false>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd)       \
                         : launch_bfh_t<WMV, WNV, false, false>(d, splitk, ws, st, ts_full, ts_s, ws_bytes, xcd))
-    if (cfg == 0 && !km && ssc_bf_hk_enabled()) {
+    if (cfg == 0 && ssc_bf_hk_enabled()) {
         BFH_CASE(2, 2);
     }
 #undef BFH_CASE
