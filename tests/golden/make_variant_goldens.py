@@ -30,6 +30,10 @@ def bg_inputs(img=96, n=1, seed=7):
     return x, text
 
 
+def to_f64(p):
+    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in p.items()}
+
+
 if __name__ == '__main__':
     b = inputs(64)
     # Residual: forward + one float64 training graph
@@ -43,9 +47,13 @@ if __name__ == '__main__':
     pb = R.init_params('bg', seed=0, img=96)
     x, text = bg_inputs()
     img_b, seg_b = R.create_residual_generator(pb, x, text)
+    # the same graph in float64: what a host with other fp32 conv kernels can be held to (the fp32 oracle itself sits up to
+    # 2e-3 from it on this 96x96 batch-norm stack, and by how much depends on the CPU's instruction set)
+    img_b64, seg_b64 = R.create_residual_generator(to_f64(pb), x.double(), text)
     np.savez_compressed(os.path.join(HERE, 'variants_seed0_42.npz'),
                         residual_gen=gen.numpy(), residual_loss_g=np.float64(r['loss_g']),
                         residual_loss_d=np.float64(r['loss_d']), residual_fake_disc=r['fake_disc'].numpy(),
                         residual_real_logit=r['real_logit'].numpy(), mru_gen=gen_m.numpy(),
-                        bg_image=img_b.numpy(), bg_region_logits=seg_b.numpy())
+                        bg_image=img_b.numpy(), bg_region_logits=seg_b.numpy(),
+                        bg_image_f64=img_b64.numpy(), bg_region_logits_f64=seg_b64.numpy())
     print('ok', float(r['loss_g']), float(r['loss_d']))

@@ -92,7 +92,17 @@ def test_variant_oracles_reproduce_frozen_outputs():
     pb = R.init_params('bg', seed=0, img=96)
     x, text = m.bg_inputs()
     img, seg = R.create_residual_generator(pb, x, text)
-    assert np.abs(img.numpy() - z['bg_image']).max() < 2e-4 and np.abs(seg.numpy() - z['bg_region_logits']).max() < 2e-4
+    # The 96x96 batch-norm stack amplifies fp32 rounding: the fp32 oracle sits up to 2e-3 from its own float64 evaluation, and
+    # by how much depends on the host's conv kernels (an AVX-512 box reads 9e-4 against the frozen fp32 image of the box that
+    # froze it).  The float64 graph is the host-independent pin; the fp32 one is held to its own distance from float64.
+    img64, seg64 = R.create_residual_generator(m.to_f64(pb), x.double(), text)
+    assert np.abs(img64.numpy() - z['bg_image_f64']).max() < 1e-9
+    assert np.abs(seg64.numpy() - z['bg_region_logits_f64']).max() < 1e-9
+    for got, ref64, frozen in ((img, img64, z['bg_image']), (seg, seg64, z['bg_region_logits'])):
+        own = float(np.abs(got.double().numpy() - ref64.numpy()).max())
+        assert own < 5e-3
+        assert float(np.abs(frozen - ref64.numpy()).max()) < 5e-3
+        assert float(np.abs(got.numpy() - frozen).max()) < max(2e-4, 1.5 * own)
 
 
 @pytest.mark.gpu
