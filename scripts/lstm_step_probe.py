@@ -24,8 +24,15 @@ for rows in [int(a) for a in sys.argv[1:]] or [576, 16, 1152]:
     hip.call('ssc_lstm_hsplit', h, rows, C, hp[0])
     for label, kw, wg in (('bf16x6 full', dict(hp_in=hp[0], hp_out=hp[1]), True), ('bf16x6 epilogue only', dict(hp_out=hp[1]), False),
                           ('bf16x6 full, no acts', dict(hp_in=hp[0], hp_out=hp[1], no_acts=True), True),
-                          ('fp32 full', dict(exact=True), True), ('fp32 epilogue only', dict(exact=True), False)):
+                          ('fp32 full', dict(exact=True), True), ('fp32 epilogue only', dict(exact=True), False),
+                          ('unfused: conv kernel GEMM + gate kernel', None, True)):
+        tmp = torch.empty(rows, 4 * C, device='cuda')
+
         def run():
+            if kw is None:      # the two-launch form of text_fusion.py (SSC_LSTM_FUSED=0)
+                hip.matmul(h, K, tmp)
+                hip.call('ssc_lstm_pointwise_fwd', tmp, g1, g2, div2, mask, div2, c, h, rows, C, co, ho, acts)
+                return
             k2 = dict(kw)
             a = None if k2.pop('no_acts', False) else acts
             hip.lstm_step_fwd(h, K, 4 * C, g1, g2, div2, mask, div2, c, rows, C, wg, co, ho, a, **k2)

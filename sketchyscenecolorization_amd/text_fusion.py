@@ -26,6 +26,15 @@ import os
 
 CELL = '/RNN/%s/multi_rnn_cell/cell_0/basic_lstm_cell/'
 FUSED_STEP = _dev_env('SSC_LSTM_FUSED', '1') != '0'     # recurrent GEMM + gate math in one launch per step
+# ... for cells of fewer rows than this.  The one-launch step has no operand reuse through LDS (64 x 32 / 64 x 64 tiles straight
+# from L2: what makes it the faster form when a step is a handful of tiles per CU) and its gate math sits behind the K loop of
+# every workgroup; with many rows the conv kernel's 128 x 128 tiles + the gate kernel are ahead.  us per step alone, one launch
+# -> two (scripts/lstm_step_probe.py): C = 512: 576 rows 23.4 -> 26.1, 1152 rows 39.2 -> 33.4, 2304 rows 71.6 -> 56.6;
+# C = 1024: 576 rows 55.0 -> 52.3, 1152 rows 93 -> 88, 2304 rows (the Background module at batch 4) 194 -> 138.  In the
+# workloads (scripts/lstm_unfused_ab.sh, threshold 1024 vs never, same box, interleaved): Background 768^2 forward 12.96 / 12.99
+# -> 12.59 / 12.65 ms; the batch-32 train steps, whose 1152-row cells run beside other chains, do not move (Pix2Pix 12.94 /
+# 12.83 / 12.80 vs 12.93 / 12.92 / 12.79 ms, MRU 185.0 / 184.4 vs 185.2 / 185.4): the threshold sits above them.
+UNFUSED_ROWS = int(_dev_env('SSC_LSTM_UNFUSED_ROWS', '2048'))
 
 
 class TextFusion(object):
@@ -80,9 +89,10 @@ class TextFusion(object):
         hip.fill(cw[0], 0.0)
         hip.fill(hw[0], 0.0)
         # bf16 arithmetic: every step also leaves its h as bf16 planes for the next one (two buffers in turn)
-        hpw = B.get(tag + '/tf/hpw', (2, hip.lstm_hplanes_floats(N, C)), zero_on_alloc=True) if FUSED_STEP and hip.lstm_bf(C, G4) else None
+        fused = FUSED_STEP and N < UNFUSED_ROWS
+        hpw = B.get(tag + '/tf/hpw', (2, hip.lstm_hplanes_floats(N, C)), zero_on_alloc=True) if fused and hip.lstm_bf(C, G4) else None
         for i in range(S):
-            if FUSED_STEP:      # the step's GEMM and its gate math in one launch
+            if fused:           # the step's GEMM and its gate math in one launch
                 hip.lstm_step_fwd(hw[i], Kw[C:2 * C], G4, EW[i * N:(i + 1) * N], None, 1, mask[i], 1, cw[i], N, C, i > 0,
                                   cw[i + 1], hw[i + 1], acts_w[i], hp_in=None if hpw is None or i == 0 else hpw[(i - 1) & 1],
                                   hp_out=None if hpw is None else hpw[i & 1])
@@ -151,9 +161,10 @@ class TextFusion(object):
         tmp_a = B.get(tag + '/tf/tmp_a', (R, G4))
         hip.fill(ca[0], 0.0)
         hip.fill(ha[0], 0.0)
-        hpa = B.get(tag + '/tf/hpa', (2, hip.lstm_hplanes_floats(R, C)), zero_on_alloc=True) if FUSED_STEP and hip.lstm_bf(C, G4) else None
+        fused = FUSED_STEP and R < UNFUSED_ROWS
+        hpa = B.get(tag + '/tf/hpa', (2, hip.lstm_hplanes_floats(R, C)), zero_on_alloc=True) if fused and hip.lstm_bf(C, G4) else None
         for i in range(S):
-            if FUSED_STEP:
+            if fused:
                 hip.lstm_step_fwd(ha[i], Ka[3 * C:4 * C], G4, Gv, Rall[i * N:(i + 1) * N], P, mask[i], P, ca[i], R, C, i > 0,
                                   ca[i + 1], ha[i + 1], acts_a[i], hp_in=None if hpa is None or i == 0 else hpa[(i - 1) & 1],
                                   hp_out=None if hpa is None else hpa[i & 1])

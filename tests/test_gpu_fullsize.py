@@ -36,9 +36,10 @@ def _bg_inputs(n, img, seed):
     return x, text
 
 
-def test_bg_generator_768_batch4_properties_and_graph_replay():
+def test_bg_generator_768_batch4_properties_and_graph_replay(monkeypatch):
     """Config 5 at its full size.  Size-independent properties: finite, tanh range, sample order equivariance (the
-    batch-statistics norms see the same set of samples), eager == hipGraph replay bit for bit."""
+    batch-statistics norms see the same set of samples), eager == hipGraph replay bit for bit; the 2304-row multimodal cell
+    runs its steps as GEMM + gate kernel (text_fusion.UNFUSED_ROWS) and agrees with the one-launch steps."""
     from sketchyscenecolorization_amd.params import Buffers, ParamStore
     from sketchyscenecolorization_amd.residual import ResidualGenerator
     n, img = 4, 768
@@ -73,6 +74,15 @@ def test_bg_generator_768_batch4_properties_and_graph_replay():
     d = fwd(xd[perm].contiguous(), text[perm].numpy())
     diff = (d - a[perm.cuda()]).abs()
     assert float(diff.max()) < 1e-2 and float(diff.mean()) < 5e-4, (float(diff.max()), float(diff.mean()))
+    # the cell's other form: every recurrent step in one launch (what cells below UNFUSED_ROWS rows take) -- another kernel for the
+    # same contraction, so a rounding-level difference, amplified by the decoder's norms like the one above
+    from sketchyscenecolorization_amd import text_fusion
+    assert text_fusion.FUSED_STEP and text_fusion.UNFUSED_ROWS <= n * (img // 32) ** 2
+    a_two = a.clone()
+    monkeypatch.setattr(text_fusion, 'UNFUSED_ROWS', 1 << 30)
+    a_one = fwd(xd, gen.text.prepare(text.numpy(), 'bg'))      # (the permuted pass left ITS tokens in the device buffers of `prep`)
+    diff = (a_one - a_two).abs()
+    assert 0.0 < float(diff.max()) < 1e-2 and float(diff.mean()) < 5e-4, (float(diff.max()), float(diff.mean()))
 
 
 def test_bg_generator_768_oracle_parity(host_threads):

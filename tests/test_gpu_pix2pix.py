@@ -261,3 +261,31 @@ def test_segmented_graphs_with_rccl_world1_match_eager():
         pytest.skip(r.stdout.strip().splitlines()[-1])
     # the marker is printed after every check and a device synchronize; communicator teardown is not under test
     assert 'RCCL_WORLD1_OK' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_caption_cells_as_gemm_plus_gate_kernel(monkeypatch):
+    """text_fusion.UNFUSED_ROWS: a cell of many rows (the Background module's 24 x 24 bottleneck at batch 4: 2304 rows) runs each
+    recurrent step as the conv kernel's GEMM + the gate kernel instead of the one-launch step.  Forced here for EVERY cell of the
+    caption branch: forward, losses and every gradient against the oracle at the bars of the default form, and next to the
+    default form's output."""
+    from sketchyscenecolorization_amd import text_fusion
+    p, tr, b, dev = make(3, 64)
+    assert text_fusion.FUSED_STEP and text_fusion.UNFUSED_ROWS > 3 * 4
+    one = tr.generate(dev['sketches'], dev['text'], dev['noise_vec'])
+    monkeypatch.setattr(text_fusion, 'UNFUSED_ROWS', 0)
+    p, tr, b, dev = make(3, 64)
+    ref = O.generate_pix2pix(p, b['sketches'], b['text'], b['noise_vec'])
+    out = tr.generate(dev['sketches'], dev['text'], dev['noise_vec'])
+    err = float((out.cpu() - ref).abs().max())
+    parity_log('pix2pix_generator_forward_two_launch_cells_vs_fp32_oracle', dict(n=3, img=64), err, 1e-3, variant='Pix2Pix',
+               forward=True)
+    assert err < 1e-3, err
+    d = float((out - one).abs().max())
+    assert 0.0 < d < 2e-5, d        # another kernel for the same contraction: rounding only (and really another kernel)
+    r = O.build_single_graph_f64(p, **b)
+    ld = tr.d_step(dev, counter=0)
+    assert abs(float(ld) - float(r['loss_d'])) < 1e-5 * max(1.0, abs(float(r['loss_d'])))
+    tr.store.load_dict(p)
+    lg = tr.g_step(dev, counter=0)
+    assert abs(float(lg) - float(r['loss_g'])) < 1e-5 * max(1.0, abs(float(r['loss_g'])))
+    _check_grads(tr.store.generator, r['grad_g'])
