@@ -48,9 +48,28 @@ class Pix2PixGenerator(object):
             (sketches.shape[0], sketches.shape[2], sketches.shape[3])
         chans = [None, 64, 128, 256, 512, 512]
         tstream = self.text_stream if hip.PROFILE is None else None     # per-kernel timing runs everything in line
+        hh = H >> 5             # encoder_5's output (five stride-2 layers)
+        ww = hh * W // H
+        P = hh * ww
+        cd = chans[5] // 8
+
+        def noise_head():
+            # fully_connected(256 -> 64*P) + miu_relu, reshaped NCHW->NHWC
+            pre = B.get(tag + '/noise_pre', (N, cd * P))
+            hip.matmul(noise_vec, s['generator/fully_connected/weights'], pre, bias=s['generator/fully_connected/biases'])
+            noise = B.get(tag + '/noise', (N, hh, ww, cd))
+            hip.call('ssc_miu_permute_fwd', pre, N, cd, P, noise)
+            return pre, noise
+
+        early = None
         if self.lstm_hybrid and tstream is not None:
             # the caption's word LSTM does not see the image: start it next to the encoder convolutions
             text = self.text.start_words(text, chans[5], tag, tstream)
+            if isinstance(text, dict) and text.get('words_stream') is tstream:
+                # ... and neither does the noise head: behind the word half on its stream instead of between the recurrence
+                # and decoder_5 on the main chain (text.forward joins that stream in front of the recurrence)
+                with torch.cuda.stream(tstream):
+                    early = noise_head()
         if nhwc_in:
             xs = sketches
         else:
@@ -72,8 +91,7 @@ class Pix2PixGenerator(object):
                                                  ab[k], st[k]))
         hip.mark(tag + '/encoders: last')
         ctx = {'tag': tag, 'N': N, 'H': H, 'W': W, 'xs': xs, 'e': e, 'ab': ab, 'st': st, 'noise_vec': noise_vec}
-        hh, ww = e[5].shape[1], e[5].shape[2]
-        P = hh * ww
+        assert (hh, ww) == (e[5].shape[1], e[5].shape[2])
         if self.lstm_hybrid:
             feat, tctx = self.text.forward(e[5], ab[5], text, tag)
             ctx['tctx'] = tctx
@@ -82,12 +100,7 @@ class Pix2PixGenerator(object):
             feat = e[5]
             v5 = lambda noise: View(feat, noise, ab[5], ACT_RELU, None)
         ctx['feat'] = feat
-        # noise head: fully_connected(256 -> 64*P) + miu_relu, reshaped NCHW->NHWC
-        cd = chans[5] // 8
-        pre = B.get(tag + '/noise_pre', (N, cd * P))
-        hip.matmul(noise_vec, s['generator/fully_connected/weights'], pre, bias=s['generator/fully_connected/biases'])
-        noise = B.get(tag + '/noise', (N, hh, ww, cd))
-        hip.call('ssc_miu_permute_fwd', pre, N, cd, P, noise)
+        pre, noise = early if early is not None else noise_head()
         ctx['noise_pre'], ctx['noise'] = pre, noise
         # decoders
         hip.mark(tag + '/caption fusion: last')

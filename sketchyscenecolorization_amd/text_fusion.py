@@ -82,12 +82,11 @@ class TextFusion(object):
         EW = B.get(tag + '/tf/EW', (S * N, G4))
         hip.matmul(emb, Kw[0:C], EW, bias=bw)
         # ---- word LSTM (state [c,h], batch rows) ----
-        cw = B.get(tag + '/tf/cw', (S + 1, N, C))
-        hw = B.get(tag + '/tf/hw', (S + 1, N, C))
+        # (state 0 of a cell is zero and nobody writes it: steps store states 1 .. S -- zeroed once with the buffer, not per pass)
+        cw = B.get(tag + '/tf/cw', (S + 1, N, C), zero_on_alloc=True)
+        hw = B.get(tag + '/tf/hw', (S + 1, N, C), zero_on_alloc=True)
         acts_w = B.get(tag + '/tf/acts_w', (S, N, G4))
         tmp_w = B.get(tag + '/tf/tmp_w', (N, G4))
-        hip.fill(cw[0], 0.0)
-        hip.fill(hw[0], 0.0)
         # bf16 arithmetic: every step also leaves its h as bf16 planes for the next one (two buffers in turn)
         fused = FUSED_STEP and N < UNFUSED_ROWS
         hpw = B.get(tag + '/tf/hpw', (2, hip.lstm_hplanes_floats(N, C)), zero_on_alloc=True) if fused and hip.lstm_bf(C, G4) else None
@@ -155,12 +154,10 @@ class TextFusion(object):
                                                                         'Rall'))
 
         # ---- multimodal LSTM (state per spatial position) ----
-        ca = B.get(tag + '/tf/ca', (S + 1, R, C))
-        ha = B.get(tag + '/tf/ha', (S + 1, R, C))
+        ca = B.get(tag + '/tf/ca', (S + 1, R, C), zero_on_alloc=True)
+        ha = B.get(tag + '/tf/ha', (S + 1, R, C), zero_on_alloc=True)
         acts_a = B.get(tag + '/tf/acts_a', (S, R, G4))
         tmp_a = B.get(tag + '/tf/tmp_a', (R, G4))
-        hip.fill(ca[0], 0.0)
-        hip.fill(ha[0], 0.0)
         fused = FUSED_STEP and R < UNFUSED_ROWS
         hpa = B.get(tag + '/tf/hpa', (2, hip.lstm_hplanes_floats(R, C)), zero_on_alloc=True) if fused and hip.lstm_bf(C, G4) else None
         for i in range(S):
