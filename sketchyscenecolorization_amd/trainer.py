@@ -41,7 +41,10 @@ class GanTrainer(object):
             # Config.sn = False switches the reference to another loss family (WGAN-GP / DRAGAN gradient penalty) and to
             # clip_by_global_norm + clip_by_norm before apply_gradients (graph_single.py:185-205, 355-386, 476-482).
             # Only the live branch (sn = True: softplus loss, spectral norm, no clipping) is built; running it with
-            # spectral norm merely switched off would be a silently different algorithm.
+            # spectral norm merely switched off would be a silently different algorithm.  (The reference cannot build that
+            # branch either: both gradient-penalty losses call discriminator(interp, num_classes=...) without the
+            # discrim_targets argument every discriminator requires -- graph_single.py:377-379, 457-459: a TypeError -- and
+            # no CLI flag sets Config.sn.)
             raise NotImplementedError('Config.sn = False (gradient-penalty losses + gradient clipping) is not built')
         self.block_type = block_type
         self.store = ParamStore(block_type, vocab_size, img, device, seed)
