@@ -444,6 +444,38 @@ def check_sk(where=''):
                                                                                  '; '.join(what)))
 
 
+_sk_ring = {'host': None, 'i': 0}
+
+
+def check_sk_begin():
+    """The asynchronous half of ``check_sk``: "did any launch so far report a hand-off timeout" is reduced on the device and
+    copied to pinned host memory behind everything queued on the current stream; nothing waits.  ``check_sk_end(handle)``
+    waits for THAT copy only (not for work queued later) and runs the full check -- names, zeroing, HandoffTimeout -- if it
+    says yes.  For callers that read a step's results while the next step is already running (main_procedure.train)."""
+    parts = [pool[:, SK_FLAG_WORDS - 1] for pool in _sk_pool.values()]
+    parts += [f[SK_FLAG_WORDS - 1:] for f in _sk_flags.values() if f.dim() == 1 and f._base is None]
+    if not parts:
+        return None
+    any_dev = (parts[0] if len(parts) == 1 else torch.cat([x.reshape(-1) for x in parts])).ne(0).any()
+    if _sk_ring['host'] is None:
+        _sk_ring['host'] = torch.zeros(64, dtype=torch.bool).pin_memory()
+    _sk_ring['i'] = (_sk_ring['i'] + 1) % 64
+    slot = _sk_ring['host'][_sk_ring['i']:_sk_ring['i'] + 1]
+    slot.copy_(any_dev.reshape(1), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return slot, ev
+
+
+def check_sk_end(handle, where=''):
+    if handle is None:
+        return
+    slot, ev = handle
+    ev.synchronize()
+    if bool(slot[0]):
+        check_sk(where)
+
+
 # ---------------------------------------------------------------------------
 # bf16-split filters (igemm_bf16.hip)
 # ---------------------------------------------------------------------------

@@ -89,6 +89,45 @@ class Fetch(object):
         self.graph, self.kind = graph, kind
 
 
+class LazyLoss(object):
+    """A fetched loss whose value is read when somebody looks at it (``Session.run(..., lazy=True)``): the device value is
+    copied to pinned host memory behind the step that produced it, and ``float()`` / ``np.asarray()`` wait for that copy
+    only -- not for whatever was launched after it.  The training loop launches the next step first and tests the previous
+    one for NaN while it runs (main_procedure.train); a tf.Session.run returns when the step is done, which on a device
+    that replays a step in 6 ms leaves it idle for as long as the host needs to prepare the next one.  Reading the value
+    also finishes the hand-off check (hip.check_sk) the fetch started."""
+    _ring = {'host': None, 'i': 0}
+
+    def __init__(self, dev_value, sk_handle, where):
+        r = LazyLoss._ring
+        if r['host'] is None:
+            r['host'] = torch.zeros(64, dtype=torch.float64).pin_memory()
+        r['i'] = (r['i'] + 1) % 64
+        self._slot = r['host'][r['i']:r['i'] + 1]
+        self._slot.copy_(dev_value.detach().reshape(-1)[:1].to(torch.float64), non_blocking=True)
+        self._ev = torch.cuda.Event()
+        self._ev.record()
+        self._sk, self._where, self._val = sk_handle, where, None
+
+    def value(self):
+        if self._val is None:
+            self._ev.synchronize()
+            self._val = np.float32(float(self._slot[0]))
+            from .. import hip
+            sk, self._sk = self._sk, None
+            hip.check_sk_end(sk, self._where)
+        return self._val
+
+    def __float__(self):
+        return float(self.value())
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.value(), dtype=dtype)
+
+    def __repr__(self):
+        return repr(self.value())
+
+
 class Counter(object):
     """tf.Variable(int32) + assign_add used for the lr schedule (main_procedure.py:105-106)."""
 
@@ -133,11 +172,13 @@ class TowerGraph(object):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
         return t / self.world
 
-    def run(self, fetches, g_follows=False, d_follows=False):
+    def run(self, fetches, g_follows=False, d_follows=False, lazy=False):
         """g_follows (with opt_d): the next run is opt_g -- its batch is dequeued now (same order as the reference's
         queue: D batch, then G batch) so that the trainer can run its generator forward inside the D-step.
         d_follows (with opt_g): the next run is opt_d -- its batch is dequeued now (again the queue order is unchanged:
-        ..., G batch, next D batch) so that the trainer can run that step's real pass inside this G-step."""
+        ..., G batch, next D batch) so that the trainer can run that step's real pass inside this G-step.
+        lazy: losses come back as LazyLoss -- the call returns when the step is LAUNCHED, the value (and the hand-off check)
+        is read when it is looked at."""
         kinds = [f.kind for f in fetches]
         c = self.counter.value if isinstance(self.counter, Counter) else int(_value(self.counter))
         if 'opt_d' in kinds:
@@ -154,13 +195,20 @@ class TowerGraph(object):
             self.last['loss_g'] = self._tower_mean(self.tr.g_step(g_batch, c, use_ahead=g_next is not None,
                                                                    next_d=self._d_next))
         out = []
+        sk_handle = None
         if 'loss_g' in kinds or 'loss_d' in kinds:
             # the loss is read back here anyway: also read the conv launches' hand-off timeout words, so that a launch that
             # stored a partial sum fails the run instead of training on (ssc_conv_desc.sk_flags, hip.check_sk)
             from .. import hip
-            hip.check_sk('Session.run')
+            if lazy:
+                sk_handle = hip.check_sk_begin()
+            else:
+                hip.check_sk('Session.run')
         for k in kinds:
-            if k in ('loss_g', 'loss_d'):
+            if k in ('loss_g', 'loss_d') and lazy and isinstance(self.last[k], torch.Tensor):
+                out.append(LazyLoss(self.last[k], sk_handle, 'Session.run'))
+                sk_handle = None        # one reader finishes the check
+            elif k in ('loss_g', 'loss_d'):
                 out.append(np.float32(float(self.last[k])))
             elif k == 'counter':
                 out.append(c)

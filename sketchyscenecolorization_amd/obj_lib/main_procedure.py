@@ -165,6 +165,17 @@ def _postprocess(nchw):
 
 
 # ----------------------------------------------------------------------------- train
+def _settle_first(pending, n):
+    """Read the first n pending losses (the steps launched before the one just issued): -1 at the first NaN."""
+    for _ in range(n):
+        who, val = pending.pop(0)
+        if np.isnan(np.sum(val)):
+            del pending[:]
+            print("NaN occurred during training %s" % who)
+            return -1
+    return 0
+
+
 def train(**kwargs):
     status = 0
     batch_size = Config.batch_size
@@ -224,6 +235,17 @@ def train(**kwargs):
     prev_time = float("-inf")
     fetch_counter, fetch_add = type(opt_g)(tower, 'counter'), type(opt_g)(tower, 'counter_add')
 
+    # The losses of an iteration are READ one launch later (graph_single.LazyLoss): sess.run returns when a step is launched,
+    # the next step is prepared and launched, and only then is the previous one tested for NaN -- while the device works.
+    # (Reading every loss where the reference does leaves a 6 ms step waiting for the host twice per iteration: 14.05 vs
+    # 12.9 ms per iteration at batch 32, scripts/cli_train_rate.sh.)  What the reference's order guarantees is kept: an
+    # iteration whose loss is NaN ends train() with -1 before any LATER snapshot or scalar line is written (a step launched
+    # in between is discarded with the process state: the caller restarts from the last snapshot); iterations that write a
+    # scalar line or a snapshot, and the last one, read their losses before they do.  SSC_CLI_LAZY_LOSS=0: every loss read
+    # where it is fetched.
+    lazy = os.environ.get('SSC_CLI_LAZY_LOSS', '1') == '1'
+    pending = []            # (which step, loss) of launches whose losses nobody has looked at yet
+
     for i in range(iter_from, max_iter_step):
         if i % count_left_time_freq == 0:
             curr_time = time()
@@ -238,9 +260,11 @@ def train(**kwargs):
             prev_time = curr_time
         for j in range(Diters):
             # g_follows: the trainer may run the G-step's generator forward inside the last D-step (trainer.run_ahead)
-            _, loss_d_out = sess.run([opt_d, loss_d], g_follows=(j == Diters - 1))
-            if np.isnan(np.sum(loss_d_out)):
-                print("NaN occurred during training D")
+            _, loss_d_out = sess.run([opt_d, loss_d], g_follows=(j == Diters - 1), lazy=lazy)
+            earlier = len(pending)
+            pending.append(('D', loss_d_out))
+            # lazy: what was launched BEFORE this step is read while this step runs; else this step's loss here and now
+            if _settle_first(pending, earlier if lazy else earlier + 1) == -1:
                 return -1
         # d_follows: the trainer may run the next iteration's real D pass inside this G-step (trainer.real_ahead; on by
         # default for the Pix2Pix pair on one GPU).  That dequeues the next D batch one sess.run early -- the queue ORDER is unchanged (..., G batch, next D
@@ -248,10 +272,13 @@ def train(**kwargs):
         # that write a snapshot do not prefetch (the scalar summary reads no queue).
         snapshot_iter = i % save_model_freq == save_model_freq - 1
         _, loss_g_out, counter_out, _ = sess.run([opt_g, loss_g, fetch_counter, fetch_add],
-                                                 d_follows=(Diters >= 1 and i + 1 < max_iter_step and not snapshot_iter))
-        if np.isnan(np.sum(loss_g_out)):
-            print("NaN occurred during training G")
-            return -1
+                                                 d_follows=(Diters >= 1 and i + 1 < max_iter_step and not snapshot_iter),
+                                                 lazy=lazy)
+        pending.append(('G', loss_g_out))
+        writes = (log_f is not None and i % summary_write_freq == 0) or snapshot_iter or i + 1 == max_iter_step
+        if not lazy or writes or num_gpu > 1:       # (many towers: one read per iteration, behind the G-step's launch)
+            if _settle_first(pending, len(pending)) == -1:
+                return -1
         if log_f is not None and i % summary_write_freq == 0:
             summ = sess.run(merged_all)
             summ['step'] = i

@@ -35,6 +35,7 @@ FUSED_STEP = _dev_env('SSC_LSTM_FUSED', '1') != '0'     # recurrent GEMM + gate 
 # -> 12.59 / 12.65 ms; the batch-32 train steps, whose 1152-row cells run beside other chains, do not move (Pix2Pix 12.94 /
 # 12.83 / 12.80 vs 12.93 / 12.92 / 12.79 ms, MRU 185.0 / 184.4 vs 185.2 / 185.4): the threshold sits above them.
 UNFUSED_ROWS = int(_dev_env('SSC_LSTM_UNFUSED_ROWS', '2048'))
+PINNED_PREP = _dev_env('SSC_PINNED_PREP', '1') != '0'       # caption tokens to the device through pinned memory (A/B: 0)
 
 
 class TextFusion(object):
@@ -60,10 +61,13 @@ class TextFusion(object):
         prep = {'S': S, 'N': N}
         if S > 0:
             tok_np = np.ascontiguousarray(text[:, steps].T).reshape(-1)        # time-major [S*N]
+            # through pinned memory, not waited for: a copy from pageable memory returns when it has HAPPENED, i.e. behind
+            # everything queued on the stream -- the caller of a training step would wait here for the previous step to end
             tok = B.get(tag + '/tf/tok', (S * N,), torch.int32)
-            tok.copy_(torch.from_numpy(tok_np))
+            pin = (lambda t: t.pin_memory()) if PINNED_PREP else (lambda t: t)
+            tok.copy_(pin(torch.from_numpy(tok_np)), non_blocking=PINNED_PREP)
             mask = B.get(tag + '/tf/mask', (S, N), torch.int32)
-            mask.copy_(torch.from_numpy((tok_np != 0).astype(np.int32)).view(S, N))
+            mask.copy_(pin(torch.from_numpy((tok_np != 0).astype(np.int32)).view(S, N)), non_blocking=PINNED_PREP)
             prep.update(tok=tok, mask=mask)
         return prep
 

@@ -49,6 +49,51 @@ def test_cli_train_resume_inference(tmp_path, monkeypatch):
     assert len(glob.glob(os.path.join(run, 'validation_results', 'with_text', '*_output.png'))) == 2
 
 
+def test_cli_train_losses_read_one_launch_late_give_the_same_run(tmp_path, monkeypatch):
+    """main_procedure.train reads an iteration's losses behind the NEXT launch (graph_single.LazyLoss; the device does not wait
+    for the host between steps) except where it writes a scalar line or a snapshot: the same run, number for number, as with
+    every loss read where the reference reads it (SSC_CLI_LAZY_LOSS=0)."""
+    import obj_colorization_main as cli
+    from sketchyscenecolorization_amd.obj_lib import graph_single
+    monkeypatch.chdir(tmp_path)
+    made = []
+    real = graph_single.LazyLoss.__init__
+
+    def counting(self, *a, **kw):
+        made.append(1)
+        real(self, *a, **kw)
+
+    monkeypatch.setattr(graph_single.LazyLoss, '__init__', counting)
+    lines, runs = {}, []
+    for lazy in ('1', '0'):
+        monkeypatch.setenv('SSC_CLI_LAZY_LOSS', lazy)
+        torch.manual_seed(11)
+        before = set(os.listdir('outputs')) if os.path.isdir('outputs') else set()
+        n0 = len(made)
+        cli.main(['--mode', 'train', '-bt', 'Pix2Pix', '-si', '1', '-bs', '2', '-mi', '7', '-smf', '4', '-swf', '3', '-clt', '2'])
+        run = os.path.join('outputs', (set(os.listdir('outputs')) - before).pop())
+        runs.append(run)
+        lines[lazy] = [json.loads(l) for l in open(os.path.join(run, 'log', 'scalars.jsonl'))]
+        assert os.path.exists(os.path.join(run, 'snapshot', 'model_3.ckpt-3'))
+        assert (len(made) - n0 == 14) if lazy == '1' else (len(made) == n0)      # two fetched losses per iteration, all lazy
+        import time
+        time.sleep(1.1)         # run directories are named by the second
+    assert [s['step'] for s in lines['1']] == [0, 3, 6]
+    # (a loss is a sum of double atomics over many blocks: its last digits depend on their order from run to run; the weights
+    # do not -- the snapshots agree bit for bit)
+    for a, b in zip(lines['1'], lines['0']):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-12 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    w = [torch.load(os.path.join(r, 'snapshot', 'model_3.ckpt-3'), map_location='cpu') for r in runs]
+    assert w[0].keys() == w[1].keys() and len(w[0]) > 50
+    for k in w[0]:
+        if torch.is_tensor(w[0][k]):
+            assert torch.equal(w[0][k], w[1][k]), k
+        else:
+            assert w[0][k] == w[1][k], k
+
+
 def test_obj_lib_api_inference_and_gradients():
     """build_single_graph through the drop-in API: training=False and training=True."""
     import torch

@@ -185,9 +185,12 @@ def test_cli_inference_192_matches_oracle(tmp_path, monkeypatch):
     assert np.array_equal(inp, mp._postprocess(x)[0])
 
 
-def test_cli_nan_loss_returns_minus_one_and_restarts_from_snapshot(tmp_path, monkeypatch, capsys):
+@pytest.mark.parametrize('swf', ['1', '100'])
+def test_cli_nan_loss_returns_minus_one_and_restarts_from_snapshot(tmp_path, monkeypatch, capsys, swf):
     """A NaN loss ends train() with -1 and the CLI continues from the last snapshot (reference
-    main_procedure.py:213-232 + obj_colorization_main.py:240-246)."""
+    main_procedure.py:213-232 + obj_colorization_main.py:240-246).  swf 1: every iteration writes a scalar line, so its losses
+    are read at once; swf 100: they are read one launch later (graph_single.LazyLoss) -- the NaN of iteration 2 then ends the
+    run behind the launch of iteration 3's D-step, still in front of iteration 3's snapshot."""
     import obj_colorization_main as cli
     from sketchyscenecolorization_amd.obj_lib import graph_single
     monkeypatch.chdir(tmp_path)
@@ -203,7 +206,7 @@ def test_cli_nan_loss_returns_minus_one_and_restarts_from_snapshot(tmp_path, mon
         return res
 
     monkeypatch.setattr(graph_single.TowerGraph, 'run', run)
-    cli.main(['--mode', 'train', '-bt', 'Pix2Pix', '-si', '1', '-bs', '2', '-mi', '5', '-smf', '2', '-swf', '1'])
+    cli.main(['--mode', 'train', '-bt', 'Pix2Pix', '-si', '1', '-bs', '2', '-mi', '5', '-smf', '2', '-swf', swf])
     text = capsys.readouterr().out
     assert state['fired'] and 'NaN occurred during training G' in text
     assert 'Training ended with status -1. Restarting..' in text and 'Launching training from checkpoint' in text
