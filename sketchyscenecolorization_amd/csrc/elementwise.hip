@@ -985,7 +985,36 @@ static void crc32c_init() {
     g_crc_ready = true;
 }
 
+// The crc32 instruction of SSE4.2 computes exactly this polynomial, 8 bytes per 3-cycle step: a record of the reference's
+// dataset carries two raw 384 x 384 x 3 images (884 KB), 64 records per training iteration -- 0.5 ms each through the tables,
+// 0.08 through the instruction (the host side of the data path is what bounds training from records, not the device).
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("sse4.2"))) static uint32_t crc32c_hw(const uint8_t* data, int64_t n) {
+    uint64_t c = 0xffffffffu;
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t v;
+        __builtin_memcpy(&v, data + i, 8);
+        c = __builtin_ia32_crc32di(c, v);
+    }
+    uint32_t c32 = (uint32_t)c;
+    for (; i < n; ++i) c32 = __builtin_ia32_crc32qi(c32, data[i]);
+    return c32 ^ 0xffffffffu;
+}
+static int crc32c_have_hw() {
+    static int have = -1;
+    if (have < 0) {
+        const char* e = getenv("SSC_CRC_TABLES");        // 1: the table form (tests compare the two)
+        have = (e != nullptr && e[0] == '1') ? 0 : (__builtin_cpu_supports("sse4.2") ? 1 : 0);
+    }
+    return have;
+}
+#endif
+
 extern "C" uint32_t ssc_crc32c(const uint8_t* data, int64_t n) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    if (crc32c_have_hw()) return crc32c_hw(data, n);
+#endif
     if (!g_crc_ready) crc32c_init();
     uint32_t c = 0xffffffffu;
     int64_t i = 0;

@@ -23,9 +23,11 @@ def _value(x):
 
 
 def _dev(x, dtype=torch.float32):
-    if isinstance(x, torch.Tensor):
-        return x.to(device='cuda', dtype=dtype).contiguous()
-    return torch.as_tensor(np.asarray(x)).to(device='cuda', dtype=dtype).contiguous()
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(np.asarray(x))
+    if not x.is_cuda:       # through pinned memory, not waited for (a pageable copy returns behind everything queued on the stream)
+        x = x.to(dtype).pin_memory().to('cuda', non_blocking=True)
+    return x.to(device='cuda', dtype=dtype).contiguous()
 
 
 def _batch(images, sketches, images_d, cls, cls_d, text, noise_vec=None):
@@ -257,7 +259,12 @@ def build_multi_tower_graph(images, sketches, images_d, image_paired_class_ids, 
     if img is None:
         probe = _value(sketches)
         img = probe.shape[2]
-    tr = models.get_trainer(block_type, vocab_size, img, process_group=pg, optimizer=optimizer)
+    # the training procedure's steps are captured into hipGraphs and replayed (as bench.py's are): an eager step is ~380 launches
+    # of ~30 us of interpreter time each -- as long as the device needs for the step at batch 32, and the host has the input
+    # queue to serve as well.  SSC_TRAIN_GRAPHS=0: every launch issued by the interpreter
+    import os
+    tr = models.get_trainer(block_type, vocab_size, img, process_group=pg, optimizer=optimizer,
+                            use_graphs=os.environ.get('SSC_TRAIN_GRAPHS', '1') == '1')
     tr.G.lstm_hybrid = bool(LSTM_hybrid)
     tr.lr_g, tr.lr_d = learning_rates['generator'], learning_rates['discriminator']
     tr.max_iter_step = max_iter_step

@@ -178,7 +178,7 @@ class PairedQueue(object):
     through a shuffle buffer of ``min_after_dequeue`` decoded examples (tf.train.maybe_shuffle_batch, :143-148)."""
 
     def __init__(self, mode, batch_size, data_format='NCHW', distance_map=False, small=False, min_after_dequeue=512,
-                 data_base_dir='data', seed=None, device_decode=None):
+                 data_base_dir='data', seed=None, device_decode=None, prefetch=None):
         """device_decode (default: on when a GPU is there and the layout is NCHW): the shuffle buffer keeps the raw
         uint8 records and a batch is resized / normalised by one kernel at dequeue (hip.decode_paired_u8, the arithmetic
         of decode_paired_example bit for bit); ``dequeue`` then returns device tensors.  The host decode costs ~3 ms per
@@ -202,6 +202,11 @@ class PairedQueue(object):
         self.device_decode = bool(device_decode)
         self._gen, self._gen_seed = None, self.rng.randrange(2 ** 31)   # drawn in both modes: same example order
         self._it = self._examples()
+        # Training from records: the host half of a batch (read, CRC, parse, stage: ~0.4 ms per 884 KB record, 64 records per
+        # iteration of a 12 ms step) runs one batch ahead on a thread of its own.  SSC_RECORD_PREFETCH=0: in the caller.
+        # (asked for by the training procedure, main_procedure.RecordQueue; a queue built directly stays synchronous)
+        self.prefetch = bool(prefetch) and self.device_decode and self.shuffle
+        self._ring, self._ring_i, self._q, self._thread, self._stop = None, 0, None, None, False
 
     def _examples(self):
         while True:
@@ -209,12 +214,14 @@ class PairedQueue(object):
             if self.shuffle:
                 self.rng.shuffle(files)
             for path in files:
+                if self.device_decode:
+                    # records as views of the mapped file: CRC in place, the images copied once (into the staging buffer)
+                    for rec in self.tf.read_records(path, views=True):
+                        yield self._raw_example(self.tf.parse_example(rec, views=True))
+                    continue
                 for rec in self.tf.read_records(path):
                     feat = self.tf.parse_example(rec)
-                    if self.device_decode:
-                        yield self._raw_example(feat)
-                    else:
-                        yield decode_paired_example(feat, self.img_dim, self.np_rng, self.fmt, self.dm)
+                    yield decode_paired_example(feat, self.img_dim, self.np_rng, self.fmt, self.dm)
             if not self.shuffle:
                 return
 
@@ -226,20 +233,90 @@ class PairedQueue(object):
                 feat.get('Category', [b''])[0].decode('utf-8', 'replace'),
                 feat.get('ImageName', [b''])[0].decode('utf-8', 'replace'))
 
-    def _decode_on_device(self, ex):
+    # ---- device decode: host half (any thread) and device half (the caller's thread and stream) ----
+    _RING = 3       # pinned staging buffers per queue: one being filled, one in flight to the device, one spare
+
+    def _stage(self, ex):
+        """Host half: the raw images of a batch into a pinned staging buffer [2, n, 384, 384, 3] (uint8).  The buffers are
+        allocated once -- a fresh 28 MB array per batch is page-faulted in every time -- and reused in turn once the copy that
+        read them has happened."""
         import torch
-        from .. import hip
-        n, size = len(ex), self.img_dim[0]
-        raw = np.empty((2, n, RECORD_HW, RECORD_HW, 3), dtype=np.uint8)
+        n = len(ex)
+        if self._ring is None or self._ring[0][0].shape[1] != n:
+            self._ring = [[torch.empty((2, n, RECORD_HW, RECORD_HW, 3), dtype=torch.uint8).pin_memory(), None]
+                          for _ in range(self._RING)]
+            self._ring_i = 0
+        slot = self._ring[self._ring_i % self._RING]
+        self._ring_i += 1
+        if slot[1] is not None:
+            slot[1].synchronize()       # the device copy out of this buffer (three batches ago) has happened
+            slot[1] = None
+        raw = slot[0].numpy()
         for k, e in enumerate(ex):
             raw[0, k] = np.frombuffer(e[0], dtype=np.uint8).reshape(RECORD_HW, RECORD_HW, 3)
             raw[1, k] = np.frombuffer(e[1], dtype=np.uint8).reshape(RECORD_HW, RECORD_HW, 3)
-        dev = torch.from_numpy(raw).cuda()
+        return slot
+
+    def _decode_on_device(self, ex, slot=None):
+        import torch
+        from .. import hip
+        n, size = len(ex), self.img_dim[0]
+        slot = slot if slot is not None else self._stage(ex)
+        dev = slot[0].to('cuda', non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
         if self._gen is None:
             self._gen = torch.Generator(device='cuda')
             self._gen.manual_seed(self._gen_seed)
         noise = torch.rand((n, size, size, 3), device='cuda', generator=self._gen) * (1.0 / 256)   # dequantisation (:117)
         return hip.decode_paired_u8(dev[0], dev[1], size, noise=noise, distance_map=self.dm)
+
+    # ---- prefetch: the host half of the NEXT batches on a thread of its own ----
+    def _producer(self):
+        """Examples are drawn, and their bytes staged, strictly in dequeue order by this one thread -- the queue's order and
+        its random numbers are those of the synchronous queue.  File reads, the CRC (a ctypes call) and the large copies
+        release the interpreter lock, so the training loop's own host work goes on beside them."""
+        import queue
+        import torch
+
+        def put(item):
+            while not self._stop:
+                try:
+                    self._q.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        try:
+            torch.cuda.set_device(self._device)     # (the current device is a per-thread setting)
+            while not self._stop:
+                ex = []
+                for _ in range(self.batch_size):
+                    try:
+                        ex.append(self._next())
+                    except StopIteration:
+                        break
+                if len(ex) < self.batch_size:
+                    put(StopIteration())
+                    return
+                if not put((ex, self._stage(ex))):
+                    return
+        except BaseException as e:       # whatever went wrong is raised in the consumer
+            put(e)
+
+    def _start_prefetch(self):
+        import queue
+        import threading
+        import torch
+        self._device = torch.cuda.current_device()
+        self._q = queue.Queue(maxsize=self._RING - 2)       # staged batches waiting: never more than the ring can hold apart
+        self._thread = threading.Thread(target=self._producer, name='PairedQueue-prefetch', daemon=True)
+        self._thread.start()
+
+    def close(self):
+        """Stop the prefetch thread (it otherwise lives, blocked on its queue, until the process ends)."""
+        self._stop = True
 
     def _next(self):
         while len(self.buf) <= self.min_after:
@@ -255,6 +332,17 @@ class PairedQueue(object):
     def dequeue(self, with_names=False):
         """One batch: (images [N,3,h,w], sketches, class ids int32 [N], caption indices int32 [N,15])
         [+ category names, image names].  Raises StopIteration when a val / test epoch is exhausted."""
+        if self.prefetch:
+            if self._thread is None:
+                self._start_prefetch()
+            item = self._q.get()
+            if isinstance(item, BaseException):
+                self._q.put(item)           # (a later call meets it again)
+                raise StopIteration if isinstance(item, StopIteration) else item
+            ex, slot = item
+            images, sketches = self._decode_on_device(ex, slot)
+            out = (images, sketches, np.array([e[2] for e in ex], dtype=np.int32), np.stack([e[3] for e in ex]))
+            return out + ([e[4] for e in ex], [e[5] for e in ex]) if with_names else out
         ex = []
         for _ in range(self.batch_size):
             try:

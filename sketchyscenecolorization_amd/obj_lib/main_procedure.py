@@ -128,15 +128,19 @@ class RecordQueue(object):
 
     def __init__(self, batch_size, small, which, data_base_dir='data', seed=None):
         from .input_pipeline import PairedQueue
+        # prefetch: the host half of the next batch (read, CRC, parse, pinned staging) on a thread of its own, in dequeue order
         self.q = PairedQueue('train', batch_size, Config.data_format, Config.distance_map != 0, small,
-                             data_base_dir=data_base_dir, seed=seed)
+                             data_base_dir=data_base_dir, seed=seed,
+                             prefetch=os.environ.get('SSC_RECORD_PREFETCH', '1') == '1')
         self.which = which
         self.cur = None
         self.img = SIZE[bool(small)][0]
 
     def advance(self):
         images, sketches, class_id, text = self.q.dequeue()
-        dev = lambda a: a if torch.is_tensor(a) else torch.from_numpy(a).cuda()     # device-decoded batches stay put
+        # device-decoded batches stay put; host arrays go through pinned memory, not waited for (a copy from pageable memory
+        # returns when it has happened: behind the training step that is running)
+        dev = lambda a: a if torch.is_tensor(a) else torch.from_numpy(a).pin_memory().to('cuda', non_blocking=True)
         if self.which == 1:
             self.cur = {'images': dev(images), 'sketches': dev(sketches), 'class_id': dev(class_id), 'text': text}
         else:

@@ -12,6 +12,7 @@ and decodes the ``Example`` protobuf (Example{features=1: Features{feature=1: ma
 parser.  CRCs are checked with the C-ABI host function ``ssc_crc32c``.
 """
 import ctypes
+import os
 import struct
 
 import numpy as np
@@ -20,11 +21,13 @@ _MASK_DELTA = 0xa282ead8
 
 
 def crc32c(data):
+    """CRC-32C of a bytes-like object, read in place (a record of the reference's dataset is 884 KB: no copy for the call)."""
     from . import hip
     fn = hip.lib().ssc_crc32c
-    fn.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int64]
     fn.restype = ctypes.c_uint32
-    return int(fn(bytes(data), len(data)))
+    a = np.frombuffer(data, dtype=np.uint8)
+    return int(fn(a.ctypes.data if a.size else None, a.size))
 
 
 def masked_crc(data):
@@ -33,8 +36,32 @@ def masked_crc(data):
 
 
 # ------------------------------------------------------------------ container
-def read_records(path, verify=True):
-    """Yield the payload of every record of a .tfrecord file."""
+def read_records(path, verify=True, views=False):
+    """Yield the payload of every record of a .tfrecord file.  views: the file is mapped and the payloads are memoryview
+    slices of the mapping (they keep it alive): nothing is copied until somebody copies it -- the training queue checks the
+    CRC in place and copies the two images of a record once, into its pinned staging buffer."""
+    if views:
+        import mmap
+        with open(path, 'rb') as f:
+            size = os.fstat(f.fileno()).st_size
+            if size == 0:
+                return
+            mm = memoryview(mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ))
+        pos = 0
+        while pos < size:
+            if pos + 12 > size:
+                raise IOError('%s: truncated record header' % path)
+            length, len_crc = struct.unpack_from('<QI', mm, pos)
+            if verify and masked_crc(mm[pos:pos + 8]) != len_crc:
+                raise IOError('%s: corrupt record length' % path)
+            if pos + 12 + length + 4 > size:
+                raise IOError('%s: truncated record' % path)
+            data = mm[pos + 12:pos + 12 + length]
+            if verify and masked_crc(data) != struct.unpack_from('<I', mm, pos + 12 + length)[0]:
+                raise IOError('%s: corrupt record data' % path)
+            yield data
+            pos += 16 + length
+        return
     with open(path, 'rb') as f:
         while True:
             head = f.read(12)
@@ -99,10 +126,13 @@ def _fields(buf):
         yield num, wt, val
 
 
-def _feature(buf):
+_VIEW_FROM = 4096       # bytes values at least this long stay views when the caller asked for views (the raw images)
+
+
+def _feature(buf, views=False):
     for num, _wt, val in _fields(buf):
         if num == 1:        # BytesList
-            return [bytes(v) for n, _w, v in _fields(val) if n == 1]
+            return [(v if views and len(v) >= _VIEW_FROM else bytes(v)) for n, _w, v in _fields(val) if n == 1]
         if num == 2:        # FloatList: packed or repeated fixed32
             out = []
             for n, w, v in _fields(val):
@@ -125,8 +155,9 @@ def _feature(buf):
     return []
 
 
-def parse_example(data):
-    """Serialized tf.train.Example -> {feature name: list of bytes / floats / ints}."""
+def parse_example(data, views=False):
+    """Serialized tf.train.Example -> {feature name: list of bytes / floats / ints}.  views: long bytes values (the raw
+    images) come back as memoryview slices of ``data`` instead of copies."""
     out = {}
     for num, _wt, feats in _fields(memoryview(data)):
         if num != 1:
@@ -139,7 +170,7 @@ def parse_example(data):
                 if n3 == 1:
                     key = bytes(v).decode('utf-8')
                 elif n3 == 2:
-                    value = _feature(v)
+                    value = _feature(v, views)
             out[key] = value
     return out
 

@@ -220,6 +220,20 @@ def test_paired_queue_device_decode_equals_host_decode(tmp_path):
         assert (dc == hc).all() and (dt == ht).all()
         assert np.array_equal(ds.cpu().numpy(), hs)
         assert np.abs(di.cpu().numpy() - hi).max() <= 2.0 / 256 + 1e-6
+    # the prefetching queue of the training procedure (host half of the next batches on a thread of its own, pinned staging
+    # buffers reused in turn): the same batches, bit for bit, as the synchronous device-decoding queue -- over more batches
+    # than the staging ring has buffers
+    qs = PairedQueue('train', 3, min_after_dequeue=2, data_base_dir=base, seed=11)
+    qp = PairedQueue('train', 3, min_after_dequeue=2, data_base_dir=base, seed=11, prefetch=True)
+    assert qp.prefetch and not qs.prefetch
+    try:
+        for _ in range(8):
+            a, b = qs.dequeue(), qp.dequeue()
+            torch.cuda.synchronize()
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and (a[2] == b[2]).all() and (a[3] == b[3]).all()
+        assert qp._thread is not None and qp._thread.is_alive()
+    finally:
+        qp.close()
 
 
 @pytest.mark.parametrize('opt', ['RMSprop', 'AdaDelta', 'AdaGrad'])
