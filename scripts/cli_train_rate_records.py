@@ -20,7 +20,8 @@ for f in range(4):
         sk = np.full((384, 384, 3), 255, np.uint8)
         sk[(7 * i) % 370:(7 * i) % 370 + 6, 40:340] = 0
         text = np.zeros(15, np.uint8)
-        text[-4:] = rng.randint(2, 58, 4)
+        ln = rng.randint(2, 11) if os.environ.get('RECORDS_VARY_CAPTIONS') == '1' else 4     # left-padded captions of 2..10 tokens
+        text[15 - ln:] = rng.randint(2, 58, ln)
         recs.append(tf.make_example({'ImageName': b'x.png', 'cartoon_data': rng.randint(0, 256, (384, 384, 3)).astype(np.uint8).tobytes(),
                                      'sketch_data': sk.tobytes(), 'Category': b'car', 'Category_id': i % 25,
                                      'Color_text': b'the car is red', 'Text_vocab_indices': text.tobytes()}))
