@@ -318,3 +318,28 @@ def test_cli_hands_an_explicit_argv_to_the_self_launched_ranks(monkeypatch):
     monkeypatch.setattr(sys, 'argv', ['obj_colorization_main.py', '--mode', 'train', '-gpu', '2'])
     cli.main()
     assert seen['argv'] is None         # the command line itself: launch_towers re-executes sys.argv
+
+
+def test_pending_losses_are_settled_in_launch_order(capsys):
+    """main_procedure._settle_first: the losses of launched steps are looked at oldest first; the first NaN names its step, drops
+    what was launched after it and returns -1 (train() then ends in front of any later snapshot); otherwise 0."""
+    import numpy as np
+    from sketchyscenecolorization_amd.obj_lib.main_procedure import _settle_first
+
+    class Lazy(object):         # what graph_single.LazyLoss looks like to numpy
+        def __init__(self, v):
+            self.v, self.read = v, False
+
+        def __array__(self, dtype=None, copy=None):
+            self.read = True
+            return np.asarray(np.float32(self.v), dtype=dtype)
+
+    a, b, c = Lazy(1.0), Lazy(2.0), Lazy(3.0)
+    pending = [('D', a), ('G', b), ('D', c)]
+    assert _settle_first(pending, 2) == 0
+    assert a.read and b.read and not c.read and pending == [('D', c)]
+    x, y, z = Lazy(0.5), Lazy(float('nan')), Lazy(1.0)
+    pending = [('D', x), ('G', y), ('D', z)]
+    assert _settle_first(pending, 3) == -1
+    assert 'NaN occurred during training G' in capsys.readouterr().out
+    assert pending == [] and not z.read
